@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference's example data (run in the build
+container only; /root/reference does not exist on the GPU box).
+
+Inputs  : /root/reference/polarization/examples/*  (data files + the numbers in the decks)
+Outputs : tests/golden/<case>.npz   -- per-atom inputs, pair_coeff table, pair_style
+                                       settings, and the known answers the reference's
+                                       own logs hold for step 0 (E_pol, E_vdwl, E_coul, G).
+Only data is stored (coordinates, charges, parameters, expected values); no reference
+source or script text is copied.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import importlib
+
+wl = importlib.import_module("lammps-induced-dipole-polarization-pair-style_amd.workload")
+
+EX = "/root/reference/polarization/examples"
+CASES = {
+    # name: (dir, data, deck, exclude_intra, log-known answers at step 0)
+    "bulk_h2": ("Bulk H2", "h2.data", "h2.input", False,
+                dict(E_pol=-0.11226309, E_vdwl=-23.427106, E_coul=5158.6145, g_ewald=0.219679,
+                     source="polarization/examples/Bulk H2/log.lammps:86-93")),
+    "mof5_methane": ("MOF5+Methane", "MOF5+PCRC.restart.pdb.data", "MOF5+PCRC.restart.pdb.input", False,
+                     dict(E_pol=-5.9227026, E_vdwl=28709884.0, E_coul=-33263.466, g_ewald=0.19132,
+                          source="polarization/examples/MOF5+Methane/log.lammps:147-151")),
+    # no log exists for this deck; known answers are the values SURVEY.md 8(c) recorded from the
+    # reference binary (ewald 1e-4 -> G=0.195492, molecule/intra exclusion, use_previous no)
+    "mof5_h2": ("MOF5+H2", "MOF5+BSSP.restart.pdb.data", "MOF5+BSSP.restart.pdb.input", True,
+                dict(E_pol=-4.897543147572293, E_vdwl=-138.9130390314951, E_coul=-16.82381605606714,
+                     g_ewald=0.195492, iterations=30, E_pol_zodid=-4.787513222298264,
+                     source="SURVEY.md section 8(c) (reference binary, run 0)")),
+    "sifsix_co2": ("SIFSIX-2-Cu-i+CO2", "BIPA+CO2.pdb.data", "BIPA+CO2.pdb.input", False,
+                   dict(g_ewald=0.0, source="no log; non-cubic box edge case")),
+}
+
+
+def main():
+    for name, (d, data, deck, excl, known) in CASES.items():
+        dat = wl.parse_lammps_data(os.path.join(EX, d, data))
+        dk = wl.parse_deck(os.path.join(EX, d, deck))
+        alpha = np.array([dk["alpha_by_type"].get(int(t), 0.0) for t in dat["type"]])
+        if known.get("g_ewald", 0.0) == 0.0:
+            cut = float(dk["pair_style_args"][1])
+            known["g_ewald"] = wl.ewald_g(1.0e-4, dat["q"], cut, dat["prd"])
+        coeff = np.array([[float(v) for v in (row + [dk["pair_style_args"][0]])[:5]] for row in dk["pair_coeff"]])
+        meta = dict(name=name, pair_style_args=dk["pair_style_args"], exclude_intra=bool(excl), known=known,
+                    ntypes=int(dat["ntypes"]))
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            x=dat["x"], q=dat["q"], alpha=alpha, type=dat["type"], molecule=dat["molecule"],
+            bonds=dat["bonds"], boxlo=dat["boxlo"], prd=dat["prd"], pair_coeff=coeff,
+            meta=np.array(json.dumps(meta)))
+        print(name, dat["natoms"], "atoms", "G=%.6f" % known["g_ewald"])
+
+
+if __name__ == "__main__":
+    main()
