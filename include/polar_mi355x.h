@@ -1,0 +1,141 @@
+/* polar_mi355x.h -- C-ABI of the MI355X-native lj/cut/coul/long/polarization pair style.
+ *
+ * Drop-in boundary for ONE hot path of aehogan/lammps-induced-dipole-polarization-pair-style:
+ * PairLJCutCoulLongPolarization::compute and the text/host interface around it
+ * (reference: src/pair_lj_cut_coul_long_polarization.{h,cpp}; "PS.cpp"/"PS.h" below).
+ * The reference has no FFI (the pair style is compiled into LAMMPS); the entry points here are
+ * what a `Pair` subclass shim binds instead of the reference's in-class code
+ * (lammps_shim/pair_lj_cut_coul_long_polarization_mi355x.cpp).
+ *
+ * Plain C types only, FP64, row-major [n][3] arrays, host pointers unless a name says `dev`.
+ * Every function returns an int status: 0 ok, >0 warning, <0 fatal (message via
+ * polar_last_error).  Not thread-safe per handle; calls are synchronous on return.
+ * The implementation is hand-written HIP for gfx950; there is NO CPU fallback: without a
+ * usable GPU every compute entry point fails with POLAR_ERR_NO_DEVICE.
+ */
+#ifndef POLAR_MI355X_H
+#define POLAR_MI355X_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POLAR_OK 0
+#define POLAR_WARN_NOT_CONVERGED 1 /* PS.cpp:1227-1235: mu reset to alpha*E, warning text in polar_last_warning */
+#define POLAR_ERR_INPUT -1         /* reference error->all() conditions; message = reference text */
+#define POLAR_ERR_NO_DEVICE -2
+#define POLAR_ERR_HIP -3
+#define POLAR_ERR_UNSUPPORTED -4   /* feature on the SURVEY 8(f) "next" list (triclinic, per-atom tallies) */
+#define POLAR_ERR_STATE -5         /* call order (e.g. compute before set_atoms) */
+
+enum { POLAR_DAMP_EXPONENTIAL = 0, POLAR_DAMP_NONE = 1 }; /* PS.cpp:51 */
+
+typedef struct polar_handle polar_handle;
+
+/* pair_style keyword state.  Defaults = PS.cpp:65-78. */
+typedef struct {
+  double cut_lj_global, cut_coul;
+  double polar_precision, polar_damp, polar_gamma;
+  int iterations_max, damping_type, zodid, fixed_iteration;
+  int polar_gs, polar_gs_ranked, use_previous, debug;
+  /* --- extension, not in the reference ---
+   * dd_cutoff <= 0 : reference semantics: static field / charge-dipole cut at cut_coul,
+   *                  dipole-dipole over ALL minimum-image pairs (exact, O(N^2)).
+   * dd_cutoff  > 0 : dipole tensor and dipole-dipole force truncated at rsq < dd_cutoff^2 and all
+   *                  polarization loops run over a device-built cell/neighbor list (O(N K)).
+   *                  Identical to the reference when dd_cutoff >= sqrt(3)/2 * L.               */
+  double dd_cutoff;
+} polar_settings;
+
+typedef struct {
+  double eng_vdwl, eng_coul, eng_pol; /* Pair::eng_vdwl/eng_coul/eng_pol (src/pair.h:36) */
+  double u_self, u_ef, u_dd;          /* the three parts of eng_pol (PS.cpp:632) */
+  double virial[6];                   /* Pair::virial when vflag asks for it */
+  double rmin;                        /* PS.cpp:196-209 */
+  double rms_dmu;                     /* sqrt(sum(dmu^2)/(3N)) of the last sweep */
+  int iterations;                     /* return value of DipoleSolverIterative (PS.cpp:1113) */
+  int sweeps;                         /* sweeps actually executed on the device */
+  int status;                         /* POLAR_OK or POLAR_WARN_NOT_CONVERGED */
+  int ncolors;                        /* colour phases per GS sweep in cutoff mode (0 otherwise) */
+  /* device time of the last compute, milliseconds (HIP events on the compute stream) */
+  double ms_total, ms_rank, ms_ljcoul, ms_static, ms_solve, ms_force, ms_list;
+  long long dd_pairs;                 /* entries of the dipole-dipole list swept per sweep */
+} polar_result;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+int polar_create(int device, polar_handle **out);
+int polar_destroy(polar_handle *h);
+const char *polar_last_error(const polar_handle *h);
+const char *polar_last_warning(const polar_handle *h);
+int polar_device_count(void); /* 0 when no GPU is usable; never throws */
+
+/* ---- host mirror of the Pair text interface (same grammar, defaults and error strings) --- */
+/* PairLJCutCoulLongPolarization::settings, PS.cpp:678-766. argv = pair_style args after the name. */
+int polar_pair_settings(polar_handle *h, int narg, const char *const *arg);
+/* ::coeff, PS.cpp:772-800.  arg = "I J epsilon sigma [cut_lj]"; ntypes = atom->ntypes. */
+int polar_pair_coeff(polar_handle *h, int ntypes, int narg, const char *const *arg);
+/* Pair::modify_params subset used with this style (src/pair.cpp:125-185): mix, shift, table, tabinner. */
+int polar_pair_modify(polar_handle *h, int narg, const char *const *arg);
+/* Pair::init + ::init_style + ::init_one for all pairs (src/pair.cpp:189-263, PS.cpp:806-921) and
+ * Pair::init_tables (src/pair.cpp:313-520).  g_ewald = force->kspace->g_ewald (PS.cpp:847),
+ * qqrd2e/special_* = Force members.  Uploads the tables to the device. */
+int polar_pair_init(polar_handle *h, double g_ewald, double qqrd2e, const double special_lj[4],
+                    const double special_coul[4]);
+/* ::init_one return value (cutoff) for a type pair, after polar_pair_init. */
+double polar_pair_cut(const polar_handle *h, int itype, int jtype);
+/* ::single, PS.cpp:1035-1097 (LJ + real-space Coulomb only).  Host arithmetic. */
+double polar_pair_single(const polar_handle *h, double qi, double qj, int itype, int jtype, double rsq,
+                         double factor_coul, double factor_lj, double *fforce);
+/* ::extract, PS.cpp:1101-1109: "cut_coul" (dim 0), "epsilon"/"sigma" (dim 2, [(n+1)*(n+1)] row-major). */
+const void *polar_pair_extract(const polar_handle *h, const char *name, int *dim);
+int polar_get_settings(const polar_handle *h, polar_settings *out);
+
+/* ---- raw setters for a LAMMPS shim that keeps LAMMPS' own tables ------------------------- */
+int polar_set_settings(polar_handle *h, const polar_settings *s);
+/* tables are [(ntypes+1)*(ntypes+1)] row-major as lj1[i][j] (PS.h:62) */
+int polar_set_types(polar_handle *h, int ntypes, const double *lj1, const double *lj2, const double *lj3,
+                    const double *lj4, const double *offset, const double *cut_ljsq, const double *cutsq);
+/* Pair::{rtable,drtable,ftable,dftable,ctable,dctable,etable,detable}; ncoultablebits==0: none */
+int polar_set_coul(polar_handle *h, double g_ewald, double qqrd2e, const double special_lj[4],
+                   const double special_coul[4], int ncoultablebits, int ncoulmask, int ncoulshiftbits,
+                   double tabinnersq, const double *rtable, const double *drtable, const double *ftable,
+                   const double *dftable, const double *ctable, const double *dctable, const double *etable,
+                   const double *detable);
+
+/* ---- per-run / per-step data (what compute() reads through atom->, domain->, list->) ----- */
+/* Domain: boxlo, prd, tilt (xy,xz,yz), periodicity, triclinic (domain.cpp:1220-1312 inputs) */
+int polar_set_box(polar_handle *h, const double boxlo[3], const double prd[3], const double tilt[3],
+                  const int periodic[3], int triclinic);
+/* atom->x,q,static_polarizability,type,molecule for nlocal+nghost atoms (src/atom.h:160-163) */
+int polar_set_atoms(polar_handle *h, int nlocal, int nghost, const double *x, const double *q,
+                    const double *alpha, const int *type, const int *molecule);
+/* NeighList inum/ilist/numneigh/firstneigh (src/neigh_list.h:46-50); call when neighbor->ago == 0 */
+int polar_set_neighbors(polar_handle *h, int inum, const int *ilist, const int *numneigh,
+                        int *const *firstneigh);
+/* same list already flattened: firstneigh[i] = offset of atom i's entries in neigh[] */
+int polar_set_neighbors_csr(polar_handle *h, int inum, const int *ilist, const int *numneigh,
+                            const long long *firstneigh, const int *neigh);
+
+/* ---- the hot path: PairLJCutCoulLongPolarization::compute(eflag,vflag), PS.cpp:125-645 ---- */
+/* f[nall][3] is ACCUMULATED (+=) like atom->f; mu[nlocal][3] is atom->mu_induced (read when
+ * use_previous, always written); ef_static[nlocal][3] (may be NULL) receives atom->ef_static.
+ * eflag: 0 / 1 (global).  vflag: 0, 1 (pairwise global virial), 2 (fdotr global virial).
+ * Per-atom energy/virial flags -> POLAR_ERR_UNSUPPORTED. */
+int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, double *ef_static,
+                  polar_result *out);
+
+/* ---- device-resident variant (bench, multi-GPU driver): no host<->device traffic ---------- */
+/* Runs compute() on the atoms/lists already resident from polar_set_*; results stay on the
+ * device (polar_dev_ptr) and only the scalars in polar_result come back. */
+int polar_compute_resident(polar_handle *h, int eflag, int vflag, polar_result *out);
+/* device pointers: "f" [nall][3], "mu" [nlocal][3], "ef_static" [nlocal][3], "x" [nall][3] */
+void *polar_dev_ptr(polar_handle *h, const char *name);
+/* copy a device-resident per-atom array back: name as above, n doubles */
+int polar_download(polar_handle *h, const char *name, double *dst, long long n);
+/* overwrite the device-resident dipoles (multi-GPU halo, use_previous across steps) */
+int polar_upload_mu(polar_handle *h, const double *mu, long long n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

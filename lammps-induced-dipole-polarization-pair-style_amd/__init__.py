@@ -1,0 +1,312 @@
+"""MI355X-native ``lj/cut/coul/long/polarization`` pair style: Python host plumbing.
+
+The product is ``libpolar_mi355x.so`` (hand-written HIP for gfx950 behind the C-ABI declared
+in ``include/polar_mi355x.h``).  This module only builds / loads that library and offers
+``PolarPair``, a thin mirror of the reference's ``Pair`` interface
+(reference: src/pair_lj_cut_coul_long_polarization.h:30-53 -- settings, coeff, init_style/
+init_one, compute, single, extract) for tests, bench.py and the multi-GPU driver.
+There is no Python or CPU implementation of the hot path here: if the library or a GPU
+is missing, ``PolarPair.compute`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libpolar_mi355x.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+_lib = None
+
+
+class PolarError(RuntimeError):
+    """Raised for every negative C-ABI status; ``str(e)`` is the reference's error text."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+def _sources():
+    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".hpp"))] + [
+        os.path.join(os.path.dirname(_HERE), "include", "polar_mi355x.h")]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU)."""
+    src = os.path.join(_CSRC, "polar_api.hip")
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in _sources())
+    if force or stale:
+        cmd = [HIPCC] + HIP_FLAGS + ["-o", LIB_PATH, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class Settings(C.Structure):
+    _fields_ = [("cut_lj_global", C.c_double), ("cut_coul", C.c_double), ("polar_precision", C.c_double),
+                ("polar_damp", C.c_double), ("polar_gamma", C.c_double), ("iterations_max", C.c_int),
+                ("damping_type", C.c_int), ("zodid", C.c_int), ("fixed_iteration", C.c_int), ("polar_gs", C.c_int),
+                ("polar_gs_ranked", C.c_int), ("use_previous", C.c_int), ("debug", C.c_int), ("dd_cutoff", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [("eng_vdwl", C.c_double), ("eng_coul", C.c_double), ("eng_pol", C.c_double), ("u_self", C.c_double),
+                ("u_ef", C.c_double), ("u_dd", C.c_double), ("virial", C.c_double * 6), ("rmin", C.c_double),
+                ("rms_dmu", C.c_double), ("iterations", C.c_int), ("sweeps", C.c_int), ("status", C.c_int),
+                ("ncolors", C.c_int), ("ms_total", C.c_double), ("ms_rank", C.c_double), ("ms_ljcoul", C.c_double),
+                ("ms_static", C.c_double), ("ms_solve", C.c_double), ("ms_force", C.c_double), ("ms_list", C.c_double),
+                ("dd_pairs", C.c_longlong)]
+
+
+_dp, _ip, _llp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong)
+_cpp = C.POINTER(C.c_char_p)
+EXPORTS = {
+    "polar_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "polar_destroy": (C.c_int, [C.c_void_p]),
+    "polar_last_error": (C.c_char_p, [C.c_void_p]),
+    "polar_last_warning": (C.c_char_p, [C.c_void_p]),
+    "polar_device_count": (C.c_int, []),
+    "polar_pair_settings": (C.c_int, [C.c_void_p, C.c_int, _cpp]),
+    "polar_pair_coeff": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _cpp]),
+    "polar_pair_modify": (C.c_int, [C.c_void_p, C.c_int, _cpp]),
+    "polar_pair_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _dp, _dp]),
+    "polar_pair_cut": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    "polar_pair_single": (C.c_double, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double,
+                                       C.c_double, _dp]),
+    "polar_pair_extract": (C.c_void_p, [C.c_void_p, C.c_char_p, _ip]),
+    "polar_get_settings": (C.c_int, [C.c_void_p, C.POINTER(Settings)]),
+    "polar_set_settings": (C.c_int, [C.c_void_p, C.POINTER(Settings)]),
+    "polar_set_types": (C.c_int, [C.c_void_p, C.c_int] + [_dp] * 7),
+    "polar_set_coul": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double]
+                       + [_dp] * 8),
+    "polar_set_box": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip, C.c_int]),
+    "polar_set_atoms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _ip, _ip]),
+    "polar_set_neighbors": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.POINTER(_ip)]),
+    "polar_set_neighbors_csr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _llp, _ip]),
+    "polar_compute": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Result)]),
+    "polar_compute_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Result)]),
+    "polar_dev_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
+    "polar_download": (C.c_int, [C.c_void_p, C.c_char_p, _dp, C.c_longlong]),
+    "polar_upload_mu": (C.c_int, [C.c_void_p, _dp, C.c_longlong]),
+}
+
+
+def lib():
+    """Load the C-ABI library.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PolarError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950); "
+                                 "there is no CPU fallback for the polarization hot path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def device_count():
+    return lib().polar_device_count()
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _argv(args):
+    arr = (C.c_char_p * max(len(args), 1))(*[str(a).encode() for a in args])
+    return arr
+
+
+class PolarPair:
+    """Mirror of the reference Pair interface on top of the C-ABI (one handle = one Pair instance)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.polar_create(device, C.byref(self.h))
+        if rc < 0:
+            raise PolarError(rc, "polar_create failed")
+        self._keep = []
+        self.nlocal = self.nghost = 0
+
+    def close(self):
+        if self.h:
+            self.L.polar_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise PolarError(rc, self.L.polar_last_error(self.h).decode())
+        return rc
+
+    # ---- text interface (reference grammar) ----
+    def settings(self, args):
+        """pair_style arguments after the style name (reference PS.cpp:678-766)."""
+        self._ck(self.L.polar_pair_settings(self.h, len(args), _argv(args)))
+
+    def coeff(self, ntypes, args):
+        """pair_coeff I J eps sigma [cut] (reference PS.cpp:772-800)."""
+        self._ck(self.L.polar_pair_coeff(self.h, ntypes, len(args), _argv(args)))
+
+    def modify(self, args):
+        self._ck(self.L.polar_pair_modify(self.h, len(args), _argv(args)))
+
+    def init(self, g_ewald, qqrd2e, special_lj=(1.0, 0.0, 0.0, 0.0), special_coul=(1.0, 0.0, 0.0, 0.0)):
+        slj = np.asarray(special_lj, dtype=np.float64)
+        sc = np.asarray(special_coul, dtype=np.float64)
+        self._ck(self.L.polar_pair_init(self.h, g_ewald, qqrd2e, _dptr(slj), _dptr(sc)))
+
+    def get_settings(self):
+        s = Settings()
+        self._ck(self.L.polar_get_settings(self.h, C.byref(s)))
+        return s
+
+    def cut(self, i, j):
+        return self.L.polar_pair_cut(self.h, i, j)
+
+    def single(self, qi, qj, itype, jtype, rsq, factor_coul=1.0, factor_lj=1.0):
+        ff = C.c_double()
+        e = self.L.polar_pair_single(self.h, qi, qj, itype, jtype, rsq, factor_coul, factor_lj, C.byref(ff))
+        return e, ff.value
+
+    def extract(self, name):
+        dim = C.c_int()
+        p = self.L.polar_pair_extract(self.h, name.encode(), C.byref(dim))
+        if not p:
+            return None
+        if dim.value == 0:
+            return C.cast(p, _dp)[0]
+        n = None
+        return p, dim.value
+
+    # ---- per-run data ----
+    def set_box(self, boxlo, prd, periodic=(1, 1, 1), tilt=(0.0, 0.0, 0.0), triclinic=0):
+        lo, pr, ti = (np.asarray(v, dtype=np.float64) for v in (boxlo, prd, tilt))
+        pe = np.asarray(periodic, dtype=np.int32)
+        self._ck(self.L.polar_set_box(self.h, _dptr(lo), _dptr(pr), _dptr(ti), _iptr(pe), triclinic))
+
+    def set_atoms(self, nlocal, nghost, x, q, alpha, typ, mol):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        typ = np.ascontiguousarray(typ, dtype=np.int32)
+        mol = np.ascontiguousarray(mol, dtype=np.int32)
+        assert x.shape == (nlocal + nghost, 3) and len(q) == len(alpha) == len(typ) == len(mol) == nlocal + nghost
+        self._ck(self.L.polar_set_atoms(self.h, nlocal, nghost, _dptr(x), _dptr(q), _dptr(alpha), _iptr(typ), _iptr(mol)))
+        self.nlocal, self.nghost = nlocal, nghost
+
+    def set_neighbors_csr(self, ilist, numneigh, firstneigh, neigh):
+        ilist = np.ascontiguousarray(ilist, dtype=np.int32)
+        numneigh = np.ascontiguousarray(numneigh, dtype=np.int32)
+        firstneigh = np.ascontiguousarray(firstneigh, dtype=np.int64)
+        neigh = np.ascontiguousarray(neigh, dtype=np.int32)
+        assert len(numneigh) == self.nlocal == len(firstneigh)
+        self._ck(self.L.polar_set_neighbors_csr(self.h, len(ilist), _iptr(ilist), _iptr(numneigh),
+                                                firstneigh.ctypes.data_as(_llp), _iptr(neigh)))
+
+    def set_neighbors_rows(self, ilist, numneigh, rows):
+        """LAMMPS layout: ``firstneigh`` as an array of row pointers (paged lists)."""
+        ilist = np.ascontiguousarray(ilist, dtype=np.int32)
+        numneigh = np.ascontiguousarray(numneigh, dtype=np.int32)
+        ptrs = (_ip * self.nlocal)()
+        keep = []
+        for i, r in enumerate(rows):
+            r = np.ascontiguousarray(r, dtype=np.int32)
+            keep.append(r)
+            ptrs[i] = _iptr(r) if len(r) else None
+        self._ck(self.L.polar_set_neighbors(self.h, len(ilist), _iptr(ilist), _iptr(numneigh), ptrs))
+
+    def load_system(self, sysm, modify_args=()):
+        """Feed a workload.PolarSystem through the same calls a LAMMPS shim would make."""
+        st = sysm.settings
+        args = [repr(st.cut_lj_global), repr(st.cut_coul),
+                "precision", repr(st.polar_precision), "max_iterations", str(st.iterations_max),
+                "damp", repr(st.polar_damp), "damp_type", "exponential" if st.damping_type == 0 else "none",
+                "polar_gs_ranked", "no", "polar_gs", "no",
+                "fixed_iteration", "yes" if st.fixed_iteration else "no", "polar_gamma", repr(st.polar_gamma),
+                "debug", "yes" if st.debug else "no", "use_previous", "yes" if st.use_previous else "no"]
+        if st.zodid:
+            args += ["zodid", "yes"]
+        elif st.polar_gs:
+            args += ["polar_gs", "yes"]
+        elif st.polar_gs_ranked:
+            args += ["polar_gs_ranked", "yes"]
+        if st.dd_cutoff > 0:
+            args += ["dd_cutoff", repr(st.dd_cutoff)]
+        self.settings(args)
+        if modify_args:
+            self.modify(list(modify_args))
+        return args
+
+    def set_system(self, sysm):
+        self.set_box(sysm.boxlo, sysm.prd)
+        self.set_atoms(sysm.nlocal, sysm.nghost, sysm.x, sysm.q, sysm.alpha, sysm.type, sysm.molecule)
+        self.set_neighbors_csr(sysm.ilist, sysm.numneigh, sysm.firstneigh, sysm.neigh)
+
+    # ---- the hot path ----
+    def compute(self, eflag=1, vflag=2, mu=None, want_ef=True):
+        n, nall = self.nlocal, self.nlocal + self.nghost
+        f = np.zeros((nall, 3))
+        mu = np.zeros((n, 3)) if mu is None else np.array(mu, dtype=np.float64, copy=True)
+        ef = np.zeros((n, 3))
+        res = Result()
+        rc = self._ck(self.L.polar_compute(self.h, eflag, vflag, _dptr(f), _dptr(mu), _dptr(ef) if want_ef else None,
+                                           C.byref(res)))
+        out = _result_dict(res)
+        out.update(f=f, mu=mu, ef_static=ef, status=rc, warning=self.L.polar_last_warning(self.h).decode())
+        return out
+
+    def compute_resident(self, eflag=1, vflag=2):
+        res = Result()
+        rc = self._ck(self.L.polar_compute_resident(self.h, eflag, vflag, C.byref(res)))
+        out = _result_dict(res)
+        out.update(status=rc, warning=self.L.polar_last_warning(self.h).decode())
+        return out
+
+    def download(self, name, n):
+        a = np.zeros(n)
+        self._ck(self.L.polar_download(self.h, name.encode(), _dptr(a), n))
+        return a
+
+
+def _result_dict(res):
+    out = {}
+    for name, _ in Result._fields_:
+        v = getattr(res, name)
+        out[name] = np.array(list(v)) if name == "virial" else v
+    return out
+
+
+def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0):
+    """Build a PolarPair from a workload.PolarSystem the way an input script would:
+    pair_style -> pair_modify -> pair_coeff -> init -> per-step data."""
+    p = PolarPair(device)
+    p.load_system(sysm, modify_args)
+    rows = coeff_rows if coeff_rows is not None else sysm.extra.get("coeff_rows")
+    if rows is None:
+        raise ValueError("pair_coeff rows are required")
+    for r in rows:
+        p.coeff(sysm.ntypes, list(r))
+    p.init(sysm.g_ewald, sysm.qqrd2e, sysm.special_lj, sysm.special_coul)
+    p.set_system(sysm)
+    return p

@@ -1,0 +1,755 @@
+// polar_api.hip -- C-ABI implementation (include/polar_mi355x.h): handle, HBM-resident state,
+// and the orchestration of PairLJCutCoulLongPolarization::compute (PS.cpp:125-645) on one MI355X.
+// All arithmetic of the hot path runs in the kernels of polar_kernels.hpp; this file holds no
+// CPU implementation of it (no fallback: without a GPU every compute call fails).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "pair_host.hpp"
+#include "polar_kernels.hpp"
+
+using namespace polar;
+
+namespace {
+
+struct HipError : std::runtime_error {
+  explicit HipError(const std::string &m) : std::runtime_error(m) {}
+};
+struct NoDevice : std::runtime_error {
+  NoDevice() : std::runtime_error("no usable HIP device: this library has no CPU fallback") {}
+};
+#define HIPCHECK(expr)                                                                             \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      throw HipError(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                     ":" + std::to_string(__LINE__) + ")");                                      \
+  } while (0)
+
+template <typename T>
+struct DBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (p) HIPCHECK(hipFree(p));
+    size_t want = n + n / 8 + 64;
+    HIPCHECK(hipMalloc((void **)&p, want * sizeof(T)));
+    cap = want;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+  }
+};
+
+inline int nblk(long long n, int per) { return (int)((n + per - 1) / per); }
+
+}  // namespace
+
+struct polar_handle {
+  int device = -1;
+  bool have_device = false;
+  hipStream_t stream = nullptr;
+  std::string err, warn;
+  PairHost ph;
+  bool types_set = false, coul_set = false, box_set = false, atoms_set = false, neigh_set = false;
+  // raw-setter copies (when the shim passes LAMMPS' own tables)
+  int ntypes = 0;
+  LJCoulParams P{};
+  Box box{};
+  double boxlo[3] = {0, 0, 0};
+  int nlocal = 0, nghost = 0;
+  // host mirrors needed by host-side colouring
+  std::vector<double> hx, halpha;
+  // device state
+  DBuf<double> d_x, d_q, d_alpha, d_f, d_ef, d_F, d_mu, d_rank, d_dmu, d_tab, d_lj;
+  DBuf<int> d_type, d_mol, d_order, d_pos, d_ilist, d_numneigh, d_neigh, d_rows;
+  DBuf<long long> d_first;
+  DBuf<AtomRec> d_rec0, d_rec1;
+  DBuf<Scal> d_scal;
+  // cutoff-mode lists
+  DBuf<int> d_cell_id, d_cell_cnt, d_cell_fill, d_cell_atoms, d_nl_cnt, d_dd_cnt, d_nl_j, d_dd_j;
+  DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
+  long long nl_pairs = 0, dd_pairs = 0;
+  int inum = 0;
+  long long nneigh = 0;
+  bool mu_resident = false;
+  // colour phases (cutoff-mode Gauss-Seidel)
+  std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
+  bool colors_valid = false;
+  double color_dist = 2.6;
+  Scal *h_scal = nullptr;  // pinned
+  hipEvent_t ev[8] = {};
+  std::vector<double> h_tmp;
+};
+
+namespace {
+
+int fail(polar_handle *h, int code, const std::string &m) {
+  if (h) h->err = m;
+  return code;
+}
+
+template <typename F>
+int guarded(polar_handle *h, F &&fn) {
+  if (!h) return POLAR_ERR_STATE;
+  try {
+    return fn();
+  } catch (const InputError &e) {
+    return fail(h, POLAR_ERR_INPUT, e.what());
+  } catch (const NoDevice &e) {
+    return fail(h, POLAR_ERR_NO_DEVICE, e.what());
+  } catch (const HipError &e) {
+    return fail(h, POLAR_ERR_HIP, e.what());
+  } catch (const std::exception &e) {
+    return fail(h, POLAR_ERR_STATE, e.what());
+  }
+}
+
+void need_device(polar_handle *h) {
+  if (!h->have_device) throw NoDevice();
+}
+
+// upload LJ tables + Coulomb tables from the host mirror (or raw setters) into P
+void upload_types(polar_handle *h, int ntypes, const double *const t[7]) {
+  need_device(h);
+  size_t m = (size_t)(ntypes + 1) * (ntypes + 1);
+  h->d_lj.ensure(7 * m);
+  for (int k = 0; k < 7; k++) HIPCHECK(hipMemcpy(h->d_lj.p + k * m, t[k], m * sizeof(double), hipMemcpyHostToDevice));
+  h->P.ntypes = ntypes;
+  h->P.lj1 = h->d_lj.p; h->P.lj2 = h->d_lj.p + m; h->P.lj3 = h->d_lj.p + 2 * m; h->P.lj4 = h->d_lj.p + 3 * m;
+  h->P.offset = h->d_lj.p + 4 * m; h->P.cut_ljsq = h->d_lj.p + 5 * m; h->P.cutsq = h->d_lj.p + 6 * m;
+  h->ntypes = ntypes;
+  h->types_set = true;
+}
+
+void upload_coul(polar_handle *h, double g_ewald, double qqrd2e, const double *slj, const double *scoul, int nbits,
+                 int mask, int shift, double tabinnersq, const double *const t[8]) {
+  need_device(h);
+  h->P.g_ewald = g_ewald; h->P.qqrd2e = qqrd2e;
+  for (int k = 0; k < 4; k++) { h->P.special_lj[k] = slj[k]; h->P.special_coul[k] = scoul[k]; }
+  h->P.ncoultablebits = nbits; h->P.ncoulmask = mask; h->P.ncoulshiftbits = shift; h->P.tabinnersq = tabinnersq;
+  size_t nt = nbits ? ((size_t)1 << nbits) : 1;
+  h->d_tab.ensure(8 * nt);
+  if (nbits)
+    for (int k = 0; k < 8; k++) HIPCHECK(hipMemcpy(h->d_tab.p + k * nt, t[k], nt * sizeof(double), hipMemcpyHostToDevice));
+  h->P.rtable = h->d_tab.p; h->P.drtable = h->d_tab.p + nt; h->P.ftable = h->d_tab.p + 2 * nt;
+  h->P.dftable = h->d_tab.p + 3 * nt; h->P.ctable = h->d_tab.p + 4 * nt; h->P.dctable = h->d_tab.p + 5 * nt;
+  h->P.etable = h->d_tab.p + 6 * nt; h->P.detable = h->d_tab.p + 7 * nt;
+  h->coul_set = true;
+}
+
+// ---- cutoff-mode list build on the device -------------------------------------------------
+void build_lists(polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  const int n = h->nlocal;
+  const double cutall = std::max(st.cut_coul, st.dd_cutoff);
+  for (int k = 0; k < 3; k++)
+    if (h->box.periodic[k] && h->box.prd[k] < 2.0 * cutall * (1.0 - 1e-12))
+      throw InputError("dd_cutoff mode needs box lengths >= 2*max(cut_coul,dd_cutoff); use exact mode (dd_cutoff 0)");
+  CellGrid g;
+  long long ncell = 1;
+  for (int k = 0; k < 3; k++) {
+    g.nc[k] = std::max(1, (int)std::floor(h->box.prd[k] / cutall));
+    g.lo[k] = h->boxlo[k];
+    g.inv[k] = g.nc[k] / h->box.prd[k];
+    ncell *= g.nc[k];
+  }
+  hipStream_t s = h->stream;
+  h->d_cell_id.ensure(n); h->d_cell_cnt.ensure(ncell + 1); h->d_cell_fill.ensure(ncell + 1);
+  h->d_cell_first.ensure(ncell + 2); h->d_cell_atoms.ensure(n);
+  HIPCHECK(hipMemsetAsync(h->d_cell_cnt.p, 0, (ncell + 1) * sizeof(int), s));
+  HIPCHECK(hipMemsetAsync(h->d_cell_fill.p, 0, (ncell + 1) * sizeof(int), s));
+  k_cell_count<<<nblk(n, 256), 256, 0, s>>>(n, h->d_x.p, g, h->box, h->d_cell_id.p, h->d_cell_cnt.p);
+  k_exclusive_scan<int><<<1, 1024, 0, s>>>(ncell, h->d_cell_cnt.p, h->d_cell_first.p);
+  k_cell_fill<<<nblk(n, 256), 256, 0, s>>>(n, (int)ncell, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_fill.p,
+                                           h->d_cell_atoms.p);
+  h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1); h->d_nl_first.ensure(n + 2); h->d_dd_first.ensure(n + 2);
+  const double cutallsq = cutall * cutall, ddsq = st.dd_cutoff * st.dd_cutoff;
+  k_nl_build<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
+      n, h->d_rec0.p, h->box, g, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_atoms.p, cutallsq, ddsq, h->d_nl_cnt.p,
+      h->d_dd_cnt.p, nullptr, nullptr, nullptr, nullptr);
+  k_exclusive_scan<int><<<1, 1024, 0, s>>>(n, h->d_nl_cnt.p, h->d_nl_first.p);
+  k_exclusive_scan<int><<<1, 1024, 0, s>>>(n, h->d_dd_cnt.p, h->d_dd_first.p);
+  long long tot[2];
+  HIPCHECK(hipMemcpyAsync(&tot[0], h->d_nl_first.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipMemcpyAsync(&tot[1], h->d_dd_first.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  h->nl_pairs = tot[0]; h->dd_pairs = tot[1];
+  h->d_nl_j.ensure((size_t)tot[0] + 64); h->d_dd_j.ensure((size_t)tot[1] + 64);
+  k_nl_build<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
+      n, h->d_rec0.p, h->box, g, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_atoms.p, cutallsq, ddsq, nullptr, nullptr,
+      h->d_nl_first.p, h->d_dd_first.p, h->d_nl_j.p, h->d_dd_j.p);
+}
+
+// ---- host-side greedy distance colouring for the colour-phase Gauss-Seidel (cutoff mode) ----
+// Atoms of one colour are >= color_dist apart, so the couplings treated Jacobi-style inside a
+// phase are weak and the splitting M = D + L_colour stays convergent for the SPD dipole system
+// (DESIGN.md "colour-phase Gauss-Seidel").  Visit order = ranked order when polar_gs_ranked.
+void build_colors(polar_handle *h, const std::vector<int> &visit) {
+  const int n = h->nlocal;
+  const double dc = h->color_dist, dcsq = dc * dc;
+  int nc[3];
+  long long ncell = 1;
+  for (int k = 0; k < 3; k++) { nc[k] = std::max(1, (int)std::floor(h->box.prd[k] / dc)); nc[k] = std::min(nc[k], 512); ncell *= nc[k]; }
+  auto cellof = [&](int i, int c[3]) {
+    for (int k = 0; k < 3; k++) {
+      double fr = (h->hx[3 * (size_t)i + k] - h->boxlo[k]) / h->box.prd[k];
+      fr -= std::floor(fr);
+      c[k] = std::min(nc[k] - 1, (int)(fr * nc[k]));
+    }
+  };
+  std::vector<std::vector<int>> cells((size_t)ncell);
+  std::vector<int> color((size_t)n, -1);
+  int ncolors = 0;
+  std::vector<char> used;
+  for (int v = 0; v < n; v++) {
+    const int i = visit[v];
+    if (h->halpha[i] == 0.0) continue;  // never updated: needs no phase
+    int c[3];
+    cellof(i, c);
+    used.assign((size_t)ncolors + 1, 0);
+    for (int dz = -1; dz <= 1; dz++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          int b[3] = {c[0] + dx, c[1] + dy, c[2] + dz};
+          bool ok = true;
+          for (int k = 0; k < 3; k++) {
+            if (h->box.periodic[k]) b[k] = (b[k] + nc[k]) % nc[k];
+            else if (b[k] < 0 || b[k] >= nc[k]) ok = false;
+          }
+          if (!ok) continue;
+          for (int j : cells[((size_t)b[2] * nc[1] + b[1]) * nc[0] + b[0]]) {
+            double rsq = 0;
+            for (int k = 0; k < 3; k++) {
+              double d = h->hx[3 * (size_t)i + k] - h->hx[3 * (size_t)j + k];
+              if (h->box.periodic[k]) d -= h->box.prd[k] * std::nearbyint(d / h->box.prd[k]);
+              rsq += d * d;
+            }
+            if (rsq < dcsq) used[color[j]] = 1;
+          }
+        }
+    int col = 0;
+    while (col < ncolors && used[col]) col++;
+    if (col == ncolors) ncolors++;
+    color[i] = col;
+    cells[((size_t)c[2] * nc[1] + c[1]) * nc[0] + c[0]].push_back(i);
+  }
+  std::vector<int> rows;
+  rows.reserve(n);
+  h->color_off.assign((size_t)ncolors + 1, 0);
+  for (int i = 0; i < n; i++)
+    if (color[i] >= 0) h->color_off[color[i] + 1]++;
+  for (int c = 0; c < ncolors; c++) h->color_off[c + 1] += h->color_off[c];
+  rows.resize((size_t)h->color_off[ncolors]);
+  std::vector<int> fill(h->color_off.begin(), h->color_off.end() - 1);
+  for (int i = 0; i < n; i++)
+    if (color[i] >= 0) rows[fill[color[i]]++] = i;
+  h->d_rows.ensure(rows.size() + 1);
+  if (!rows.empty()) HIPCHECK(hipMemcpy(h->d_rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->colors_valid = true;
+}
+
+template <bool AP>
+void launch_rank(polar_handle *h, int pass) {
+  const int n = h->nlocal, ntot = h->nlocal + h->nghost;
+  dim3 grid(nblk(n, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
+  if (pass == 1)
+    k_rank<AP, 1><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, h->d_nl_first.p,
+                                                 h->d_nl_j.p, h->d_scal.p, h->d_rank.p);
+  else
+    k_rank<AP, 2><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, h->d_nl_first.p,
+                                                 h->d_nl_j.p, h->d_scal.p, h->d_rank.p);
+}
+
+template <bool AP, int DAMP, int EP>
+void launch_field(polar_handle *h, int nrows, const int *rows) {
+  const polar_settings &st = h->ph.st;
+  k_field<AP, DAMP, EP><<<nblk(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(
+      nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, h->d_dd_first.p, h->d_dd_j.p,
+      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_scal.p);
+}
+template <int EP>
+void launch_field_dyn(polar_handle *h, bool ap, int nrows, const int *rows) {
+  const bool expd = h->ph.st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  if (ap) { if (expd) launch_field<true, 0, EP>(h, nrows, rows); else launch_field<true, 1, EP>(h, nrows, rows); }
+  else    { if (expd) launch_field<false, 0, EP>(h, nrows, rows); else launch_field<false, 1, EP>(h, nrows, rows); }
+}
+
+template <bool AP, int DAMP>
+void launch_force(polar_handle *h, int eflag, int vpair) {
+  const polar_settings &st = h->ph.st;
+  dim3 grid(nblk(h->nlocal, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
+  const double ccs = st.cut_coul * st.cut_coul, dds = st.dd_cutoff * st.dd_cutoff, e2s = std::sqrt(h->P.qqrd2e);
+#define LF(E, V)                                                                                                    \
+  k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
+                                                               h->d_mol.p, h->box, h->d_nl_first.p, h->d_nl_j.p,  \
+                                                               ccs, dds, st.polar_damp, e2s, h->d_f.p, h->d_scal.p)
+  if (eflag) { if (vpair) LF(true, true); else LF(true, false); }
+  else       { if (vpair) LF(false, true); else LF(false, false); }
+#undef LF
+}
+
+void read_scal(polar_handle *h) {
+  HIPCHECK(hipMemcpyAsync(h->h_scal, h->d_scal.p, sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+}
+
+// ---- the solve: a6+a7 (PS.cpp:1113-1238) -----------------------------------------------------
+void solve(polar_handle *h, bool ap, polar_result *out) {
+  const polar_settings &st = h->ph.st;
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  const bool gs = st.polar_gs || st.polar_gs_ranked;
+  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  const int max_sweeps = st.iterations_max + 1;
+  const int check_every = 4;
+  out->ncolors = 0;
+
+  std::vector<int> order;
+  if (gs && (ap || !h->colors_valid)) {
+    order.resize(n);
+    std::iota(order.begin(), order.end(), 0);
+    if (st.polar_gs_ranked) {  // stable descending sort == the reference's bubble sort (PS.cpp:1130-1143)
+      std::vector<double> rk(n);
+      HIPCHECK(hipMemcpyAsync(rk.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rk[a] > rk[b]; });
+    }
+  }
+
+  if (!gs) {  // Jacobi, reference "polar_gs no / polar_gs_ranked no"
+    for (int sw = 0; sw < max_sweeps; sw++) {
+      launch_field_dyn<EP_JACOBI>(h, ap, n, nullptr);
+      k_solver_step<<<1, 1, 0, s>>>(h->d_scal.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 1);
+      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
+        read_scal(h);
+        if (h->h_scal->done) break;
+      }
+    }
+  } else if (ap) {  // exact-order blocked Gauss-Seidel
+    std::vector<int> pos(n);
+    for (int k = 0; k < n; k++) pos[order[k]] = k;
+    h->d_order.ensure(n); h->d_pos.ensure(n); h->d_dmu.ensure(3 * 64);
+    HIPCHECK(hipMemcpyAsync(h->d_order.p, order.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(h->d_pos.p, pos.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
+    launch_field_dyn<EP_FIELD>(h, true, n, nullptr);
+    for (int sw = 0; sw < max_sweeps; sw++) {
+      for (int b0 = 0; b0 < n; b0 += 64) {
+        if (expd) {
+          k_gs_block_seq<0><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_dmu.p, h->d_scal.p);
+          k_gs_block_push<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_order.p, h->d_pos.p, h->d_rec0.p, h->box, st.polar_damp, h->d_dmu.p, h->d_F.p, h->d_scal.p);
+        } else {
+          k_gs_block_seq<1><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_dmu.p, h->d_scal.p);
+          k_gs_block_push<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_order.p, h->d_pos.p, h->d_rec0.p, h->box, st.polar_damp, h->d_dmu.p, h->d_F.p, h->d_scal.p);
+        }
+      }
+      k_solver_step<<<1, 1, 0, s>>>(h->d_scal.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0);
+      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
+        read_scal(h);
+        if (h->h_scal->done) break;
+      }
+    }
+  } else {  // colour-phase Gauss-Seidel over the dd list
+    if (!h->colors_valid) build_colors(h, order);
+    const int ncol = (int)h->color_off.size() - 1;
+    out->ncolors = ncol;
+    for (int sw = 0; sw < max_sweeps; sw++) {
+      for (int c = 0; c < ncol; c++) {
+        const int cnt = h->color_off[c + 1] - h->color_off[c];
+        if (cnt > 0) launch_field_dyn<EP_INPLACE>(h, false, cnt, h->d_rows.p + h->color_off[c]);
+      }
+      k_solver_step<<<1, 1, 0, s>>>(h->d_scal.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0);
+      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
+        read_scal(h);
+        if (h->h_scal->done) break;
+      }
+    }
+  }
+  k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef.p);
+}
+
+int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, polar_result *out) {
+  need_device(h);
+  if (!h->types_set || !h->coul_set) throw std::runtime_error("polar_compute before pair tables were set (polar_pair_init or polar_set_types/polar_set_coul)");
+  if (!h->box_set || !h->atoms_set || !h->neigh_set) throw std::runtime_error("polar_compute before polar_set_box/polar_set_atoms/polar_set_neighbors");
+  if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not implemented (SURVEY 8(f) rank 3)");
+  const polar_settings &st = h->ph.st;
+  const int n = h->nlocal, nall = h->nlocal + h->nghost;
+  const bool ap = !(st.dd_cutoff > 0.0);
+  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  const int vmode = vflag % 4;
+  hipStream_t s = h->stream;
+  h->warn.clear();
+  memset(out, 0, sizeof(*out));
+
+  h->d_f.ensure(3 * (size_t)nall); h->d_ef.ensure(3 * (size_t)n); h->d_F.ensure(3 * (size_t)n);
+  h->d_mu.ensure(3 * (size_t)n); h->d_rank.ensure(n); h->d_rec0.ensure(n); h->d_rec1.ensure(n);
+  HIPCHECK(hipEventRecord(h->ev[0], s));
+  HIPCHECK(hipMemsetAsync(h->d_f.p, 0, 3 * (size_t)nall * sizeof(double), s));
+  k_zero_scal<<<1, 1, 0, s>>>(h->d_scal.p, 0);
+  const double *mu0 = nullptr;
+  if (st.use_previous) {
+    if (mu_host) {
+      HIPCHECK(hipMemcpyAsync(h->d_mu.p, mu_host, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+      mu0 = h->d_mu.p;
+    } else if (h->mu_resident) mu0 = h->d_mu.p;
+  }
+  k_pack<<<nblk(n, 256), 256, 0, s>>>(n, h->d_x.p, h->d_q.p, h->d_alpha.p, mu0, h->d_rec0.p, h->d_rec1.p);
+  if (!ap) build_lists(h);
+  HIPCHECK(hipEventRecord(h->ev[1], s));
+
+  if (st.polar_gs_ranked) {  // a2
+    if (ap) { launch_rank<true>(h, 1); launch_rank<true>(h, 2); }
+    else    { launch_rank<false>(h, 1); launch_rank<false>(h, 2); }
+  }
+  HIPCHECK(hipEventRecord(h->ev[2], s));
+
+  {  // a3
+    LJCoulParams P = h->P;
+    P.newton_pair = 1; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul;
+    dim3 grid(nblk(h->inum, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
+    if (h->inum > 0) {
+#define LJ(E, V) k_ljcoul<E, V><<<grid, block, 0, s>>>(P, h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_x.p, h->d_q.p, h->d_type.p, h->d_f.p, h->d_scal.p)
+      if (eflag) { if (vmode == 1) LJ(true, true); else LJ(true, false); }
+      else       { if (vmode == 1) LJ(false, true); else LJ(false, false); }
+#undef LJ
+    }
+  }
+  HIPCHECK(hipEventRecord(h->ev[3], s));
+
+  {  // a4 + a5
+    dim3 grid(nblk(n, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
+    const double ccs = st.cut_coul * st.cut_coul, e2s = std::sqrt(h->P.qqrd2e);
+    if (ap) k_static_field<true><<<grid, block, 0, s>>>(n, h->d_rec0.p, h->d_mol.p, h->box, nullptr, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef.p, h->d_rec0.p, h->d_rec1.p);
+    else    k_static_field<false><<<grid, block, 0, s>>>(n, h->d_rec0.p, h->d_mol.p, h->box, h->d_nl_first.p, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef.p, h->d_rec0.p, h->d_rec1.p);
+  }
+  HIPCHECK(hipEventRecord(h->ev[4], s));
+
+  if (!st.zodid) solve(h, ap, out);  // a6 + a7 (PS.cpp:389)
+  HIPCHECK(hipEventRecord(h->ev[5], s));
+
+  // a8
+  if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1); else launch_force<true, 1>(h, eflag, vmode == 1); }
+  else    { if (expd) launch_force<false, 0>(h, eflag, vmode == 1); else launch_force<false, 1>(h, eflag, vmode == 1); }
+  if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_scal.p);  // a10
+  k_unpack_mu<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_mu.p);
+  HIPCHECK(hipEventRecord(h->ev[6], s));
+  read_scal(h);
+  h->mu_resident = true;
+
+  const Scal &sc = *h->h_scal;
+  out->eng_vdwl = sc.eng_vdwl; out->eng_coul = sc.eng_coul;
+  out->u_self = sc.u_self; out->u_ef = sc.u_ef; out->u_dd = sc.u_dd;
+  out->eng_pol = sc.u_self + sc.u_ef + sc.u_dd;  // PS.cpp:632 (all zero when eflag == 0)
+  for (int k = 0; k < 6; k++) out->virial[k] = sc.virial[k];
+  long long rb = (long long)sc.rmin_bits;
+  memcpy(&out->rmin, &rb, sizeof(double));
+  out->rms_dmu = std::sqrt(std::max(0.0, sc.last_change));
+  out->iterations = sc.iterations; out->sweeps = sc.sweeps; out->status = sc.status ? POLAR_WARN_NOT_CONVERGED : POLAR_OK;
+  out->dd_pairs = ap ? (long long)n * (n - 1) : h->dd_pairs;
+  float ms;
+  auto el = [&](int a, int b) { HIPCHECK(hipEventElapsedTime(&ms, h->ev[a], h->ev[b])); return (double)ms; };
+  out->ms_list = el(0, 1); out->ms_rank = el(1, 2); out->ms_ljcoul = el(2, 3); out->ms_static = el(3, 4);
+  out->ms_solve = el(4, 5); out->ms_force = el(5, 6); out->ms_total = el(0, 6);
+  if (sc.status) h->warn = "Number of iterations exceeding max_iterations, setting dipoles to alpha*E";  // PS.cpp:1233
+  return out->status;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int polar_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int polar_create(int device, polar_handle **out) {
+  if (!out) return POLAR_ERR_STATE;
+  polar_handle *h = new polar_handle();
+  *out = h;
+  h->device = device;
+  if (const char *e = getenv("POLAR_COLOR_DIST")) h->color_dist = atof(e);
+  int n = polar_device_count();
+  if (n <= 0 || device < 0 || device >= n) {
+    h->have_device = false;  // host mirror still usable; compute entry points will fail loudly
+    h->err = "no usable HIP device";
+    return POLAR_OK;
+  }
+  return guarded(h, [&]() {
+    HIPCHECK(hipSetDevice(device));
+    HIPCHECK(hipStreamCreate(&h->stream));
+    for (auto &e : h->ev) HIPCHECK(hipEventCreate(&e));
+    HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
+    h->d_scal.ensure(1);
+    h->have_device = true;
+    return POLAR_OK;
+  });
+}
+
+int polar_destroy(polar_handle *h) {
+  if (!h) return POLAR_OK;
+  if (h->have_device) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    h->d_x.release(); h->d_q.release(); h->d_alpha.release(); h->d_f.release(); h->d_ef.release(); h->d_F.release();
+    h->d_mu.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
+    h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();
+    h->d_numneigh.release(); h->d_neigh.release(); h->d_rows.release(); h->d_first.release();
+    h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release();
+    h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release(); h->d_cell_atoms.release();
+    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_nl_j.release(); h->d_dd_j.release();
+    h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release();
+    if (h->h_scal) (void)hipHostFree(h->h_scal);
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+  }
+  delete h;
+  return POLAR_OK;
+}
+
+const char *polar_last_error(const polar_handle *h) { return h ? h->err.c_str() : "null handle"; }
+const char *polar_last_warning(const polar_handle *h) { return h ? h->warn.c_str() : ""; }
+
+int polar_pair_settings(polar_handle *h, int narg, const char *const *arg) {
+  return guarded(h, [&]() { h->ph.settings(narg, arg); h->colors_valid = false; return POLAR_OK; });
+}
+int polar_pair_coeff(polar_handle *h, int ntypes, int narg, const char *const *arg) {
+  return guarded(h, [&]() { h->ph.coeff(ntypes, narg, arg); return POLAR_OK; });
+}
+int polar_pair_modify(polar_handle *h, int narg, const char *const *arg) {
+  return guarded(h, [&]() { h->ph.modify(narg, arg); return POLAR_OK; });
+}
+int polar_pair_init(polar_handle *h, double g_ewald, double qqrd2e, const double special_lj[4],
+                    const double special_coul[4]) {
+  return guarded(h, [&]() {
+    PairHost &p = h->ph;
+    p.init(g_ewald, qqrd2e, special_lj, special_coul);
+    if (h->have_device) {
+      HIPCHECK(hipSetDevice(h->device));
+      const double *t[7] = {p.lj1.data(), p.lj2.data(), p.lj3.data(), p.lj4.data(), p.offset.data(), p.cut_ljsq.data(), p.cutsq.data()};
+      upload_types(h, p.ntypes, t);
+      const double *c[8];
+      double dummy = 0.0;
+      for (int k = 0; k < 8; k++) c[k] = p.tab.nbits ? p.tab.t[k].data() : &dummy;
+      upload_coul(h, g_ewald, qqrd2e, special_lj, special_coul, p.tab.nbits, p.tab.mask, p.tab.shift, p.tab.tabinnersq, c);
+    }
+    return POLAR_OK;
+  });
+}
+double polar_pair_cut(const polar_handle *h, int i, int j) {
+  if (!h || !h->ph.inited || i < 1 || j < 1 || i > h->ph.ntypes || j > h->ph.ntypes) return -1.0;
+  return std::sqrt(h->ph.cutsq[(size_t)i * h->ph.w() + j]);
+}
+double polar_pair_single(const polar_handle *h, double qi, double qj, int itype, int jtype, double rsq,
+                         double factor_coul, double factor_lj, double *fforce) {
+  double ff = 0.0, e = h->ph.single(qi, qj, itype, jtype, rsq, factor_coul, factor_lj, ff);
+  if (fforce) *fforce = ff;
+  return e;
+}
+const void *polar_pair_extract(const polar_handle *h, const char *name, int *dim) {
+  if (!h || !name) return nullptr;
+  if (dim) *dim = 0;
+  if (strcmp(name, "cut_coul") == 0) return &h->ph.st.cut_coul;
+  if (dim) *dim = 2;
+  if (strcmp(name, "epsilon") == 0) return h->ph.epsilon.data();
+  if (strcmp(name, "sigma") == 0) return h->ph.sigma.data();
+  return nullptr;
+}
+int polar_get_settings(const polar_handle *h, polar_settings *out) {
+  if (!h || !out) return POLAR_ERR_STATE;
+  *out = h->ph.st;
+  return POLAR_OK;
+}
+int polar_set_settings(polar_handle *h, const polar_settings *s) {
+  return guarded(h, [&]() {
+    if (s->zodid && (s->polar_gs || s->polar_gs_ranked)) throw InputError("Zodid doesn't work with polar_gs or polar_gs_ranked");
+    if (s->polar_gs && s->polar_gs_ranked) throw InputError("polar_gs and polar_gs_ranked are mutually exclusive");
+    h->ph.st = *s;
+    h->colors_valid = false;
+    return POLAR_OK;
+  });
+}
+int polar_set_types(polar_handle *h, int ntypes, const double *lj1, const double *lj2, const double *lj3,
+                    const double *lj4, const double *offset, const double *cut_ljsq, const double *cutsq) {
+  return guarded(h, [&]() {
+    HIPCHECK(hipSetDevice(h->device));
+    const double *t[7] = {lj1, lj2, lj3, lj4, offset, cut_ljsq, cutsq};
+    upload_types(h, ntypes, t);
+    return POLAR_OK;
+  });
+}
+int polar_set_coul(polar_handle *h, double g_ewald, double qqrd2e, const double special_lj[4],
+                   const double special_coul[4], int nbits, int mask, int shift, double tabinnersq,
+                   const double *rtable, const double *drtable, const double *ftable, const double *dftable,
+                   const double *ctable, const double *dctable, const double *etable, const double *detable) {
+  return guarded(h, [&]() {
+    HIPCHECK(hipSetDevice(h->device));
+    const double *c[8] = {rtable, drtable, ftable, dftable, ctable, dctable, etable, detable};
+    upload_coul(h, g_ewald, qqrd2e, special_lj, special_coul, nbits, mask, shift, tabinnersq, c);
+    return POLAR_OK;
+  });
+}
+
+int polar_set_box(polar_handle *h, const double boxlo[3], const double prd[3], const double tilt[3],
+                  const int periodic[3], int triclinic) {
+  return guarded(h, [&]() {
+    if (triclinic || (tilt && (tilt[0] != 0.0 || tilt[1] != 0.0 || tilt[2] != 0.0)))
+      return fail(h, POLAR_ERR_UNSUPPORTED, "triclinic boxes are not implemented (SURVEY 8(f) rank 3)");
+    for (int k = 0; k < 3; k++) {
+      if (!(prd[k] > 0.0) || !std::isfinite(prd[k])) throw InputError("box lengths must be positive and finite");
+      h->box.prd[k] = prd[k]; h->box.half[k] = 0.5 * prd[k]; h->box.periodic[k] = periodic[k] ? 1 : 0;
+      h->boxlo[k] = boxlo[k];
+    }
+    h->box_set = true;
+    h->colors_valid = false;
+    return POLAR_OK;
+  });
+}
+
+int polar_set_atoms(polar_handle *h, int nlocal, int nghost, const double *x, const double *q, const double *alpha,
+                    const int *type, const int *molecule) {
+  return guarded(h, [&]() {
+    need_device(h);
+    HIPCHECK(hipSetDevice(h->device));
+    if (nlocal < 0 || nghost < 0) throw InputError("negative atom count");
+    const size_t nall = (size_t)nlocal + nghost;
+    for (size_t k = 0; k < 3 * nall; k++)
+      if (!std::isfinite(x[k])) throw InputError("non-finite atom coordinate");
+    for (size_t k = 0; k < nall; k++)
+      if (alpha[k] < 0.0) throw InputError("Invalid value in set command");  // src/set.cpp:174-184 rejects negatives
+    if (nlocal != h->nlocal) { h->colors_valid = false; h->mu_resident = false; }
+    h->nlocal = nlocal; h->nghost = nghost;
+    h->d_x.ensure(3 * nall + 3); h->d_q.ensure(nall + 1); h->d_alpha.ensure(nall + 1); h->d_type.ensure(nall + 1); h->d_mol.ensure(nall + 1);
+    hipStream_t s = h->stream;
+    HIPCHECK(hipMemcpyAsync(h->d_x.p, x, 3 * nall * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(h->d_q.p, q, nall * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(h->d_alpha.p, alpha, nall * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(h->d_type.p, type, nall * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(h->d_mol.p, molecule, nall * sizeof(int), hipMemcpyHostToDevice, s));
+    h->hx.assign(x, x + 3 * (size_t)nlocal);
+    h->halpha.assign(alpha, alpha + nlocal);
+    HIPCHECK(hipStreamSynchronize(s));
+    h->atoms_set = true;
+    return POLAR_OK;
+  });
+}
+
+int polar_set_neighbors_csr(polar_handle *h, int inum, const int *ilist, const int *numneigh,
+                            const long long *firstneigh, const int *neigh) {
+  return guarded(h, [&]() {
+    need_device(h);
+    HIPCHECK(hipSetDevice(h->device));
+    if (!h->atoms_set) throw std::runtime_error("polar_set_neighbors before polar_set_atoms");
+    const int n = h->nlocal, nall = h->nlocal + h->nghost;
+    long long total = 0;
+    for (int ii = 0; ii < inum; ii++) {
+      const int i = ilist[ii];
+      if (i < 0 || i >= n) throw InputError("neighbor list row index out of range");
+      if (numneigh[i] < 0 || firstneigh[i] < 0) throw InputError("negative neighbor count/offset");
+      total = std::max(total, firstneigh[i] + numneigh[i]);
+      for (int k = 0; k < numneigh[i]; k++) {
+        const int j = neigh[firstneigh[i] + k] & 0x3FFFFFFF;
+        if (j >= nall) throw InputError("neighbor index out of range");
+      }
+    }
+    h->inum = inum; h->nneigh = total;
+    h->d_ilist.ensure(inum + 1); h->d_numneigh.ensure(n + 1); h->d_first.ensure(n + 1); h->d_neigh.ensure((size_t)total + 1);
+    hipStream_t s = h->stream;
+    HIPCHECK(hipMemcpyAsync(h->d_ilist.p, ilist, inum * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(h->d_numneigh.p, numneigh, n * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(h->d_first.p, firstneigh, n * sizeof(long long), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(h->d_neigh.p, neigh, (size_t)total * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    h->neigh_set = true;
+    h->colors_valid = false;  // reneighbor step: refresh the colour phases too
+    return POLAR_OK;
+  });
+}
+
+int polar_set_neighbors(polar_handle *h, int inum, const int *ilist, const int *numneigh, int *const *firstneigh) {
+  if (!h) return POLAR_ERR_STATE;
+  // flatten LAMMPS' paged int** rows into one CSR buffer
+  std::vector<long long> first((size_t)std::max(h->nlocal, 1), 0);
+  long long total = 0;
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = ilist[ii];
+    if (i < 0 || i >= h->nlocal) return fail(h, POLAR_ERR_INPUT, "neighbor list row index out of range");
+    first[i] = total;
+    total += numneigh[i];
+  }
+  std::vector<int> flat((size_t)total + 1);
+  std::vector<int> nn((size_t)std::max(h->nlocal, 1), 0);
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = ilist[ii];
+    nn[i] = numneigh[i];
+    if (numneigh[i] > 0) memcpy(flat.data() + first[i], firstneigh[i], (size_t)numneigh[i] * sizeof(int));
+  }
+  return polar_set_neighbors_csr(h, inum, ilist, nn.data(), first.data(), flat.data());
+}
+
+int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, double *ef_static, polar_result *out) {
+  return guarded(h, [&]() {
+    if (!f || !mu || !out) throw std::runtime_error("polar_compute: null output pointer");
+    need_device(h);
+    HIPCHECK(hipSetDevice(h->device));
+    int rc = do_compute(h, eflag, vflag, mu, out);
+    if (rc < 0) return rc;
+    const size_t n = h->nlocal, nall = (size_t)h->nlocal + h->nghost;
+    h->h_tmp.resize(3 * nall);
+    HIPCHECK(hipMemcpy(h->h_tmp.data(), h->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < 3 * nall; k++) f[k] += h->h_tmp[k];
+    HIPCHECK(hipMemcpy(mu, h->d_mu.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (ef_static) HIPCHECK(hipMemcpy(ef_static, h->d_ef.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    return rc;
+  });
+}
+
+int polar_compute_resident(polar_handle *h, int eflag, int vflag, polar_result *out) {
+  return guarded(h, [&]() {
+    if (!out) throw std::runtime_error("polar_compute_resident: null result pointer");
+    need_device(h);
+    HIPCHECK(hipSetDevice(h->device));
+    return do_compute(h, eflag, vflag, nullptr, out);
+  });
+}
+
+void *polar_dev_ptr(polar_handle *h, const char *name) {
+  if (!h || !name || !h->have_device) return nullptr;
+  if (strcmp(name, "f") == 0) return h->d_f.p;
+  if (strcmp(name, "mu") == 0) return h->d_mu.p;
+  if (strcmp(name, "ef_static") == 0) return h->d_ef.p;
+  if (strcmp(name, "x") == 0) return h->d_x.p;
+  return nullptr;
+}
+int polar_download(polar_handle *h, const char *name, double *dst, long long n) {
+  return guarded(h, [&]() {
+    need_device(h);
+    void *p = polar_dev_ptr(h, name);
+    if (!p) throw std::runtime_error("polar_download: unknown array name");
+    HIPCHECK(hipMemcpy(dst, p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return POLAR_OK;
+  });
+}
+int polar_upload_mu(polar_handle *h, const double *mu, long long n) {
+  return guarded(h, [&]() {
+    need_device(h);
+    h->d_mu.ensure((size_t)n);
+    HIPCHECK(hipMemcpy(h->d_mu.p, mu, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    h->mu_resident = true;
+    return POLAR_OK;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,802 @@
+// polar_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the
+// lj/cut/coul/long/polarization hot path.  FP64 throughout (the reference is FP64).
+//
+// Mapping used by every pair kernel: ONE WAVEFRONT PER ATOM ROW.  A 256-thread workgroup holds
+// four rows; the 64 lanes stride the row's neighbor stream (coalesced 4-byte index loads), gather
+// the 64-byte atom records of their j's (one cache line each), and the three field / force
+// components are reduced across the wave with DPP/permute shuffles (no LDS, no atomics on i).
+// No MFMA anywhere: this is a sparse neighbor stencil, not a dense contraction.
+//
+// Reference line numbers ("PS.cpp") are into
+// /root/reference/src/pair_lj_cut_coul_long_polarization.cpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace polar {
+
+// 64-byte atom record: one L2 line-half per gathered neighbor.
+struct __attribute__((aligned(64))) AtomRec {
+  double x, y, z, q;     // position, charge
+  double mx, my, mz, a;  // induced dipole, static polarizability
+};
+
+struct Box {
+  double prd[3], half[3];
+  int periodic[3];
+};
+
+// Device-resident solver/accumulator block (one per handle).
+struct Scal {
+  double eng_vdwl, eng_coul, u_self, u_ef, u_dd;
+  double virial[6];
+  double change;           // sum (mu_new - mu_old)^2 of the running sweep
+  double last_change;      // change / (3N) of the last finished sweep
+  unsigned long long rmin_bits;  // double bits of rmin (positive doubles order like uint64)
+  int iterations, done, status, cur, sweeps, pad;
+};
+
+#define POLAR_WAVE 64
+#define POLAR_BLOCK 256
+#define POLAR_ROWS_PER_BLOCK (POLAR_BLOCK / POLAR_WAVE)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Domain::closest_image wrap of one component d = xj - xi (domain.cpp:1231-1257): the reference's
+// add/subtract sequence, not a rint() wrap, so that pairs at exactly L/2 pick the same image.
+__device__ __forceinline__ double wrap_ci(double d, double L, double h, int periodic) {
+  if (periodic) {
+    if (d < 0.0) {
+      while (d < 0.0) d += L;
+      if (d > h) d -= L;
+    } else {
+      while (d > 0.0) d -= L;
+      if (d < -h) d += L;
+    }
+  }
+  return d;
+}
+
+// del = x_i - closest_image(x_j)
+__device__ __forceinline__ void min_image_del(const Box &b, double xi, double yi, double zi, double xj, double yj,
+                                              double zj, double &dx, double &dy, double &dz) {
+  dx = -wrap_ci(xj - xi, b.prd[0], b.half[0], b.periodic[0]);
+  dy = -wrap_ci(yj - yi, b.prd[1], b.half[1], b.periodic[1]);
+  dz = -wrap_ci(zj - zi, b.prd[2], b.half[2], b.periodic[2]);
+}
+
+// Dipole field tensor scalars of build_dipole_field_matrix (PS.cpp:1284-1306):
+//   T_pq = delta_pq * s3 - d_p d_q * s5,  s3 = damp1 / r^3,  s5 = 3 damp2 / r^5
+template <int DAMP>
+__device__ __forceinline__ void tensor_scalars(double r2, double pd, double &s3, double &s5) {
+  double rinv = rsqrt(r2);
+  double r = r2 * rinv;
+  double rinv2 = rinv * rinv;
+  double r3 = rinv * rinv2;
+  double r5 = r3 * rinv2;
+  if (DAMP == 0) {  // exponential (Thole-like) damping
+    double ar = pd * r;
+    double e = exp(-ar);
+    double p2 = 1.0 + ar + 0.5 * ar * ar;
+    double p3 = p2 + ar * ar * ar * (1.0 / 6.0);
+    s3 = (1.0 - e * p2) * r3;
+    s5 = 3.0 * (1.0 - e * p3) * r5;
+  } else {
+    s3 = r3;
+    s5 = 3.0 * r5;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pack: x/q/alpha (+ initial mu) -> 64-byte records (both Jacobi buffers)
+__global__ void k_pack(int n, const double *__restrict__ x, const double *__restrict__ q,
+                       const double *__restrict__ alpha, const double *__restrict__ mu0, AtomRec *__restrict__ r0,
+                       AtomRec *__restrict__ r1) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  AtomRec r;
+  r.x = x[3 * i]; r.y = x[3 * i + 1]; r.z = x[3 * i + 2]; r.q = q[i];
+  r.mx = mu0 ? mu0[3 * i] : 0.0; r.my = mu0 ? mu0[3 * i + 1] : 0.0; r.mz = mu0 ? mu0[3 * i + 2] : 0.0;
+  r.a = alpha[i];
+  r0[i] = r;
+  r1[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// a2  rank metric, PS.cpp:192-227.  Pass 1: rmin; pass 2: rank_metric.
+// ALLPAIRS: raw (non-minimum-image) distances to locals AND ghosts, exactly as the reference.
+// list mode (extension): minimum-image distances over the library's full list.
+template <bool ALLPAIRS, int PASS>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, const double *__restrict__ x,
+                                                      const double *__restrict__ alpha, const int *__restrict__ mol,
+                                                      Box box, const long long *__restrict__ nl_first,
+                                                      const int *__restrict__ nl_j, Scal *scal,
+                                                      double *__restrict__ rank_metric) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= nlocal) return;
+  const double xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2], ai = alpha[i];
+  const int mi = mol[i];
+  double rmin = (PASS == 1) ? 1000.0 : __longlong_as_double((long long)scal->rmin_bits);
+  double acc = 0.0;
+  long long beg = 0, end = ntotal;
+  if (!ALLPAIRS) { beg = nl_first[i]; end = nl_first[i + 1]; }
+  for (long long base = beg; base < end; base += 64) {
+    const long long p = base + lane;
+    bool hit = false;
+    double term = 0.0;
+    if (p < end) {
+      const int j = ALLPAIRS ? (int)p : nl_j[p];
+      if (j != i) {
+        double dx = xi - x[3 * j], dy = yi - x[3 * j + 1], dz = zi - x[3 * j + 2];
+        if (!ALLPAIRS) min_image_del(box, xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2], dx, dy, dz);
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const bool molok = (mi != mol[j]) || mi == 0;
+        if (PASS == 1) {
+          if (ai > 0 && alpha[j] > 0 && molok) rmin = fmin(rmin, r);
+        } else if (rmin * 1.5 > r && molok) {
+          hit = true;
+          term = ai * alpha[j];
+        }
+      }
+    }
+    if (PASS == 2) {
+      // add the (few) qualifying terms in ascending j, like the reference's serial loop, so that
+      // ties in rank_metric -- and with them the ranked sweep order -- come out bit-identical
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        acc += __shfl(term, b, 64);
+        m &= m - 1;
+      }
+    }
+  }
+  if (PASS == 1) {
+    rmin = wave_min(rmin);
+    if (lane == 0) atomicMin(&scal->rmin_bits, (unsigned long long)__double_as_longlong(rmin));
+  } else {
+    if (lane == 0) rank_metric[i] = acc;  // identical in every lane
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a3  LJ + real-space Ewald Coulomb over the LAMMPS half list, PS.cpp:232-321.
+// One wave per listed atom i; -F is deposited on j (local or ghost) with FP64 atomics so that
+// ghost forces come back exactly as LAMMPS' reverse_comm expects.
+struct LJCoulParams {
+  int ntypes, newton_pair, nlocal;
+  int ncoultablebits, ncoulmask, ncoulshiftbits;
+  double tabinnersq, cut_coulsq, g_ewald, qqrd2e;
+  double special_lj[4], special_coul[4];
+  const double *lj1, *lj2, *lj3, *lj4, *offset, *cut_ljsq, *cutsq;
+  const double *rtable, *drtable, *ftable, *dftable, *ctable, *dctable, *etable, *detable;
+};
+
+template <bool EFLAG, bool VPAIR>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum, const int *__restrict__ ilist,
+                                                        const int *__restrict__ numneigh,
+                                                        const long long *__restrict__ first,
+                                                        const int *__restrict__ neigh, const double *__restrict__ x,
+                                                        const double *__restrict__ q, const int *__restrict__ type,
+                                                        double *__restrict__ f, Scal *scal) {
+  const double EWALD_F = 1.12837917, EWALD_P = 0.3275911, A1 = 0.254829592, A2 = -0.284496736, A3 = 1.421413741,
+               A4 = -1.453152027, A5 = 1.061405429;  // PS.cpp:43-49
+  const int lane = threadIdx.x & 63;
+  const int ii = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ii >= inum) return;
+  const int i = ilist[ii];
+  const double qtmp = q[i], xtmp = x[3 * i], ytmp = x[3 * i + 1], ztmp = x[3 * i + 2];
+  const int itype = type[i], w = P.ntypes + 1;
+  const int *jlist = neigh + first[i];
+  const int jnum = numneigh[i];
+  double fx = 0, fy = 0, fz = 0, ev = 0, ec = 0;
+  double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  for (int jj = lane; jj < jnum; jj += 64) {
+    int j = jlist[jj];
+    const int sb = (j >> 30) & 3;  // sbmask, src/pair.h:241
+    const double factor_lj = P.special_lj[sb], factor_coul = P.special_coul[sb];
+    j &= 0x3FFFFFFF;  // NEIGHMASK
+    const double delx = xtmp - x[3 * j], dely = ytmp - x[3 * j + 1], delz = ztmp - x[3 * j + 2];
+    const double rsq = delx * delx + dely * dely + delz * delz;
+    const int ij = itype * w + type[j];
+    if (rsq < P.cutsq[ij]) {
+      const double r2inv = 1.0 / rsq;
+      double forcecoul = 0.0, forcelj = 0.0, prefactor = 0.0, erfc_ = 0.0, fraction = 0.0, r6inv = 0.0;
+      int itable = 0;
+      bool direct = true;
+      if (rsq < P.cut_coulsq) {
+        direct = (!P.ncoultablebits) || (rsq <= P.tabinnersq);
+        if (direct) {
+          const double r = sqrt(rsq), grij = P.g_ewald * r, expm2 = exp(-grij * grij);
+          const double t = 1.0 / (1.0 + EWALD_P * grij);
+          erfc_ = t * (A1 + t * (A2 + t * (A3 + t * (A4 + t * A5)))) * expm2;
+          prefactor = P.qqrd2e * qtmp * q[j] / r;
+          forcecoul = prefactor * (erfc_ + EWALD_F * grij * expm2);
+          if (factor_coul < 1.0) forcecoul -= (1.0 - factor_coul) * prefactor;
+        } else {
+          const float rsqf = (float)rsq;  // union_int_float_t lookup, PS.cpp:268-272
+          itable = (__float_as_int(rsqf) & P.ncoulmask) >> P.ncoulshiftbits;
+          fraction = ((double)rsqf - P.rtable[itable]) * P.drtable[itable];
+          double table = P.ftable[itable] + fraction * P.dftable[itable];
+          forcecoul = qtmp * q[j] * table;
+          if (factor_coul < 1.0) {
+            table = P.ctable[itable] + fraction * P.dctable[itable];
+            prefactor = qtmp * q[j] * table;
+            forcecoul -= (1.0 - factor_coul) * prefactor;
+          }
+        }
+      }
+      if (rsq < P.cut_ljsq[ij]) {
+        r6inv = r2inv * r2inv * r2inv;
+        forcelj = r6inv * (P.lj1[ij] * r6inv - P.lj2[ij]);
+      }
+      const double fpair = (forcecoul + factor_lj * forcelj) * r2inv;
+      fx += delx * fpair; fy += dely * fpair; fz += delz * fpair;
+      if (P.newton_pair || j < P.nlocal) {
+        atomicAdd(&f[3 * j], -delx * fpair);
+        atomicAdd(&f[3 * j + 1], -dely * fpair);
+        atomicAdd(&f[3 * j + 2], -delz * fpair);
+      }
+      double wgt = 1.0;  // ev_tally, src/pair.cpp:854-950
+      if (!P.newton_pair) wgt = 0.5 * ((i < P.nlocal) + (j < P.nlocal));
+      if (EFLAG) {
+        if (rsq < P.cut_coulsq) {
+          double ecoul;
+          if (direct) ecoul = prefactor * erfc_;
+          else ecoul = qtmp * q[j] * (P.etable[itable] + fraction * P.detable[itable]);
+          if (factor_coul < 1.0) ecoul -= (1.0 - factor_coul) * prefactor;
+          ec += wgt * ecoul;
+        }
+        if (rsq < P.cut_ljsq[ij]) ev += wgt * factor_lj * (r6inv * (P.lj3[ij] * r6inv - P.lj4[ij]) - P.offset[ij]);
+      }
+      if (VPAIR) {
+        v0 += wgt * delx * delx * fpair; v1 += wgt * dely * dely * fpair; v2 += wgt * delz * delz * fpair;
+        v3 += wgt * delx * dely * fpair; v4 += wgt * delx * delz * fpair; v5 += wgt * dely * delz * fpair;
+      }
+    }
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) {
+    atomicAdd(&f[3 * i], fx); atomicAdd(&f[3 * i + 1], fy); atomicAdd(&f[3 * i + 2], fz);
+  }
+  if (EFLAG) {
+    ev = wave_sum(ev); ec = wave_sum(ec);
+    if (lane == 0) { atomicAdd(&scal->eng_vdwl, ev); atomicAdd(&scal->eng_coul, ec); }
+  }
+  if (VPAIR) {
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
+    if (lane == 0) {
+      atomicAdd(&scal->virial[0], v0); atomicAdd(&scal->virial[1], v1); atomicAdd(&scal->virial[2], v2);
+      atomicAdd(&scal->virial[3], v3); atomicAdd(&scal->virial[4], v4); atomicAdd(&scal->virial[5], v5);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a4 + a5  static field (shifted-force Coulomb, PS.cpp:324-361), unit scale and initial guess
+// (PS.cpp:363-386).  Full-row evaluation: E_i = sum_j ef_temp * q_j * del_ij, which is the
+// reference's i<j scatter seen from row i (del is antisymmetric under the image rule).
+template <bool ALLPAIRS>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(int nlocal, const AtomRec *__restrict__ rec,
+                                                              const int *__restrict__ mol, Box box,
+                                                              const long long *__restrict__ nl_first,
+                                                              const int *__restrict__ nl_j, double cut_coulsq,
+                                                              double e2s, double gamma, int use_previous,
+                                                              double *__restrict__ ef, AtomRec *__restrict__ rec0,
+                                                              AtomRec *__restrict__ rec1) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= nlocal) return;
+  const AtomRec ri = rec[i];
+  const int mi = mol[i];
+  const double f_shift = -1.0 / cut_coulsq;
+  double ex = 0, ey = 0, ez = 0;
+  long long beg = 0, end = nlocal;
+  if (!ALLPAIRS) { beg = nl_first[i]; end = nl_first[i + 1]; }
+  for (long long p = beg + lane; p < end; p += 64) {
+    const int j = ALLPAIRS ? (int)p : nl_j[p];
+    if (j == i) continue;
+    const AtomRec rj = rec[j];
+    double dx, dy, dz;
+    min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+    const double rsq = dx * dx + dy * dy + dz * dz;
+    if (rsq <= cut_coulsq && ((mi != mol[j]) || mi == 0)) {  // note <=, PS.cpp:342
+      const double rinv = rsqrt(rsq);
+      const double ef_temp = (rinv * rinv + f_shift) * rinv * rj.q;
+      ex += ef_temp * dx; ey += ef_temp * dy; ez += ef_temp * dz;
+    }
+  }
+  ex = wave_sum(ex); ey = wave_sum(ey); ez = wave_sum(ez);
+  if (lane == 0) {
+    ex *= e2s; ey *= e2s; ez *= e2s;
+    ef[3 * i] = ex; ef[3 * i + 1] = ey; ef[3 * i + 2] = ez;
+    if (!use_previous) {  // mu = gamma * alpha * E
+      const double a = ri.a;
+      double mx = a * ex, my = a * ey, mz = a * ez;
+      mx *= gamma; my *= gamma; mz *= gamma;
+      rec0[i].mx = mx; rec0[i].my = my; rec0[i].mz = mz;
+      rec1[i].mx = mx; rec1[i].my = my; rec1[i].mz = mz;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a6 + a7  the dipole-field sweep (matrix-free): for row i
+//     ef_ind_i = - sum_j T_ij mu_j ,   mu_new_i = alpha_i (E_static_i + ef_ind_i)
+// (PS.cpp:1158-1180 with the tensor of PS.cpp:1273-1306 recomputed per pair).
+// Epilogues:
+//   EP_JACOBI : read rec[cur], write rec[1-cur] (reference "polar_gs no")
+//   EP_INPLACE: write mu into the same buffer (colour-phase Gauss-Seidel; rows of one colour do
+//               not read each other's NEW values by construction of the phases)
+//   EP_FIELD  : store ef_ind only (initial field of the blocked sequential Gauss-Seidel)
+enum { EP_JACOBI = 0, EP_INPLACE = 1, EP_FIELD = 2 };
+
+template <bool ALLPAIRS, int DAMP, int EP>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__restrict__ rows, int nlocal,
+                                                       AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, Box box,
+                                                       const long long *__restrict__ dd_first,
+                                                       const int *__restrict__ dd_j, double ddcutsq, double pd,
+                                                       const double *__restrict__ ef, double *__restrict__ Fout,
+                                                       Scal *scal) {
+  if (scal->done) return;  // device-resident loop control: finished solves turn later launches into no-ops
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = rows ? rows[row] : row;
+  const int cur = scal->cur;
+  const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+  const AtomRec ri = src[i];
+  double fx = 0, fy = 0, fz = 0;
+  if (ri.a != 0.0 || EP == EP_FIELD) {
+    long long beg = 0, end = nlocal;
+    if (!ALLPAIRS) { beg = dd_first[i]; end = dd_first[i + 1]; }
+    for (long long p = beg + lane; p < end; p += 64) {
+      const int j = ALLPAIRS ? (int)p : dd_j[p];
+      if (j == i) continue;
+      const AtomRec rj = src[j];
+      double dx, dy, dz;
+      min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      if (ALLPAIRS || r2 < ddcutsq) {
+        double s3, s5;
+        tensor_scalars<DAMP>(r2, pd, s3, s5);
+        const double md = rj.mx * dx + rj.my * dy + rj.mz * dz;
+        const double c = s5 * md;
+        fx -= s3 * rj.mx - c * dx;
+        fy -= s3 * rj.my - c * dy;
+        fz -= s3 * rj.mz - c * dz;
+      }
+    }
+    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  }
+  if (lane == 0) {
+    if (EP == EP_FIELD) {
+      Fout[3 * i] = fx; Fout[3 * i + 1] = fy; Fout[3 * i + 2] = fz;
+    } else {
+      const double a = ri.a;
+      const double mx = a * (ef[3 * i] + fx), my = a * (ef[3 * i + 1] + fy), mz = a * (ef[3 * i + 2] + fz);
+      const double ddx = mx - ri.mx, ddy = my - ri.my, ddz = mz - ri.mz;
+      dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz;
+      const double c = ddx * ddx + ddy * ddy + ddz * ddz;
+      if (c != 0.0) atomicAdd(&scal->change, c);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a7  sequential (ranked) Gauss-Seidel, exact-order, blocked for the GPU.
+// F_j = -sum_k T_jk mu_k is kept current for every atom.  For a block of 64 consecutive atoms of
+// the ranked order:
+//   k_gs_block_seq  (ONE wave): in order k = 0..63   mu_k <- alpha_k (E_k + F_k), then every
+//                   other lane of the block applies  F_l -= T_lk dmu_k  (wave broadcast) --
+//                   exactly the reference's "use the newest mu" recurrence (PS.cpp:1158-1180)
+//   k_gs_block_push (all rows outside the block): F_j -= sum_k T_jk dmu_k
+// so atoms later in the order see the new dipoles, atoms earlier keep a current field for the
+// next sweep.  Arithmetic differs from the reference only in summation order.
+template <int DAMP>
+__global__ __launch_bounds__(64) void k_gs_block_seq(int nlocal, int b0, const int *__restrict__ order,
+                                                     AtomRec *__restrict__ rec, Box box, double pd,
+                                                     const double *__restrict__ ef, double *__restrict__ F,
+                                                     double *__restrict__ dmu_blk, Scal *scal) {
+  if (scal->done) return;
+  const int lane = threadIdx.x;
+  const int cnt = min(64, nlocal - b0);
+  const bool act = lane < cnt;
+  const int i = act ? order[b0 + lane] : 0;
+  AtomRec r = rec[i];
+  double Fx = act ? F[3 * i] : 0, Fy = act ? F[3 * i + 1] : 0, Fz = act ? F[3 * i + 2] : 0;
+  const double Ex = act ? ef[3 * i] : 0, Ey = act ? ef[3 * i + 1] : 0, Ez = act ? ef[3 * i + 2] : 0;
+  const double mx0 = r.mx, my0 = r.my, mz0 = r.mz;
+  double dsq = 0.0;
+  for (int k = 0; k < cnt; k++) {
+    const double nx = r.a * (Ex + Fx), ny = r.a * (Ey + Fy), nz = r.a * (Ez + Fz);
+    const double ddx = nx - r.mx, ddy = ny - r.my, ddz = nz - r.mz;
+    const double bx = __shfl(r.x, k, 64), by = __shfl(r.y, k, 64), bz = __shfl(r.z, k, 64);
+    const double bdx = __shfl(ddx, k, 64), bdy = __shfl(ddy, k, 64), bdz = __shfl(ddz, k, 64);
+    if (lane == k) {
+      r.mx = nx; r.my = ny; r.mz = nz;
+    } else if (act && (bdx != 0.0 || bdy != 0.0 || bdz != 0.0)) {
+      double dx, dy, dz;
+      min_image_del(box, r.x, r.y, r.z, bx, by, bz, dx, dy, dz);
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      double s3, s5;
+      tensor_scalars<DAMP>(r2, pd, s3, s5);
+      const double md = bdx * dx + bdy * dy + bdz * dz;
+      const double c = s5 * md;
+      Fx -= s3 * bdx - c * dx; Fy -= s3 * bdy - c * dy; Fz -= s3 * bdz - c * dz;
+    }
+  }
+  if (act) {
+    const double tx = r.mx - mx0, ty = r.my - my0, tz = r.mz - mz0;
+    dsq = tx * tx + ty * ty + tz * tz;
+    rec[i].mx = r.mx; rec[i].my = r.my; rec[i].mz = r.mz;
+    F[3 * i] = Fx; F[3 * i + 1] = Fy; F[3 * i + 2] = Fz;
+    dmu_blk[3 * lane] = tx; dmu_blk[3 * lane + 1] = ty; dmu_blk[3 * lane + 2] = tz;
+  }
+  dsq = wave_sum(dsq);
+  if (lane == 0 && dsq != 0.0) atomicAdd(&scal->change, dsq);
+}
+
+template <int DAMP>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_gs_block_push(int nlocal, int b0, const int *__restrict__ order,
+                                                               const int *__restrict__ pos_in_order,
+                                                               const AtomRec *__restrict__ rec, Box box, double pd,
+                                                               const double *__restrict__ dmu_blk,
+                                                               double *__restrict__ F, const Scal *scal) {
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (j >= nlocal) return;
+  const int pj = pos_in_order[j];
+  if (pj >= b0 && pj < b0 + 64) return;  // rows of the block were updated by k_gs_block_seq
+  const AtomRec rj = rec[j];
+  if (rj.a == 0.0) return;  // mu_j stays 0: its field is never read
+  const int cnt = min(64, nlocal - b0);
+  double fx = 0, fy = 0, fz = 0;
+  if (lane < cnt) {
+    const double bdx = dmu_blk[3 * lane], bdy = dmu_blk[3 * lane + 1], bdz = dmu_blk[3 * lane + 2];
+    if (bdx != 0.0 || bdy != 0.0 || bdz != 0.0) {
+      const AtomRec rk = rec[order[b0 + lane]];
+      double dx, dy, dz;
+      min_image_del(box, rj.x, rj.y, rj.z, rk.x, rk.y, rk.z, dx, dy, dz);
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      double s3, s5;
+      tensor_scalars<DAMP>(r2, pd, s3, s5);
+      const double md = bdx * dx + bdy * dy + bdz * dz;
+      const double c = s5 * md;
+      fx = -(s3 * bdx - c * dx); fy = -(s3 * bdy - c * dy); fz = -(s3 * bdz - c * dz);
+    }
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) { F[3 * j] += fx; F[3 * j + 1] += fy; F[3 * j + 2] += fz; }
+}
+
+// ------------------------------------------------------------------------------------------
+// a7 loop control, one thread: the reference's end-of-sweep logic (PS.cpp:1193-1236) kept on the
+// device so the host never has to look at ||dmu||^2 between sweeps.
+__global__ void k_solver_step(Scal *scal, int nlocal, int fixed_iteration, int iterations_max, double precision,
+                              int jacobi) {
+  if (scal->done) return;
+  const double change = scal->change / ((double)nlocal * 3.0);
+  scal->last_change = change;
+  scal->change = 0.0;
+  scal->sweeps += 1;
+  int keep = 1;
+  if (!fixed_iteration) keep = change > precision * precision;
+  else if (scal->iterations >= iterations_max) { scal->done = 1; return; }  // returns BEFORE the copy
+  if (jacobi) scal->cur ^= 1;  // "mu = mu_new"
+  scal->iterations += 1;
+  if (scal->iterations > iterations_max) { scal->status = 1; scal->done = 1; return; }
+  if (!keep) scal->done = 1;
+}
+
+// divergence fallback mu = alpha * E (no gamma), PS.cpp:1227-1235
+__global__ void k_fallback(int n, const Scal *scal, AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
+                           const double *__restrict__ ef) {
+  if (!scal->status) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  AtomRec *r = scal->cur ? recB : recA;
+  const double a = r[i].a;
+  r[i].mx = a * ef[3 * i]; r[i].my = a * ef[3 * i + 1]; r[i].mz = a * ef[3 * i + 2];
+}
+
+// copy the final dipoles out of the record buffer that holds them
+__global__ void k_unpack_mu(int n, const Scal *scal, const AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
+                            double *__restrict__ mu) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const AtomRec *r = scal->cur ? recB : recA;
+  mu[3 * i] = r[i].mx; mu[3 * i + 1] = r[i].my; mu[3 * i + 2] = r[i].mz;
+}
+
+// ------------------------------------------------------------------------------------------
+// a8  polarization forces and energies, PS.cpp:406-641, evaluated per row (force on i from every j).
+// The pair force is antisymmetric, so summing rows reproduces the reference's i<j scatter;
+// pair energies are counted from both rows and halved.
+template <bool ALLPAIRS, int DAMP, bool EFLAG, bool VPAIR>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(int nlocal, const Scal *scal_in,
+                                                             const AtomRec *__restrict__ recA,
+                                                             const AtomRec *__restrict__ recB,
+                                                             const int *__restrict__ mol, Box box,
+                                                             const long long *__restrict__ nl_first,
+                                                             const int *__restrict__ nl_j, double cut_coulsq,
+                                                             double ddcutsq, double pd, double e2s,
+                                                             double *__restrict__ f, Scal *scal) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= nlocal) return;
+  const AtomRec *__restrict__ rec = scal_in->cur ? recB : recA;
+  const AtomRec ri = rec[i];
+  const int mi = mol[i];
+  const double f_shift = -1.0 / cut_coulsq;
+  double fx = 0, fy = 0, fz = 0, uef = 0, udd = 0;
+  double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  long long beg = 0, end = nlocal;
+  if (!ALLPAIRS) { beg = nl_first[i]; end = nl_first[i + 1]; }
+  for (long long p = beg + lane; p < end; p += 64) {
+    const int j = ALLPAIRS ? (int)p : nl_j[p];
+    if (j == i) continue;
+    const AtomRec rj = rec[j];
+    double dx, dy, dz;
+    min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+    const double xsq = dx * dx, ysq = dy * dy, zsq = dz * dz;
+    const double rsq = xsq + ysq + zsq;
+    const double rinv = rsqrt(rsq);
+    const double r2inv = rinv * rinv;
+    const double r = rsq * rinv;
+    const double r3inv = r2inv * rinv;
+    double px = 0, py = 0, pz = 0;
+    if (rsq < cut_coulsq && ((mi != mol[j]) || mi == 0)) {  // note <, PS.cpp:454
+      // shifted-force charge-dipole tensor G_pq = delta_pq (r^-2 + f_shift) r^2 ... written as the
+      // reference does: M_pp = (-2 p^2 + q^2 + s^2) r2inv + f_shift (q^2 + s^2), M_pq = -pq (3 r2inv + f_shift)
+      const double mxx = (-2.0 * xsq + ysq + zsq) * r2inv + f_shift * (ysq + zsq);
+      const double myy = (-2.0 * ysq + xsq + zsq) * r2inv + f_shift * (xsq + zsq);
+      const double mzz = (-2.0 * zsq + xsq + ysq) * r2inv + f_shift * (xsq + ysq);
+      const double k = -(3.0 * r2inv + f_shift);
+      const double mxy = k * dx * dy, mxz = k * dx * dz, myz = k * dy * dz;
+      const double ef_temp = (r2inv + f_shift) * rinv * e2s;
+      if (ri.a != 0.0 && rj.q != 0.0) {  // dipole on i, charge on j
+        const double cf = rj.q * e2s * r3inv;
+        px += cf * (ri.mx * mxx + ri.my * mxy + ri.mz * mxz);
+        py += cf * (ri.mx * mxy + ri.my * myy + ri.mz * myz);
+        pz += cf * (ri.mx * mxz + ri.my * myz + ri.mz * mzz);
+        if (EFLAG) uef -= ef_temp * rj.q * (ri.mx * dx + ri.my * dy + ri.mz * dz);
+      }
+      if (rj.a != 0.0 && ri.q != 0.0) {  // dipole on j, charge on i
+        const double cf = ri.q * e2s * r3inv;
+        px -= cf * (rj.mx * mxx + rj.my * mxy + rj.mz * mxz);
+        py -= cf * (rj.mx * mxy + rj.my * myy + rj.mz * myz);
+        pz -= cf * (rj.mx * mxz + rj.my * myz + rj.mz * mzz);
+        if (EFLAG) uef += ef_temp * ri.q * (rj.mx * dx + rj.my * dy + rj.mz * dz);
+      }
+    }
+    if (ri.a != 0.0 && rj.a != 0.0 && (ALLPAIRS || rsq < ddcutsq)) {  // dipole-dipole, PS.cpp:512-602
+      const double r5inv = r3inv * r2inv, r7inv = r5inv * r2inv;
+      const double pdotp = ri.mx * rj.mx + ri.my * rj.my + ri.mz * rj.mz;
+      const double pidotr = ri.mx * dx + ri.my * dy + ri.mz * dz;
+      const double pjdotr = rj.mx * dx + rj.my * dy + rj.mz * dz;
+      double pre_r, pre2, pre3;
+      if (DAMP == 0) {
+        const double t1 = exp(-pd * r);
+        const double t2 = 1.0 + pd * r + 0.5 * pd * pd * r * r;
+        const double t3 = t2 + (1.0 / 6.0) * pd * pd * pd * r * r * r;
+        const double g2 = 1.0 - t1 * t2, g3 = 1.0 - t1 * t3;
+        const double pre1 = 3.0 * r5inv * pdotp * g2 - 15.0 * r7inv * pidotr * pjdotr * g3;
+        pre2 = 3.0 * r5inv * pjdotr * g3;
+        pre3 = 3.0 * r5inv * pidotr * g3;
+        const double pre4 = -pdotp * r3inv * (-t1 * (pd * rinv + pd * pd) + t1 * pd * t2 * rinv);
+        const double pre5 = 3.0 * pidotr * pjdotr * r5inv *
+                            (-t1 * (pd * rinv + pd * pd + 0.5 * r * pd * pd * pd) + t1 * pd * t3 * rinv);
+        pre_r = pre1 + pre4 + pre5;
+        if (EFLAG) udd += r3inv * pdotp * g2 - 3.0 * r5inv * pidotr * pjdotr * g3;
+      } else {
+        pre_r = 3.0 * r5inv * pdotp - 15.0 * r7inv * pidotr * pjdotr;
+        pre2 = 3.0 * r5inv * pjdotr;
+        pre3 = 3.0 * r5inv * pidotr;
+        if (EFLAG) udd += r3inv * pdotp - 3.0 * r5inv * pidotr * pjdotr;
+      }
+      px += pre_r * dx + pre2 * ri.mx + pre3 * rj.mx;
+      py += pre_r * dy + pre2 * ri.my + pre3 * rj.my;
+      pz += pre_r * dz + pre2 * ri.mz + pre3 * rj.mz;
+    }
+    fx += px; fy += py; fz += pz;
+    if (VPAIR) {  // ev_tally_xyz, src/pair.cpp:1001-1075 (each pair seen from both rows -> 0.5)
+      v0 += 0.5 * dx * px; v1 += 0.5 * dy * py; v2 += 0.5 * dz * pz;
+      v3 += 0.5 * dx * py; v4 += 0.5 * dx * pz; v5 += 0.5 * dy * pz;
+    }
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) { atomicAdd(&f[3 * i], fx); atomicAdd(&f[3 * i + 1], fy); atomicAdd(&f[3 * i + 2], fz); }
+  if (EFLAG) {
+    uef = wave_sum(uef); udd = wave_sum(udd);
+    if (lane == 0) {
+      if (ri.a != 0.0) atomicAdd(&scal->u_self, 0.5 * (ri.mx * ri.mx + ri.my * ri.my + ri.mz * ri.mz) / ri.a);
+      atomicAdd(&scal->u_ef, 0.5 * uef);
+      atomicAdd(&scal->u_dd, 0.5 * udd);
+    }
+  }
+  if (VPAIR) {
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
+    if (lane == 0) {
+      atomicAdd(&scal->virial[0], v0); atomicAdd(&scal->virial[1], v1); atomicAdd(&scal->virial[2], v2);
+      atomicAdd(&scal->virial[3], v3); atomicAdd(&scal->virial[4], v4); atomicAdd(&scal->virial[5], v5);
+    }
+  }
+}
+
+// a10  virial_fdotr_compute, src/pair.cpp:1495-1540: sum over locals AND ghosts of f_i x_i
+__global__ __launch_bounds__(POLAR_BLOCK) void k_virial_fdotr(int nall, const double *__restrict__ x,
+                                                              const double *__restrict__ f, Scal *scal) {
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nall; i += gridDim.x * blockDim.x) {
+    const double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
+    const double xx = x[3 * i], yy = x[3 * i + 1], zz = x[3 * i + 2];
+    v[0] += fx * xx; v[1] += fy * yy; v[2] += fz * zz; v[3] += fy * xx; v[4] += fz * xx; v[5] += fz * yy;
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double s = wave_sum(v[k]);
+    if (lane == 0 && s != 0.0) atomicAdd(&scal->virial[k], s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cutoff-mode lists (extension): cell binning + CSR full lists over LOCAL atoms, minimum image.
+struct CellGrid {
+  int nc[3];
+  double lo[3], inv[3];  // cell index = floor((x - lo) * inv) wrapped
+};
+
+__device__ __forceinline__ int cell_of(const CellGrid &g, const Box &b, double x, double y, double z) {
+  int c[3];
+  const double p[3] = {x, y, z};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double fr = (p[k] - g.lo[k]) / b.prd[k];
+    fr -= floor(fr);
+    int ck = (int)(fr * g.nc[k]);
+    c[k] = ck >= g.nc[k] ? g.nc[k] - 1 : ck;
+  }
+  return (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
+}
+
+__global__ void k_cell_count(int n, const double *__restrict__ x, CellGrid g, Box b, int *__restrict__ cell_id,
+                             int *__restrict__ cell_cnt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int c = cell_of(g, b, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
+  cell_id[i] = c;
+  atomicAdd(&cell_cnt[c], 1);
+}
+
+// single-workgroup exclusive scan (n up to a few million; run once per list build)
+template <typename T>
+__global__ __launch_bounds__(1024) void k_exclusive_scan(long long n, const T *__restrict__ in,
+                                                         long long *__restrict__ out) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x;
+  const long long chunk = (n + 1023) / 1024;
+  const long long a = t * chunk, bnd = (a + chunk < n) ? a + chunk : n;
+  long long s = 0;
+  for (long long k = a; k < bnd; k++) s += (long long)in[k];
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    long long run = 0;
+    for (int k = 0; k < 1024; k++) { long long v = part[k]; part[k] = run; run += v; }
+    out[n] = run;
+  }
+  __syncthreads();
+  long long run = part[t];
+  for (long long k = a; k < bnd; k++) { out[k] = run; run += (long long)in[k]; }
+}
+
+// deterministic fill: atoms of a cell in ascending atom index (thread per cell, cells are small)
+__global__ void k_cell_fill(int n, int ncell, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
+                            int *__restrict__ fill, int *__restrict__ cell_atoms) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int c = cell_id[i];
+  int slot = atomicAdd(&fill[c], 1);
+  cell_atoms[cell_first[c] + slot] = i;
+}
+__global__ void k_cell_sort(int ncell, const long long *__restrict__ cell_first, int *__restrict__ cell_atoms) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  long long a = cell_first[c], b = cell_first[c + 1];
+  for (long long p = a + 1; p < b; p++) {
+    int v = cell_atoms[p];
+    long long q = p - 1;
+    while (q >= a && cell_atoms[q] > v) { cell_atoms[q + 1] = cell_atoms[q]; q--; }
+    cell_atoms[q + 1] = v;
+  }
+}
+
+// PASS 0: count, PASS 1: fill.  One wave per atom; lanes stride the atoms of the <=27 distinct
+// neighbor cells; ballot + mbcnt keeps the output order deterministic.
+//   nl : every j with rsq <= cutallsq                      (static field, forces, rank metric)
+//   dd : alpha_i != 0, alpha_j != 0 and rsq < ddcutsq      (the dipole sweep stream)
+template <int PASS>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int nlocal, const AtomRec *__restrict__ rec, Box box,
+                                                          CellGrid g, const int *__restrict__ cell_id,
+                                                          const long long *__restrict__ cell_first,
+                                                          const int *__restrict__ cell_atoms, double cutallsq,
+                                                          double ddcutsq, int *__restrict__ nl_cnt,
+                                                          int *__restrict__ dd_cnt,
+                                                          const long long *__restrict__ nl_first,
+                                                          const long long *__restrict__ dd_first,
+                                                          int *__restrict__ nl_j, int *__restrict__ dd_j) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= nlocal) return;
+  const AtomRec ri = rec[i];
+  const int ci = cell_id[i];
+  const int c0 = ci % g.nc[0], c1 = (ci / g.nc[0]) % g.nc[1], c2 = ci / (g.nc[0] * g.nc[1]);
+  long long nlp = (PASS == 1) ? nl_first[i] : 0, ddp = (PASS == 1) ? dd_first[i] : 0;
+  int ncount = 0, dcount = 0;
+  // distinct neighbor cells per dimension: nc>=3 -> {-1,0,1}; nc==2 -> {0,1}; nc==1 -> {0}
+  const int lo0 = g.nc[0] >= 3 ? -1 : 0, hi0 = g.nc[0] >= 2 ? 1 : 0;
+  const int lo1 = g.nc[1] >= 3 ? -1 : 0, hi1 = g.nc[1] >= 2 ? 1 : 0;
+  const int lo2 = g.nc[2] >= 3 ? -1 : 0, hi2 = g.nc[2] >= 2 ? 1 : 0;
+  for (int dz = lo2; dz <= hi2; dz++)
+    for (int dy = lo1; dy <= hi1; dy++)
+      for (int dx = lo0; dx <= hi0; dx++) {
+        const int b0 = (c0 + dx + g.nc[0]) % g.nc[0], b1 = (c1 + dy + g.nc[1]) % g.nc[1],
+                  b2 = (c2 + dz + g.nc[2]) % g.nc[2];
+        const int cj = (b2 * g.nc[1] + b1) * g.nc[0] + b0;
+        const long long a = cell_first[cj], b = cell_first[cj + 1];
+        for (long long base = a; base < b; base += 64) {
+          const long long p = base + lane;
+          bool in_nl = false, in_dd = false;
+          int j = -1;
+          if (p < b) {
+            j = cell_atoms[p];
+            if (j != i) {
+              const AtomRec rj = rec[j];
+              double ex, ey, ez;
+              min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
+              const double rsq = ex * ex + ey * ey + ez * ez;
+              in_nl = rsq <= cutallsq;
+              in_dd = (ri.a != 0.0) && (rj.a != 0.0) && (rsq < ddcutsq);
+            }
+          }
+          const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
+          if (PASS == 1) {
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            if (in_nl) nl_j[nlp + __popcll(m_nl & below)] = j;
+            if (in_dd) dd_j[ddp + __popcll(m_dd & below)] = j;
+            nlp += __popcll(m_nl);
+            ddp += __popcll(m_dd);
+          } else {
+            ncount += __popcll(m_nl);
+            dcount += __popcll(m_dd);
+          }
+        }
+      }
+  if (PASS == 0 && lane == 0) { nl_cnt[i] = ncount; dd_cnt[i] = dcount; }
+}
+
+// small utilities
+__global__ void k_zero_scal(Scal *s, int keep_solver) {
+  s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;
+  for (int k = 0; k < 6; k++) s->virial[k] = 0.0;
+  s->change = 0.0; s->last_change = 0.0;
+  s->rmin_bits = (unsigned long long)__double_as_longlong(1000.0);
+  if (!keep_solver) { s->iterations = 0; s->done = 0; s->status = 0; s->cur = 0; s->sweeps = 0; }
+}
+__global__ void k_set_done(Scal *s, int done) { s->done = done; }
+
+}  // namespace polar

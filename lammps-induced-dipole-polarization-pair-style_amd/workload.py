@@ -394,7 +394,8 @@ def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings,
         boxlo=np.asarray(boxlo, dtype=np.float64), prd=np.asarray(prd, dtype=np.float64), ntypes=ntypes,
         tables=tables, coul=coul, g_ewald=g_ewald, qqrd2e=QQR2E_REAL,
         special_lj=np.asarray(special_lj, dtype=np.float64), special_coul=np.asarray(special_coul, dtype=np.float64),
-        ilist=ilist, numneigh=numneigh, firstneigh=first, neigh=neigh, settings=settings, owner=owner, name=name)
+        ilist=ilist, numneigh=numneigh, firstneigh=first, neigh=neigh, settings=settings, owner=owner, name=name,
+        extra={"coeff_rows": [list(map(str, r)) for r in coeff_rows]})
 
 
 # --------------------------------------------------------------------------- synthetic boxes
@@ -535,3 +536,36 @@ def load_fixture(path, extra_args=(), g_ewald=None, ncoultablebits=12):
                        meta["ntypes"], rows, st, g, bonds=z["bonds"], exclude_intra=meta["exclude_intra"],
                        ncoultablebits=ncoultablebits, name=meta["name"])
     return sysm, meta
+
+
+def replicate_fixture(path, nx, ny, nz, extra_args=(), g_ewald=None, skin=2.0):
+    """``replicate nx ny nz`` of a golden fixture (BASELINE configs[1..4] are replicated boxes).
+    Follows LAMMPS' replicate semantics: molecule ids are offset per replica (so framework
+    replicas no longer exclude each other, SURVEY.md 8(d) caveat); bonds are not replicated
+    (intramolecular pairs are removed by ``neigh_modify exclude molecule/intra`` anyway)."""
+    import json
+
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    st = parse_pair_style_args(list(meta["pair_style_args"]) + list(extra_args))
+    x0, prd0 = z["x"], z["prd"]
+    n0 = len(x0)
+    molmax = int(z["molecule"].max())
+    xs, mols = [], []
+    r = 0
+    for ix in range(nx):
+        for iy in range(ny):
+            for iz in range(nz):
+                xs.append(x0 + np.array([ix, iy, iz]) * prd0)
+                mols.append(z["molecule"] + r * molmax)
+                r += 1
+    nrep = nx * ny * nz
+    x = np.concatenate(xs)
+    rows = [[str(int(c[0])), str(int(c[1])), repr(float(c[2])), repr(float(c[3])), repr(float(c[4]))]
+            for c in z["pair_coeff"]]
+    prd = prd0 * np.array([nx, ny, nz])
+    q = np.tile(z["q"], nrep)
+    g = ewald_g(1.0e-4, q, st.cut_coul, prd) if g_ewald is None else g_ewald
+    return make_system(x, q, np.tile(z["alpha"], nrep), np.tile(z["type"], nrep), np.concatenate(mols),
+                       z["boxlo"], prd, meta["ntypes"], rows, st, g, bonds=None, exclude_intra=True, skin=skin,
+                       name=f"{meta['name']}_rep{nx}x{ny}x{nz}")
