@@ -99,7 +99,8 @@ def main():
     # dominant kernel: k_field (dipole-field sweep).  One sweep = ncolors launches.
     launches = out["sweeps"] * max(out["ncolors"], 1)
     rows = int(np.count_nonzero(s.alpha[:n]))
-    bytes_sweep = 4.0 * out["dd_pairs"] + rows * 112.0  # int32 index stream + per-row offset/x/mu/E/alpha/mu_new
+    # per pair: int32 j + cached tensor scalars (s3,s5: 16 B); per row: offset 8 + x 24 + mu 24 + E 24 + alpha 8 + mu_new 24
+    bytes_sweep = 20.0 * out["dd_pairs"] + rows * 112.0
     bytes_launch = bytes_sweep / max(out["ncolors"], 1)
     ms_launch = (ms_solve / args.steps) / launches      # HIP events on the library's stream around the solve
     achieved = bytes_launch / (ms_launch * 1e-3) / 1e9

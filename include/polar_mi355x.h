@@ -135,6 +135,29 @@ int polar_download(polar_handle *h, const char *name, double *dst, long long n);
 /* overwrite the device-resident dipoles (multi-GPU halo, use_previous across steps) */
 int polar_upload_mu(polar_handle *h, const double *mu, long long n);
 
+
+/* ---- stepwise / sharded interface (multi-GPU driver: one process per GPU, rows sharded) ------
+ * The reference is single-process only (README.md:5; its pack_comm/unpack_comm are dead code,
+ * PS.h:51-52).  With dd_cutoff > 0 the path shards by rows: every rank holds all atoms, owns the
+ * rows [lo,hi), and exchanges dipoles between sweeps (RCCL, driven from parallel.py).          */
+/* run all kernels on this HIP stream (e.g. torch's current stream) instead of the private one */
+int polar_set_stream(polar_handle *h, void *hip_stream);
+int polar_set_row_range(polar_handle *h, int lo, int hi); /* hi < 0: all rows */
+/* 1: the LJ/coul list is a LAMMPS *full* list (each pair in both rows): force on i only, tallies halved */
+int polar_set_list_style(polar_handle *h, int full);
+/* compute() split at the exchange points: begin = list build, LJ+coul, static field, initial guess */
+int polar_step_begin(polar_handle *h, int eflag, int vflag);
+int polar_step_sweep(polar_handle *h); /* one sweep over the owned rows */
+/* end-of-sweep control (PS.cpp:1193-1236) on the device; dev_global_change = all-reduced sum of
+ * (dmu)^2 in device memory, or NULL to use this handle's own sum */
+int polar_step_sweep_end(polar_handle *h, const double *dev_global_change);
+int polar_step_state(polar_handle *h, int *done, int *iterations, int *status); /* synchronises */
+int polar_step_finish(polar_handle *h, polar_result *out); /* forces/energies of the owned rows */
+/* dipoles of rows [lo,hi) <-> a packed device buffer [(hi-lo)][3] */
+int polar_mu_gather(polar_handle *h, long long lo, long long hi, double *dev_dst);
+int polar_mu_scatter(polar_handle *h, long long lo, long long hi, const double *dev_src);
+int polar_change_export(polar_handle *h, double *dev_dst); /* this handle's running sum of (dmu)^2 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,17 @@ EXPORTS = {
     "polar_dev_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
     "polar_download": (C.c_int, [C.c_void_p, C.c_char_p, _dp, C.c_longlong]),
     "polar_upload_mu": (C.c_int, [C.c_void_p, _dp, C.c_longlong]),
+    "polar_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "polar_set_row_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "polar_set_list_style": (C.c_int, [C.c_void_p, C.c_int]),
+    "polar_step_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "polar_step_sweep": (C.c_int, [C.c_void_p]),
+    "polar_step_sweep_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "polar_step_state": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
+    "polar_step_finish": (C.c_int, [C.c_void_p, C.POINTER(Result)]),
+    "polar_mu_gather": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "polar_mu_scatter": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "polar_change_export": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 

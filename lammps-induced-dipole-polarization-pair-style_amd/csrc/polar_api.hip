@@ -67,6 +67,11 @@ struct polar_handle {
   Box box{};
   double boxlo[3] = {0, 0, 0};
   int nlocal = 0, nghost = 0;
+  int row_lo = 0, row_hi = -1;   // rows this handle owns (multi-GPU row sharding); -1 = all
+  int full_list = 0;             // LJ/coul list is a LAMMPS full list
+  int step_eflag = 0, step_vflag = 0;
+  bool in_step = false;
+  bool own_stream = true;
   // host mirrors needed by host-side colouring
   std::vector<double> hx, halpha;
   // device state
@@ -75,15 +80,18 @@ struct polar_handle {
   DBuf<long long> d_first;
   DBuf<AtomRec> d_rec0, d_rec1;
   DBuf<Scal> d_scal;
+  DBuf<double> d_slots;
   // cutoff-mode lists
   DBuf<int> d_cell_id, d_cell_cnt, d_cell_fill, d_cell_atoms, d_nl_cnt, d_dd_cnt, d_nl_j, d_dd_j;
   DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
+  DBuf<double2> d_dd_s;
   long long nl_pairs = 0, dd_pairs = 0;
   int inum = 0;
   long long nneigh = 0;
   bool mu_resident = false;
   // colour phases (cutoff-mode Gauss-Seidel)
   std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
+  std::vector<int> h_rows;     // rows sorted by colour (host copy)
   bool colors_valid = false;
   double color_dist = 2.6;
   Scal *h_scal = nullptr;  // pinned
@@ -174,8 +182,11 @@ void build_lists(polar_handle *h) {
                                            h->d_cell_atoms.p);
   h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1); h->d_nl_first.ensure(n + 2); h->d_dd_first.ensure(n + 2);
   const double cutallsq = cutall * cutall, ddsq = st.dd_cutoff * st.dd_cutoff;
-  k_nl_build<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
-      n, h->d_rec0.p, h->box, g, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_atoms.p, cutallsq, ddsq, h->d_nl_cnt.p,
+  const int r0 = h->row_lo, nr = (h->row_hi < 0 ? n : h->row_hi) - h->row_lo;
+  HIPCHECK(hipMemsetAsync(h->d_nl_cnt.p, 0, (n + 1) * sizeof(int), s));
+  HIPCHECK(hipMemsetAsync(h->d_dd_cnt.p, 0, (n + 1) * sizeof(int), s));
+  k_nl_build<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
+      r0, nr, h->d_rec0.p, h->box, g, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_atoms.p, cutallsq, ddsq, h->d_nl_cnt.p,
       h->d_dd_cnt.p, nullptr, nullptr, nullptr, nullptr);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>(n, h->d_nl_cnt.p, h->d_nl_first.p);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>(n, h->d_dd_cnt.p, h->d_dd_first.p);
@@ -185,9 +196,14 @@ void build_lists(polar_handle *h) {
   HIPCHECK(hipStreamSynchronize(s));
   h->nl_pairs = tot[0]; h->dd_pairs = tot[1];
   h->d_nl_j.ensure((size_t)tot[0] + 64); h->d_dd_j.ensure((size_t)tot[1] + 64);
-  k_nl_build<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
-      n, h->d_rec0.p, h->box, g, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_atoms.p, cutallsq, ddsq, nullptr, nullptr,
+  k_nl_build<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
+      r0, nr, h->d_rec0.p, h->box, g, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_atoms.p, cutallsq, ddsq, nullptr, nullptr,
       h->d_nl_first.p, h->d_dd_first.p, h->d_nl_j.p, h->d_dd_j.p);
+  h->d_dd_s.ensure((size_t)tot[1] + 64);
+  if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
+    k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(r0, nr, h->d_rec0.p, h->box, h->d_dd_first.p, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
+  else
+    k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(r0, nr, h->d_rec0.p, h->box, h->d_dd_first.p, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
 }
 
 // ---- host-side greedy distance colouring for the colour-phase Gauss-Seidel (cutoff mode) ----
@@ -253,6 +269,7 @@ void build_colors(polar_handle *h, const std::vector<int> &visit) {
   std::vector<int> fill(h->color_off.begin(), h->color_off.end() - 1);
   for (int i = 0; i < n; i++)
     if (color[i] >= 0) rows[fill[color[i]]++] = i;
+  h->h_rows = rows;
   h->d_rows.ensure(rows.size() + 1);
   if (!rows.empty()) HIPCHECK(hipMemcpy(h->d_rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
   h->colors_valid = true;
@@ -262,37 +279,56 @@ template <bool AP>
 void launch_rank(polar_handle *h, int pass) {
   const int n = h->nlocal, ntot = h->nlocal + h->nghost;
   dim3 grid(nblk(n, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
+  if (pass == 2) k_fold_scal<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, 1);
   if (pass == 1)
     k_rank<AP, 1><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, h->d_nl_first.p,
-                                                 h->d_nl_j.p, h->d_scal.p, h->d_rank.p);
+                                                 h->d_nl_j.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
   else
     k_rank<AP, 2><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, h->d_nl_first.p,
-                                                 h->d_nl_j.p, h->d_scal.p, h->d_rank.p);
+                                                 h->d_nl_j.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
 }
 
 template <bool AP, int DAMP, int EP>
-void launch_field(polar_handle *h, int nrows, const int *rows) {
+void launch_field(polar_handle *h, int row0, int nrows, const int *rows) {
   const polar_settings &st = h->ph.st;
+  if (nrows <= 0) return;
   k_field<AP, DAMP, EP><<<nblk(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(
-      nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, h->d_dd_first.p, h->d_dd_j.p,
-      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_scal.p);
+      row0, nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, h->d_dd_first.p, h->d_dd_j.p, h->d_dd_s.p,
+      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_scal.p, h->d_slots.p);
 }
 template <int EP>
-void launch_field_dyn(polar_handle *h, bool ap, int nrows, const int *rows) {
+void launch_field_dyn(polar_handle *h, bool ap, int row0, int nrows, const int *rows) {
   const bool expd = h->ph.st.damping_type == POLAR_DAMP_EXPONENTIAL;
-  if (ap) { if (expd) launch_field<true, 0, EP>(h, nrows, rows); else launch_field<true, 1, EP>(h, nrows, rows); }
-  else    { if (expd) launch_field<false, 0, EP>(h, nrows, rows); else launch_field<false, 1, EP>(h, nrows, rows); }
+  if (ap) { if (expd) launch_field<true, 0, EP>(h, row0, nrows, rows); else launch_field<true, 1, EP>(h, row0, nrows, rows); }
+  else    { if (expd) launch_field<false, 0, EP>(h, row0, nrows, rows); else launch_field<false, 1, EP>(h, row0, nrows, rows); }
+}
+inline int own_lo(const polar_handle *h) { return h->row_lo; }
+inline int own_n(const polar_handle *h) { return (h->row_hi < 0 ? h->nlocal : h->row_hi) - h->row_lo; }
+
+// one sweep over the rows this handle owns (Jacobi, or the colour phases restricted to the range)
+void sweep_once(polar_handle *h, bool ap) {
+  const polar_settings &st = h->ph.st;
+  const bool gs = st.polar_gs || st.polar_gs_ranked;
+  if (!gs) { launch_field_dyn<EP_JACOBI>(h, ap, own_lo(h), own_n(h), nullptr); return; }
+  const int ncol = (int)h->color_off.size() - 1;
+  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
+  for (int c = 0; c < ncol; c++) {
+    const int *b = h->h_rows.data() + h->color_off[c], *e = h->h_rows.data() + h->color_off[c + 1];
+    const int *bl = std::lower_bound(b, e, lo), *eh = std::lower_bound(b, e, hi);  // rows ascend inside a colour
+    const int cnt = (int)(eh - bl);
+    if (cnt > 0) launch_field_dyn<EP_INPLACE>(h, false, 0, cnt, h->d_rows.p + (bl - h->h_rows.data()));
+  }
 }
 
 template <bool AP, int DAMP>
 void launch_force(polar_handle *h, int eflag, int vpair) {
   const polar_settings &st = h->ph.st;
-  dim3 grid(nblk(h->nlocal, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
+  dim3 grid(nblk(own_n(h), POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
   const double ccs = st.cut_coul * st.cut_coul, dds = st.dd_cutoff * st.dd_cutoff, e2s = std::sqrt(h->P.qqrd2e);
 #define LF(E, V)                                                                                                    \
-  k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
+  k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(own_lo(h), own_n(h), h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
                                                                h->d_mol.p, h->box, h->d_nl_first.p, h->d_nl_j.p,  \
-                                                               ccs, dds, st.polar_damp, e2s, h->d_f.p, h->d_scal.p)
+                                                               ccs, dds, st.polar_damp, e2s, h->d_f.p, h->d_slots.p)
   if (eflag) { if (vpair) LF(true, true); else LF(true, false); }
   else       { if (vpair) LF(false, true); else LF(false, false); }
 #undef LF
@@ -304,6 +340,22 @@ void read_scal(polar_handle *h) {
 }
 
 // ---- the solve: a6+a7 (PS.cpp:1113-1238) -----------------------------------------------------
+void ensure_colors(polar_handle *h) {
+  if (h->colors_valid) return;
+  const polar_settings &st = h->ph.st;
+  const int n = h->nlocal;
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  const bool sharded = own_n(h) != n;
+  if (st.polar_gs_ranked && !sharded) {  // ranked visiting order (a sharded handle only knows its own rows' metric)
+    std::vector<double> rk(n);
+    HIPCHECK(hipMemcpyAsync(rk.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rk[a] > rk[b]; });
+  }
+  build_colors(h, order);
+}
+
 void solve(polar_handle *h, bool ap, polar_result *out) {
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
@@ -314,9 +366,18 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
   const int check_every = 4;
   out->ncolors = 0;
 
-  std::vector<int> order;
-  if (gs && (ap || !h->colors_valid)) {
-    order.resize(n);
+  if (!gs || !ap) {  // Jacobi (reference "polar_gs no") or colour-phase Gauss-Seidel over the dd list
+    if (gs) { ensure_colors(h); out->ncolors = (int)h->color_off.size() - 1; }
+    for (int sw = 0; sw < max_sweeps; sw++) {
+      sweep_once(h, ap);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr);
+      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
+        read_scal(h);
+        if (h->h_scal->done) break;
+      }
+    }
+  } else {  // exact-order blocked Gauss-Seidel (reference semantics)
+    std::vector<int> order(n), pos(n);
     std::iota(order.begin(), order.end(), 0);
     if (st.polar_gs_ranked) {  // stable descending sort == the reference's bubble sort (PS.cpp:1130-1143)
       std::vector<double> rk(n);
@@ -324,78 +385,51 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
       HIPCHECK(hipStreamSynchronize(s));
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rk[a] > rk[b]; });
     }
-  }
-
-  if (!gs) {  // Jacobi, reference "polar_gs no / polar_gs_ranked no"
-    for (int sw = 0; sw < max_sweeps; sw++) {
-      launch_field_dyn<EP_JACOBI>(h, ap, n, nullptr);
-      k_solver_step<<<1, 1, 0, s>>>(h->d_scal.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 1);
-      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
-        read_scal(h);
-        if (h->h_scal->done) break;
-      }
-    }
-  } else if (ap) {  // exact-order blocked Gauss-Seidel
-    std::vector<int> pos(n);
     for (int k = 0; k < n; k++) pos[order[k]] = k;
     h->d_order.ensure(n); h->d_pos.ensure(n); h->d_dmu.ensure(3 * 64);
     HIPCHECK(hipMemcpyAsync(h->d_order.p, order.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(h->d_pos.p, pos.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
-    launch_field_dyn<EP_FIELD>(h, true, n, nullptr);
+    HIPCHECK(hipStreamSynchronize(s));  // order/pos are stack vectors
+    launch_field_dyn<EP_FIELD>(h, true, 0, n, nullptr);
     for (int sw = 0; sw < max_sweeps; sw++) {
       for (int b0 = 0; b0 < n; b0 += 64) {
         if (expd) {
-          k_gs_block_seq<0><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_dmu.p, h->d_scal.p);
+          k_gs_block_seq<0><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
           k_gs_block_push<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_order.p, h->d_pos.p, h->d_rec0.p, h->box, st.polar_damp, h->d_dmu.p, h->d_F.p, h->d_scal.p);
         } else {
-          k_gs_block_seq<1><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_dmu.p, h->d_scal.p);
+          k_gs_block_seq<1><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
           k_gs_block_push<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_order.p, h->d_pos.p, h->d_rec0.p, h->box, st.polar_damp, h->d_dmu.p, h->d_F.p, h->d_scal.p);
         }
       }
-      k_solver_step<<<1, 1, 0, s>>>(h->d_scal.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0);
-      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
-        read_scal(h);
-        if (h->h_scal->done) break;
-      }
-    }
-  } else {  // colour-phase Gauss-Seidel over the dd list
-    if (!h->colors_valid) build_colors(h, order);
-    const int ncol = (int)h->color_off.size() - 1;
-    out->ncolors = ncol;
-    for (int sw = 0; sw < max_sweeps; sw++) {
-      for (int c = 0; c < ncol; c++) {
-        const int cnt = h->color_off[c + 1] - h->color_off[c];
-        if (cnt > 0) launch_field_dyn<EP_INPLACE>(h, false, cnt, h->d_rows.p + h->color_off[c]);
-      }
-      k_solver_step<<<1, 1, 0, s>>>(h->d_scal.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
       }
     }
   }
-  k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef.p);
 }
 
-int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, polar_result *out) {
+// PS.cpp:125-386: everything before the solve
+void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   need_device(h);
   if (!h->types_set || !h->coul_set) throw std::runtime_error("polar_compute before pair tables were set (polar_pair_init or polar_set_types/polar_set_coul)");
   if (!h->box_set || !h->atoms_set || !h->neigh_set) throw std::runtime_error("polar_compute before polar_set_box/polar_set_atoms/polar_set_neighbors");
-  if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not implemented (SURVEY 8(f) rank 3)");
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal, nall = h->nlocal + h->nghost;
   const bool ap = !(st.dd_cutoff > 0.0);
-  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  if (ap && own_n(h) != n) throw InputError("row sharding needs dd_cutoff > 0 (exact all-pairs mode runs as replicas only)");
   const int vmode = vflag % 4;
   hipStream_t s = h->stream;
   h->warn.clear();
-  memset(out, 0, sizeof(*out));
+  h->step_eflag = eflag; h->step_vflag = vflag;
 
   h->d_f.ensure(3 * (size_t)nall); h->d_ef.ensure(3 * (size_t)n); h->d_F.ensure(3 * (size_t)n);
   h->d_mu.ensure(3 * (size_t)n); h->d_rank.ensure(n); h->d_rec0.ensure(n); h->d_rec1.ensure(n);
   HIPCHECK(hipEventRecord(h->ev[0], s));
   HIPCHECK(hipMemsetAsync(h->d_f.p, 0, 3 * (size_t)nall * sizeof(double), s));
   k_zero_scal<<<1, 1, 0, s>>>(h->d_scal.p, 0);
+  k_zero_slots<<<nblk(POLAR_NSLOT, 256), 256, 0, s>>>(h->d_slots.p);
   const double *mu0 = nullptr;
   if (st.use_previous) {
     if (mu_host) {
@@ -407,7 +441,8 @@ int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, pol
   if (!ap) build_lists(h);
   HIPCHECK(hipEventRecord(h->ev[1], s));
 
-  if (st.polar_gs_ranked) {  // a2
+  // a2: every step in exact mode (reference); in cutoff mode only when the colour phases are rebuilt
+  if (st.polar_gs_ranked && (ap || !h->colors_valid)) {
     if (ap) { launch_rank<true>(h, 1); launch_rank<true>(h, 2); }
     else    { launch_rank<false>(h, 1); launch_rank<false>(h, 2); }
   }
@@ -415,10 +450,10 @@ int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, pol
 
   {  // a3
     LJCoulParams P = h->P;
-    P.newton_pair = 1; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul;
+    P.newton_pair = 1; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list;
     dim3 grid(nblk(h->inum, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
     if (h->inum > 0) {
-#define LJ(E, V) k_ljcoul<E, V><<<grid, block, 0, s>>>(P, h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_x.p, h->d_q.p, h->d_type.p, h->d_f.p, h->d_scal.p)
+#define LJ(E, V) k_ljcoul<E, V><<<grid, block, 0, s>>>(P, h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_x.p, h->d_q.p, h->d_type.p, h->d_f.p, h->d_slots.p)
       if (eflag) { if (vmode == 1) LJ(true, true); else LJ(true, false); }
       else       { if (vmode == 1) LJ(false, true); else LJ(false, false); }
 #undef LJ
@@ -427,21 +462,29 @@ int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, pol
   HIPCHECK(hipEventRecord(h->ev[3], s));
 
   {  // a4 + a5
-    dim3 grid(nblk(n, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
+    dim3 grid(nblk(own_n(h), POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
     const double ccs = st.cut_coul * st.cut_coul, e2s = std::sqrt(h->P.qqrd2e);
-    if (ap) k_static_field<true><<<grid, block, 0, s>>>(n, h->d_rec0.p, h->d_mol.p, h->box, nullptr, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef.p, h->d_rec0.p, h->d_rec1.p);
-    else    k_static_field<false><<<grid, block, 0, s>>>(n, h->d_rec0.p, h->d_mol.p, h->box, h->d_nl_first.p, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef.p, h->d_rec0.p, h->d_rec1.p);
+    if (ap) k_static_field<true><<<grid, block, 0, s>>>(own_lo(h), own_n(h), n, h->d_rec0.p, h->d_mol.p, h->box, nullptr, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef.p, h->d_rec0.p, h->d_rec1.p);
+    else    k_static_field<false><<<grid, block, 0, s>>>(own_lo(h), own_n(h), n, h->d_rec0.p, h->d_mol.p, h->box, h->d_nl_first.p, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef.p, h->d_rec0.p, h->d_rec1.p);
   }
   HIPCHECK(hipEventRecord(h->ev[4], s));
+}
 
-  if (!st.zodid) solve(h, ap, out);  // a6 + a7 (PS.cpp:389)
+// PS.cpp:406-645: everything after the solve
+int phase_finish(polar_handle *h, polar_result *out) {
+  const polar_settings &st = h->ph.st;
+  const int n = h->nlocal, nall = h->nlocal + h->nghost;
+  const bool ap = !(st.dd_cutoff > 0.0);
+  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  const int eflag = h->step_eflag, vmode = h->step_vflag % 4;
+  hipStream_t s = h->stream;
+  k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef.p);
   HIPCHECK(hipEventRecord(h->ev[5], s));
-
-  // a8
   if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1); else launch_force<true, 1>(h, eflag, vmode == 1); }
   else    { if (expd) launch_force<false, 0>(h, eflag, vmode == 1); else launch_force<false, 1>(h, eflag, vmode == 1); }
-  if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_scal.p);  // a10
+  if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_slots.p);  // a10
   k_unpack_mu<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_mu.p);
+  k_fold_scal<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, 0);
   HIPCHECK(hipEventRecord(h->ev[6], s));
   read_scal(h);
   h->mu_resident = true;
@@ -462,6 +505,18 @@ int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, pol
   out->ms_solve = el(4, 5); out->ms_force = el(5, 6); out->ms_total = el(0, 6);
   if (sc.status) h->warn = "Number of iterations exceeding max_iterations, setting dipoles to alpha*E";  // PS.cpp:1233
   return out->status;
+}
+
+int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, polar_result *out) {
+  if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not implemented (SURVEY 8(f) rank 3)");
+  memset(out, 0, sizeof(*out));
+  phase_begin(h, eflag, vflag, mu_host);
+  const bool ap = !(h->ph.st.dd_cutoff > 0.0);
+  if (!h->ph.st.zodid) solve(h, ap, out);  // a6 + a7 (PS.cpp:389)
+  const int nc = out->ncolors;
+  int rc = phase_finish(h, out);
+  out->ncolors = nc;
+  return rc;
 }
 
 }  // namespace
@@ -493,6 +548,7 @@ int polar_create(int device, polar_handle **out) {
     for (auto &e : h->ev) HIPCHECK(hipEventCreate(&e));
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
     h->d_scal.ensure(1);
+    h->d_slots.ensure((size_t)POLAR_NSLOT * POLAR_SLOT_STRIDE);
     h->have_device = true;
     return POLAR_OK;
   });
@@ -507,13 +563,13 @@ int polar_destroy(polar_handle *h) {
     h->d_mu.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
     h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();
     h->d_numneigh.release(); h->d_neigh.release(); h->d_rows.release(); h->d_first.release();
-    h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release();
+    h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release(); h->d_cell_atoms.release();
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_nl_j.release(); h->d_dd_j.release();
-    h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release();
+    h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release();
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   }
   delete h;
   return POLAR_OK;
@@ -609,7 +665,7 @@ int polar_set_box(polar_handle *h, const double boxlo[3], const double prd[3], c
       return fail(h, POLAR_ERR_UNSUPPORTED, "triclinic boxes are not implemented (SURVEY 8(f) rank 3)");
     for (int k = 0; k < 3; k++) {
       if (!(prd[k] > 0.0) || !std::isfinite(prd[k])) throw InputError("box lengths must be positive and finite");
-      h->box.prd[k] = prd[k]; h->box.half[k] = 0.5 * prd[k]; h->box.periodic[k] = periodic[k] ? 1 : 0;
+      h->box.prd[k] = prd[k]; h->box.half[k] = 0.5 * prd[k]; h->box.inv[k] = 1.0 / prd[k]; h->box.periodic[k] = periodic[k] ? 1 : 0;
       h->boxlo[k] = boxlo[k];
     }
     h->box_set = true;
@@ -748,6 +804,98 @@ int polar_upload_mu(polar_handle *h, const double *mu, long long n) {
     h->d_mu.ensure((size_t)n);
     HIPCHECK(hipMemcpy(h->d_mu.p, mu, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     h->mu_resident = true;
+    return POLAR_OK;
+  });
+}
+
+/* ---- stepwise / sharded interface (multi-GPU driver, parallel.py) --------------------------- */
+int polar_set_stream(polar_handle *h, void *hip_stream) {
+  return guarded(h, [&]() {
+    need_device(h);
+    if (h->own_stream && h->stream) { HIPCHECK(hipStreamSynchronize(h->stream)); HIPCHECK(hipStreamDestroy(h->stream)); }
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return POLAR_OK;
+  });
+}
+int polar_set_row_range(polar_handle *h, int lo, int hi) {
+  return guarded(h, [&]() {
+    if (lo < 0 || (hi >= 0 && hi < lo)) throw InputError("bad row range");
+    h->row_lo = lo; h->row_hi = hi;
+    return POLAR_OK;
+  });
+}
+int polar_set_list_style(polar_handle *h, int full) {
+  if (!h) return POLAR_ERR_STATE;
+  h->full_list = full ? 1 : 0;
+  return POLAR_OK;
+}
+int polar_step_begin(polar_handle *h, int eflag, int vflag) {
+  return guarded(h, [&]() {
+    HIPCHECK(hipSetDevice(h->device));
+    if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not implemented");
+    phase_begin(h, eflag, vflag, nullptr);
+    const polar_settings &st = h->ph.st;
+    if (!st.zodid && (st.polar_gs || st.polar_gs_ranked)) ensure_colors(h);
+    h->in_step = true;
+    return POLAR_OK;
+  });
+}
+int polar_step_sweep(polar_handle *h) {
+  return guarded(h, [&]() {
+    if (!h->in_step) throw std::runtime_error("polar_step_sweep outside polar_step_begin/finish");
+    sweep_once(h, false);
+    return POLAR_OK;
+  });
+}
+int polar_step_sweep_end(polar_handle *h, const double *dev_global_change) {
+  return guarded(h, [&]() {
+    if (!h->in_step) throw std::runtime_error("polar_step_sweep_end outside polar_step_begin/finish");
+    const polar_settings &st = h->ph.st;
+    const bool gs = st.polar_gs || st.polar_gs_ranked;
+    k_solver_step<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, h->nlocal, st.fixed_iteration, st.iterations_max, st.polar_precision,
+                                          gs ? 0 : 1, dev_global_change);
+    return POLAR_OK;
+  });
+}
+int polar_step_state(polar_handle *h, int *done, int *iterations, int *status) {
+  return guarded(h, [&]() {
+    need_device(h);
+    read_scal(h);
+    if (done) *done = h->h_scal->done;
+    if (iterations) *iterations = h->h_scal->iterations;
+    if (status) *status = h->h_scal->status;
+    return POLAR_OK;
+  });
+}
+int polar_step_finish(polar_handle *h, polar_result *out) {
+  return guarded(h, [&]() {
+    if (!h->in_step) throw std::runtime_error("polar_step_finish without polar_step_begin");
+    memset(out, 0, sizeof(*out));
+    int rc = phase_finish(h, out);
+    out->ncolors = (h->ph.st.polar_gs || h->ph.st.polar_gs_ranked) ? (int)h->color_off.size() - 1 : 0;
+    h->in_step = false;
+    return rc;
+  });
+}
+int polar_mu_gather(polar_handle *h, long long lo, long long hi, double *dev_dst) {
+  return guarded(h, [&]() {
+    need_device(h);
+    if (hi > lo) k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst);
+    return POLAR_OK;
+  });
+}
+int polar_mu_scatter(polar_handle *h, long long lo, long long hi, const double *dev_src) {
+  return guarded(h, [&]() {
+    need_device(h);
+    if (hi > lo) k_mu_scatter<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src);
+    return POLAR_OK;
+  });
+}
+int polar_change_export(polar_handle *h, double *dev_dst) {
+  return guarded(h, [&]() {
+    need_device(h);
+    k_fold_change<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, dev_dst);
     return POLAR_OK;
   });
 }

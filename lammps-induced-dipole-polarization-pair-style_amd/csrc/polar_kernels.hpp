@@ -23,7 +23,7 @@ struct __attribute__((aligned(64))) AtomRec {
 };
 
 struct Box {
-  double prd[3], half[3];
+  double prd[3], half[3], inv[3];
   int periodic[3];
 };
 
@@ -36,6 +36,16 @@ struct Scal {
   unsigned long long rmin_bits;  // double bits of rmin (positive doubles order like uint64)
   int iterations, done, status, cur, sweeps, pad;
 };
+
+// Contended accumulators (energies, virial, sum dmu^2, rmin) are spread over NSLOT cache lines:
+// every wave adds into the line picked by its workgroup id, a single-workgroup kernel folds the
+// lines.  (One shared address costs ~12 ns per atomic on MI355X: 36k rows -> 0.4 ms per launch.)
+#define POLAR_NSLOT 1024
+#define POLAR_SLOT_STRIDE 16
+enum { SL_EVDWL = 0, SL_ECOUL, SL_USELF, SL_UEF, SL_UDD, SL_V0, SL_V1, SL_V2, SL_V3, SL_V4, SL_V5, SL_CHANGE, SL_RMIN };
+__device__ __forceinline__ double *slot_ptr(double *slots, int field) {
+  return slots + (size_t)(blockIdx.x & (POLAR_NSLOT - 1)) * POLAR_SLOT_STRIDE + field;
+}
 
 #define POLAR_WAVE 64
 #define POLAR_BLOCK 256
@@ -73,6 +83,23 @@ __device__ __forceinline__ void min_image_del(const Box &b, double xi, double yi
   dx = -wrap_ci(xj - xi, b.prd[0], b.half[0], b.periodic[0]);
   dy = -wrap_ci(yj - yi, b.prd[1], b.half[1], b.periodic[1]);
   dz = -wrap_ci(zj - zi, b.prd[2], b.half[2], b.periodic[2]);
+}
+
+// Branch-free minimum image for the LIST kernels (dd_cutoff extension): d - L*rint(d/L).
+// Equals closest_image except for pairs at exactly L/2, which lie outside every cutoff there
+// (the list path requires L >= 2*cutoff).  The all-pairs (reference-exact) kernels keep wrap_ci.
+__device__ __forceinline__ void min_image_rint(const Box &b, double xi, double yi, double zi, double xj, double yj,
+                                               double zj, double &dx, double &dy, double &dz) {
+  dx = xi - xj; dy = yi - yj; dz = zi - zj;
+  if (b.periodic[0]) dx = fma(-b.prd[0], rint(dx * b.inv[0]), dx);
+  if (b.periodic[1]) dy = fma(-b.prd[1], rint(dy * b.inv[1]), dy);
+  if (b.periodic[2]) dz = fma(-b.prd[2], rint(dz * b.inv[2]), dz);
+}
+template <bool EXACT>
+__device__ __forceinline__ void pair_del(const Box &b, double xi, double yi, double zi, double xj, double yj,
+                                         double zj, double &dx, double &dy, double &dz) {
+  if (EXACT) min_image_del(b, xi, yi, zi, xj, yj, zj, dx, dy, dz);
+  else min_image_rint(b, xi, yi, zi, xj, yj, zj, dx, dy, dz);
 }
 
 // Dipole field tensor scalars of build_dipole_field_matrix (PS.cpp:1284-1306):
@@ -121,6 +148,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, co
                                                       const double *__restrict__ alpha, const int *__restrict__ mol,
                                                       Box box, const long long *__restrict__ nl_first,
                                                       const int *__restrict__ nl_j, Scal *scal,
+                                                      double *__restrict__ slots,
                                                       double *__restrict__ rank_metric) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -139,7 +167,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, co
       const int j = ALLPAIRS ? (int)p : nl_j[p];
       if (j != i) {
         double dx = xi - x[3 * j], dy = yi - x[3 * j + 1], dz = zi - x[3 * j + 2];
-        if (!ALLPAIRS) min_image_del(box, xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2], dx, dy, dz);
+        if (!ALLPAIRS) min_image_rint(box, xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2], dx, dy, dz);
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         const bool molok = (mi != mol[j]) || mi == 0;
         if (PASS == 1) {
@@ -163,7 +191,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, co
   }
   if (PASS == 1) {
     rmin = wave_min(rmin);
-    if (lane == 0) atomicMin(&scal->rmin_bits, (unsigned long long)__double_as_longlong(rmin));
+    if (lane == 0)
+      atomicMin((unsigned long long *)slot_ptr(slots, SL_RMIN), (unsigned long long)__double_as_longlong(rmin));
   } else {
     if (lane == 0) rank_metric[i] = acc;  // identical in every lane
   }
@@ -175,6 +204,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, co
 // ghost forces come back exactly as LAMMPS' reverse_comm expects.
 struct LJCoulParams {
   int ntypes, newton_pair, nlocal;
+  int full_list;  // 1: LAMMPS full list (each pair in both rows): force on i only, tallies halved
   int ncoultablebits, ncoulmask, ncoulshiftbits;
   double tabinnersq, cut_coulsq, g_ewald, qqrd2e;
   double special_lj[4], special_coul[4];
@@ -188,7 +218,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
                                                         const long long *__restrict__ first,
                                                         const int *__restrict__ neigh, const double *__restrict__ x,
                                                         const double *__restrict__ q, const int *__restrict__ type,
-                                                        double *__restrict__ f, Scal *scal) {
+                                                        double *__restrict__ f, double *__restrict__ slots) {
   const double EWALD_F = 1.12837917, EWALD_P = 0.3275911, A1 = 0.254829592, A2 = -0.284496736, A3 = 1.421413741,
                A4 = -1.453152027, A5 = 1.061405429;  // PS.cpp:43-49
   const int lane = threadIdx.x & 63;
@@ -242,13 +272,14 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
       }
       const double fpair = (forcecoul + factor_lj * forcelj) * r2inv;
       fx += delx * fpair; fy += dely * fpair; fz += delz * fpair;
-      if (P.newton_pair || j < P.nlocal) {
+      if (!P.full_list && (P.newton_pair || j < P.nlocal)) {
         atomicAdd(&f[3 * j], -delx * fpair);
         atomicAdd(&f[3 * j + 1], -dely * fpair);
         atomicAdd(&f[3 * j + 2], -delz * fpair);
       }
       double wgt = 1.0;  // ev_tally, src/pair.cpp:854-950
-      if (!P.newton_pair) wgt = 0.5 * ((i < P.nlocal) + (j < P.nlocal));
+      if (P.full_list) wgt = 0.5;  // ev_tally_full, src/pair.cpp:957-995
+      else if (!P.newton_pair) wgt = 0.5 * ((i < P.nlocal) + (j < P.nlocal));
       if (EFLAG) {
         if (rsq < P.cut_coulsq) {
           double ecoul;
@@ -271,13 +302,13 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
   }
   if (EFLAG) {
     ev = wave_sum(ev); ec = wave_sum(ec);
-    if (lane == 0) { atomicAdd(&scal->eng_vdwl, ev); atomicAdd(&scal->eng_coul, ec); }
+    if (lane == 0) { atomicAdd(slot_ptr(slots, SL_EVDWL), ev); atomicAdd(slot_ptr(slots, SL_ECOUL), ec); }
   }
   if (VPAIR) {
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
     if (lane == 0) {
-      atomicAdd(&scal->virial[0], v0); atomicAdd(&scal->virial[1], v1); atomicAdd(&scal->virial[2], v2);
-      atomicAdd(&scal->virial[3], v3); atomicAdd(&scal->virial[4], v4); atomicAdd(&scal->virial[5], v5);
+      atomicAdd(slot_ptr(slots, SL_V0), v0); atomicAdd(slot_ptr(slots, SL_V1), v1); atomicAdd(slot_ptr(slots, SL_V2), v2);
+      atomicAdd(slot_ptr(slots, SL_V3), v3); atomicAdd(slot_ptr(slots, SL_V4), v4); atomicAdd(slot_ptr(slots, SL_V5), v5);
     }
   }
 }
@@ -287,7 +318,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
 // (PS.cpp:363-386).  Full-row evaluation: E_i = sum_j ef_temp * q_j * del_ij, which is the
 // reference's i<j scatter seen from row i (del is antisymmetric under the image rule).
 template <bool ALLPAIRS>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(int nlocal, const AtomRec *__restrict__ rec,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(int row0, int nrows, int nlocal,
+                                                              const AtomRec *__restrict__ rec,
                                                               const int *__restrict__ mol, Box box,
                                                               const long long *__restrict__ nl_first,
                                                               const int *__restrict__ nl_j, double cut_coulsq,
@@ -295,8 +327,9 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(int nlocal, const 
                                                               double *__restrict__ ef, AtomRec *__restrict__ rec0,
                                                               AtomRec *__restrict__ rec1) {
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (i >= nlocal) return;
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = row0 + row;
   const AtomRec ri = rec[i];
   const int mi = mol[i];
   const double f_shift = -1.0 / cut_coulsq;
@@ -308,7 +341,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(int nlocal, const 
     if (j == i) continue;
     const AtomRec rj = rec[j];
     double dx, dy, dz;
-    min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+    pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
     const double rsq = dx * dx + dy * dy + dz * dz;
     if (rsq <= cut_coulsq && ((mi != mol[j]) || mi == 0)) {  // note <=, PS.cpp:342
       const double rinv = rsqrt(rsq);
@@ -342,17 +375,18 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(int nlocal, const 
 enum { EP_JACOBI = 0, EP_INPLACE = 1, EP_FIELD = 2 };
 
 template <bool ALLPAIRS, int DAMP, int EP>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__restrict__ rows, int nlocal,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_field(int row0, int nrows, const int *__restrict__ rows, int nlocal,
                                                        AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, Box box,
                                                        const long long *__restrict__ dd_first,
-                                                       const int *__restrict__ dd_j, double ddcutsq, double pd,
+                                                       const int *__restrict__ dd_j,
+                                                       const double2 *__restrict__ dd_s, double ddcutsq, double pd,
                                                        const double *__restrict__ ef, double *__restrict__ Fout,
-                                                       Scal *scal) {
+                                                       const Scal *scal, double *__restrict__ slots) {
   if (scal->done) return;  // device-resident loop control: finished solves turn later launches into no-ops
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
-  const int i = rows ? rows[row] : row;
+  const int i = rows ? rows[row] : row0 + row;
   const int cur = scal->cur;
   const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
   AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
@@ -361,14 +395,14 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__r
   if (ri.a != 0.0 || EP == EP_FIELD) {
     long long beg = 0, end = nlocal;
     if (!ALLPAIRS) { beg = dd_first[i]; end = dd_first[i + 1]; }
-    for (long long p = beg + lane; p < end; p += 64) {
-      const int j = ALLPAIRS ? (int)p : dd_j[p];
-      if (j == i) continue;
-      const AtomRec rj = src[j];
-      double dx, dy, dz;
-      min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
-      const double r2 = dx * dx + dy * dy + dz * dz;
-      if (ALLPAIRS || r2 < ddcutsq) {
+    if (ALLPAIRS) {
+      for (long long p = beg + lane; p < end; p += 64) {
+        const int j = (int)p;
+        if (j == i) continue;
+        const AtomRec rj = src[j];
+        double dx, dy, dz;
+        min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+        const double r2 = dx * dx + dy * dy + dz * dz;
         double s3, s5;
         tensor_scalars<DAMP>(r2, pd, s3, s5);
         const double md = rj.mx * dx + rj.my * dy + rj.mz * dz;
@@ -376,6 +410,21 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__r
         fx -= s3 * rj.mx - c * dx;
         fy -= s3 * rj.my - c * dy;
         fz -= s3 * rj.mz - c * dz;
+      }
+    } else {
+      // list mode: the damped tensor scalars (s3, s5) were cached per pair by k_dd_scalars, so a
+      // sweep streams 20 B per pair (int32 j + two doubles) and gathers one 64-B record
+      for (long long p = beg + lane; p < end; p += 64) {
+        const int j = dd_j[p];
+        const double2 sc = dd_s[p];
+        const AtomRec rj = src[j];
+        double dx, dy, dz;
+        min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+        const double md = rj.mx * dx + rj.my * dy + rj.mz * dz;
+        const double c = sc.y * md;
+        fx -= sc.x * rj.mx - c * dx;
+        fy -= sc.x * rj.my - c * dy;
+        fz -= sc.x * rj.mz - c * dz;
       }
     }
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
@@ -389,8 +438,31 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__r
       const double ddx = mx - ri.mx, ddy = my - ri.my, ddz = mz - ri.mz;
       dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz;
       const double c = ddx * ddx + ddy * ddy + ddz * ddz;
-      if (c != 0.0) atomicAdd(&scal->change, c);
+      if (c != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), c);
     }
+  }
+}
+
+// a6 for the list path: the damped tensor scalars of every listed pair, once per step
+// (the sparse, matrix-free-storage analog of build_dipole_field_matrix, PS.cpp:1273-1306).
+template <int DAMP>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(int row0, int nrows, const AtomRec *__restrict__ rec, Box box,
+                                                            const long long *__restrict__ dd_first,
+                                                            const int *__restrict__ dd_j, double pd,
+                                                            double2 *__restrict__ dd_s) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = row0 + row;
+  const double xi = rec[i].x, yi = rec[i].y, zi = rec[i].z;
+  const long long beg = dd_first[i], end = dd_first[i + 1];
+  for (long long p = beg + lane; p < end; p += 64) {
+    const int j = dd_j[p];
+    double dx, dy, dz;
+    min_image_rint(box, xi, yi, zi, rec[j].x, rec[j].y, rec[j].z, dx, dy, dz);
+    double s3, s5;
+    tensor_scalars<DAMP>(dx * dx + dy * dy + dz * dz, pd, s3, s5);
+    dd_s[p] = make_double2(s3, s5);
   }
 }
 
@@ -408,7 +480,8 @@ template <int DAMP>
 __global__ __launch_bounds__(64) void k_gs_block_seq(int nlocal, int b0, const int *__restrict__ order,
                                                      AtomRec *__restrict__ rec, Box box, double pd,
                                                      const double *__restrict__ ef, double *__restrict__ F,
-                                                     double *__restrict__ dmu_blk, Scal *scal) {
+                                                     double *__restrict__ dmu_blk, const Scal *scal,
+                                                     double *__restrict__ slots) {
   if (scal->done) return;
   const int lane = threadIdx.x;
   const int cnt = min(64, nlocal - b0);
@@ -445,7 +518,7 @@ __global__ __launch_bounds__(64) void k_gs_block_seq(int nlocal, int b0, const i
     dmu_blk[3 * lane] = tx; dmu_blk[3 * lane + 1] = ty; dmu_blk[3 * lane + 2] = tz;
   }
   dsq = wave_sum(dsq);
-  if (lane == 0 && dsq != 0.0) atomicAdd(&scal->change, dsq);
+  if (lane == 0 && dsq != 0.0) atomicAdd(slots + (size_t)((b0 >> 6) & (POLAR_NSLOT - 1)) * POLAR_SLOT_STRIDE + SL_CHANGE, dsq);
 }
 
 template <int DAMP>
@@ -485,12 +558,23 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_gs_block_push(int nlocal, int b
 // ------------------------------------------------------------------------------------------
 // a7 loop control, one thread: the reference's end-of-sweep logic (PS.cpp:1193-1236) kept on the
 // device so the host never has to look at ||dmu||^2 between sweeps.
-__global__ void k_solver_step(Scal *scal, int nlocal, int fixed_iteration, int iterations_max, double precision,
-                              int jacobi) {
+__global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double *__restrict__ slots, int nlocal,
+                                                           int fixed_iteration, int iterations_max, double precision,
+                                                           int jacobi, const double *__restrict__ global_change) {
   if (scal->done) return;
-  const double change = scal->change / ((double)nlocal * 3.0);
+  __shared__ double red[POLAR_NSLOT / 64];
+  double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
+  slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE] = 0.0;
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double sum = 0.0;
+  for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+  scal->change = sum;  // this handle's own sum (exported to the all-reduce in multi-GPU runs)
+  // multi-GPU: the all-reduced sum over ranks arrives through global_change (device memory)
+  const double change = (global_change ? *global_change : sum) / ((double)nlocal * 3.0);
   scal->last_change = change;
-  scal->change = 0.0;
   scal->sweeps += 1;
   int keep = 1;
   if (!fixed_iteration) keep = change > precision * precision;
@@ -499,6 +583,61 @@ __global__ void k_solver_step(Scal *scal, int nlocal, int fixed_iteration, int i
   scal->iterations += 1;
   if (scal->iterations > iterations_max) { scal->status = 1; scal->done = 1; return; }
   if (!keep) scal->done = 1;
+}
+
+// fold the change slots into scal->change without touching the loop state (multi-GPU export)
+__global__ __launch_bounds__(POLAR_NSLOT) void k_fold_change(Scal *scal, double *__restrict__ slots, double *dst) {
+  __shared__ double red[POLAR_NSLOT / 64];
+  double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
+  slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE] = 0.0;
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double sum = 0.0;
+  for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+  scal->change = sum;
+  *dst = sum;
+}
+
+// fold energies / virial / rmin slots into the Scal block (run before the host reads it)
+__global__ __launch_bounds__(POLAR_NSLOT) void k_fold_scal(Scal *scal, double *__restrict__ slots, int rmin_only) {
+  __shared__ double red[POLAR_NSLOT / 64];
+  const int t = threadIdx.x;
+  {
+    unsigned long long b = ((unsigned long long *)slots)[(size_t)t * POLAR_SLOT_STRIDE + SL_RMIN];
+    double r = __longlong_as_double((long long)b);
+    r = wave_min(r);
+    if ((t & 63) == 0) red[t >> 6] = r;
+    __syncthreads();
+    if (t == 0) {
+      double m = red[0];
+      for (int k = 1; k < POLAR_NSLOT / 64; k++) m = fmin(m, red[k]);
+      scal->rmin_bits = (unsigned long long)__double_as_longlong(m);
+    }
+    __syncthreads();
+  }
+  if (rmin_only) return;
+  for (int f = SL_EVDWL; f <= SL_V5; f++) {
+    double v = slots[(size_t)t * POLAR_SLOT_STRIDE + f];
+    v = wave_sum(v);
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) {
+      double sum = 0.0;
+      for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+      double *dst = f == SL_EVDWL ? &scal->eng_vdwl : f == SL_ECOUL ? &scal->eng_coul : f == SL_USELF ? &scal->u_self
+                  : f == SL_UEF ? &scal->u_ef : f == SL_UDD ? &scal->u_dd : &scal->virial[f - SL_V0];
+      *dst = sum;
+    }
+    __syncthreads();
+  }
+}
+__global__ void k_zero_slots(double *__restrict__ slots) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= POLAR_NSLOT) return;
+  for (int f = 0; f < POLAR_SLOT_STRIDE; f++) slots[(size_t)t * POLAR_SLOT_STRIDE + f] = 0.0;
+  ((unsigned long long *)slots)[(size_t)t * POLAR_SLOT_STRIDE + SL_RMIN] = (unsigned long long)__double_as_longlong(1000.0);
 }
 
 // divergence fallback mu = alpha * E (no gamma), PS.cpp:1227-1235
@@ -526,17 +665,18 @@ __global__ void k_unpack_mu(int n, const Scal *scal, const AtomRec *__restrict__
 // The pair force is antisymmetric, so summing rows reproduces the reference's i<j scatter;
 // pair energies are counted from both rows and halved.
 template <bool ALLPAIRS, int DAMP, bool EFLAG, bool VPAIR>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(int nlocal, const Scal *scal_in,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(int row0, int nrows, int nlocal, const Scal *scal_in,
                                                              const AtomRec *__restrict__ recA,
                                                              const AtomRec *__restrict__ recB,
                                                              const int *__restrict__ mol, Box box,
                                                              const long long *__restrict__ nl_first,
                                                              const int *__restrict__ nl_j, double cut_coulsq,
                                                              double ddcutsq, double pd, double e2s,
-                                                             double *__restrict__ f, Scal *scal) {
+                                                             double *__restrict__ f, double *__restrict__ slots) {
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (i >= nlocal) return;
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = row0 + row;
   const AtomRec *__restrict__ rec = scal_in->cur ? recB : recA;
   const AtomRec ri = rec[i];
   const int mi = mol[i];
@@ -550,7 +690,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(int nlocal, const S
     if (j == i) continue;
     const AtomRec rj = rec[j];
     double dx, dy, dz;
-    min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+    pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
     const double xsq = dx * dx, ysq = dy * dy, zsq = dz * dz;
     const double rsq = xsq + ysq + zsq;
     const double rinv = rsqrt(rsq);
@@ -622,23 +762,23 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(int nlocal, const S
   if (EFLAG) {
     uef = wave_sum(uef); udd = wave_sum(udd);
     if (lane == 0) {
-      if (ri.a != 0.0) atomicAdd(&scal->u_self, 0.5 * (ri.mx * ri.mx + ri.my * ri.my + ri.mz * ri.mz) / ri.a);
-      atomicAdd(&scal->u_ef, 0.5 * uef);
-      atomicAdd(&scal->u_dd, 0.5 * udd);
+      if (ri.a != 0.0) atomicAdd(slot_ptr(slots, SL_USELF), 0.5 * (ri.mx * ri.mx + ri.my * ri.my + ri.mz * ri.mz) / ri.a);
+      atomicAdd(slot_ptr(slots, SL_UEF), 0.5 * uef);
+      atomicAdd(slot_ptr(slots, SL_UDD), 0.5 * udd);
     }
   }
   if (VPAIR) {
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
     if (lane == 0) {
-      atomicAdd(&scal->virial[0], v0); atomicAdd(&scal->virial[1], v1); atomicAdd(&scal->virial[2], v2);
-      atomicAdd(&scal->virial[3], v3); atomicAdd(&scal->virial[4], v4); atomicAdd(&scal->virial[5], v5);
+      atomicAdd(slot_ptr(slots, SL_V0), v0); atomicAdd(slot_ptr(slots, SL_V1), v1); atomicAdd(slot_ptr(slots, SL_V2), v2);
+      atomicAdd(slot_ptr(slots, SL_V3), v3); atomicAdd(slot_ptr(slots, SL_V4), v4); atomicAdd(slot_ptr(slots, SL_V5), v5);
     }
   }
 }
 
 // a10  virial_fdotr_compute, src/pair.cpp:1495-1540: sum over locals AND ghosts of f_i x_i
 __global__ __launch_bounds__(POLAR_BLOCK) void k_virial_fdotr(int nall, const double *__restrict__ x,
-                                                              const double *__restrict__ f, Scal *scal) {
+                                                              const double *__restrict__ f, double *__restrict__ slots) {
   double v[6] = {0, 0, 0, 0, 0, 0};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nall; i += gridDim.x * blockDim.x) {
     const double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
@@ -649,7 +789,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_virial_fdotr(int nall, const do
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     double s = wave_sum(v[k]);
-    if (lane == 0 && s != 0.0) atomicAdd(&scal->virial[k], s);
+    if (lane == 0 && s != 0.0) atomicAdd(slot_ptr(slots, SL_V0 + k), s);
   }
 }
 
@@ -730,7 +870,7 @@ __global__ void k_cell_sort(int ncell, const long long *__restrict__ cell_first,
 //   nl : every j with rsq <= cutallsq                      (static field, forces, rank metric)
 //   dd : alpha_i != 0, alpha_j != 0 and rsq < ddcutsq      (the dipole sweep stream)
 template <int PASS>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int nlocal, const AtomRec *__restrict__ rec, Box box,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int row0, int nrows, const AtomRec *__restrict__ rec, Box box,
                                                           CellGrid g, const int *__restrict__ cell_id,
                                                           const long long *__restrict__ cell_first,
                                                           const int *__restrict__ cell_atoms, double cutallsq,
@@ -740,8 +880,9 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int nlocal, const Atom
                                                           const long long *__restrict__ dd_first,
                                                           int *__restrict__ nl_j, int *__restrict__ dd_j) {
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (i >= nlocal) return;
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = row0 + row;
   const AtomRec ri = rec[i];
   const int ci = cell_id[i];
   const int c0 = ci % g.nc[0], c1 = (ci / g.nc[0]) % g.nc[1], c2 = ci / (g.nc[0] * g.nc[1]);
@@ -767,7 +908,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int nlocal, const Atom
             if (j != i) {
               const AtomRec rj = rec[j];
               double ex, ey, ez;
-              min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
+              min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
               const double rsq = ex * ex + ey * ey + ez * ez;
               in_nl = rsq <= cutallsq;
               in_dd = (ri.a != 0.0) && (rj.a != 0.0) && (rsq < ddcutsq);
@@ -787,6 +928,22 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int nlocal, const Atom
         }
       }
   if (PASS == 0 && lane == 0) { nl_cnt[i] = ncount; dd_cnt[i] = dcount; }
+}
+
+// multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers
+__global__ void k_mu_gather(long long lo, long long hi, const Scal *scal, const AtomRec *__restrict__ recA,
+                            const AtomRec *__restrict__ recB, double *__restrict__ dst) {
+  long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  const AtomRec *r = scal->cur ? recB : recA;
+  dst[3 * (i - lo)] = r[i].mx; dst[3 * (i - lo) + 1] = r[i].my; dst[3 * (i - lo) + 2] = r[i].mz;
+}
+__global__ void k_mu_scatter(long long lo, long long hi, const Scal *scal, AtomRec *__restrict__ recA,
+                             AtomRec *__restrict__ recB, const double *__restrict__ src) {
+  long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  AtomRec *r = scal->cur ? recB : recA;
+  r[i].mx = src[3 * (i - lo)]; r[i].my = src[3 * (i - lo) + 1]; r[i].mz = src[3 * (i - lo) + 2];
 }
 
 // small utilities

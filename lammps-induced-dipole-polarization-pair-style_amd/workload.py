@@ -147,12 +147,13 @@ def build_ghosts(x, boxlo, prd, cutghost):
 
 
 def build_half_list(x_all, owner, shift, nlocal, cutneigh, molecule=None, special=None,
-                    exclude_intra=False, rows=None):
+                    exclude_intra=False, rows=None, full=False):
     """Half neighbor list with newton on: every (atom, image) pair within ``cutneigh``
     is stored exactly once, in the list of a LOCAL atom i; j may be a ghost index.
     Special pairs keep their 2-bit code in bits 30-31 (kspace styles keep them in the
     list, reference: src/neighbor.cpp special_flag=2 with a KSpace style).
-    ``rows``: optional subset of local atoms that own lists (multi-GPU shards)."""
+    ``rows``: optional subset of local atoms that own lists (multi-GPU shards).
+    ``full``: LAMMPS *full* list instead (every pair in the rows of both atoms; newton off)."""
     from scipy.spatial import cKDTree
 
     tree = cKDTree(x_all)
@@ -173,10 +174,8 @@ def build_half_list(x_all, owner, shift, nlocal, cutneigh, molecule=None, specia
         lex = (sj[:, 0] > 0) | ((sj[:, 0] == 0) & (sj[:, 1] > 0)) | (
             (sj[:, 0] == 0) & (sj[:, 1] == 0) & (sj[:, 2] > 0))
         keep = np.where(is_local, j > i_rep, (oj > i_rep) | ((oj == i_rep) & lex))
-        if rows is not None:
-            # shard mode: partner rows may live on another shard -> keep pair if i is the
-            # smaller owner OR the partner's owner is not one of our rows (handled by caller)
-            pass
+        if full:
+            keep = j != i_rep
         if exclude_intra and molecule is not None:
             keep &= molecule[i_rep] != molecule[oj]
         i_rep, j, oj = i_rep[keep], j[keep], oj[keep]
@@ -373,7 +372,7 @@ class PolarSystem:
 
 def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings, g_ewald,
                 bonds=None, exclude_intra=False, skin=2.0, ncoultablebits=12, name="",
-                special_lj=(1.0, 0.0, 0.0, 0.0), special_coul=(1.0, 0.0, 0.0, 0.0)):
+                special_lj=(1.0, 0.0, 0.0, 0.0), special_coul=(1.0, 0.0, 0.0, 0.0), rows=None, full=False):
     """Assemble ghosts, the half list, LJ tables and Coulomb tables for one frame."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     n = len(x)
@@ -384,7 +383,7 @@ def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings,
     special = build_special(n, bonds) if bonds is not None and len(bonds) else None
     ilist, numneigh, first, neigh = build_half_list(
         x_all, owner, shift, n, cutneigh, molecule=np.asarray(mol), special=special,
-        exclude_intra=exclude_intra)
+        exclude_intra=exclude_intra, rows=rows, full=full)
     coul = init_coul_tables(settings.cut_coul, g_ewald, QQR2E_REAL, ncoultablebits) if ncoultablebits else dict(
         nbits=0, mask=0, shift=0, tabinnersq=0.0, tables=np.zeros((8, 1)))
     g = lambda a, dt: np.ascontiguousarray(np.asarray(a)[owner], dtype=dt)
@@ -538,7 +537,7 @@ def load_fixture(path, extra_args=(), g_ewald=None, ncoultablebits=12):
     return sysm, meta
 
 
-def replicate_fixture(path, nx, ny, nz, extra_args=(), g_ewald=None, skin=2.0):
+def replicate_fixture(path, nx, ny, nz, extra_args=(), g_ewald=None, skin=2.0, rows=None, full=False):
     """``replicate nx ny nz`` of a golden fixture (BASELINE configs[1..4] are replicated boxes).
     Follows LAMMPS' replicate semantics: molecule ids are offset per replica (so framework
     replicas no longer exclude each other, SURVEY.md 8(d) caveat); bonds are not replicated
@@ -553,19 +552,19 @@ def replicate_fixture(path, nx, ny, nz, extra_args=(), g_ewald=None, skin=2.0):
     molmax = int(z["molecule"].max())
     xs, mols = [], []
     r = 0
-    for ix in range(nx):
+    for iz in range(nz):          # z outermost: contiguous index ranges are z slabs
         for iy in range(ny):
-            for iz in range(nz):
+            for ix in range(nx):
                 xs.append(x0 + np.array([ix, iy, iz]) * prd0)
                 mols.append(z["molecule"] + r * molmax)
                 r += 1
     nrep = nx * ny * nz
     x = np.concatenate(xs)
-    rows = [[str(int(c[0])), str(int(c[1])), repr(float(c[2])), repr(float(c[3])), repr(float(c[4]))]
-            for c in z["pair_coeff"]]
+    coeff_rows = [[str(int(c[0])), str(int(c[1])), repr(float(c[2])), repr(float(c[3])), repr(float(c[4]))]
+                  for c in z["pair_coeff"]]
     prd = prd0 * np.array([nx, ny, nz])
     q = np.tile(z["q"], nrep)
     g = ewald_g(1.0e-4, q, st.cut_coul, prd) if g_ewald is None else g_ewald
     return make_system(x, q, np.tile(z["alpha"], nrep), np.tile(z["type"], nrep), np.concatenate(mols),
-                       z["boxlo"], prd, meta["ntypes"], rows, st, g, bonds=None, exclude_intra=True, skin=skin,
-                       name=f"{meta['name']}_rep{nx}x{ny}x{nz}")
+                       z["boxlo"], prd, meta["ntypes"], coeff_rows, st, g, bonds=None, exclude_intra=True, skin=skin,
+                       name=f"{meta['name']}_rep{nx}x{ny}x{nz}", rows=rows, full=full)
