@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reps", type=int, nargs=3, default=[3, 3, 3], help="replication of the 1349-atom cell per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra", nargs="*", default=[], help="extra pair_style keywords (experiments)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,7 +80,7 @@ def main():
         return par.bench_distributed(args, rank, world, local_rank)
 
     torch.cuda.set_device(0)
-    s = build_workload(wl, tuple(args.reps))
+    s = build_workload(wl, tuple(args.reps), args.extra)
     p = pkg.pair_from_system(s, device=0)
 
     for _ in range(args.warmup):

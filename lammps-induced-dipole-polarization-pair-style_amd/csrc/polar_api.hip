@@ -77,12 +77,17 @@ struct polar_handle {
   // device state
   DBuf<double> d_x, d_q, d_alpha, d_f, d_ef, d_F, d_mu, d_rank, d_dmu, d_tab, d_lj;
   DBuf<int> d_type, d_mol, d_order, d_pos, d_ilist, d_numneigh, d_neigh, d_rows;
+  DBuf<int> d_mol_s, d_perm, d_inv, d_rows_orig, d_ownrows;  // s-space bookkeeping (see polar_kernels.hpp)
+  DBuf<double> d_ef_s;
+  CellGrid grid{};
+  long long ncell = 0;
+  bool sorted = false;  // true while the records are in cell order (list mode)
   DBuf<long long> d_first;
   DBuf<AtomRec> d_rec0, d_rec1;
   DBuf<Scal> d_scal;
   DBuf<double> d_slots;
   // cutoff-mode lists
-  DBuf<int> d_cell_id, d_cell_cnt, d_cell_fill, d_cell_atoms, d_nl_cnt, d_dd_cnt, d_nl_j, d_dd_j;
+  DBuf<int> d_cell_id, d_cell_cnt, d_cell_fill, d_nl_cnt, d_dd_cnt, d_nl_j, d_dd_j;
   DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
   DBuf<double2> d_dd_s;
   long long nl_pairs = 0, dd_pairs = 0;
@@ -155,15 +160,21 @@ void upload_coul(polar_handle *h, double g_ewald, double qqrd2e, const double *s
   h->coul_set = true;
 }
 
-// ---- cutoff-mode list build on the device -------------------------------------------------
-void build_lists(polar_handle *h) {
+// ---- cutoff-mode: cell sort (perm/inv), then CSR lists in s space, all on the device ----------
+inline int own_lo(const polar_handle *h) { return h->row_lo; }
+inline int own_n(const polar_handle *h) { return (h->row_hi < 0 ? h->nlocal : h->row_hi) - h->row_lo; }
+inline bool sharded(const polar_handle *h) { return own_n(h) != h->nlocal; }
+// rows a per-row kernel should visit: nullptr = all rows 0..n-1 (identity)
+inline const int *own_rows(const polar_handle *h) { return (h->sorted && sharded(h)) ? h->d_ownrows.p : nullptr; }
+
+void build_cells(polar_handle *h) {
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
   const double cutall = std::max(st.cut_coul, st.dd_cutoff);
   for (int k = 0; k < 3; k++)
     if (h->box.periodic[k] && h->box.prd[k] < 2.0 * cutall * (1.0 - 1e-12))
       throw InputError("dd_cutoff mode needs box lengths >= 2*max(cut_coul,dd_cutoff); use exact mode (dd_cutoff 0)");
-  CellGrid g;
+  CellGrid &g = h->grid;
   long long ncell = 1;
   for (int k = 0; k < 3; k++) {
     g.nc[k] = std::max(1, (int)std::floor(h->box.prd[k] / cutall));
@@ -171,23 +182,37 @@ void build_lists(polar_handle *h) {
     g.inv[k] = g.nc[k] / h->box.prd[k];
     ncell *= g.nc[k];
   }
+  h->ncell = ncell;
   hipStream_t s = h->stream;
   h->d_cell_id.ensure(n); h->d_cell_cnt.ensure(ncell + 1); h->d_cell_fill.ensure(ncell + 1);
-  h->d_cell_first.ensure(ncell + 2); h->d_cell_atoms.ensure(n);
+  h->d_cell_first.ensure(ncell + 2); h->d_perm.ensure(n + 1); h->d_inv.ensure(n + 1);
   HIPCHECK(hipMemsetAsync(h->d_cell_cnt.p, 0, (ncell + 1) * sizeof(int), s));
   HIPCHECK(hipMemsetAsync(h->d_cell_fill.p, 0, (ncell + 1) * sizeof(int), s));
   k_cell_count<<<nblk(n, 256), 256, 0, s>>>(n, h->d_x.p, g, h->box, h->d_cell_id.p, h->d_cell_cnt.p);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>(ncell, h->d_cell_cnt.p, h->d_cell_first.p);
-  k_cell_fill<<<nblk(n, 256), 256, 0, s>>>(n, (int)ncell, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_fill.p,
-                                           h->d_cell_atoms.p);
+  k_cell_fill<<<nblk(n, 256), 256, 0, s>>>(n, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_fill.p, h->d_perm.p, h->d_inv.p);
+  h->sorted = true;
+  if (sharded(h)) {
+    h->d_ownrows.ensure(own_n(h) + 1);
+    k_map_range<<<nblk(own_n(h), 256), 256, 0, s>>>(own_lo(h), own_n(h), h->d_inv.p, h->d_ownrows.p);
+  }
+}
+
+void build_lists(polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  const int n = h->nlocal;
+  const double cutall = std::max(st.cut_coul, st.dd_cutoff);
+  hipStream_t s = h->stream;
+  const CellGrid &g = h->grid;
   h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1); h->d_nl_first.ensure(n + 2); h->d_dd_first.ensure(n + 2);
   const double cutallsq = cutall * cutall, ddsq = st.dd_cutoff * st.dd_cutoff;
-  const int r0 = h->row_lo, nr = (h->row_hi < 0 ? n : h->row_hi) - h->row_lo;
+  const int nr = own_n(h);
+  const int *rows = own_rows(h);
   HIPCHECK(hipMemsetAsync(h->d_nl_cnt.p, 0, (n + 1) * sizeof(int), s));
   HIPCHECK(hipMemsetAsync(h->d_dd_cnt.p, 0, (n + 1) * sizeof(int), s));
   k_nl_build<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
-      r0, nr, h->d_rec0.p, h->box, g, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_atoms.p, cutallsq, ddsq, h->d_nl_cnt.p,
-      h->d_dd_cnt.p, nullptr, nullptr, nullptr, nullptr);
+      rows, nr, h->d_rec0.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->d_nl_cnt.p, h->d_dd_cnt.p, nullptr,
+      nullptr, nullptr, nullptr);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>(n, h->d_nl_cnt.p, h->d_nl_first.p);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>(n, h->d_dd_cnt.p, h->d_dd_first.p);
   long long tot[2];
@@ -197,13 +222,13 @@ void build_lists(polar_handle *h) {
   h->nl_pairs = tot[0]; h->dd_pairs = tot[1];
   h->d_nl_j.ensure((size_t)tot[0] + 64); h->d_dd_j.ensure((size_t)tot[1] + 64);
   k_nl_build<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
-      r0, nr, h->d_rec0.p, h->box, g, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_atoms.p, cutallsq, ddsq, nullptr, nullptr,
-      h->d_nl_first.p, h->d_dd_first.p, h->d_nl_j.p, h->d_dd_j.p);
+      rows, nr, h->d_rec0.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, nullptr, nullptr, h->d_nl_first.p,
+      h->d_dd_first.p, h->d_nl_j.p, h->d_dd_j.p);
   h->d_dd_s.ensure((size_t)tot[1] + 64);
   if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
-    k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(r0, nr, h->d_rec0.p, h->box, h->d_dd_first.p, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
+    k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, h->d_dd_first.p, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
   else
-    k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(r0, nr, h->d_rec0.p, h->box, h->d_dd_first.p, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
+    k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, h->d_dd_first.p, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
 }
 
 // ---- host-side greedy distance colouring for the colour-phase Gauss-Seidel (cutoff mode) ----
@@ -262,16 +287,28 @@ void build_colors(polar_handle *h, const std::vector<int> &visit) {
   std::vector<int> rows;
   rows.reserve(n);
   h->color_off.assign((size_t)ncolors + 1, 0);
+  // the colouring is global (every rank computes the same one); a sharded handle keeps only its rows
+  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
+  auto mine = [&](int i) { return color[i] >= 0 && i >= lo && i < hi; };
   for (int i = 0; i < n; i++)
-    if (color[i] >= 0) h->color_off[color[i] + 1]++;
+    if (mine(i)) h->color_off[color[i] + 1]++;
   for (int c = 0; c < ncolors; c++) h->color_off[c + 1] += h->color_off[c];
   rows.resize((size_t)h->color_off[ncolors]);
   std::vector<int> fill(h->color_off.begin(), h->color_off.end() - 1);
-  for (int i = 0; i < n; i++)
-    if (color[i] >= 0) rows[fill[color[i]]++] = i;
+  // inside a colour, keep the rows in cell order of the colouring grid: neighbouring waves of a
+  // phase then work on neighbouring atoms (shared records in L1/L2)
+  for (auto &cell : cells)
+    for (int i : cell)
+      if (mine(i)) rows[fill[color[i]]++] = i;
   h->h_rows = rows;
+  h->d_rows_orig.ensure(rows.size() + 1);
   h->d_rows.ensure(rows.size() + 1);
-  if (!rows.empty()) HIPCHECK(hipMemcpy(h->d_rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!rows.empty()) HIPCHECK(hipMemcpy(h->d_rows_orig.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (getenv("POLAR_DEBUG")) {
+    fprintf(stderr, "[polar] %d colour phases (dist %.2f):", ncolors, h->color_dist);
+    for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
+    fprintf(stderr, "\n");
+  }
   h->colors_valid = true;
 }
 
@@ -282,41 +319,36 @@ void launch_rank(polar_handle *h, int pass) {
   if (pass == 2) k_fold_scal<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, 1);
   if (pass == 1)
     k_rank<AP, 1><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, h->d_nl_first.p,
-                                                 h->d_nl_j.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
+                                                 h->d_nl_j.p, h->d_rec0.p, h->d_mol_s.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
   else
     k_rank<AP, 2><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, h->d_nl_first.p,
-                                                 h->d_nl_j.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
+                                                 h->d_nl_j.p, h->d_rec0.p, h->d_mol_s.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
 }
 
 template <bool AP, int DAMP, int EP>
-void launch_field(polar_handle *h, int row0, int nrows, const int *rows) {
+void launch_field(polar_handle *h, int nrows, const int *rows) {
   const polar_settings &st = h->ph.st;
   if (nrows <= 0) return;
   k_field<AP, DAMP, EP><<<nblk(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(
-      row0, nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, h->d_dd_first.p, h->d_dd_j.p, h->d_dd_s.p,
-      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_scal.p, h->d_slots.p);
+      nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, h->d_dd_first.p, h->d_dd_j.p, h->d_dd_s.p,
+      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_scal.p, h->d_slots.p);
 }
 template <int EP>
-void launch_field_dyn(polar_handle *h, bool ap, int row0, int nrows, const int *rows) {
+void launch_field_dyn(polar_handle *h, bool ap, int nrows, const int *rows) {
   const bool expd = h->ph.st.damping_type == POLAR_DAMP_EXPONENTIAL;
-  if (ap) { if (expd) launch_field<true, 0, EP>(h, row0, nrows, rows); else launch_field<true, 1, EP>(h, row0, nrows, rows); }
-  else    { if (expd) launch_field<false, 0, EP>(h, row0, nrows, rows); else launch_field<false, 1, EP>(h, row0, nrows, rows); }
+  if (ap) { if (expd) launch_field<true, 0, EP>(h, nrows, rows); else launch_field<true, 1, EP>(h, nrows, rows); }
+  else    { if (expd) launch_field<false, 0, EP>(h, nrows, rows); else launch_field<false, 1, EP>(h, nrows, rows); }
 }
-inline int own_lo(const polar_handle *h) { return h->row_lo; }
-inline int own_n(const polar_handle *h) { return (h->row_hi < 0 ? h->nlocal : h->row_hi) - h->row_lo; }
 
-// one sweep over the rows this handle owns (Jacobi, or the colour phases restricted to the range)
+// one sweep over the rows this handle owns (Jacobi, or the colour phases)
 void sweep_once(polar_handle *h, bool ap) {
   const polar_settings &st = h->ph.st;
   const bool gs = st.polar_gs || st.polar_gs_ranked;
-  if (!gs) { launch_field_dyn<EP_JACOBI>(h, ap, own_lo(h), own_n(h), nullptr); return; }
+  if (!gs) { launch_field_dyn<EP_JACOBI>(h, ap, own_n(h), own_rows(h)); return; }
   const int ncol = (int)h->color_off.size() - 1;
-  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
   for (int c = 0; c < ncol; c++) {
-    const int *b = h->h_rows.data() + h->color_off[c], *e = h->h_rows.data() + h->color_off[c + 1];
-    const int *bl = std::lower_bound(b, e, lo), *eh = std::lower_bound(b, e, hi);  // rows ascend inside a colour
-    const int cnt = (int)(eh - bl);
-    if (cnt > 0) launch_field_dyn<EP_INPLACE>(h, false, 0, cnt, h->d_rows.p + (bl - h->h_rows.data()));
+    const int cnt = h->color_off[c + 1] - h->color_off[c];
+    if (cnt > 0) launch_field_dyn<EP_INPLACE>(h, false, cnt, h->d_rows.p + h->color_off[c]);
   }
 }
 
@@ -326,8 +358,8 @@ void launch_force(polar_handle *h, int eflag, int vpair) {
   dim3 grid(nblk(own_n(h), POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
   const double ccs = st.cut_coul * st.cut_coul, dds = st.dd_cutoff * st.dd_cutoff, e2s = std::sqrt(h->P.qqrd2e);
 #define LF(E, V)                                                                                                    \
-  k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(own_lo(h), own_n(h), h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
-                                                               h->d_mol.p, h->box, h->d_nl_first.p, h->d_nl_j.p,  \
+  k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(own_rows(h), own_n(h), h->sorted ? h->d_perm.p : nullptr, h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
+                                                               h->d_mol_s.p, h->box, h->d_nl_first.p, h->d_nl_j.p,  \
                                                                ccs, dds, st.polar_damp, e2s, h->d_f.p, h->d_slots.p)
   if (eflag) { if (vpair) LF(true, true); else LF(true, false); }
   else       { if (vpair) LF(false, true); else LF(false, false); }
@@ -348,12 +380,20 @@ void ensure_colors(polar_handle *h) {
   std::iota(order.begin(), order.end(), 0);
   const bool sharded = own_n(h) != n;
   if (st.polar_gs_ranked && !sharded) {  // ranked visiting order (a sharded handle only knows its own rows' metric)
-    std::vector<double> rk(n);
-    HIPCHECK(hipMemcpyAsync(rk.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> rs(n), rk(n);
+    std::vector<int> perm(n);
+    HIPCHECK(hipMemcpyAsync(rs.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(perm.data(), h->d_perm.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n; k++) rk[perm[k]] = rs[k];  // rank metric was computed in s space
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rk[a] > rk[b]; });
   }
   build_colors(h, order);
+}
+// per step: the colour rows (orig ids) -> s space of this step's cell order
+void map_color_rows(polar_handle *h) {
+  const int tot = h->color_off.empty() ? 0 : h->color_off.back();
+  if (tot > 0) k_map_rows<<<nblk(tot, 256), 256, 0, h->stream>>>(tot, h->d_inv.p, h->d_rows_orig.p, h->d_rows.p);
 }
 
 void solve(polar_handle *h, bool ap, polar_result *out) {
@@ -367,7 +407,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
   out->ncolors = 0;
 
   if (!gs || !ap) {  // Jacobi (reference "polar_gs no") or colour-phase Gauss-Seidel over the dd list
-    if (gs) { ensure_colors(h); out->ncolors = (int)h->color_off.size() - 1; }
+    if (gs) { if (!h->colors_valid) { ensure_colors(h); map_color_rows(h); } out->ncolors = (int)h->color_off.size() - 1; }
     for (int sw = 0; sw < max_sweeps; sw++) {
       sweep_once(h, ap);
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr);
@@ -390,14 +430,14 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     HIPCHECK(hipMemcpyAsync(h->d_order.p, order.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(h->d_pos.p, pos.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHECK(hipStreamSynchronize(s));  // order/pos are stack vectors
-    launch_field_dyn<EP_FIELD>(h, true, 0, n, nullptr);
+    launch_field_dyn<EP_FIELD>(h, true, n, nullptr);
     for (int sw = 0; sw < max_sweeps; sw++) {
       for (int b0 = 0; b0 < n; b0 += 64) {
         if (expd) {
-          k_gs_block_seq<0><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
+          k_gs_block_seq<0><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
           k_gs_block_push<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_order.p, h->d_pos.p, h->d_rec0.p, h->box, st.polar_damp, h->d_dmu.p, h->d_F.p, h->d_scal.p);
         } else {
-          k_gs_block_seq<1><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
+          k_gs_block_seq<1><<<1, 64, 0, s>>>(n, b0, h->d_order.p, h->d_rec0.p, h->box, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
           k_gs_block_push<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_order.p, h->d_pos.p, h->d_rec0.p, h->box, st.polar_damp, h->d_dmu.p, h->d_F.p, h->d_scal.p);
         }
       }
@@ -426,6 +466,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
 
   h->d_f.ensure(3 * (size_t)nall); h->d_ef.ensure(3 * (size_t)n); h->d_F.ensure(3 * (size_t)n);
   h->d_mu.ensure(3 * (size_t)n); h->d_rank.ensure(n); h->d_rec0.ensure(n); h->d_rec1.ensure(n);
+  h->d_ef_s.ensure(3 * (size_t)n); h->d_mol_s.ensure(n + 1);
   HIPCHECK(hipEventRecord(h->ev[0], s));
   HIPCHECK(hipMemsetAsync(h->d_f.p, 0, 3 * (size_t)nall * sizeof(double), s));
   k_zero_scal<<<1, 1, 0, s>>>(h->d_scal.p, 0);
@@ -437,8 +478,14 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
       mu0 = h->d_mu.p;
     } else if (h->mu_resident) mu0 = h->d_mu.p;
   }
-  k_pack<<<nblk(n, 256), 256, 0, s>>>(n, h->d_x.p, h->d_q.p, h->d_alpha.p, mu0, h->d_rec0.p, h->d_rec1.p);
-  if (!ap) build_lists(h);
+  h->sorted = false;
+  if (!ap) build_cells(h);  // cell order: perm / inv
+  k_pack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_x.p, h->d_q.p, h->d_alpha.p, h->d_mol.p, mu0,
+                                      h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p);
+  if (!ap) {
+    build_lists(h);
+    if (h->colors_valid) map_color_rows(h);
+  }
   HIPCHECK(hipEventRecord(h->ev[1], s));
 
   // a2: every step in exact mode (reference); in cutoff mode only when the colour phases are rebuilt
@@ -464,8 +511,8 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   {  // a4 + a5
     dim3 grid(nblk(own_n(h), POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
     const double ccs = st.cut_coul * st.cut_coul, e2s = std::sqrt(h->P.qqrd2e);
-    if (ap) k_static_field<true><<<grid, block, 0, s>>>(own_lo(h), own_n(h), n, h->d_rec0.p, h->d_mol.p, h->box, nullptr, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef.p, h->d_rec0.p, h->d_rec1.p);
-    else    k_static_field<false><<<grid, block, 0, s>>>(own_lo(h), own_n(h), n, h->d_rec0.p, h->d_mol.p, h->box, h->d_nl_first.p, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef.p, h->d_rec0.p, h->d_rec1.p);
+    if (ap) k_static_field<true><<<grid, block, 0, s>>>(nullptr, n, n, h->d_rec0.p, h->d_mol_s.p, h->box, nullptr, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
+    else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, h->d_nl_first.p, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
   }
   HIPCHECK(hipEventRecord(h->ev[4], s));
 }
@@ -478,12 +525,12 @@ int phase_finish(polar_handle *h, polar_result *out) {
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
   const int eflag = h->step_eflag, vmode = h->step_vflag % 4;
   hipStream_t s = h->stream;
-  k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef.p);
+  k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p);
   HIPCHECK(hipEventRecord(h->ev[5], s));
   if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1); else launch_force<true, 1>(h, eflag, vmode == 1); }
   else    { if (expd) launch_force<false, 0>(h, eflag, vmode == 1); else launch_force<false, 1>(h, eflag, vmode == 1); }
   if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_slots.p);  // a10
-  k_unpack_mu<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_mu.p);
+  k_unpack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p, h->d_mu.p, h->d_ef.p);
   k_fold_scal<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, 0);
   HIPCHECK(hipEventRecord(h->ev[6], s));
   read_scal(h);
@@ -563,8 +610,9 @@ int polar_destroy(polar_handle *h) {
     h->d_mu.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
     h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();
     h->d_numneigh.release(); h->d_neigh.release(); h->d_rows.release(); h->d_first.release();
+    h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release();
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
-    h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release(); h->d_cell_atoms.release();
+    h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release();
     if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -621,6 +669,7 @@ const void *polar_pair_extract(const polar_handle *h, const char *name, int *dim
   if (dim) *dim = 2;
   if (strcmp(name, "epsilon") == 0) return h->ph.epsilon.data();
   if (strcmp(name, "sigma") == 0) return h->ph.sigma.data();
+  if (strcmp(name, "cut_lj") == 0) return h->ph.cut_lj.data();
   return nullptr;
 }
 int polar_get_settings(const polar_handle *h, polar_settings *out) {
@@ -836,7 +885,7 @@ int polar_step_begin(polar_handle *h, int eflag, int vflag) {
     if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not implemented");
     phase_begin(h, eflag, vflag, nullptr);
     const polar_settings &st = h->ph.st;
-    if (!st.zodid && (st.polar_gs || st.polar_gs_ranked)) ensure_colors(h);
+    if (!st.zodid && (st.polar_gs || st.polar_gs_ranked) && !h->colors_valid) { ensure_colors(h); map_color_rows(h); }
     h->in_step = true;
     return POLAR_OK;
   });
@@ -881,14 +930,14 @@ int polar_step_finish(polar_handle *h, polar_result *out) {
 int polar_mu_gather(polar_handle *h, long long lo, long long hi, double *dev_dst) {
   return guarded(h, [&]() {
     need_device(h);
-    if (hi > lo) k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst);
+    if (hi > lo) k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst);
     return POLAR_OK;
   });
 }
 int polar_mu_scatter(polar_handle *h, long long lo, long long hi, const double *dev_src) {
   return guarded(h, [&]() {
     need_device(h);
-    if (hi > lo) k_mu_scatter<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src);
+    if (hi > lo) k_mu_scatter<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src);
     return POLAR_OK;
   });
 }

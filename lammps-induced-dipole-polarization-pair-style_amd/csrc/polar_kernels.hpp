@@ -7,6 +7,13 @@
 // components are reduced across the wave with DPP/permute shuffles (no LDS, no atomics on i).
 // No MFMA anywhere: this is a sparse neighbor stencil, not a dense contraction.
 //
+// Index spaces: "orig" = LAMMPS' atom index (inputs x/q/alpha/mol, outputs f/mu/ef_static);
+// "s" = the library's internal order.  In list (dd_cutoff) mode s is CELL ORDER (perm[s] = orig,
+// inv[orig] = s): the atoms of a cell are contiguous, so a row's neighbor stream -- emitted cell by
+// cell -- makes the 64 lanes of a wave gather CONSECUTIVE 64-byte records, and the rows of one
+// workgroup (neighbouring atoms) re-read the same records out of L1.  In exact (all-pairs) mode
+// s == orig (perm == nullptr).
+//
 // Reference line numbers ("PS.cpp") are into
 // /root/reference/src/pair_lj_cut_coul_long_polarization.cpp.
 #pragma once
@@ -18,9 +25,16 @@ namespace polar {
 
 // 64-byte atom record: one L2 line-half per gathered neighbor.
 struct __attribute__((aligned(64))) AtomRec {
-  double x, y, z, q;     // position, charge
-  double mx, my, mz, a;  // induced dipole, static polarizability
+  double x, y, z;     // position              } the sweep gathers only these first 48 bytes
+  double mx, my, mz;  // induced dipole        }
+  double q, a;        // charge, static polarizability
 };
+struct XM { double x, y, z, mx, my, mz; };  // the 48-byte prefix of an AtomRec
+__device__ __forceinline__ XM load_xm(const AtomRec *__restrict__ r) {
+  const double2 *p = reinterpret_cast<const double2 *>(r);
+  const double2 a = p[0], b = p[1], c = p[2];  // 3 x dwordx4
+  return XM{a.x, a.y, b.x, b.y, c.x, c.y};
+}
 
 struct Box {
   double prd[3], half[3], inv[3];
@@ -126,17 +140,19 @@ __device__ __forceinline__ void tensor_scalars(double r2, double pd, double &s3,
 
 // ------------------------------------------------------------------------------------------
 // pack: x/q/alpha (+ initial mu) -> 64-byte records (both Jacobi buffers)
-__global__ void k_pack(int n, const double *__restrict__ x, const double *__restrict__ q,
-                       const double *__restrict__ alpha, const double *__restrict__ mu0, AtomRec *__restrict__ r0,
-                       AtomRec *__restrict__ r1) {
+__global__ void k_pack(int n, const int *__restrict__ perm, const double *__restrict__ x, const double *__restrict__ q,
+                       const double *__restrict__ alpha, const int *__restrict__ mol, const double *__restrict__ mu0,
+                       AtomRec *__restrict__ r0, AtomRec *__restrict__ r1, int *__restrict__ mol_s) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int o = perm ? perm[i] : i;
   AtomRec r;
-  r.x = x[3 * i]; r.y = x[3 * i + 1]; r.z = x[3 * i + 2]; r.q = q[i];
-  r.mx = mu0 ? mu0[3 * i] : 0.0; r.my = mu0 ? mu0[3 * i + 1] : 0.0; r.mz = mu0 ? mu0[3 * i + 2] : 0.0;
-  r.a = alpha[i];
+  r.x = x[3 * o]; r.y = x[3 * o + 1]; r.z = x[3 * o + 2]; r.q = q[o];
+  r.mx = mu0 ? mu0[3 * o] : 0.0; r.my = mu0 ? mu0[3 * o + 1] : 0.0; r.mz = mu0 ? mu0[3 * o + 2] : 0.0;
+  r.a = alpha[o];
   r0[i] = r;
   r1[i] = r;
+  mol_s[i] = mol[o];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -147,14 +163,18 @@ template <bool ALLPAIRS, int PASS>
 __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, const double *__restrict__ x,
                                                       const double *__restrict__ alpha, const int *__restrict__ mol,
                                                       Box box, const long long *__restrict__ nl_first,
-                                                      const int *__restrict__ nl_j, Scal *scal,
+                                                      const int *__restrict__ nl_j,
+                                                      const AtomRec *__restrict__ rec,
+                                                      const int *__restrict__ mol_s, Scal *scal,
                                                       double *__restrict__ slots,
                                                       double *__restrict__ rank_metric) {
+  // ALLPAIRS: orig space (x/alpha/mol incl. ghosts).  List mode: s space (records, mol_s).
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (i >= nlocal) return;
-  const double xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2], ai = alpha[i];
-  const int mi = mol[i];
+  const double xi = ALLPAIRS ? x[3 * i] : rec[i].x, yi = ALLPAIRS ? x[3 * i + 1] : rec[i].y,
+               zi = ALLPAIRS ? x[3 * i + 2] : rec[i].z, ai = ALLPAIRS ? alpha[i] : rec[i].a;
+  const int mi = ALLPAIRS ? mol[i] : mol_s[i];
   double rmin = (PASS == 1) ? 1000.0 : __longlong_as_double((long long)scal->rmin_bits);
   double acc = 0.0;
   long long beg = 0, end = ntotal;
@@ -166,15 +186,23 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, co
     if (p < end) {
       const int j = ALLPAIRS ? (int)p : nl_j[p];
       if (j != i) {
-        double dx = xi - x[3 * j], dy = yi - x[3 * j + 1], dz = zi - x[3 * j + 2];
-        if (!ALLPAIRS) min_image_rint(box, xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2], dx, dy, dz);
+        double dx, dy, dz, aj;
+        int mj;
+        if (ALLPAIRS) {
+          dx = xi - x[3 * j]; dy = yi - x[3 * j + 1]; dz = zi - x[3 * j + 2];
+          aj = alpha[j]; mj = mol[j];
+        } else {
+          const AtomRec rj = rec[j];
+          min_image_rint(box, xi, yi, zi, rj.x, rj.y, rj.z, dx, dy, dz);
+          aj = rj.a; mj = mol_s[j];
+        }
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
-        const bool molok = (mi != mol[j]) || mi == 0;
+        const bool molok = (mi != mj) || mi == 0;
         if (PASS == 1) {
-          if (ai > 0 && alpha[j] > 0 && molok) rmin = fmin(rmin, r);
+          if (ai > 0 && aj > 0 && molok) rmin = fmin(rmin, r);
         } else if (rmin * 1.5 > r && molok) {
           hit = true;
-          term = ai * alpha[j];
+          term = ai * aj;
         }
       }
     }
@@ -318,7 +346,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
 // (PS.cpp:363-386).  Full-row evaluation: E_i = sum_j ef_temp * q_j * del_ij, which is the
 // reference's i<j scatter seen from row i (del is antisymmetric under the image rule).
 template <bool ALLPAIRS>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(int row0, int nrows, int nlocal,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restrict__ rows, int nrows, int nlocal,
                                                               const AtomRec *__restrict__ rec,
                                                               const int *__restrict__ mol, Box box,
                                                               const long long *__restrict__ nl_first,
@@ -329,7 +357,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(int row0, int nrow
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
-  const int i = row0 + row;
+  const int i = rows ? rows[row] : row;
   const AtomRec ri = rec[i];
   const int mi = mol[i];
   const double f_shift = -1.0 / cut_coulsq;
@@ -375,7 +403,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(int row0, int nrow
 enum { EP_JACOBI = 0, EP_INPLACE = 1, EP_FIELD = 2 };
 
 template <bool ALLPAIRS, int DAMP, int EP>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_field(int row0, int nrows, const int *__restrict__ rows, int nlocal,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__restrict__ rows, int nlocal,
                                                        AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, Box box,
                                                        const long long *__restrict__ dd_first,
                                                        const int *__restrict__ dd_j,
@@ -386,7 +414,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int row0, int nrows, cons
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
-  const int i = rows ? rows[row] : row0 + row;
+  const int i = rows ? rows[row] : row;
   const int cur = scal->cur;
   const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
   AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
@@ -413,18 +441,34 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int row0, int nrows, cons
       }
     } else {
       // list mode: the damped tensor scalars (s3, s5) were cached per pair by k_dd_scalars, so a
-      // sweep streams 20 B per pair (int32 j + two doubles) and gathers one 64-B record
-      for (long long p = beg + lane; p < end; p += 64) {
-        const int j = dd_j[p];
-        const double2 sc = dd_s[p];
-        const AtomRec rj = src[j];
-        double dx, dy, dz;
-        min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
-        const double md = rj.mx * dx + rj.my * dy + rj.mz * dz;
-        const double c = sc.y * md;
-        fx -= sc.x * rj.mx - c * dx;
-        fy -= sc.x * rj.my - c * dy;
-        fz -= sc.x * rj.mz - c * dz;
+      // sweep streams 20 B per pair (int32 j + two doubles) and gathers 48 B of one record.
+      // Four pairs per lane and trip: the index/scalar loads of a trip are independent and the four
+      // record gathers go out together, so a row of <= 256 neighbors costs two memory latencies
+      // instead of two per 64 neighbors (the colour-phase launches are latency-, not ALU-bound).
+      constexpr int U = 4;
+      for (long long base = beg; base < end; base += 64 * U) {
+        int jv[U];
+        double2 sv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const long long p = base + u * 64 + lane;
+          const bool ok = p < end;
+          jv[u] = ok ? dd_j[p] : i;
+          sv[u] = ok ? dd_s[p] : make_double2(0.0, 0.0);
+        }
+        XM rv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) rv[u] = load_xm(src + jv[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          double dx, dy, dz;
+          min_image_rint(box, ri.x, ri.y, ri.z, rv[u].x, rv[u].y, rv[u].z, dx, dy, dz);
+          const double md = rv[u].mx * dx + rv[u].my * dy + rv[u].mz * dz;
+          const double c = sv[u].y * md;
+          fx -= sv[u].x * rv[u].mx - c * dx;
+          fy -= sv[u].x * rv[u].my - c * dy;
+          fz -= sv[u].x * rv[u].mz - c * dz;
+        }
       }
     }
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
@@ -446,14 +490,15 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int row0, int nrows, cons
 // a6 for the list path: the damped tensor scalars of every listed pair, once per step
 // (the sparse, matrix-free-storage analog of build_dipole_field_matrix, PS.cpp:1273-1306).
 template <int DAMP>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(int row0, int nrows, const AtomRec *__restrict__ rec, Box box,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restrict__ rows, int nrows, const AtomRec *__restrict__ rec,
+                                                            Box box,
                                                             const long long *__restrict__ dd_first,
                                                             const int *__restrict__ dd_j, double pd,
                                                             double2 *__restrict__ dd_s) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
-  const int i = row0 + row;
+  const int i = rows ? rows[row] : row;
   const double xi = rec[i].x, yi = rec[i].y, zi = rec[i].z;
   const long long beg = dd_first[i], end = dd_first[i + 1];
   for (long long p = beg + lane; p < end; p += 64) {
@@ -651,13 +696,16 @@ __global__ void k_fallback(int n, const Scal *scal, AtomRec *__restrict__ recA, 
   r[i].mx = a * ef[3 * i]; r[i].my = a * ef[3 * i + 1]; r[i].mz = a * ef[3 * i + 2];
 }
 
-// copy the final dipoles out of the record buffer that holds them
-__global__ void k_unpack_mu(int n, const Scal *scal, const AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
-                            double *__restrict__ mu) {
+// copy the final dipoles and the static field out (records are in s order, outputs in orig order)
+__global__ void k_unpack(int n, const int *__restrict__ perm, const Scal *scal, const AtomRec *__restrict__ recA,
+                         const AtomRec *__restrict__ recB, const double *__restrict__ ef_s, double *__restrict__ mu,
+                         double *__restrict__ ef) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const AtomRec *r = scal->cur ? recB : recA;
-  mu[3 * i] = r[i].mx; mu[3 * i + 1] = r[i].my; mu[3 * i + 2] = r[i].mz;
+  const int o = perm ? perm[i] : i;
+  mu[3 * o] = r[i].mx; mu[3 * o + 1] = r[i].my; mu[3 * o + 2] = r[i].mz;
+  ef[3 * o] = ef_s[3 * i]; ef[3 * o + 1] = ef_s[3 * i + 1]; ef[3 * o + 2] = ef_s[3 * i + 2];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -665,7 +713,8 @@ __global__ void k_unpack_mu(int n, const Scal *scal, const AtomRec *__restrict__
 // The pair force is antisymmetric, so summing rows reproduces the reference's i<j scatter;
 // pair energies are counted from both rows and halved.
 template <bool ALLPAIRS, int DAMP, bool EFLAG, bool VPAIR>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(int row0, int nrows, int nlocal, const Scal *scal_in,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restrict__ rows, int nrows, const int *__restrict__ perm,
+                                                             int nlocal, const Scal *scal_in,
                                                              const AtomRec *__restrict__ recA,
                                                              const AtomRec *__restrict__ recB,
                                                              const int *__restrict__ mol, Box box,
@@ -676,7 +725,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(int row0, int nrows
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
-  const int i = row0 + row;
+  const int i = rows ? rows[row] : row;
   const AtomRec *__restrict__ rec = scal_in->cur ? recB : recA;
   const AtomRec ri = rec[i];
   const int mi = mol[i];
@@ -758,7 +807,10 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(int row0, int nrows
     }
   }
   fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
-  if (lane == 0) { atomicAdd(&f[3 * i], fx); atomicAdd(&f[3 * i + 1], fy); atomicAdd(&f[3 * i + 2], fz); }
+  if (lane == 0) {
+    const int o = perm ? perm[i] : i;  // forces leave in LAMMPS' order
+    atomicAdd(&f[3 * o], fx); atomicAdd(&f[3 * o + 1], fy); atomicAdd(&f[3 * o + 2], fz);
+  }
   if (EFLAG) {
     uef = wave_sum(uef); udd = wave_sum(udd);
     if (lane == 0) {
@@ -844,25 +896,24 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(long long n, const T *_
   for (long long k = a; k < bnd; k++) { out[k] = run; run += (long long)in[k]; }
 }
 
-// deterministic fill: atoms of a cell in ascending atom index (thread per cell, cells are small)
-__global__ void k_cell_fill(int n, int ncell, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
-                            int *__restrict__ fill, int *__restrict__ cell_atoms) {
+// counting-sort fill: perm[s] = orig index of the atom stored at sorted position s, inv = inverse.
+// (Order inside a cell follows the atomics, i.e. it only permutes floating-point summation order.)
+__global__ void k_cell_fill(int n, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
+                            int *__restrict__ fill, int *__restrict__ perm, int *__restrict__ inv) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int c = cell_id[i];
-  int slot = atomicAdd(&fill[c], 1);
-  cell_atoms[cell_first[c] + slot] = i;
+  const int c = cell_id[i];
+  const int s = (int)cell_first[c] + atomicAdd(&fill[c], 1);
+  perm[s] = i;
+  inv[i] = s;
 }
-__global__ void k_cell_sort(int ncell, const long long *__restrict__ cell_first, int *__restrict__ cell_atoms) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncell) return;
-  long long a = cell_first[c], b = cell_first[c + 1];
-  for (long long p = a + 1; p < b; p++) {
-    int v = cell_atoms[p];
-    long long q = p - 1;
-    while (q >= a && cell_atoms[q] > v) { cell_atoms[q + 1] = cell_atoms[q]; q--; }
-    cell_atoms[q + 1] = v;
-  }
+__global__ void k_map_rows(int n, const int *__restrict__ inv, const int *__restrict__ in, int *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = inv[in[i]];
+}
+__global__ void k_map_range(int lo, int n, const int *__restrict__ inv, int *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = inv[lo + i];
 }
 
 // PASS 0: count, PASS 1: fill.  One wave per atom; lanes stride the atoms of the <=27 distinct
@@ -870,10 +921,9 @@ __global__ void k_cell_sort(int ncell, const long long *__restrict__ cell_first,
 //   nl : every j with rsq <= cutallsq                      (static field, forces, rank metric)
 //   dd : alpha_i != 0, alpha_j != 0 and rsq < ddcutsq      (the dipole sweep stream)
 template <int PASS>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int row0, int nrows, const AtomRec *__restrict__ rec, Box box,
-                                                          CellGrid g, const int *__restrict__ cell_id,
-                                                          const long long *__restrict__ cell_first,
-                                                          const int *__restrict__ cell_atoms, double cutallsq,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict__ rows, int nrows, const AtomRec *__restrict__ rec,
+                                                          Box box, CellGrid g,
+                                                          const long long *__restrict__ cell_first, double cutallsq,
                                                           double ddcutsq, int *__restrict__ nl_cnt,
                                                           int *__restrict__ dd_cnt,
                                                           const long long *__restrict__ nl_first,
@@ -882,9 +932,9 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int row0, int nrows, c
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
-  const int i = row0 + row;
+  const int i = rows ? rows[row] : row;  // s space: the atoms of cell c are the indices [cell_first[c], cell_first[c+1])
   const AtomRec ri = rec[i];
-  const int ci = cell_id[i];
+  const int ci = cell_of(g, box, ri.x, ri.y, ri.z);
   const int c0 = ci % g.nc[0], c1 = (ci / g.nc[0]) % g.nc[1], c2 = ci / (g.nc[0] * g.nc[1]);
   long long nlp = (PASS == 1) ? nl_first[i] : 0, ddp = (PASS == 1) ? dd_first[i] : 0;
   int ncount = 0, dcount = 0;
@@ -904,7 +954,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int row0, int nrows, c
           bool in_nl = false, in_dd = false;
           int j = -1;
           if (p < b) {
-            j = cell_atoms[p];
+            j = (int)p;
             if (j != i) {
               const AtomRec rj = rec[j];
               double ex, ey, ez;
@@ -931,19 +981,22 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(int row0, int nrows, c
 }
 
 // multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers
-__global__ void k_mu_gather(long long lo, long long hi, const Scal *scal, const AtomRec *__restrict__ recA,
-                            const AtomRec *__restrict__ recB, double *__restrict__ dst) {
+__global__ void k_mu_gather(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
+                            const AtomRec *__restrict__ recA, const AtomRec *__restrict__ recB,
+                            double *__restrict__ dst) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
   const AtomRec *r = scal->cur ? recB : recA;
-  dst[3 * (i - lo)] = r[i].mx; dst[3 * (i - lo) + 1] = r[i].my; dst[3 * (i - lo) + 2] = r[i].mz;
+  const long long s = inv ? inv[i] : i;
+  dst[3 * (i - lo)] = r[s].mx; dst[3 * (i - lo) + 1] = r[s].my; dst[3 * (i - lo) + 2] = r[s].mz;
 }
-__global__ void k_mu_scatter(long long lo, long long hi, const Scal *scal, AtomRec *__restrict__ recA,
-                             AtomRec *__restrict__ recB, const double *__restrict__ src) {
+__global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
+                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
   AtomRec *r = scal->cur ? recB : recA;
-  r[i].mx = src[3 * (i - lo)]; r[i].my = src[3 * (i - lo) + 1]; r[i].mz = src[3 * (i - lo) + 2];
+  const long long s = inv ? inv[i] : i;
+  r[s].mx = src[3 * (i - lo)]; r[s].my = src[3 * (i - lo) + 1]; r[s].mz = src[3 * (i - lo) + 2];
 }
 
 // small utilities

@@ -1,0 +1,320 @@
+/* ----------------------------------------------------------------------
+   LAMMPS shim of the MI355X-native lj/cut/coul/long/polarization pair style.
+   See the header.  Reference counterparts are cited per function
+   ("PS.cpp" = the reference's src/pair_lj_cut_coul_long_polarization.cpp).
+------------------------------------------------------------------------- */
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "pair_lj_cut_coul_long_polarization_mi355x.h"
+#include "atom.h"
+#include "comm.h"
+#include "domain.h"
+#include "error.h"
+#include "force.h"
+#include "kspace.h"
+#include "memory.h"
+#include "neigh_list.h"
+#include "neighbor.h"
+#include "update.h"
+
+#include "polar_mi355x.h"
+
+using namespace LAMMPS_NS;
+
+static_assert(sizeof(tagint) == sizeof(int), "the C-ABI takes 32-bit molecule ids (default LAMMPS_SMALLBIG build)");
+
+/* ---------------------------------------------------------------------- */
+
+PairLJCutCoulLongPolarizationMI355X::PairLJCutCoulLongPolarizationMI355X(LAMMPS *lmp) : Pair(lmp)
+{
+  // same flags as the reference constructor, PS.cpp:55-61
+  ewaldflag = pppmflag = 1;
+  respa_enable = 0;
+  writedata = 1;
+  ftable = NULL;
+  epsilon = sigma = cut_lj = NULL;
+  pair_inited = 0;
+  cut_lj_global = cut_coul = 0.0;
+  h = NULL;
+  const char *dev = getenv("POLAR_DEVICE");
+  int rc = polar_create(dev ? atoi(dev) : 0, &h);
+  if (rc < 0 || polar_device_count() < 1)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization (MI355X) found no usable HIP device");
+}
+
+PairLJCutCoulLongPolarizationMI355X::~PairLJCutCoulLongPolarizationMI355X()
+{
+  if (allocated) {
+    memory->destroy(setflag);
+    memory->destroy(cutsq);
+    memory->sfree(epsilon);
+    memory->sfree(sigma);
+    memory->sfree(cut_lj);
+  }
+  polar_destroy(h);
+}
+
+void PairLJCutCoulLongPolarizationMI355X::check(int rc)
+{
+  if (rc < 0) error->all(FLERR,polar_last_error(h));
+  else if (rc == POLAR_WARN_NOT_CONVERGED) error->warning(FLERR,polar_last_warning(h));  // PS.cpp:1233
+}
+
+/* ---------------------------------------------------------------------- */
+
+void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
+{
+  if (eflag || vflag) ev_setup(eflag,vflag);
+  else evflag = vflag_fdotr = 0;
+  if (eflag_atom || vflag_atom)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization (MI355X): per-atom energy/virial not supported yet");
+
+  // what compute() reads through domain->, atom-> and list-> (PS.cpp:125-188)
+  double tilt[3] = {domain->xy,domain->xz,domain->yz};
+  int periodic[3] = {domain->xperiodic,domain->yperiodic,domain->zperiodic};
+  check(polar_set_box(h,domain->boxlo,domain->prd,tilt,periodic,domain->triclinic));
+  check(polar_set_atoms(h,atom->nlocal,atom->nghost,&atom->x[0][0],atom->q,atom->static_polarizability,
+                        atom->type,(const int *) atom->molecule));
+  if (neighbor->ago == 0)
+    check(polar_set_neighbors(h,list->inum,list->ilist,list->numneigh,list->firstneigh));
+
+  // global virial: fdotr is left to the base class (it needs the reverse-communicated ghosts'
+  // x, which LAMMPS owns); a pairwise global virial (vflag_global == 1) is tallied on the device
+  polar_result res;
+  int rc = polar_compute(h,eflag_either ? 1 : 0,vflag_global ? 1 : 0,&atom->f[0][0],
+                         &atom->mu_induced[0][0],&atom->ef_static[0][0],&res);
+  check(rc);
+
+  if (eflag_global) {
+    eng_vdwl += res.eng_vdwl;
+    eng_coul += res.eng_coul;
+  }
+  force->pair->eng_pol = res.eng_pol;   // PS.cpp:641 (zero on steps without eflag)
+  if (vflag_global) for (int k = 0; k < 6; k++) virial[k] += res.virial[k];
+  if (vflag_fdotr) virial_fdotr_compute();
+}
+
+/* ---------------------------------------------------------------------- */
+
+void PairLJCutCoulLongPolarizationMI355X::allocate()
+{
+  allocated = 1;
+  int n = atom->ntypes;
+  memory->create(setflag,n+1,n+1,"pair:setflag");
+  for (int i = 1; i <= n; i++)
+    for (int j = i; j <= n; j++)
+      setflag[i][j] = 0;
+  memory->create(cutsq,n+1,n+1,"pair:cutsq");
+  epsilon = (double **) memory->smalloc((n+1)*sizeof(double *),"pair:epsilon");
+  sigma = (double **) memory->smalloc((n+1)*sizeof(double *),"pair:sigma");
+  cut_lj = (double **) memory->smalloc((n+1)*sizeof(double *),"pair:cut_lj");
+}
+
+// row-pointer views into the library's [(n+1)*(n+1)] tables so that extract("epsilon"/"sigma")
+// hands out the double** fix adapt and friends expect (PS.cpp:1101-1109)
+void PairLJCutCoulLongPolarizationMI355X::sync_views()
+{
+  int dim, n = atom->ntypes;
+  double *e = (double *) polar_pair_extract(h,"epsilon",&dim);
+  double *s = (double *) polar_pair_extract(h,"sigma",&dim);
+  double *c = (double *) polar_pair_extract(h,"cut_lj",&dim);
+  for (int i = 0; i <= n; i++) {
+    epsilon[i] = e + (size_t) i*(n+1);
+    sigma[i] = s + (size_t) i*(n+1);
+    cut_lj[i] = c + (size_t) i*(n+1);
+  }
+}
+
+/* ---------------------------------------------------------------------- */
+
+void PairLJCutCoulLongPolarizationMI355X::settings(int narg, char **arg)
+{
+  // identical grammar, ordering quirks and error strings: parsed by the library, PS.cpp:678-766
+  check(polar_pair_settings(h,narg,arg));
+  polar_settings st;
+  polar_get_settings(h,&st);
+  cut_lj_global = st.cut_lj_global;
+  cut_coul = st.cut_coul;
+}
+
+void PairLJCutCoulLongPolarizationMI355X::coeff(int narg, char **arg)
+{
+  if (narg < 4 || narg > 5) error->all(FLERR,"Incorrect args for pair coefficients");
+  if (!allocated) allocate();
+  check(polar_pair_coeff(h,atom->ntypes,narg,arg));   // PS.cpp:772-800
+  sync_views();
+  int ilo,ihi,jlo,jhi;
+  force->bounds(FLERR,arg[0],atom->ntypes,ilo,ihi);
+  force->bounds(FLERR,arg[1],atom->ntypes,jlo,jhi);
+  for (int i = ilo; i <= ihi; i++)
+    for (int j = MAX(jlo,i); j <= jhi; j++) setflag[i][j] = 1;
+}
+
+/* ---------------------------------------------------------------------- */
+
+void PairLJCutCoulLongPolarizationMI355X::init_style()
+{
+  // PS.cpp:806-852
+  if (!atom->q_flag)
+    error->all(FLERR,"Pair style lj/cut/coul/long requires atom attribute q");
+  if (!atom->static_polarizability_flag)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization requires atom attribute polarizability");
+  if (strstr(update->integrate_style,"respa"))
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization does not support rRESPA");  // respa_enable = 0
+  neighbor->request(this,instance_me);     // default half list, newton on
+  if (force->kspace == NULL) error->all(FLERR,"Pair style requires a KSpace style");
+
+  // pair_modify state lives in the Pair base class; mirror it into the library, then let it build
+  // lj1..lj4/offset/cutsq (init_one) and the Coulomb tables (init_tables) and upload them
+  char bits[32],inner[64];
+  sprintf(bits,"%d",ncoultablebits);
+  sprintf(inner,"%.17g",tabinner);
+  const char *mix = mix_flag == GEOMETRIC ? "geometric" : (mix_flag == ARITHMETIC ? "arithmetic" : "sixthpower");
+  const char *mod[10] = {"mix",mix,"shift",offset_flag ? "yes" : "no","table",bits,"tabinner",inner,
+                         "tail",tail_flag ? "yes" : "no"};
+  check(polar_pair_modify(h,10,mod));
+  check(polar_pair_init(h,force->kspace->g_ewald,force->qqrd2e,force->special_lj,force->special_coul));
+  sync_views();
+  pair_inited = 1;
+}
+
+double PairLJCutCoulLongPolarizationMI355X::init_one(int i, int j)
+{
+  // mixing / lj1..lj4 / offset were computed for every pair by polar_pair_init (PS.cpp:858-890)
+  double cut = polar_pair_cut(h,i,j);
+
+  // long-range tail correction, PS.cpp:897-918 (host-side bookkeeping of the Pair base class)
+  if (tail_flag) {
+    int *type = atom->type;
+    int nlocal = atom->nlocal;
+    double count[2],all[2];
+    count[0] = count[1] = 0.0;
+    for (int k = 0; k < nlocal; k++) {
+      if (type[k] == i) count[0] += 1.0;
+      if (type[k] == j) count[1] += 1.0;
+    }
+    MPI_Allreduce(count,all,2,MPI_DOUBLE,MPI_SUM,world);
+    const double PI = 3.14159265358979323846;
+    double sig2 = sigma[i][j]*sigma[i][j];
+    double sig6 = sig2*sig2*sig2;
+    double rc3 = cut_lj[i][j]*cut_lj[i][j]*cut_lj[i][j];
+    double rc6 = rc3*rc3;
+    double rc9 = rc3*rc6;
+    etail_ij = 8.0*PI*all[0]*all[1]*epsilon[i][j] * sig6 * (sig6 - 3.0*rc6) / (9.0*rc9);
+    ptail_ij = 16.0*PI*all[0]*all[1]*epsilon[i][j] * sig6 * (2.0*sig6 - 3.0*rc6) / (9.0*rc9);
+  }
+  return cut;
+}
+
+/* ----------------------------------------------------------------------
+   restart / data files: same records as the reference (PS.cpp:927-1031); like the reference,
+   the polarization keywords and the dipoles are NOT persisted
+------------------------------------------------------------------------- */
+
+void PairLJCutCoulLongPolarizationMI355X::write_restart(FILE *fp)
+{
+  write_restart_settings(fp);
+  for (int i = 1; i <= atom->ntypes; i++)
+    for (int j = i; j <= atom->ntypes; j++) {
+      fwrite(&setflag[i][j],sizeof(int),1,fp);
+      if (setflag[i][j]) {
+        fwrite(&epsilon[i][j],sizeof(double),1,fp);
+        fwrite(&sigma[i][j],sizeof(double),1,fp);
+        fwrite(&cut_lj[i][j],sizeof(double),1,fp);
+      }
+    }
+}
+
+void PairLJCutCoulLongPolarizationMI355X::read_restart(FILE *fp)
+{
+  read_restart_settings(fp);
+  allocate();
+  int me = comm->me;
+  for (int i = 1; i <= atom->ntypes; i++)
+    for (int j = i; j <= atom->ntypes; j++) {
+      int flag = 0;
+      double v[3] = {0.0,0.0,0.0};
+      if (me == 0) fread(&flag,sizeof(int),1,fp);
+      MPI_Bcast(&flag,1,MPI_INT,0,world);
+      if (flag) {
+        if (me == 0) fread(v,sizeof(double),3,fp);
+        MPI_Bcast(v,3,MPI_DOUBLE,0,world);
+        char a[5][32];
+        sprintf(a[0],"%d",i); sprintf(a[1],"%d",j);
+        sprintf(a[2],"%.17g",v[0]); sprintf(a[3],"%.17g",v[1]); sprintf(a[4],"%.17g",v[2]);
+        const char *argv[5] = {a[0],a[1],a[2],a[3],a[4]};
+        check(polar_pair_coeff(h,atom->ntypes,5,argv));
+        setflag[i][j] = 1;
+      }
+    }
+  sync_views();
+}
+
+void PairLJCutCoulLongPolarizationMI355X::write_restart_settings(FILE *fp)
+{
+  fwrite(&cut_lj_global,sizeof(double),1,fp);
+  fwrite(&cut_coul,sizeof(double),1,fp);
+  fwrite(&offset_flag,sizeof(int),1,fp);
+  fwrite(&mix_flag,sizeof(int),1,fp);
+  fwrite(&tail_flag,sizeof(int),1,fp);
+  fwrite(&ncoultablebits,sizeof(int),1,fp);
+  fwrite(&tabinner,sizeof(double),1,fp);
+}
+
+void PairLJCutCoulLongPolarizationMI355X::read_restart_settings(FILE *fp)
+{
+  if (comm->me == 0) {
+    fread(&cut_lj_global,sizeof(double),1,fp);
+    fread(&cut_coul,sizeof(double),1,fp);
+    fread(&offset_flag,sizeof(int),1,fp);
+    fread(&mix_flag,sizeof(int),1,fp);
+    fread(&tail_flag,sizeof(int),1,fp);
+    fread(&ncoultablebits,sizeof(int),1,fp);
+    fread(&tabinner,sizeof(double),1,fp);
+  }
+  MPI_Bcast(&cut_lj_global,1,MPI_DOUBLE,0,world);
+  MPI_Bcast(&cut_coul,1,MPI_DOUBLE,0,world);
+  MPI_Bcast(&offset_flag,1,MPI_INT,0,world);
+  MPI_Bcast(&mix_flag,1,MPI_INT,0,world);
+  MPI_Bcast(&tail_flag,1,MPI_INT,0,world);
+  MPI_Bcast(&ncoultablebits,1,MPI_INT,0,world);
+  MPI_Bcast(&tabinner,1,MPI_DOUBLE,0,world);
+  // polarization keywords are not in the restart file (reference behaviour): defaults apply
+  char a[2][32];
+  sprintf(a[0],"%.17g",cut_lj_global); sprintf(a[1],"%.17g",cut_coul);
+  const char *argv[2] = {a[0],a[1]};
+  check(polar_pair_settings(h,2,argv));
+}
+
+void PairLJCutCoulLongPolarizationMI355X::write_data(FILE *fp)
+{
+  for (int i = 1; i <= atom->ntypes; i++)
+    fprintf(fp,"%d %g %g\n",i,epsilon[i][i],sigma[i][i]);
+}
+
+void PairLJCutCoulLongPolarizationMI355X::write_data_all(FILE *fp)
+{
+  for (int i = 1; i <= atom->ntypes; i++)
+    for (int j = i; j <= atom->ntypes; j++)
+      fprintf(fp,"%d %d %g %g %g\n",i,j,epsilon[i][j],sigma[i][j],cut_lj[i][j]);
+}
+
+/* ---------------------------------------------------------------------- */
+
+double PairLJCutCoulLongPolarizationMI355X::single(int i, int j, int itype, int jtype, double rsq,
+                                                   double factor_coul, double factor_lj, double &fforce)
+{
+  return polar_pair_single(h,atom->q[i],atom->q[j],itype,jtype,rsq,factor_coul,factor_lj,&fforce);  // PS.cpp:1035-1097
+}
+
+void *PairLJCutCoulLongPolarizationMI355X::extract(const char *str, int &dim)
+{
+  dim = 0;
+  if (strcmp(str,"cut_coul") == 0) return (void *) &cut_coul;
+  dim = 2;
+  if (strcmp(str,"epsilon") == 0) return (void *) epsilon;
+  if (strcmp(str,"sigma") == 0) return (void *) sigma;
+  return NULL;
+}

@@ -1,0 +1,59 @@
+/* -*- c++ -*- ----------------------------------------------------------
+   LAMMPS-side shim of the MI355X-native polarization pair style.
+
+   Registers under the SAME style name as the reference's
+   src/pair_lj_cut_coul_long_polarization.h:14-18, so input decks are unchanged:
+       pair_style lj/cut/coul/long/polarization ...
+   Replace the reference's two pair_lj_cut_coul_long_polarization.{h,cpp} files by this pair and
+   link libpolar_mi355x.so.  All arithmetic of compute() runs in the library
+   (hand-written HIP, include/polar_mi355x.h); this class only maps LAMMPS' object graph onto
+   the C-ABI and the C-ABI's status codes onto error->all / error->warning.
+------------------------------------------------------------------------- */
+
+#ifdef PAIR_CLASS
+
+PairStyle(lj/cut/coul/long/polarization,PairLJCutCoulLongPolarizationMI355X)
+
+#else
+
+#ifndef LMP_PAIR_LJ_CUT_COUL_LONG_POLARIZATION_MI355X_H
+#define LMP_PAIR_LJ_CUT_COUL_LONG_POLARIZATION_MI355X_H
+
+#include "pair.h"
+
+struct polar_handle;
+
+namespace LAMMPS_NS {
+
+class PairLJCutCoulLongPolarizationMI355X : public Pair {
+ public:
+  PairLJCutCoulLongPolarizationMI355X(class LAMMPS *);
+  virtual ~PairLJCutCoulLongPolarizationMI355X();
+  virtual void compute(int, int);
+  virtual void settings(int, char **);
+  void coeff(int, char **);
+  virtual void init_style();
+  virtual double init_one(int, int);
+  void write_restart(FILE *);
+  void read_restart(FILE *);
+  virtual void write_restart_settings(FILE *);
+  virtual void read_restart_settings(FILE *);
+  void write_data(FILE *);
+  void write_data_all(FILE *);
+  virtual double single(int, int, int, int, double, double, double, double &);
+  virtual void *extract(const char *, int &);
+
+ protected:
+  polar_handle *h;
+  double cut_lj_global, cut_coul;
+  double **epsilon, **sigma, **cut_lj;   // row-pointer views into the library's tables (extract())
+  int pair_inited;
+  virtual void allocate();
+  void check(int rc);                    // C-ABI status -> error->all / error->warning
+  void sync_views();
+};
+
+}
+
+#endif
+#endif
