@@ -114,7 +114,8 @@ def main():
                    "natoms": n, "sweeps": out["sweeps"], "colors": out["ncolors"], "dd_pairs": out["dd_pairs"],
                    "ms_per_dipole_iteration": (ms_solve / args.steps) / max(out["sweeps"], 1),
                    "ms_solve": ms_solve / args.steps, "ms_ljcoul": out["ms_ljcoul"], "ms_force": out["ms_force"],
-                   "ms_static": out["ms_static"], "ms_list": out["ms_list"], "ms_rank": out["ms_rank"]},
+                   "ms_static": out["ms_static"], "ms_list": out["ms_list"], "ms_rank": out["ms_rank"],
+                   "rms_dmu_last_sweep": out["rms_dmu"], "eng_pol": out["eng_pol"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_field (dipole-field sweep)",
                      "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch},

@@ -117,6 +117,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise PolarError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950); "
                                  "there is no CPU fallback for the polarization hot path")
+        # Load order matters: torch ships its own ROCm runtime libraries.  If this library pulled in
+        # the system libamdhip64 first, a later `import torch` would bind to it and find no GPU; with
+        # torch first, both share torch's runtime (same SONAME), so torch streams / tensors can be
+        # handed to the kernels (polar_set_stream, parallel.py).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported

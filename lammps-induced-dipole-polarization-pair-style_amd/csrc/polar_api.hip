@@ -89,7 +89,9 @@ struct polar_handle {
   // cutoff-mode lists
   DBuf<int> d_cell_id, d_cell_cnt, d_cell_fill, d_nl_cnt, d_dd_cnt, d_nl_j, d_dd_j;
   DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
-  DBuf<double2> d_dd_s;
+  DBuf<double2> d_dd_s, d_sxy, d_szq, d_smxy0, d_smxy1, d_smza0, d_smza1;
+  SplitRec sp{};          // list-mode sweep arrays (see polar_kernels.hpp); sp.xy == nullptr in exact mode
+  bool split_live = false;  // dipoles currently live in the split arrays (between k_split and k_merge)
   long long nl_pairs = 0, dd_pairs = 0;
   int inum = 0;
   long long nneigh = 0;
@@ -331,7 +333,7 @@ void launch_field(polar_handle *h, int nrows, const int *rows) {
   if (nrows <= 0) return;
   k_field<AP, DAMP, EP><<<nblk(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(
       nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, h->d_dd_first.p, h->d_dd_j.p, h->d_dd_s.p,
-      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_scal.p, h->d_slots.p);
+      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_scal.p, h->d_slots.p, AP ? SplitRec{} : h->sp);
 }
 template <int EP>
 void launch_field_dyn(polar_handle *h, bool ap, int nrows, const int *rows) {
@@ -514,6 +516,16 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     if (ap) k_static_field<true><<<grid, block, 0, s>>>(nullptr, n, n, h->d_rec0.p, h->d_mol_s.p, h->box, nullptr, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
     else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, h->d_nl_first.p, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
   }
+  if (!ap) {  // the sweep works on the split arrays
+    h->d_sxy.ensure(n); h->d_szq.ensure(n); h->d_smxy0.ensure(n); h->d_smxy1.ensure(n); h->d_smza0.ensure(n); h->d_smza1.ensure(n);
+    h->sp.xy = h->d_sxy.p; h->sp.zq = h->d_szq.p; h->sp.mxy[0] = h->d_smxy0.p; h->sp.mxy[1] = h->d_smxy1.p;
+    h->sp.mza[0] = h->d_smza0.p; h->sp.mza[1] = h->d_smza1.p;
+    k_split<<<nblk(n, 256), 256, 0, s>>>(n, h->d_rec0.p, h->sp);
+    h->split_live = true;
+  } else {
+    h->sp = SplitRec{};
+    h->split_live = false;
+  }
   HIPCHECK(hipEventRecord(h->ev[4], s));
 }
 
@@ -525,6 +537,12 @@ int phase_finish(polar_handle *h, polar_result *out) {
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
   const int eflag = h->step_eflag, vmode = h->step_vflag % 4;
   hipStream_t s = h->stream;
+  if (h->split_live) {
+    const bool jac = !(st.polar_gs || st.polar_gs_ranked);
+    // Jacobi: the buffer index is scal->cur; GS: buffer 0 (use the always-zero `pad` field)
+    k_merge<<<nblk(n, 256), 256, 0, s>>>(n, jac ? &h->d_scal.p->cur : &h->d_scal.p->pad, h->sp, h->d_rec0.p, h->d_rec1.p);
+    h->split_live = false;
+  }
   k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p);
   HIPCHECK(hipEventRecord(h->ev[5], s));
   if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1); else launch_force<true, 1>(h, eflag, vmode == 1); }
@@ -615,6 +633,7 @@ int polar_destroy(polar_handle *h) {
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release();
+    h->d_sxy.release(); h->d_szq.release(); h->d_smxy0.release(); h->d_smxy1.release(); h->d_smza0.release(); h->d_smza1.release();
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -930,14 +949,14 @@ int polar_step_finish(polar_handle *h, polar_result *out) {
 int polar_mu_gather(polar_handle *h, long long lo, long long hi, double *dev_dst) {
   return guarded(h, [&]() {
     need_device(h);
-    if (hi > lo) k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst);
+    if (hi > lo) k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst, h->split_live ? h->sp : SplitRec{}, !(h->ph.st.polar_gs || h->ph.st.polar_gs_ranked));
     return POLAR_OK;
   });
 }
 int polar_mu_scatter(polar_handle *h, long long lo, long long hi, const double *dev_src) {
   return guarded(h, [&]() {
     need_device(h);
-    if (hi > lo) k_mu_scatter<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src);
+    if (hi > lo) k_mu_scatter<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src, h->split_live ? h->sp : SplitRec{}, !(h->ph.st.polar_gs || h->ph.st.polar_gs_ranked));
     return POLAR_OK;
   });
 }

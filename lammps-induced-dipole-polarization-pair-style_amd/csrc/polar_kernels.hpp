@@ -99,6 +99,36 @@ __device__ __forceinline__ void min_image_del(const Box &b, double xi, double yi
   dz = -wrap_ci(zj - zi, b.prd[2], b.half[2], b.periodic[2]);
 }
 
+// Split ("16-byte SoA") copy of the records for the list-mode sweep: four double2 arrays in s
+// order.  A wave whose lanes hold consecutive j then reads DENSE cache lines (64 lanes x 16 B =
+// 8 lines per load instruction) instead of one 16-B piece out of 32 different lines of the 64-byte
+// AoS records -- the sweep's gathers are bound by L1 line transactions, not bytes.
+struct SplitRec {
+  double2 *xy;      // {x, y}
+  double2 *zq;      // {z, q}
+  double2 *mxy[2];  // {mu_x, mu_y}   two buffers: Jacobi ping-pong (GS uses [0] only)
+  double2 *mza[2];  // {mu_z, alpha}
+};
+__global__ void k_split(int n, const AtomRec *__restrict__ rec, SplitRec sp) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const AtomRec r = rec[i];
+  sp.xy[i] = make_double2(r.x, r.y);
+  sp.zq[i] = make_double2(r.z, r.q);
+  sp.mxy[0][i] = sp.mxy[1][i] = make_double2(r.mx, r.my);
+  sp.mza[0][i] = sp.mza[1][i] = make_double2(r.mz, r.a);
+}
+// dipoles back into both record buffers (forces, fallback and unpack read records)
+struct Scal;
+__global__ void k_merge(int n, const int *cur_ptr, SplitRec sp, AtomRec *__restrict__ r0, AtomRec *__restrict__ r1) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cur = *cur_ptr;
+  const double2 a = sp.mxy[cur][i], b = sp.mza[cur][i];
+  r0[i].mx = a.x; r0[i].my = a.y; r0[i].mz = b.x;
+  r1[i].mx = a.x; r1[i].my = a.y; r1[i].mz = b.x;
+}
+
 // Branch-free minimum image for the LIST kernels (dd_cutoff extension): d - L*rint(d/L).
 // Equals closest_image except for pairs at exactly L/2, which lie outside every cutoff there
 // (the list path requires L >= 2*cutoff).  The all-pairs (reference-exact) kernels keep wrap_ci.
@@ -409,16 +439,22 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__r
                                                        const int *__restrict__ dd_j,
                                                        const double2 *__restrict__ dd_s, double ddcutsq, double pd,
                                                        const double *__restrict__ ef, double *__restrict__ Fout,
-                                                       const Scal *scal, double *__restrict__ slots) {
+                                                       const Scal *scal, double *__restrict__ slots, SplitRec sp) {
   if (scal->done) return;  // device-resident loop control: finished solves turn later launches into no-ops
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
   const int i = rows ? rows[row] : row;
   const int cur = scal->cur;
+  const int sb = (EP == EP_JACOBI) ? cur : 0, db = (EP == EP_JACOBI) ? (cur ^ 1) : 0;  // split-array buffers
   const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
   AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
-  const AtomRec ri = src[i];
+  AtomRec ri;
+  if (ALLPAIRS) ri = src[i];
+  else {
+    const double2 a = sp.xy[i], b = sp.zq[i], c = sp.mxy[sb][i], d = sp.mza[sb][i];
+    ri.x = a.x; ri.y = a.y; ri.z = b.x; ri.q = b.y; ri.mx = c.x; ri.my = c.y; ri.mz = d.x; ri.a = d.y;
+  }
   double fx = 0, fy = 0, fz = 0;
   if (ri.a != 0.0 || EP == EP_FIELD) {
     long long beg = 0, end = nlocal;
@@ -458,7 +494,10 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__r
         }
         XM rv[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) rv[u] = load_xm(src + jv[u]);
+        for (int u = 0; u < U; u++) {
+          const double2 a = sp.xy[jv[u]], b = sp.zq[jv[u]], c = sp.mxy[sb][jv[u]], d = sp.mza[sb][jv[u]];
+          rv[u] = XM{a.x, a.y, b.x, c.x, c.y, d.x};
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) {
           double dx, dy, dz;
@@ -480,7 +519,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__r
       const double a = ri.a;
       const double mx = a * (ef[3 * i] + fx), my = a * (ef[3 * i + 1] + fy), mz = a * (ef[3 * i + 2] + fz);
       const double ddx = mx - ri.mx, ddy = my - ri.my, ddz = mz - ri.mz;
-      dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz;
+      if (ALLPAIRS) { dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz; }
+      else { sp.mxy[db][i] = make_double2(mx, my); sp.mza[db][i] = make_double2(mz, a); }
       const double c = ddx * ddx + ddy * ddy + ddz * ddz;
       if (c != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), c);
     }
@@ -983,19 +1023,32 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
 // multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers
 __global__ void k_mu_gather(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
                             const AtomRec *__restrict__ recA, const AtomRec *__restrict__ recB,
-                            double *__restrict__ dst) {
+                            double *__restrict__ dst, SplitRec sp, int jacobi) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
-  const AtomRec *r = scal->cur ? recB : recA;
   const long long s = inv ? inv[i] : i;
+  if (sp.xy) {
+    const int cur = jacobi ? scal->cur : 0;
+    const double2 a = sp.mxy[cur][s], b = sp.mza[cur][s];
+    dst[3 * (i - lo)] = a.x; dst[3 * (i - lo) + 1] = a.y; dst[3 * (i - lo) + 2] = b.x;
+    return;
+  }
+  const AtomRec *r = scal->cur ? recB : recA;
   dst[3 * (i - lo)] = r[s].mx; dst[3 * (i - lo) + 1] = r[s].my; dst[3 * (i - lo) + 2] = r[s].mz;
 }
 __global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
-                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src) {
+                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src,
+                             SplitRec sp, int jacobi) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
-  AtomRec *r = scal->cur ? recB : recA;
   const long long s = inv ? inv[i] : i;
+  if (sp.xy) {
+    const int cur = jacobi ? scal->cur : 0;
+    sp.mxy[cur][s] = make_double2(src[3 * (i - lo)], src[3 * (i - lo) + 1]);
+    sp.mza[cur][s].x = src[3 * (i - lo) + 2];
+    return;
+  }
+  AtomRec *r = scal->cur ? recB : recA;
   r[s].mx = src[3 * (i - lo)]; r[s].my = src[3 * (i - lo) + 1]; r[s].mz = src[3 * (i - lo) + 2];
 }
 
@@ -1003,7 +1056,7 @@ __global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__
 __global__ void k_zero_scal(Scal *s, int keep_solver) {
   s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;
   for (int k = 0; k < 6; k++) s->virial[k] = 0.0;
-  s->change = 0.0; s->last_change = 0.0;
+  s->change = 0.0; s->last_change = 0.0; s->pad = 0;
   s->rmin_bits = (unsigned long long)__double_as_longlong(1000.0);
   if (!keep_solver) { s->iterations = 0; s->done = 0; s->status = 0; s->cur = 0; s->sweeps = 0; }
 }

@@ -113,3 +113,101 @@ def test_no_silent_fallback_library_is_loaded(pkg):
     assert pkg.device_count() >= 1
     with open("/proc/self/maps") as fh:
         assert any("libpolar_mi355x.so" in ln for ln in fh)
+
+
+class _LoopbackDist:
+    """Stand-in for torch.distributed when several 'ranks' live in ONE process on one GPU: the
+    collectives are executed when the last rank arrives (ranks are stepped in lock-step by the test)."""
+
+    def __init__(self, world):
+        self.world, self.pending = world, []
+
+
+def _run_sharded_lockstep(pkg, par, s, world, eflag=1, vflag=2):
+    """Drive `world` HipShardBackend handles through parallel.run_step's protocol in lock-step,
+    exchanging dipoles through device tensors exactly as exchange_mu does."""
+    import torch
+
+    counts, offs = par.split_rows(s.nlocal, world)
+    bes = []
+    for r in range(world):
+        lo, hi = int(offs[r]), int(offs[r + 1])
+        # each rank only gets ITS rows of a full (newton-off) LJ/coul list
+        rows = np.arange(lo, hi)
+        p = pkg.pair_from_system(s)
+        ilist = rows.astype(np.int32)
+        p.set_neighbors_csr(ilist, s.extra["full_numneigh"], s.extra["full_first"], s.extra["full_neigh"])
+        bes.append(par.HipShardBackend(p, lo, hi, 0))
+
+    def exchange():
+        own = [be.own_mu().clone() for be in bes]
+        for r, be in enumerate(bes):
+            for q in range(world):
+                if q != r:
+                    be.set_mu(int(offs[q]), int(offs[q + 1]), own[q])
+
+    for be in bes:
+        be.begin(eflag, vflag)
+    exchange()
+    be0 = bes[0]
+    for sw in range(be0.max_it + 1):
+        for be in bes:
+            be.sweep()
+        if not be0.fixed:
+            tot = sum(be.local_change().clone() for be in bes)
+            for be in bes:
+                be.sweep_end(tot)
+        else:
+            for be in bes:
+                be.sweep_end(None)
+        exchange()
+        if not be0.fixed and sw % 4 == 3 and all(be.state()[0] for be in bes):
+            break
+    outs = [be.finish() for be in bes]
+    torch.cuda.synchronize()
+    n = s.nlocal
+    f = np.zeros((n, 3)); mu = np.zeros((n, 3))
+    for r, be in enumerate(bes):
+        lo, hi = int(offs[r]), int(offs[r + 1])
+        fr = be.pair.download("f", 3 * (s.nlocal + s.nghost)).reshape(-1, 3)
+        f[lo:hi] = fr[lo:hi]
+        assert np.all(fr[:lo] == 0) and np.all(fr[hi:n] == 0)      # a shard touches only its rows
+        mu[lo:hi] = be.pair.download("mu", 3 * n).reshape(-1, 3)[lo:hi]
+    tot = {k: sum(o[k] for o in outs) for k in ("eng_vdwl", "eng_coul", "eng_pol")}
+    return f, mu, tot, outs
+
+
+def _full_list_system(wl, case, extra):
+    s, _ = wl.load_fixture(os.path.join(GOLD, case + ".npz"), extra_args=extra)
+    z = np.load(os.path.join(GOLD, case + ".npz"))
+    import math
+    cutneigh = math.sqrt(s.tables["cutsq"][1:, 1:].max()) + 2.0
+    x_all, owner, shift = wl.build_ghosts(z["x"], z["boxlo"], z["prd"], cutneigh)
+    special = wl.build_special(s.nlocal, z["bonds"]) if len(z["bonds"]) else None
+    meta_excl = case == "mof5_h2"
+    il, nn, first, neigh = wl.build_half_list(x_all, owner, shift, s.nlocal, cutneigh, molecule=np.asarray(z["molecule"]),
+                                              special=special, exclude_intra=meta_excl, full=True)
+    s.extra.update(full_numneigh=nn, full_first=first, full_neigh=neigh)
+    return s
+
+
+@pytest.mark.parametrize("mode", ["jacobi", "gs"])
+def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
+    """The multi-GPU kernels paths (row ranges in cell order, full-list LJ/coul, gather/scatter of
+    dipoles, externally reduced sum dmu^2) on ONE GPU: three shards stepped in lock-step must
+    reproduce the unsharded result (Jacobi: same iteration; GS: same fixed point)."""
+    import importlib
+    par = importlib.import_module(pkg.__name__ + ".parallel")
+    extra = ["use_previous", "no", "dd_cutoff", "9.0"]
+    extra += (["polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "6"] if mode == "jacobi"
+              else ["precision", "1e-13", "max_iterations", "200"])
+    s = _full_list_system(wl, "bulk_h2", extra)
+    ref = pkg.pair_from_system(s).compute()
+    fref = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
+    f, mu, tot, outs = _run_sharded_lockstep(pkg, par, s, world=3)
+    tol = 1e-11 if mode == "jacobi" else 1e-8
+    assert np.max(np.abs(mu - ref["mu"])) / np.max(np.abs(ref["mu"])) < tol
+    assert force_rel_err(f, fref) < max(tol, 1e-9)
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert rel(tot[k], ref[k]) < max(tol, 1e-10)
+    assert len({o["iterations"] for o in outs}) == 1
