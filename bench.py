@@ -75,7 +75,7 @@ def main():
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
-    if world > 1:
+    if world > 1 or os.environ.get("POLAR_FORCE_DIST"):  # the env switch lets a 1-GPU box rehearse the distributed path
         par = importlib.import_module(PKG + ".parallel")
         return par.bench_distributed(args, rank, world, local_rank)
 

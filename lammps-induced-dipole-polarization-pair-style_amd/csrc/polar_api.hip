@@ -82,16 +82,17 @@ struct polar_handle {
   CellGrid grid{};
   long long ncell = 0;
   bool sorted = false;  // true while the records are in cell order (list mode)
-  DBuf<long long> d_first;
+  DBuf<long long> d_first, d_sym_first;
+  DBuf<int> d_sym_cnt, d_sym_fill, d_sym_j;
+  bool sym_valid = false;  // symmetrised list matches the uploaded half list
   DBuf<AtomRec> d_rec0, d_rec1;
   DBuf<Scal> d_scal;
   DBuf<double> d_slots;
   // cutoff-mode lists
   DBuf<int> d_cell_id, d_cell_cnt, d_cell_fill, d_nl_cnt, d_dd_cnt, d_nl_j, d_dd_j;
   DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
-  DBuf<double2> d_dd_s, d_sxy, d_szq, d_smxy0, d_smxy1, d_smza0, d_smza1;
-  SplitRec sp{};          // list-mode sweep arrays (see polar_kernels.hpp); sp.xy == nullptr in exact mode
-  bool split_live = false;  // dipoles currently live in the split arrays (between k_split and k_merge)
+  DBuf<double2> d_dd_s;
+  DBuf<double4> d_xq;
   long long nl_pairs = 0, dd_pairs = 0;
   int inum = 0;
   long long nneigh = 0;
@@ -101,6 +102,8 @@ struct polar_handle {
   std::vector<int> h_rows;     // rows sorted by colour (host copy)
   bool colors_valid = false;
   double color_dist = 2.6;
+  int field_block = 256;
+  int ablate = 0;  // lab switches for k_field (POLAR_ABLATE), 0 in production
   Scal *h_scal = nullptr;  // pinned
   hipEvent_t ev[8] = {};
   std::vector<double> h_tmp;
@@ -133,15 +136,21 @@ void need_device(polar_handle *h) {
   if (!h->have_device) throw NoDevice();
 }
 
-// upload LJ tables + Coulomb tables from the host mirror (or raw setters) into P
+// upload LJ tables + Coulomb tables from the host mirror (or raw setters) into P, repacked so that
+// the half-list loop reads one 64-byte line per type pair / per Coulomb bin
 void upload_types(polar_handle *h, int ntypes, const double *const t[7]) {
   need_device(h);
-  size_t m = (size_t)(ntypes + 1) * (ntypes + 1);
-  h->d_lj.ensure(7 * m);
-  for (int k = 0; k < 7; k++) HIPCHECK(hipMemcpy(h->d_lj.p + k * m, t[k], m * sizeof(double), hipMemcpyHostToDevice));
+  const size_t m = (size_t)(ntypes + 1) * (ntypes + 1);
+  std::vector<double> pack(8 * m, 0.0);
+  // t = lj1, lj2, lj3, lj4, offset, cut_ljsq, cutsq  ->  cutsq, cut_ljsq, lj1, lj2, lj3, lj4, offset, pad
+  for (size_t k = 0; k < m; k++) {
+    pack[8 * k + 0] = t[6][k]; pack[8 * k + 1] = t[5][k]; pack[8 * k + 2] = t[0][k]; pack[8 * k + 3] = t[1][k];
+    pack[8 * k + 4] = t[2][k]; pack[8 * k + 5] = t[3][k]; pack[8 * k + 6] = t[4][k];
+  }
+  h->d_lj.ensure(8 * m);
+  HIPCHECK(hipMemcpy(h->d_lj.p, pack.data(), 8 * m * sizeof(double), hipMemcpyHostToDevice));
   h->P.ntypes = ntypes;
-  h->P.lj1 = h->d_lj.p; h->P.lj2 = h->d_lj.p + m; h->P.lj3 = h->d_lj.p + 2 * m; h->P.lj4 = h->d_lj.p + 3 * m;
-  h->P.offset = h->d_lj.p + 4 * m; h->P.cut_ljsq = h->d_lj.p + 5 * m; h->P.cutsq = h->d_lj.p + 6 * m;
+  h->P.ljpack = h->d_lj.p;
   h->ntypes = ntypes;
   h->types_set = true;
 }
@@ -152,13 +161,16 @@ void upload_coul(polar_handle *h, double g_ewald, double qqrd2e, const double *s
   h->P.g_ewald = g_ewald; h->P.qqrd2e = qqrd2e;
   for (int k = 0; k < 4; k++) { h->P.special_lj[k] = slj[k]; h->P.special_coul[k] = scoul[k]; }
   h->P.ncoultablebits = nbits; h->P.ncoulmask = mask; h->P.ncoulshiftbits = shift; h->P.tabinnersq = tabinnersq;
-  size_t nt = nbits ? ((size_t)1 << nbits) : 1;
-  h->d_tab.ensure(8 * nt);
+  const size_t nt = nbits ? ((size_t)1 << nbits) : 1;
+  std::vector<double> pack(8 * nt, 0.0);
+  // t = r, dr, f, df, c, dc, e, de  ->  r, dr, f, df, e, de, c, dc
+  static const int order[8] = {0, 1, 2, 3, 6, 7, 4, 5};
   if (nbits)
-    for (int k = 0; k < 8; k++) HIPCHECK(hipMemcpy(h->d_tab.p + k * nt, t[k], nt * sizeof(double), hipMemcpyHostToDevice));
-  h->P.rtable = h->d_tab.p; h->P.drtable = h->d_tab.p + nt; h->P.ftable = h->d_tab.p + 2 * nt;
-  h->P.dftable = h->d_tab.p + 3 * nt; h->P.ctable = h->d_tab.p + 4 * nt; h->P.dctable = h->d_tab.p + 5 * nt;
-  h->P.etable = h->d_tab.p + 6 * nt; h->P.detable = h->d_tab.p + 7 * nt;
+    for (size_t b = 0; b < nt; b++)
+      for (int k = 0; k < 8; k++) pack[8 * b + k] = t[order[k]][b];
+  h->d_tab.ensure(8 * nt);
+  HIPCHECK(hipMemcpy(h->d_tab.p, pack.data(), 8 * nt * sizeof(double), hipMemcpyHostToDevice));
+  h->P.ctab = h->d_tab.p;
   h->coul_set = true;
 }
 
@@ -331,9 +343,11 @@ template <bool AP, int DAMP, int EP>
 void launch_field(polar_handle *h, int nrows, const int *rows) {
   const polar_settings &st = h->ph.st;
   if (nrows <= 0) return;
-  k_field<AP, DAMP, EP><<<nblk(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(
+  const int fb = h->field_block;  // threads per workgroup = 64 x rows that share one L1
+  const size_t lds = AP ? 0 : (size_t)(fb / 64) * 64 * 5 * sizeof(double2);  // per-wave staging tiles (list mode)
+  k_field<AP, DAMP, EP><<<nblk(nrows, fb / 64), fb, lds, h->stream>>>(
       nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, h->d_dd_first.p, h->d_dd_j.p, h->d_dd_s.p,
-      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_scal.p, h->d_slots.p, AP ? SplitRec{} : h->sp);
+      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_scal.p, h->d_slots.p, h->ablate);
 }
 template <int EP>
 void launch_field_dyn(polar_handle *h, bool ap, int nrows, const int *rows) {
@@ -499,10 +513,34 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
 
   {  // a3
     LJCoulParams P = h->P;
-    P.newton_pair = 1; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list;
-    dim3 grid(nblk(h->inum, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
+    P.newton_pair = 1; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list; P.ablate = h->ablate;
+    h->d_xq.ensure(nall + 1);
+    k_pack_lj<<<nblk(nall, 256), 256, 0, s>>>(nall, h->d_x.p, h->d_q.p, h->d_xq.p);
+    const size_t ljlds = (size_t)(h->ntypes + 1) * (h->ntypes + 1) * 8 * sizeof(double);
+    if (ljlds > 64 * 1024) throw InputError("too many atom types for the LDS-resident LJ table (max 31)");
+    dim3 block(POLAR_BLOCK);
+    const bool symmetrise = !h->full_list && !getenv("POLAR_LJ_ATOMICS");
+    if (symmetrise && !h->sym_valid && h->inum > 0) {  // once per uploaded list (reneighbor steps)
+      dim3 g0(nblk(h->inum, POLAR_ROWS_PER_BLOCK));
+      h->d_sym_cnt.ensure(nall + 1); h->d_sym_fill.ensure(nall + 1); h->d_sym_first.ensure(nall + 2);
+      h->d_sym_j.ensure(2 * (size_t)h->nneigh + 64);
+      HIPCHECK(hipMemsetAsync(h->d_sym_cnt.p, 0, (nall + 1) * sizeof(int), s));
+      HIPCHECK(hipMemsetAsync(h->d_sym_fill.p, 0, (nall + 1) * sizeof(int), s));
+      k_sym_count<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_cnt.p);
+      k_exclusive_scan<int><<<1, 1024, 0, s>>>(nall, h->d_sym_cnt.p, h->d_sym_first.p);
+      k_sym_fill<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_first.p,
+                                      h->d_sym_fill.p, h->d_sym_j.p);
+      h->sym_valid = true;
+    }
+    const int nrows_lj = symmetrise ? nall : h->inum;
+    dim3 grid(nblk(nrows_lj, POLAR_ROWS_PER_BLOCK));
+    if (symmetrise) P.full_list = 1;  // rows of the symmetrised list: force on the row atom only, tallies halved
+    const int *il = symmetrise ? nullptr : h->d_ilist.p;
+    const int *nn = symmetrise ? nullptr : h->d_numneigh.p;
+    const long long *fi = symmetrise ? h->d_sym_first.p : h->d_first.p;
+    const int *nj = symmetrise ? h->d_sym_j.p : h->d_neigh.p;
     if (h->inum > 0) {
-#define LJ(E, V) k_ljcoul<E, V><<<grid, block, 0, s>>>(P, h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_x.p, h->d_q.p, h->d_type.p, h->d_f.p, h->d_slots.p)
+#define LJ(E, V) k_ljcoul<E, V><<<grid, block, ljlds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p)
       if (eflag) { if (vmode == 1) LJ(true, true); else LJ(true, false); }
       else       { if (vmode == 1) LJ(false, true); else LJ(false, false); }
 #undef LJ
@@ -516,16 +554,6 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     if (ap) k_static_field<true><<<grid, block, 0, s>>>(nullptr, n, n, h->d_rec0.p, h->d_mol_s.p, h->box, nullptr, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
     else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, h->d_nl_first.p, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
   }
-  if (!ap) {  // the sweep works on the split arrays
-    h->d_sxy.ensure(n); h->d_szq.ensure(n); h->d_smxy0.ensure(n); h->d_smxy1.ensure(n); h->d_smza0.ensure(n); h->d_smza1.ensure(n);
-    h->sp.xy = h->d_sxy.p; h->sp.zq = h->d_szq.p; h->sp.mxy[0] = h->d_smxy0.p; h->sp.mxy[1] = h->d_smxy1.p;
-    h->sp.mza[0] = h->d_smza0.p; h->sp.mza[1] = h->d_smza1.p;
-    k_split<<<nblk(n, 256), 256, 0, s>>>(n, h->d_rec0.p, h->sp);
-    h->split_live = true;
-  } else {
-    h->sp = SplitRec{};
-    h->split_live = false;
-  }
   HIPCHECK(hipEventRecord(h->ev[4], s));
 }
 
@@ -537,12 +565,6 @@ int phase_finish(polar_handle *h, polar_result *out) {
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
   const int eflag = h->step_eflag, vmode = h->step_vflag % 4;
   hipStream_t s = h->stream;
-  if (h->split_live) {
-    const bool jac = !(st.polar_gs || st.polar_gs_ranked);
-    // Jacobi: the buffer index is scal->cur; GS: buffer 0 (use the always-zero `pad` field)
-    k_merge<<<nblk(n, 256), 256, 0, s>>>(n, jac ? &h->d_scal.p->cur : &h->d_scal.p->pad, h->sp, h->d_rec0.p, h->d_rec1.p);
-    h->split_live = false;
-  }
   k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p);
   HIPCHECK(hipEventRecord(h->ev[5], s));
   if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1); else launch_force<true, 1>(h, eflag, vmode == 1); }
@@ -601,6 +623,8 @@ int polar_create(int device, polar_handle **out) {
   *out = h;
   h->device = device;
   if (const char *e = getenv("POLAR_COLOR_DIST")) h->color_dist = atof(e);
+  if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
+  if (const char *e = getenv("POLAR_FIELD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->field_block = v; }
   int n = polar_device_count();
   if (n <= 0 || device < 0 || device >= n) {
     h->have_device = false;  // host mirror still usable; compute entry points will fail loudly
@@ -628,12 +652,12 @@ int polar_destroy(polar_handle *h) {
     h->d_mu.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
     h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();
     h->d_numneigh.release(); h->d_neigh.release(); h->d_rows.release(); h->d_first.release();
+    h->d_sym_first.release(); h->d_sym_cnt.release(); h->d_sym_fill.release(); h->d_sym_j.release();
     h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release();
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_nl_j.release(); h->d_dd_j.release();
-    h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release();
-    h->d_sxy.release(); h->d_szq.release(); h->d_smxy0.release(); h->d_smxy1.release(); h->d_smza0.release(); h->d_smza1.release();
+    h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release();
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -797,6 +821,7 @@ int polar_set_neighbors_csr(polar_handle *h, int inum, const int *ilist, const i
     HIPCHECK(hipMemcpyAsync(h->d_neigh.p, neigh, (size_t)total * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHECK(hipStreamSynchronize(s));
     h->neigh_set = true;
+    h->sym_valid = false;
     h->colors_valid = false;  // reneighbor step: refresh the colour phases too
     return POLAR_OK;
   });
@@ -949,14 +974,14 @@ int polar_step_finish(polar_handle *h, polar_result *out) {
 int polar_mu_gather(polar_handle *h, long long lo, long long hi, double *dev_dst) {
   return guarded(h, [&]() {
     need_device(h);
-    if (hi > lo) k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst, h->split_live ? h->sp : SplitRec{}, !(h->ph.st.polar_gs || h->ph.st.polar_gs_ranked));
+    if (hi > lo) k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst);
     return POLAR_OK;
   });
 }
 int polar_mu_scatter(polar_handle *h, long long lo, long long hi, const double *dev_src) {
   return guarded(h, [&]() {
     need_device(h);
-    if (hi > lo) k_mu_scatter<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src, h->split_live ? h->sp : SplitRec{}, !(h->ph.st.polar_gs || h->ph.st.polar_gs_ranked));
+    if (hi > lo) k_mu_scatter<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src);
     return POLAR_OK;
   });
 }

@@ -25,16 +25,13 @@ namespace polar {
 
 // 64-byte atom record: one L2 line-half per gathered neighbor.
 struct __attribute__((aligned(64))) AtomRec {
-  double x, y, z;     // position              } the sweep gathers only these first 48 bytes
-  double mx, my, mz;  // induced dipole        }
-  double q, a;        // charge, static polarizability
+  // component-interleaved: 16-byte piece k (k = 0,1,2) holds (position_k, dipole_k); piece 3 = (q, alpha).
+  // A QUAD of lanes reads one whole record with one coalesced 64-byte access (see k_field, list mode).
+  double x, mx;
+  double y, my;
+  double z, mz;
+  double q, a;
 };
-struct XM { double x, y, z, mx, my, mz; };  // the 48-byte prefix of an AtomRec
-__device__ __forceinline__ XM load_xm(const AtomRec *__restrict__ r) {
-  const double2 *p = reinterpret_cast<const double2 *>(r);
-  const double2 a = p[0], b = p[1], c = p[2];  // 3 x dwordx4
-  return XM{a.x, a.y, b.x, b.y, c.x, c.y};
-}
 
 struct Box {
   double prd[3], half[3], inv[3];
@@ -99,34 +96,22 @@ __device__ __forceinline__ void min_image_del(const Box &b, double xi, double yi
   dz = -wrap_ci(zj - zi, b.prd[2], b.half[2], b.periodic[2]);
 }
 
-// Split ("16-byte SoA") copy of the records for the list-mode sweep: four double2 arrays in s
-// order.  A wave whose lanes hold consecutive j then reads DENSE cache lines (64 lanes x 16 B =
-// 8 lines per load instruction) instead of one 16-B piece out of 32 different lines of the 64-byte
-// AoS records -- the sweep's gathers are bound by L1 line transactions, not bytes.
-struct SplitRec {
-  double2 *xy;      // {x, y}
-  double2 *zq;      // {z, q}
-  double2 *mxy[2];  // {mu_x, mu_y}   two buffers: Jacobi ping-pong (GS uses [0] only)
-  double2 *mza[2];  // {mu_z, alpha}
-};
-__global__ void k_split(int n, const AtomRec *__restrict__ rec, SplitRec sp) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const AtomRec r = rec[i];
-  sp.xy[i] = make_double2(r.x, r.y);
-  sp.zq[i] = make_double2(r.z, r.q);
-  sp.mxy[0][i] = sp.mxy[1][i] = make_double2(r.mx, r.my);
-  sp.mza[0][i] = sp.mza[1][i] = make_double2(r.mz, r.a);
+// quad (4-lane) exchange through DPP quad_perm -- no LDS crossbar
+__device__ __forceinline__ double quad_xor(double v, const int which) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if (which == 1) {  // lanes 0<->1, 2<->3   quad_perm [1,0,3,2]
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+  } else {           // lanes 0<->2, 1<->3   quad_perm [2,3,0,1]
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+  }
+  return __hiloint2double(hi, lo);
 }
-// dipoles back into both record buffers (forces, fallback and unpack read records)
-struct Scal;
-__global__ void k_merge(int n, const int *cur_ptr, SplitRec sp, AtomRec *__restrict__ r0, AtomRec *__restrict__ r1) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int cur = *cur_ptr;
-  const double2 a = sp.mxy[cur][i], b = sp.mza[cur][i];
-  r0[i].mx = a.x; r0[i].my = a.y; r0[i].mz = b.x;
-  r1[i].mx = a.x; r1[i].my = a.y; r1[i].mz = b.x;
+__device__ __forceinline__ double quad_sum(double v) {
+  v += quad_xor(v, 1);
+  v += quad_xor(v, 2);
+  return v;
 }
 
 // Branch-free minimum image for the LIST kernels (dd_cutoff extension): d - L*rint(d/L).
@@ -264,29 +249,87 @@ struct LJCoulParams {
   int ntypes, newton_pair, nlocal;
   int full_list;  // 1: LAMMPS full list (each pair in both rows): force on i only, tallies halved
   int ncoultablebits, ncoulmask, ncoulshiftbits;
+  int ablate;     // lab switch (POLAR_ABLATE & 32: no deposit on j)
   double tabinnersq, cut_coulsq, g_ewald, qqrd2e;
   double special_lj[4], special_coul[4];
-  const double *lj1, *lj2, *lj3, *lj4, *offset, *cut_ljsq, *cutsq;
-  const double *rtable, *drtable, *ftable, *dftable, *ctable, *dctable, *etable, *detable;
+  const double *ljpack;   // [(ntypes+1)^2][8] = cutsq, cut_ljsq, lj1, lj2, lj3, lj4, offset, pad
+  const double *ctab;     // [ntable][8]      = r, dr, f, df, e, de, c, dc  (one 64-byte line per bin)
 };
 
-template <bool EFLAG, bool VPAIR>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum, const int *__restrict__ ilist,
-                                                        const int *__restrict__ numneigh,
-                                                        const long long *__restrict__ first,
-                                                        const int *__restrict__ neigh, const double *__restrict__ x,
-                                                        const double *__restrict__ q, const int *__restrict__ type,
-                                                        double *__restrict__ f, double *__restrict__ slots) {
-  const double EWALD_F = 1.12837917, EWALD_P = 0.3275911, A1 = 0.254829592, A2 = -0.284496736, A3 = 1.421413741,
-               A4 = -1.453152027, A5 = 1.061405429;  // PS.cpp:43-49
+// per-atom pack for the half-list loop: 32-byte {x,y,z,q} + type, locals AND ghosts, orig order
+__global__ void k_pack_lj(int nall, const double *__restrict__ x, const double *__restrict__ q, double4 *__restrict__ xq) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nall) xq[i] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], q[i]);
+}
+
+// Symmetrised copy of LAMMPS' half list, built on the device when the list is uploaded: every pair
+// (i,j) of the half list appears in the row of i AND in the row of j (ghost atoms get rows too), so
+// the force loop needs no atomics on j -- the three scattered FP64 atomics per pair were 85 % of
+// the kernel.  Each row then accumulates the full force on its atom; pair tallies count 1/2 per row.
+__global__ __launch_bounds__(POLAR_BLOCK) void k_sym_count(int inum, const int *__restrict__ ilist,
+                                                           const int *__restrict__ numneigh,
+                                                           const long long *__restrict__ first,
+                                                           const int *__restrict__ neigh, int *__restrict__ cnt) {
   const int lane = threadIdx.x & 63;
   const int ii = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (ii >= inum) return;
   const int i = ilist[ii];
-  const double qtmp = q[i], xtmp = x[3 * i], ytmp = x[3 * i + 1], ztmp = x[3 * i + 2];
-  const int itype = type[i], w = P.ntypes + 1;
+  const int *jl = neigh + first[i];
+  const int jn = numneigh[i];
+  for (int jj = lane; jj < jn; jj += 64) atomicAdd(&cnt[jl[jj] & 0x3FFFFFFF], 1);
+  if (lane == 0) atomicAdd(&cnt[i], jn);
+}
+__global__ __launch_bounds__(POLAR_BLOCK) void k_sym_fill(int inum, const int *__restrict__ ilist,
+                                                          const int *__restrict__ numneigh,
+                                                          const long long *__restrict__ first,
+                                                          const int *__restrict__ neigh,
+                                                          const long long *__restrict__ sfirst, int *__restrict__ fill,
+                                                          int *__restrict__ sj) {
+  const int lane = threadIdx.x & 63;
+  const int ii = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ii >= inum) return;
+  const int i = ilist[ii];
+  const int *jl = neigh + first[i];
+  const int jn = numneigh[i];
+  // own row: one slot range per wave, entries in list order
+  long long base = 0;
+  if (lane == 0) base = sfirst[i] + atomicAdd(&fill[i], jn);
+  base = __shfl(base, 0, 64);
+  for (int jj = lane; jj < jn; jj += 64) {
+    const int e = jl[jj];
+    const int j = e & 0x3FFFFFFF;
+    sj[base + jj] = e;                                                 // j with its special bits
+    sj[sfirst[j] + atomicAdd(&fill[j], 1)] = i | (e & 0xC0000000);     // reverse entry, same bits
+  }
+}
+
+// One wave per listed atom i.  Per pair: 1 coalesced index load, two 16-byte gathers of {x,y,z,q},
+// one 4-byte gather of the type, the type-pair parameters out of LDS, and the Coulomb bin as one
+// 64-byte line -- the loop is bound by L1 transactions and by the three FP64 atomics that deposit
+// -F on j (LAMMPS' newton-on contract: ghosts are folded back by reverse_comm).
+template <bool EFLAG, bool VPAIR>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum, const int *__restrict__ ilist,
+                                                        const int *__restrict__ numneigh,
+                                                        const long long *__restrict__ first,
+                                                        const int *__restrict__ neigh,
+                                                        const double4 *__restrict__ xq, const int *__restrict__ type,
+                                                        double *__restrict__ f, double *__restrict__ slots) {
+  const double EWALD_F = 1.12837917, EWALD_P = 0.3275911, A1 = 0.254829592, A2 = -0.284496736, A3 = 1.421413741,
+               A4 = -1.453152027, A5 = 1.061405429;  // PS.cpp:43-49
+  extern __shared__ double lj_lds[];
+  const int w = P.ntypes + 1;
+  for (int t = threadIdx.x; t < w * w * 8; t += blockDim.x) lj_lds[t] = P.ljpack[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int ii = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ii >= inum) return;
+  const int i = ilist ? ilist[ii] : ii;
+  const double4 pi = xq[i];
+  const double qtmp = pi.w, xtmp = pi.x, ytmp = pi.y, ztmp = pi.z;
+  const int itype = type[i];
   const int *jlist = neigh + first[i];
-  const int jnum = numneigh[i];
+  const int jnum = numneigh ? numneigh[i] : (int)(first[i + 1] - first[i]);
+  if (jnum == 0) return;
   double fx = 0, fy = 0, fz = 0, ev = 0, ec = 0;
   double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
   for (int jj = lane; jj < jnum; jj += 64) {
@@ -294,13 +337,15 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
     const int sb = (j >> 30) & 3;  // sbmask, src/pair.h:241
     const double factor_lj = P.special_lj[sb], factor_coul = P.special_coul[sb];
     j &= 0x3FFFFFFF;  // NEIGHMASK
-    const double delx = xtmp - x[3 * j], dely = ytmp - x[3 * j + 1], delz = ztmp - x[3 * j + 2];
+    const double4 pj = xq[j];
+    const double delx = xtmp - pj.x, dely = ytmp - pj.y, delz = ztmp - pj.z;
     const double rsq = delx * delx + dely * dely + delz * delz;
-    const int ij = itype * w + type[j];
-    if (rsq < P.cutsq[ij]) {
+    const double *lj = lj_lds + (itype * w + type[j]) * 8;
+    if (rsq < lj[0]) {
       const double r2inv = 1.0 / rsq;
+      const double qiqj = qtmp * pj.w;
       double forcecoul = 0.0, forcelj = 0.0, prefactor = 0.0, erfc_ = 0.0, fraction = 0.0, r6inv = 0.0;
-      int itable = 0;
+      double2 tab_e = make_double2(0.0, 0.0);
       bool direct = true;
       if (rsq < P.cut_coulsq) {
         direct = (!P.ncoultablebits) || (rsq <= P.tabinnersq);
@@ -308,29 +353,31 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
           const double r = sqrt(rsq), grij = P.g_ewald * r, expm2 = exp(-grij * grij);
           const double t = 1.0 / (1.0 + EWALD_P * grij);
           erfc_ = t * (A1 + t * (A2 + t * (A3 + t * (A4 + t * A5)))) * expm2;
-          prefactor = P.qqrd2e * qtmp * q[j] / r;
+          prefactor = P.qqrd2e * qiqj / r;
           forcecoul = prefactor * (erfc_ + EWALD_F * grij * expm2);
           if (factor_coul < 1.0) forcecoul -= (1.0 - factor_coul) * prefactor;
         } else {
           const float rsqf = (float)rsq;  // union_int_float_t lookup, PS.cpp:268-272
-          itable = (__float_as_int(rsqf) & P.ncoulmask) >> P.ncoulshiftbits;
-          fraction = ((double)rsqf - P.rtable[itable]) * P.drtable[itable];
-          double table = P.ftable[itable] + fraction * P.dftable[itable];
-          forcecoul = qtmp * q[j] * table;
+          const int itable = (__float_as_int(rsqf) & P.ncoulmask) >> P.ncoulshiftbits;
+          const double2 *bin = reinterpret_cast<const double2 *>(P.ctab + (size_t)itable * 8);
+          const double2 rdr = bin[0], fdf = bin[1];
+          if (EFLAG) tab_e = bin[2];
+          fraction = ((double)rsqf - rdr.x) * rdr.y;
+          forcecoul = qiqj * (fdf.x + fraction * fdf.y);
           if (factor_coul < 1.0) {
-            table = P.ctable[itable] + fraction * P.dctable[itable];
-            prefactor = qtmp * q[j] * table;
+            const double2 cdc = bin[3];
+            prefactor = qiqj * (cdc.x + fraction * cdc.y);
             forcecoul -= (1.0 - factor_coul) * prefactor;
           }
         }
       }
-      if (rsq < P.cut_ljsq[ij]) {
+      if (rsq < lj[1]) {
         r6inv = r2inv * r2inv * r2inv;
-        forcelj = r6inv * (P.lj1[ij] * r6inv - P.lj2[ij]);
+        forcelj = r6inv * (lj[2] * r6inv - lj[3]);
       }
       const double fpair = (forcecoul + factor_lj * forcelj) * r2inv;
       fx += delx * fpair; fy += dely * fpair; fz += delz * fpair;
-      if (!P.full_list && (P.newton_pair || j < P.nlocal)) {
+      if (!P.full_list && (P.newton_pair || j < P.nlocal) && !(P.ablate & 32)) {
         atomicAdd(&f[3 * j], -delx * fpair);
         atomicAdd(&f[3 * j + 1], -dely * fpair);
         atomicAdd(&f[3 * j + 2], -delz * fpair);
@@ -342,11 +389,11 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
         if (rsq < P.cut_coulsq) {
           double ecoul;
           if (direct) ecoul = prefactor * erfc_;
-          else ecoul = qtmp * q[j] * (P.etable[itable] + fraction * P.detable[itable]);
+          else ecoul = qiqj * (tab_e.x + fraction * tab_e.y);
           if (factor_coul < 1.0) ecoul -= (1.0 - factor_coul) * prefactor;
           ec += wgt * ecoul;
         }
-        if (rsq < P.cut_ljsq[ij]) ev += wgt * factor_lj * (r6inv * (P.lj3[ij] * r6inv - P.lj4[ij]) - P.offset[ij]);
+        if (rsq < lj[1]) ev += wgt * factor_lj * (r6inv * (lj[4] * r6inv - lj[5]) - lj[6]);
       }
       if (VPAIR) {
         v0 += wgt * delx * delx * fpair; v1 += wgt * dely * dely * fpair; v2 += wgt * delz * delz * fpair;
@@ -433,28 +480,22 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restr
 enum { EP_JACOBI = 0, EP_INPLACE = 1, EP_FIELD = 2 };
 
 template <bool ALLPAIRS, int DAMP, int EP>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__restrict__ rows, int nlocal,
+__global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict__ rows, int nlocal,
                                                        AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, Box box,
                                                        const long long *__restrict__ dd_first,
                                                        const int *__restrict__ dd_j,
                                                        const double2 *__restrict__ dd_s, double ddcutsq, double pd,
                                                        const double *__restrict__ ef, double *__restrict__ Fout,
-                                                       const Scal *scal, double *__restrict__ slots, SplitRec sp) {
+                                                       const Scal *scal, double *__restrict__ slots, int ablate) {
   if (scal->done) return;  // device-resident loop control: finished solves turn later launches into no-ops
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // blockDim.x/64 rows per workgroup
   if (row >= nrows) return;
   const int i = rows ? rows[row] : row;
   const int cur = scal->cur;
-  const int sb = (EP == EP_JACOBI) ? cur : 0, db = (EP == EP_JACOBI) ? (cur ^ 1) : 0;  // split-array buffers
   const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
   AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
-  AtomRec ri;
-  if (ALLPAIRS) ri = src[i];
-  else {
-    const double2 a = sp.xy[i], b = sp.zq[i], c = sp.mxy[sb][i], d = sp.mza[sb][i];
-    ri.x = a.x; ri.y = a.y; ri.z = b.x; ri.q = b.y; ri.mx = c.x; ri.my = c.y; ri.mz = d.x; ri.a = d.y;
-  }
+  const AtomRec ri = src[i];
   double fx = 0, fy = 0, fz = 0;
   if (ri.a != 0.0 || EP == EP_FIELD) {
     long long beg = 0, end = nlocal;
@@ -476,41 +517,72 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__r
         fz -= s3 * rj.mz - c * dz;
       }
     } else {
-      // list mode: the damped tensor scalars (s3, s5) were cached per pair by k_dd_scalars, so a
-      // sweep streams 20 B per pair (int32 j + two doubles) and gathers 48 B of one record.
-      // Four pairs per lane and trip: the index/scalar loads of a trip are independent and the four
-      // record gathers go out together, so a row of <= 256 neighbors costs two memory latencies
-      // instead of two per 64 neighbors (the colour-phase launches are latency-, not ALU-bound).
-      constexpr int U = 4;
-      for (long long base = beg; base < end; base += 64 * U) {
-        int jv[U];
-        double2 sv[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const long long p = base + u * 64 + lane;
-          const bool ok = p < end;
-          jv[u] = ok ? dd_j[p] : i;
-          sv[u] = ok ? dd_s[p] : make_double2(0.0, 0.0);
-        }
-        XM rv[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const double2 a = sp.xy[jv[u]], b = sp.zq[jv[u]], c = sp.mxy[sb][jv[u]], d = sp.mza[sb][jv[u]];
-          rv[u] = XM{a.x, a.y, b.x, c.x, c.y, d.x};
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          double dx, dy, dz;
-          min_image_rint(box, ri.x, ri.y, ri.z, rv[u].x, rv[u].y, rv[u].z, dx, dy, dz);
-          const double md = rv[u].mx * dx + rv[u].my * dy + rv[u].mz * dz;
-          const double c = sv[u].y * md;
-          fx -= sv[u].x * rv[u].mx - c * dx;
-          fy -= sv[u].x * rv[u].my - c * dy;
-          fz -= sv[u].x * rv[u].mz - c * dz;
-        }
+      // list mode.  The damped tensor scalars (s3, s5) were cached per pair by k_dd_scalars, so a
+      // sweep streams 20 B per pair (int32 j + two doubles) and gathers one 64-byte record.
+      //   gather : scattered 16-byte loads cost one L1 (TCP) transaction per LANE, so the records of
+      //            a trip's 64 pairs are fetched QUAD-cooperatively -- lane k of quad q loads piece k
+      //            of record (r*16+q): 4 load instructions, each quad one coalesced 64-byte access;
+      //   LDS    : the pieces are written to a per-wave staging tile (80-byte pitch: conflict-free
+      //            b128 reads) and every lane reads back ITS pair's record: a wave-local transpose,
+      //            no workgroup barrier (rows have different trip counts);
+      //   math   : lane-per-pair, 64 pairs per VALU instruction.
+      if (ablate & 1) end = beg;  // lab: no pair loop at all
+      extern __shared__ double2 stage_all[];
+      double2 *stage = stage_all + (size_t)(threadIdx.x >> 6) * (64 * 5);
+      const int q4 = lane >> 2, k = lane & 3;
+      // Three trips in flight (software pipeline): while trip t is transposed and computed, the
+      // records of trip t+1 are being gathered and the index/scalar stream of trip t+2 is being read,
+      // so a row pays its memory latencies once instead of twice per 64 pairs.
+#define POLAR_LOAD_STREAM(BASE, JM, SC)                                   \
+  {                                                                      \
+    const long long p_ = (BASE) + lane;                                  \
+    const bool ok_ = p_ < end;                                           \
+    JM = (ok_ && !(ablate & 8)) ? dd_j[p_] : i;                          \
+    SC = (ok_ && !(ablate & 4)) ? dd_s[p_] : make_double2(0.0, 0.0);     \
+  }
+#define POLAR_GATHER(JM, P0, P1, P2, P3)                                                   \
+  {                                                                                        \
+    int j0_ = __shfl(JM, q4, 64), j1_ = __shfl(JM, 16 + q4, 64);                            \
+    int j2_ = __shfl(JM, 32 + q4, 64), j3_ = __shfl(JM, 48 + q4, 64);                       \
+    if (ablate & 2) j0_ = j1_ = j2_ = j3_ = i;                                             \
+    P0 = reinterpret_cast<const double2 *>(src + j0_)[k];                                   \
+    P1 = reinterpret_cast<const double2 *>(src + j1_)[k];                                   \
+    P2 = reinterpret_cast<const double2 *>(src + j2_)[k];                                   \
+    P3 = reinterpret_cast<const double2 *>(src + j3_)[k];                                   \
+  }
+      int jm0 = i, jm1 = i, jm2 = i;
+      double2 sc0 = make_double2(0.0, 0.0), sc1 = sc0, sc2 = sc0;
+      double2 pa0 = sc0, pa1 = sc0, pa2 = sc0, pa3 = sc0, pb0 = sc0, pb1 = sc0, pb2 = sc0, pb3 = sc0;
+      if (beg < end) {
+        POLAR_LOAD_STREAM(beg, jm0, sc0);
+        POLAR_LOAD_STREAM(beg + 64, jm1, sc1);
+        POLAR_GATHER(jm0, pa0, pa1, pa2, pa3);
       }
+      for (long long base = beg; base < end; base += 64) {
+        POLAR_LOAD_STREAM(base + 128, jm2, sc2);   // trip t+2 (predicated off past the row's end)
+        POLAR_GATHER(jm1, pb0, pb1, pb2, pb3);     // trip t+1
+        stage[(q4)*5 + k] = pa0; stage[(16 + q4) * 5 + k] = pa1;  // trip t
+        stage[(32 + q4) * 5 + k] = pa2; stage[(48 + q4) * 5 + k] = pa3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double2 a = stage[lane * 5], b = stage[lane * 5 + 1], c2 = stage[lane * 5 + 2];
+        __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next trip
+        double dx, dy, dz;
+        min_image_rint(box, ri.x, ri.y, ri.z, a.x, b.x, c2.x, dx, dy, dz);
+        const double md = a.y * dx + b.y * dy + c2.y * dz;
+        const double c = sc0.y * md;
+        fx -= sc0.x * a.y - c * dx;
+        fy -= sc0.x * b.y - c * dy;
+        fz -= sc0.x * c2.y - c * dz;
+        jm1 = jm2; sc0 = sc1; sc1 = sc2;
+        pa0 = pb0; pa1 = pb1; pa2 = pb2; pa3 = pb3;
+      }
+#undef POLAR_LOAD_STREAM
+#undef POLAR_GATHER
+      fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
     }
-    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+    if (ALLPAIRS) { fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz); }
   }
   if (lane == 0) {
     if (EP == EP_FIELD) {
@@ -519,10 +591,9 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field(int nrows, const int *__r
       const double a = ri.a;
       const double mx = a * (ef[3 * i] + fx), my = a * (ef[3 * i + 1] + fy), mz = a * (ef[3 * i + 2] + fz);
       const double ddx = mx - ri.mx, ddy = my - ri.my, ddz = mz - ri.mz;
-      if (ALLPAIRS) { dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz; }
-      else { sp.mxy[db][i] = make_double2(mx, my); sp.mza[db][i] = make_double2(mz, a); }
+      dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz;
       const double c = ddx * ddx + ddy * ddy + ddz * ddz;
-      if (c != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), c);
+      if (c != 0.0 && !(ablate & 16)) atomicAdd(slot_ptr(slots, SL_CHANGE), c);
     }
   }
 }
@@ -1023,31 +1094,18 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
 // multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers
 __global__ void k_mu_gather(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
                             const AtomRec *__restrict__ recA, const AtomRec *__restrict__ recB,
-                            double *__restrict__ dst, SplitRec sp, int jacobi) {
+                            double *__restrict__ dst) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
   const long long s = inv ? inv[i] : i;
-  if (sp.xy) {
-    const int cur = jacobi ? scal->cur : 0;
-    const double2 a = sp.mxy[cur][s], b = sp.mza[cur][s];
-    dst[3 * (i - lo)] = a.x; dst[3 * (i - lo) + 1] = a.y; dst[3 * (i - lo) + 2] = b.x;
-    return;
-  }
   const AtomRec *r = scal->cur ? recB : recA;
   dst[3 * (i - lo)] = r[s].mx; dst[3 * (i - lo) + 1] = r[s].my; dst[3 * (i - lo) + 2] = r[s].mz;
 }
 __global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
-                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src,
-                             SplitRec sp, int jacobi) {
+                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
   const long long s = inv ? inv[i] : i;
-  if (sp.xy) {
-    const int cur = jacobi ? scal->cur : 0;
-    sp.mxy[cur][s] = make_double2(src[3 * (i - lo)], src[3 * (i - lo) + 1]);
-    sp.mza[cur][s].x = src[3 * (i - lo) + 2];
-    return;
-  }
   AtomRec *r = scal->cur ? recB : recA;
   r[s].mx = src[3 * (i - lo)]; r[s].my = src[3 * (i - lo) + 1]; r[s].mz = src[3 * (i - lo) + 2];
 }
