@@ -94,6 +94,11 @@ struct polar_handle {
   DBuf<double2> d_dd_s;
   DBuf<double4> d_xq;
   long long nl_pairs = 0, dd_pairs = 0;
+  long long nl_pitch = 0, dd_pitch = 0;   // pitched row lists (see polar_kernels.hpp RowList)
+  DBuf<int> d_overflow;
+  DBuf<unsigned long long> d_ddtot;
+  int *h_flags = nullptr;                   // pinned: [0] overflow (needed count), [1..] unused
+  unsigned long long *h_ddtot = nullptr;    // pinned: 64 x 16 partial totals
   int inum = 0;
   long long nneigh = 0;
   bool mu_resident = false;
@@ -218,31 +223,32 @@ void build_lists(polar_handle *h) {
   const double cutall = std::max(st.cut_coul, st.dd_cutoff);
   hipStream_t s = h->stream;
   const CellGrid &g = h->grid;
-  h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1); h->d_nl_first.ensure(n + 2); h->d_dd_first.ensure(n + 2);
+  if (h->nl_pitch == 0) {  // first build: 1.5x the mean sphere population, rounded to 64
+    double vol = h->box.prd[0] * h->box.prd[1] * h->box.prd[2];
+    double mean = n / vol * 4.18879020478639 * cutall * cutall * cutall;
+    h->nl_pitch = h->dd_pitch = (((long long)(1.5 * mean) + 64) / 64 + 1) * 64;
+  }
+  h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1);
+  h->d_nl_j.ensure((size_t)n * h->nl_pitch + 64); h->d_dd_j.ensure((size_t)n * h->dd_pitch + 64);
+  h->d_dd_s.ensure((size_t)n * h->dd_pitch + 64);
   const double cutallsq = cutall * cutall, ddsq = st.dd_cutoff * st.dd_cutoff;
   const int nr = own_n(h);
   const int *rows = own_rows(h);
   HIPCHECK(hipMemsetAsync(h->d_nl_cnt.p, 0, (n + 1) * sizeof(int), s));
   HIPCHECK(hipMemsetAsync(h->d_dd_cnt.p, 0, (n + 1) * sizeof(int), s));
-  k_nl_build<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
-      rows, nr, h->d_rec0.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->d_nl_cnt.p, h->d_dd_cnt.p, nullptr,
-      nullptr, nullptr, nullptr);
-  k_exclusive_scan<int><<<1, 1024, 0, s>>>(n, h->d_nl_cnt.p, h->d_nl_first.p);
-  k_exclusive_scan<int><<<1, 1024, 0, s>>>(n, h->d_dd_cnt.p, h->d_dd_first.p);
-  long long tot[2];
-  HIPCHECK(hipMemcpyAsync(&tot[0], h->d_nl_first.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipMemcpyAsync(&tot[1], h->d_dd_first.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
-  h->nl_pairs = tot[0]; h->dd_pairs = tot[1];
-  h->d_nl_j.ensure((size_t)tot[0] + 64); h->d_dd_j.ensure((size_t)tot[1] + 64);
-  k_nl_build<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
-      rows, nr, h->d_rec0.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, nullptr, nullptr, h->d_nl_first.p,
-      h->d_dd_first.p, h->d_nl_j.p, h->d_dd_j.p);
-  h->d_dd_s.ensure((size_t)tot[1] + 64);
+  HIPCHECK(hipMemsetAsync(h->d_overflow.p, 0, 16 * sizeof(int), s));
+  HIPCHECK(hipMemsetAsync(h->d_ddtot.p, 0, 64 * 16 * sizeof(unsigned long long), s));
+  k_nl_build<<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
+      rows, nr, h->d_rec0.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,
+      h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, h->d_overflow.p, h->d_ddtot.p);
+  const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
   if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
-    k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, h->d_dd_first.p, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
+    k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
   else
-    k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, h->d_dd_first.p, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
+    k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
+  // overflow flag and dd total come back with the end-of-step read (no sync here)
+  HIPCHECK(hipMemcpyAsync(h->h_flags, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 }
 
 // ---- host-side greedy distance colouring for the colour-phase Gauss-Seidel (cutoff mode) ----
@@ -332,10 +338,10 @@ void launch_rank(polar_handle *h, int pass) {
   dim3 grid(nblk(n, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
   if (pass == 2) k_fold_scal<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, 1);
   if (pass == 1)
-    k_rank<AP, 1><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, h->d_nl_first.p,
+    k_rank<AP, 1><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch},
                                                  h->d_nl_j.p, h->d_rec0.p, h->d_mol_s.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
   else
-    k_rank<AP, 2><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, h->d_nl_first.p,
+    k_rank<AP, 2><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch},
                                                  h->d_nl_j.p, h->d_rec0.p, h->d_mol_s.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
 }
 
@@ -346,7 +352,7 @@ void launch_field(polar_handle *h, int nrows, const int *rows) {
   const int fb = h->field_block;  // threads per workgroup = 64 x rows that share one L1
   const size_t lds = AP ? 0 : (size_t)(fb / 64) * 64 * 5 * sizeof(double2);  // per-wave staging tiles (list mode)
   k_field<AP, DAMP, EP><<<nblk(nrows, fb / 64), fb, lds, h->stream>>>(
-      nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, h->d_dd_first.p, h->d_dd_j.p, h->d_dd_s.p,
+      nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, RowList{h->d_dd_cnt.p, h->dd_pitch}, h->d_dd_j.p, h->d_dd_s.p,
       st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_scal.p, h->d_slots.p, h->ablate);
 }
 template <int EP>
@@ -375,7 +381,7 @@ void launch_force(polar_handle *h, int eflag, int vpair) {
   const double ccs = st.cut_coul * st.cut_coul, dds = st.dd_cutoff * st.dd_cutoff, e2s = std::sqrt(h->P.qqrd2e);
 #define LF(E, V)                                                                                                    \
   k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(own_rows(h), own_n(h), h->sorted ? h->d_perm.p : nullptr, h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
-                                                               h->d_mol_s.p, h->box, h->d_nl_first.p, h->d_nl_j.p,  \
+                                                               h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p,  \
                                                                ccs, dds, st.polar_damp, e2s, h->d_f.p, h->d_slots.p)
   if (eflag) { if (vpair) LF(true, true); else LF(true, false); }
   else       { if (vpair) LF(false, true); else LF(false, false); }
@@ -551,8 +557,8 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   {  // a4 + a5
     dim3 grid(nblk(own_n(h), POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
     const double ccs = st.cut_coul * st.cut_coul, e2s = std::sqrt(h->P.qqrd2e);
-    if (ap) k_static_field<true><<<grid, block, 0, s>>>(nullptr, n, n, h->d_rec0.p, h->d_mol_s.p, h->box, nullptr, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
-    else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, h->d_nl_first.p, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
+    if (ap) k_static_field<true><<<grid, block, 0, s>>>(nullptr, n, n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{nullptr, 0}, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
+    else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
   }
   HIPCHECK(hipEventRecord(h->ev[4], s));
 }
@@ -585,6 +591,11 @@ int phase_finish(polar_handle *h, polar_result *out) {
   memcpy(&out->rmin, &rb, sizeof(double));
   out->rms_dmu = std::sqrt(std::max(0.0, sc.last_change));
   out->iterations = sc.iterations; out->sweeps = sc.sweeps; out->status = sc.status ? POLAR_WARN_NOT_CONVERGED : POLAR_OK;
+  if (!ap) {
+    unsigned long long tot = 0;
+    for (int k = 0; k < 64; k++) tot += h->h_ddtot[16 * k];
+    h->dd_pairs = (long long)tot;
+  }
   out->dd_pairs = ap ? (long long)n * (n - 1) : h->dd_pairs;
   float ms;
   auto el = [&](int a, int b) { HIPCHECK(hipEventElapsedTime(&ms, h->ev[a], h->ev[b])); return (double)ms; };
@@ -597,12 +608,22 @@ int phase_finish(polar_handle *h, polar_result *out) {
 int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, polar_result *out) {
   if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not implemented (SURVEY 8(f) rank 3)");
   memset(out, 0, sizeof(*out));
-  phase_begin(h, eflag, vflag, mu_host);
   const bool ap = !(h->ph.st.dd_cutoff > 0.0);
-  if (!h->ph.st.zodid) solve(h, ap, out);  // a6 + a7 (PS.cpp:389)
-  const int nc = out->ncolors;
-  int rc = phase_finish(h, out);
-  out->ncolors = nc;
+  int rc = 0;
+  for (int attempt = 0; attempt < 4; attempt++) {
+    h->h_flags[0] = 0;
+    phase_begin(h, eflag, vflag, mu_host);
+    if (!h->ph.st.zodid) solve(h, ap, out);  // a6 + a7 (PS.cpp:389)
+    const int nc = out->ncolors;
+    rc = phase_finish(h, out);
+    out->ncolors = nc;
+    if (ap || h->h_flags[0] == 0) break;
+    // a row did not fit its pitch: grow it to the reported need (+25 %) and redo the step
+    const long long need = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
+    h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
+    memset(out, 0, sizeof(*out));
+  }
+  if (!ap && h->h_flags[0] != 0) throw std::runtime_error("neighbor list pitch overflow persists");
   return rc;
 }
 
@@ -636,6 +657,9 @@ int polar_create(int device, polar_handle **out) {
     HIPCHECK(hipStreamCreate(&h->stream));
     for (auto &e : h->ev) HIPCHECK(hipEventCreate(&e));
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_flags, 16 * sizeof(int)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_ddtot, 64 * 16 * sizeof(unsigned long long)));
+    h->d_overflow.ensure(16); h->d_ddtot.ensure(64 * 16);
     h->d_scal.ensure(1);
     h->d_slots.ensure((size_t)POLAR_NSLOT * POLAR_SLOT_STRIDE);
     h->have_device = true;
@@ -658,6 +682,9 @@ int polar_destroy(polar_handle *h) {
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release();
+    h->d_overflow.release(); h->d_ddtot.release();
+    if (h->h_flags) (void)hipHostFree(h->h_flags);
+    if (h->h_ddtot) (void)hipHostFree(h->h_ddtot);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -670,7 +697,7 @@ const char *polar_last_error(const polar_handle *h) { return h ? h->err.c_str() 
 const char *polar_last_warning(const polar_handle *h) { return h ? h->warn.c_str() : ""; }
 
 int polar_pair_settings(polar_handle *h, int narg, const char *const *arg) {
-  return guarded(h, [&]() { h->ph.settings(narg, arg); h->colors_valid = false; return POLAR_OK; });
+  return guarded(h, [&]() { h->ph.settings(narg, arg); h->colors_valid = false; h->nl_pitch = h->dd_pitch = 0; return POLAR_OK; });
 }
 int polar_pair_coeff(polar_handle *h, int ntypes, int narg, const char *const *arg) {
   return guarded(h, [&]() { h->ph.coeff(ntypes, narg, arg); return POLAR_OK; });
@@ -927,6 +954,7 @@ int polar_step_begin(polar_handle *h, int eflag, int vflag) {
   return guarded(h, [&]() {
     HIPCHECK(hipSetDevice(h->device));
     if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not implemented");
+    h->h_flags[0] = 0;
     phase_begin(h, eflag, vflag, nullptr);
     const polar_settings &st = h->ph.st;
     if (!st.zodid && (st.polar_gs || st.polar_gs_ranked) && !h->colors_valid) { ensure_colors(h); map_color_rows(h); }
@@ -968,6 +996,11 @@ int polar_step_finish(polar_handle *h, polar_result *out) {
     int rc = phase_finish(h, out);
     out->ncolors = (h->ph.st.polar_gs || h->ph.st.polar_gs_ranked) ? (int)h->color_off.size() - 1 : 0;
     h->in_step = false;
+    if (h->h_flags[0] != 0) {  // the driver must redo the step (all ranks see their own flag)
+      const long long need = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
+      h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
+      return fail(h, POLAR_ERR_STATE, "neighbor list pitch overflow: pitch enlarged, repeat the step");
+    }
     return rc;
   });
 }

@@ -114,6 +114,19 @@ __device__ __forceinline__ double quad_sum(double v) {
   return v;
 }
 
+// Pitched row lists (list mode): row i owns the slots [i*pitch, i*pitch + cnt[i]).  A fixed pitch lets
+// k_nl_build emit both lists in ONE pass (no count pass, no prefix scans, no host sync for the
+// totals); a row that would overflow sets a flag and the step is redone with a larger pitch.
+struct RowList {
+  const int *cnt;
+  long long pitch;
+};
+__device__ __forceinline__ void row_range(const RowList &L, int i, long long &beg, long long &end) {
+  beg = (long long)i * L.pitch;
+  const long long c = L.cnt[i];
+  end = beg + (c < L.pitch ? c : L.pitch);
+}
+
 // Branch-free minimum image for the LIST kernels (dd_cutoff extension): d - L*rint(d/L).
 // Equals closest_image except for pairs at exactly L/2, which lie outside every cutoff there
 // (the list path requires L >= 2*cutoff).  The all-pairs (reference-exact) kernels keep wrap_ci.
@@ -177,7 +190,7 @@ __global__ void k_pack(int n, const int *__restrict__ perm, const double *__rest
 template <bool ALLPAIRS, int PASS>
 __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, const double *__restrict__ x,
                                                       const double *__restrict__ alpha, const int *__restrict__ mol,
-                                                      Box box, const long long *__restrict__ nl_first,
+                                                      Box box, RowList nl,
                                                       const int *__restrict__ nl_j,
                                                       const AtomRec *__restrict__ rec,
                                                       const int *__restrict__ mol_s, Scal *scal,
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, co
   double rmin = (PASS == 1) ? 1000.0 : __longlong_as_double((long long)scal->rmin_bits);
   double acc = 0.0;
   long long beg = 0, end = ntotal;
-  if (!ALLPAIRS) { beg = nl_first[i]; end = nl_first[i + 1]; }
+  if (!ALLPAIRS) row_range(nl, i, beg, end);
   for (long long base = beg; base < end; base += 64) {
     const long long p = base + lane;
     bool hit = false;
@@ -426,7 +439,7 @@ template <bool ALLPAIRS>
 __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restrict__ rows, int nrows, int nlocal,
                                                               const AtomRec *__restrict__ rec,
                                                               const int *__restrict__ mol, Box box,
-                                                              const long long *__restrict__ nl_first,
+                                                              RowList nl,
                                                               const int *__restrict__ nl_j, double cut_coulsq,
                                                               double e2s, double gamma, int use_previous,
                                                               double *__restrict__ ef, AtomRec *__restrict__ rec0,
@@ -440,7 +453,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restr
   const double f_shift = -1.0 / cut_coulsq;
   double ex = 0, ey = 0, ez = 0;
   long long beg = 0, end = nlocal;
-  if (!ALLPAIRS) { beg = nl_first[i]; end = nl_first[i + 1]; }
+  if (!ALLPAIRS) row_range(nl, i, beg, end);
   for (long long p = beg + lane; p < end; p += 64) {
     const int j = ALLPAIRS ? (int)p : nl_j[p];
     if (j == i) continue;
@@ -482,7 +495,7 @@ enum { EP_JACOBI = 0, EP_INPLACE = 1, EP_FIELD = 2 };
 template <bool ALLPAIRS, int DAMP, int EP>
 __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict__ rows, int nlocal,
                                                        AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, Box box,
-                                                       const long long *__restrict__ dd_first,
+                                                       RowList ddl,
                                                        const int *__restrict__ dd_j,
                                                        const double2 *__restrict__ dd_s, double ddcutsq, double pd,
                                                        const double *__restrict__ ef, double *__restrict__ Fout,
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
   double fx = 0, fy = 0, fz = 0;
   if (ri.a != 0.0 || EP == EP_FIELD) {
     long long beg = 0, end = nlocal;
-    if (!ALLPAIRS) { beg = dd_first[i]; end = dd_first[i + 1]; }
+    if (!ALLPAIRS) row_range(ddl, i, beg, end);
     if (ALLPAIRS) {
       for (long long p = beg + lane; p < end; p += 64) {
         const int j = (int)p;
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
 template <int DAMP>
 __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restrict__ rows, int nrows, const AtomRec *__restrict__ rec,
                                                             Box box,
-                                                            const long long *__restrict__ dd_first,
+                                                            RowList ddl,
                                                             const int *__restrict__ dd_j, double pd,
                                                             double2 *__restrict__ dd_s) {
   const int lane = threadIdx.x & 63;
@@ -611,7 +624,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restric
   if (row >= nrows) return;
   const int i = rows ? rows[row] : row;
   const double xi = rec[i].x, yi = rec[i].y, zi = rec[i].z;
-  const long long beg = dd_first[i], end = dd_first[i + 1];
+  long long beg, end;
+  row_range(ddl, i, beg, end);
   for (long long p = beg + lane; p < end; p += 64) {
     const int j = dd_j[p];
     double dx, dy, dz;
@@ -829,7 +843,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
                                                              const AtomRec *__restrict__ recA,
                                                              const AtomRec *__restrict__ recB,
                                                              const int *__restrict__ mol, Box box,
-                                                             const long long *__restrict__ nl_first,
+                                                             RowList nl,
                                                              const int *__restrict__ nl_j, double cut_coulsq,
                                                              double ddcutsq, double pd, double e2s,
                                                              double *__restrict__ f, double *__restrict__ slots) {
@@ -844,7 +858,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
   double fx = 0, fy = 0, fz = 0, uef = 0, udd = 0;
   double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
   long long beg = 0, end = nlocal;
-  if (!ALLPAIRS) { beg = nl_first[i]; end = nl_first[i + 1]; }
+  if (!ALLPAIRS) row_range(nl, i, beg, end);
   for (long long p = beg + lane; p < end; p += 64) {
     const int j = ALLPAIRS ? (int)p : nl_j[p];
     if (j == i) continue;
@@ -1027,19 +1041,19 @@ __global__ void k_map_range(int lo, int n, const int *__restrict__ inv, int *__r
   if (i < n) out[i] = inv[lo + i];
 }
 
-// PASS 0: count, PASS 1: fill.  One wave per atom; lanes stride the atoms of the <=27 distinct
-// neighbor cells; ballot + mbcnt keeps the output order deterministic.
+// One wave per atom row; lanes stride the atoms of the <=27 distinct neighbor cells (contiguous s
+// ranges); ballot + popcount compacts in order.  Single pass into the pitched lists:
 //   nl : every j with rsq <= cutallsq                      (static field, forces, rank metric)
 //   dd : alpha_i != 0, alpha_j != 0 and rsq < ddcutsq      (the dipole sweep stream)
-template <int PASS>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict__ rows, int nrows, const AtomRec *__restrict__ rec,
-                                                          Box box, CellGrid g,
+// cnt[] receives the TRUE counts; writes stop at the pitch and *overflow is raised.
+__global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict__ rows, int nrows,
+                                                          const AtomRec *__restrict__ rec, Box box, CellGrid g,
                                                           const long long *__restrict__ cell_first, double cutallsq,
-                                                          double ddcutsq, int *__restrict__ nl_cnt,
-                                                          int *__restrict__ dd_cnt,
-                                                          const long long *__restrict__ nl_first,
-                                                          const long long *__restrict__ dd_first,
-                                                          int *__restrict__ nl_j, int *__restrict__ dd_j) {
+                                                          double ddcutsq, long long nl_pitch, long long dd_pitch,
+                                                          int *__restrict__ nl_cnt, int *__restrict__ dd_cnt,
+                                                          int *__restrict__ nl_j, int *__restrict__ dd_j,
+                                                          int *__restrict__ overflow,
+                                                          unsigned long long *__restrict__ dd_total) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -1047,12 +1061,13 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   const AtomRec ri = rec[i];
   const int ci = cell_of(g, box, ri.x, ri.y, ri.z);
   const int c0 = ci % g.nc[0], c1 = (ci / g.nc[0]) % g.nc[1], c2 = ci / (g.nc[0] * g.nc[1]);
-  long long nlp = (PASS == 1) ? nl_first[i] : 0, ddp = (PASS == 1) ? dd_first[i] : 0;
+  const long long nl0 = (long long)i * nl_pitch, dd0 = (long long)i * dd_pitch;
   int ncount = 0, dcount = 0;
   // distinct neighbor cells per dimension: nc>=3 -> {-1,0,1}; nc==2 -> {0,1}; nc==1 -> {0}
   const int lo0 = g.nc[0] >= 3 ? -1 : 0, hi0 = g.nc[0] >= 2 ? 1 : 0;
   const int lo1 = g.nc[1] >= 3 ? -1 : 0, hi1 = g.nc[1] >= 2 ? 1 : 0;
   const int lo2 = g.nc[2] >= 3 ? -1 : 0, hi2 = g.nc[2] >= 2 ? 1 : 0;
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int dz = lo2; dz <= hi2; dz++)
     for (int dy = lo1; dy <= hi1; dy++)
       for (int dx = lo0; dx <= hi0; dx++) {
@@ -1063,32 +1078,28 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
         for (long long base = a; base < b; base += 64) {
           const long long p = base + lane;
           bool in_nl = false, in_dd = false;
-          int j = -1;
-          if (p < b) {
-            j = (int)p;
-            if (j != i) {
-              const AtomRec rj = rec[j];
-              double ex, ey, ez;
-              min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
-              const double rsq = ex * ex + ey * ey + ez * ez;
-              in_nl = rsq <= cutallsq;
-              in_dd = (ri.a != 0.0) && (rj.a != 0.0) && (rsq < ddcutsq);
-            }
+          const int j = (int)p;
+          if (p < b && j != i) {
+            const AtomRec rj = rec[j];
+            double ex, ey, ez;
+            min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
+            const double rsq = ex * ex + ey * ey + ez * ez;
+            in_nl = rsq <= cutallsq;
+            in_dd = (ri.a != 0.0) && (rj.a != 0.0) && (rsq < ddcutsq);
           }
           const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
-          if (PASS == 1) {
-            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            if (in_nl) nl_j[nlp + __popcll(m_nl & below)] = j;
-            if (in_dd) dd_j[ddp + __popcll(m_dd & below)] = j;
-            nlp += __popcll(m_nl);
-            ddp += __popcll(m_dd);
-          } else {
-            ncount += __popcll(m_nl);
-            dcount += __popcll(m_dd);
-          }
+          const int kn = ncount + __popcll(m_nl & below), kd = dcount + __popcll(m_dd & below);
+          if (in_nl && kn < nl_pitch) nl_j[nl0 + kn] = j;
+          if (in_dd && kd < dd_pitch) dd_j[dd0 + kd] = j;
+          ncount += __popcll(m_nl);
+          dcount += __popcll(m_dd);
         }
       }
-  if (PASS == 0 && lane == 0) { nl_cnt[i] = ncount; dd_cnt[i] = dcount; }
+  if (lane == 0) {
+    nl_cnt[i] = ncount; dd_cnt[i] = dcount;
+    if (ncount > nl_pitch || dcount > dd_pitch) atomicMax(overflow, ncount > dcount ? ncount : dcount);
+    if (dcount) atomicAdd(dd_total + (blockIdx.x & 63) * 16, (unsigned long long)(dcount < dd_pitch ? dcount : (int)dd_pitch));
+  }
 }
 
 // multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers
