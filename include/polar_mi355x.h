@@ -156,6 +156,10 @@ int polar_step_finish(polar_handle *h, polar_result *out); /* forces/energies of
 /* dipoles of rows [lo,hi) <-> a packed device buffer [(hi-lo)][3] */
 int polar_mu_gather(polar_handle *h, long long lo, long long hi, double *dev_dst);
 int polar_mu_scatter(polar_handle *h, long long lo, long long hi, const double *dev_src);
+/* halo form: dipoles of the atoms listed in dev_idx (orig ids, device memory; negative = padding) <->
+ * packed buffer [n][3]; the scatter skips padding and rows this handle owns */
+int polar_mu_gather_idx(polar_handle *h, const int *dev_idx, long long n, double *dev_dst);
+int polar_mu_scatter_idx(polar_handle *h, const int *dev_idx, long long n, const double *dev_src);
 int polar_change_export(polar_handle *h, double *dev_dst); /* this handle's running sum of (dmu)^2 */
 
 #ifdef __cplusplus

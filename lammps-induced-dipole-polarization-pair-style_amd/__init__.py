@@ -106,6 +106,8 @@ EXPORTS = {
     "polar_step_finish": (C.c_int, [C.c_void_p, C.POINTER(Result)]),
     "polar_mu_gather": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
     "polar_mu_scatter": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "polar_mu_gather_idx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "polar_mu_scatter_idx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "polar_change_export": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 

@@ -1018,6 +1018,20 @@ int polar_mu_scatter(polar_handle *h, long long lo, long long hi, const double *
     return POLAR_OK;
   });
 }
+int polar_mu_gather_idx(polar_handle *h, const int *dev_idx, long long n, double *dev_dst) {
+  return guarded(h, [&]() {
+    need_device(h);
+    if (n > 0) k_mu_gather_idx<<<nblk(n, 256), 256, 0, h->stream>>>(n, dev_idx, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst);
+    return POLAR_OK;
+  });
+}
+int polar_mu_scatter_idx(polar_handle *h, const int *dev_idx, long long n, const double *dev_src) {
+  return guarded(h, [&]() {
+    need_device(h);
+    if (n > 0) k_mu_scatter_idx<<<nblk(n, 256), 256, 0, h->stream>>>(n, dev_idx, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src, own_lo(h), own_lo(h) + own_n(h));
+    return POLAR_OK;
+  });
+}
 int polar_change_export(polar_handle *h, double *dev_dst) {
   return guarded(h, [&]() {
     need_device(h);

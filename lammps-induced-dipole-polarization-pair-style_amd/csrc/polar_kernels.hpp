@@ -1121,6 +1121,30 @@ __global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__
   r[s].mx = src[3 * (i - lo)]; r[s].my = src[3 * (i - lo) + 1]; r[s].mz = src[3 * (i - lo) + 2];
 }
 
+// halo exchange by index list (orig ids; negative entries are padding and skipped)
+__global__ void k_mu_gather_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
+                                const AtomRec *__restrict__ recA, const AtomRec *__restrict__ recB,
+                                double *__restrict__ dst) {
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int o = idx[t];
+  if (o < 0) return;
+  const AtomRec *r = scal->cur ? recB : recA;
+  const int s = inv ? inv[o] : o;
+  dst[3 * t] = r[s].mx; dst[3 * t + 1] = r[s].my; dst[3 * t + 2] = r[s].mz;
+}
+__global__ void k_mu_scatter_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
+                                 AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src,
+                                 int own_lo, int own_hi) {
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int o = idx[t];
+  if (o < 0 || (o >= own_lo && o < own_hi)) return;  // padding, or a row this handle owns itself
+  AtomRec *r = scal->cur ? recB : recA;
+  const int s = inv ? inv[o] : o;
+  r[s].mx = src[3 * t]; r[s].my = src[3 * t + 1]; r[s].mz = src[3 * t + 2];
+}
+
 // small utilities
 __global__ void k_zero_scal(Scal *s, int keep_solver) {
   s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;

@@ -139,12 +139,24 @@ def _run_sharded_lockstep(pkg, par, s, world, eflag=1, vflag=2):
         p.set_neighbors_csr(ilist, s.extra["full_numneigh"], s.extra["full_first"], s.extra["full_neigh"])
         bes.append(par.HipShardBackend(p, lo, hi, 0))
 
+    plan = par.HaloPlan(s.x[:s.nlocal], s.prd, offs, reach=11.0)
+    hbufs = [par.halo_buffers(be, plan, r) for r, be in enumerate(bes)]
+    use_idx = {"n": 0}
+
     def exchange():
-        own = [be.own_mu().clone() for be in bes]
-        for r, be in enumerate(bes):
-            for q in range(world):
-                if q != r:
-                    be.set_mu(int(offs[q]), int(offs[q + 1]), own[q])
+        use_idx["n"] += 1
+        if use_idx["n"] % 2:        # alternate: contiguous-range form ...
+            own = [be.own_mu().clone() for be in bes]
+            for r, be in enumerate(bes):
+                for q in range(world):
+                    if q != r:
+                        be.set_mu(int(offs[q]), int(offs[q + 1]), own[q])
+        else:                        # ... and the index-list (halo) form, loopback "all-gather"
+            for r, be in enumerate(bes):
+                be.gather_idx(hbufs[r]["idx_own"], hbufs[r]["send"])
+            recv = torch.cat([hb["send"] for hb in hbufs])
+            for r, be in enumerate(bes):
+                be.scatter_idx(hbufs[r]["idx_all"], recv)
 
     for be in bes:
         be.begin(eflag, vflag)

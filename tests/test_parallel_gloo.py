@@ -87,6 +87,20 @@ class NumpyShardBackend:
     def set_mu(self, lo, hi, buf):
         self.mu[3 * lo:3 * hi] = buf.numpy()[: 3 * (hi - lo)]
 
+    def index_tensor(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32))
+
+    def gather_idx(self, idx, out):
+        ix = idx.numpy()
+        o = out.numpy()
+        ok = ix >= 0
+        o.reshape(-1, 3)[ok] = self.mu.reshape(-1, 3)[ix[ok]]
+
+    def scatter_idx(self, idx, src):
+        ix = idx.numpy()
+        ok = (ix >= 0) & ~((ix >= self.lo) & (ix < self.hi))
+        self.mu.reshape(-1, 3)[ix[ok]] = src.numpy().reshape(-1, 3)[ok]
+
     def state(self):
         return self.done, self.iterations, self.status
 
@@ -124,7 +138,7 @@ def _problem(extra):
     return s, T, E, ref
 
 
-def _worker(rank, world, port, extra, gs, q):
+def _worker(rank, world, port, extra, gs, q, use_halo=False):
     import torch.distributed as dist
 
     sys.path.insert(0, ROOT)
@@ -135,7 +149,12 @@ def _worker(rank, world, port, extra, gs, q):
     counts, offs = par.split_rows(s.nlocal, world)
     be = NumpyShardBackend(T, E, s.alpha[:s.nlocal].copy(), int(offs[rank]), int(offs[rank + 1]), gs,
                            bool(st.fixed_iteration), st.iterations_max, st.polar_precision, st.polar_gamma)
-    out = par.run_step(be, dist, rank, world, counts, offs)
+    halo = None
+    if use_halo:  # dense tensor here: every atom sees every atom, so the plan must select all rows
+        plan = par.HaloPlan(s.x[:s.nlocal], s.prd, offs, reach=1.0e9)
+        assert plan.counts == counts
+        halo = (plan, par.halo_buffers(be, plan, rank))
+    out = par.run_step(be, dist, rank, world, counts, offs, halo=halo)
     q.put((rank, be.mu.copy(), out["eng_pol"], out["iterations"], out["sweeps"], out["status"],
            ref["mu"].reshape(-1), ref["iterations"], ref["sweeps"]))
     dist.barrier()
@@ -148,13 +167,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(extra, gs, world=2):
+def _run(extra, gs, world=2, use_halo=False):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, extra, gs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, extra, gs, q, use_halo)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))
@@ -197,3 +216,36 @@ def test_two_rank_gauss_seidel_converges_to_the_same_fixed_point():
     assert np.max(np.abs(mu0[:half] - muref[:half])) < 1e-9 * scale
     assert np.max(np.abs(mu1[half:] - muref[half:])) < 1e-9 * scale
     assert abs(e0 - e1) < 1e-12 * abs(e0)
+
+
+def test_halo_exchange_path_matches_full_exchange():
+    """Same Jacobi check through the halo (index-list) exchange."""
+    res = _run(["polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "5"], gs=False, use_halo=True)
+    (r0, mu0, e0, it0, sw0, st0, muref, itref, swref), (r1, mu1, e1, it1, sw1, st1, _, _, _) = res
+    n3 = len(muref)
+    half = 3 * ((n3 // 3 + 1) // 2)
+    assert np.max(np.abs(mu0[:half] - muref[:half])) < 1e-12 * np.max(np.abs(muref))
+    assert np.max(np.abs(mu1[half:] - muref[half:])) < 1e-12 * np.max(np.abs(muref))
+
+
+def test_halo_plan_selects_boundary_layers_of_slabs():
+    par = importlib.import_module(PKG + ".parallel")
+    rng = np.random.default_rng(0)
+    L = np.array([20.0, 20.0, 80.0])
+    n, world = 4000, 4
+    x = rng.uniform(0, 1, (n, 3)) * L
+    x = x[np.argsort(x[:, 2])]                      # contiguous index ranges = z slabs
+    counts, offs = par.split_rows(n, world)
+    plan = par.HaloPlan(x, L, offs, reach=5.0)
+    for q in range(world):
+        own = np.arange(offs[q], offs[q + 1])
+        ids = plan.idx_all[q * plan.maxc:(q + 1) * plan.maxc]
+        ids = ids[ids >= 0]
+        assert np.all((ids >= offs[q]) & (ids < offs[q + 1]))
+        # brute force: owned atoms within 5.0 (minimum image) of any atom of another rank must be in the halo
+        others = np.concatenate([np.arange(offs[r], offs[r + 1]) for r in range(world) if r != q])
+        d = x[own][:, None, :] - x[others][None, :, :]
+        d -= L * np.round(d / L)
+        near = own[(np.sum(d * d, axis=2) < 25.0).any(axis=1)]
+        assert set(near.tolist()) <= set(ids.tolist())
+        assert len(ids) < 0.7 * len(own)            # and it is a real subset for slabs
