@@ -39,7 +39,7 @@ def build_workload(wl, reps, extra=()):
     return wl.replicate_fixture(os.path.join(ROOT, "tests", "golden", "mof5_h2.npz"), *reps, extra_args=args)
 
 
-def cpu_baseline(wl, reps=(2, 2, 1)):
+def cpu_baseline(wl, reps=(3, 2, 2)):
     """Oracle (CPU restatement, 1 core) on a bounded sample of the same workload: the same cell,
     cutoffs and solver settings at a smaller replication (cost per atom is N-independent in
     cutoff mode)."""
@@ -105,6 +105,11 @@ def main():
     bytes_launch = bytes_sweep / max(out["ncolors"], 1)
     ms_launch = (ms_solve / args.steps) / launches      # HIP events on the library's stream around the solve
     achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
+    # HBM bytes per launch from PMC counters cannot be read inside this process; the value below was
+    # collected with tools/pmc_traffic.sh on this exact workload (separate --pmc passes, per launch:
+    # FETCH_SIZE 31,254 KB -> x2 on gfx950 for 16-B/lane streams, WRITE_SIZE 413 KB;
+    # profiles/r01_v10_kfield_traffic_pmc.txt) and is reported only for that workload.
+    traffic = 64.4e6 if (tuple(args.reps) == (3, 3, 3) and not args.extra) else None
     line = {
         "metric": "atom-steps/sec", "value": value, "unit": "atom-steps/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
@@ -117,7 +122,7 @@ def main():
                    "ms_static": out["ms_static"], "ms_list": out["ms_list"], "ms_rank": out["ms_rank"],
                    "rms_dmu_last_sweep": out["rms_dmu"], "eng_pol": out["eng_pol"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_field (dipole-field sweep)",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_field (dipole-field sweep)",
                      "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch},
     }
     if not args.no_cpu_baseline:
