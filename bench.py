@@ -97,7 +97,7 @@ def main():
     n = s.nlocal
     ms_step = 1e3 * dt / args.steps
     value = n * args.steps / dt
-    # dominant kernel: k_field (dipole-field sweep).  One sweep = ncolors launches.
+    # dominant kernel: k_field_rows (dipole-field sweep).  One sweep = ncolors launches.
     launches = out["sweeps"] * max(out["ncolors"], 1)
     rows = int(np.count_nonzero(s.alpha[:n]))
     # per pair: int32 j + cached tensor scalars (s3,s5: 16 B); per row: offset 8 + x 24 + mu 24 + E 24 + alpha 8 + mu_new 24
@@ -122,7 +122,7 @@ def main():
                    "ms_static": out["ms_static"], "ms_list": out["ms_list"], "ms_rank": out["ms_rank"],
                    "rms_dmu_last_sweep": out["rms_dmu"], "eng_pol": out["eng_pol"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_field (dipole-field sweep)",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_field_rows (dipole-field sweep, one launch per colour phase)",
                      "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch},
     }
     if not args.no_cpu_baseline:

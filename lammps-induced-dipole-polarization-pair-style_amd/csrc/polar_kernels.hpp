@@ -62,10 +62,30 @@ __device__ __forceinline__ double *slot_ptr(double *slots, int field) {
 #define POLAR_BLOCK 256
 #define POLAR_ROWS_PER_BLOCK (POLAR_BLOCK / POLAR_WAVE)
 
+// Wave-wide reductions through DPP (data-parallel primitives: no LDS crossbar round trips).
+// quad_perm xor1, xor2 -> row_half_mirror -> row_mirror give every lane its 16-lane row total;
+// row_bcast15 / row_bcast31 (GFX9/CDNA) carry row totals into the following rows, so lane 63 ends
+// with the wave total, which readlane broadcasts.  ~18 short VALU ops per double instead of 12
+// dependent ds_bpermute round trips.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_get(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_get<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_get<0x140, 0xF>(v);  // row_mirror: all 16 lanes of a row hold the row total
+  v += dpp_get<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp_get<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+  return lane63(v);
 }
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
@@ -555,8 +575,10 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
   }
 #define POLAR_GATHER(JM, P0, P1, P2, P3)                                                   \
   {                                                                                        \
-    int j0_ = __shfl(JM, q4, 64), j1_ = __shfl(JM, 16 + q4, 64);                            \
-    int j2_ = __shfl(JM, 32 + q4, 64), j3_ = __shfl(JM, 48 + q4, 64);                       \
+    int j0_, j1_, j2_, j3_;                                                                 \
+    if (ablate & 128) { j0_ = JM; j1_ = JM ^ 1; j2_ = JM ^ 2; j3_ = JM ^ 3; } /* lab: no bpermute */ \
+    else { j0_ = __shfl(JM, q4, 64); j1_ = __shfl(JM, 16 + q4, 64);                         \
+           j2_ = __shfl(JM, 32 + q4, 64); j3_ = __shfl(JM, 48 + q4, 64); }                  \
     if (ablate & 2) j0_ = j1_ = j2_ = j3_ = i;                                             \
     P0 = reinterpret_cast<const double2 *>(src + j0_)[k];                                   \
     P1 = reinterpret_cast<const double2 *>(src + j1_)[k];                                   \
@@ -574,13 +596,18 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
       for (long long base = beg; base < end; base += 64) {
         POLAR_LOAD_STREAM(base + 128, jm2, sc2);   // trip t+2 (predicated off past the row's end)
         POLAR_GATHER(jm1, pb0, pb1, pb2, pb3);     // trip t+1
+        double2 a, b, c2;
+        if (ablate & 64) {  // lab: no LDS transpose (wrong numbers, timing only)
+          a = pa0; b = pa1; c2 = make_double2(pa2.x + pa3.x, pa2.y + pa3.y);
+        } else {
         stage[(q4)*5 + k] = pa0; stage[(16 + q4) * 5 + k] = pa1;  // trip t
         stage[(32 + q4) * 5 + k] = pa2; stage[(48 + q4) * 5 + k] = pa3;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double2 a = stage[lane * 5], b = stage[lane * 5 + 1], c2 = stage[lane * 5 + 2];
+        a = stage[lane * 5]; b = stage[lane * 5 + 1]; c2 = stage[lane * 5 + 2];
         __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next trip
+        }
         double dx, dy, dz;
         min_image_rint(box, ri.x, ri.y, ri.z, a.x, b.x, c2.x, dx, dy, dz);
         const double md = a.y * dx + b.y * dy + c2.y * dz;
@@ -609,6 +636,181 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
       if (c != 0.0 && !(ablate & 16)) atomicAdd(slot_ptr(slots, SL_CHANGE), c);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// List-mode sweep, production form: ONE WAVE STREAMS SEVERAL ROWS.
+// A row has only ~6 trips of 64 pairs, so a per-row software pipeline spends most of its life
+// filling and draining (measured: memory time was not overlapped at all).  Here a wave owns `rpw`
+// consecutive rows of the launch and runs ONE continuous 3-stage pipeline across them:
+//   slot g:  stream(j, s3/s5) of trip g+2  |  quad-cooperative record gather of trip g+1  |
+//            LDS transpose + lane-per-pair math of trip g
+// Row boundaries only reset the accumulators (wave reduction + epilogue by lane 0).  The body is
+// unrolled six times so the three stream sets and two gather sets rotate by name (no copies, no
+// wait right behind an issue).  Per-row data (index, count, x_i, mu_i, alpha_i, E_i) sits in a
+// small per-wave LDS table filled by lanes 0..rpw-1.
+#define POLAR_RPW 8
+template <int EP>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_field_rows(int nrows, const int *__restrict__ rows, int rpw,
+                                                            AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
+                                                            Box box, RowList ddl, const int *__restrict__ dd_j,
+                                                            const double2 *__restrict__ dd_s,
+                                                            const double *__restrict__ ef, const Scal *scal,
+                                                            double *__restrict__ slots) {
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep the control flow scalar
+  const int r0 = (blockIdx.x * POLAR_ROWS_PER_BLOCK + wv) * rpw;
+  if (r0 >= nrows) return;
+  const int nr = min(rpw, nrows - r0);
+  const int cur = scal->cur;
+  const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+
+  __shared__ double s_info[POLAR_ROWS_PER_BLOCK][POLAR_RPW][10];  // x,y,z, mx,my,mz, a, Ex,Ey,Ez
+  __shared__ int s_idx[POLAR_ROWS_PER_BLOCK][POLAR_RPW][2];        // atom index, pair count
+  __shared__ double2 s_stage[POLAR_ROWS_PER_BLOCK][64 * 5];
+  double (*info)[10] = s_info[wv];
+  int (*idx)[2] = s_idx[wv];
+  double2 *stage = s_stage[wv];
+
+  double chg = 0.0;  // sum |dmu|^2 of this wave's rows (lane 0)
+  if (lane < nr) {
+    const int i = rows ? rows[r0 + lane] : r0 + lane;
+    const AtomRec r = src[i];
+    const double e0 = ef[3 * i], e1 = ef[3 * i + 1], e2 = ef[3 * i + 2];
+    long long c = ddl.cnt[i];
+    if (c > ddl.pitch) c = ddl.pitch;
+    if (r.a == 0.0) c = 0;
+    info[lane][0] = r.x; info[lane][1] = r.y; info[lane][2] = r.z;
+    info[lane][3] = r.mx; info[lane][4] = r.my; info[lane][5] = r.mz;
+    info[lane][6] = r.a; info[lane][7] = e0; info[lane][8] = e1; info[lane][9] = e2;
+    idx[lane][0] = i; idx[lane][1] = (int)c;
+    if (c == 0) {  // no listed neighbor: mu_new = alpha * E right away
+      const double mx = r.a * e0, my = r.a * e1, mz = r.a * e2;
+      dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz;
+      const double ax = mx - r.mx, ay = my - r.my, az = mz - r.mz;
+      chg = ax * ax + ay * ay + az * az;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  chg = wave_sum(chg);  // all in lane registers; lane 0 keeps the running total
+
+  const int q4 = lane >> 2, k = lane & 3;
+  const char *srcb = reinterpret_cast<const char *>(src) + k * 16;
+  const bool allper = box.periodic[0] && box.periodic[1] && box.periodic[2];
+
+  // stream cursor: row sr (within this wave), offset so inside it; skips empty rows
+  int sr = 0, so = 0, s_i = 0, s_cnt = 0;
+#define POLAR_CURSOR_NORMALISE()                                            \
+  while (sr < nr) {                                                         \
+    s_i = __builtin_amdgcn_readfirstlane(idx[sr][0]);                       \
+    s_cnt = __builtin_amdgcn_readfirstlane(idx[sr][1]);                     \
+    if (so < s_cnt) break;                                                  \
+    sr++; so = 0;                                                           \
+  }
+  POLAR_CURSOR_NORMALISE();
+  const int i_any = __builtin_amdgcn_readfirstlane(idx[0][0]);
+
+// The loaded values are NOT touched here (a select on them would force a wait right behind the
+// issue); lanes past the row's end are masked when the values are consumed (REM = valid lanes).
+// The loads are issued unconditionally from a clamped address (no branch around a VMEM op: the
+// compiler's s_waitcnt bookkeeping stays exact only in straight-line code).
+#define POLAR_LOAD_STREAM(JM, SC, ROW, LAST, REM)                                          \
+  {                                                                                        \
+    const bool live_ = sr < nr;                                                            \
+    REM = live_ ? s_cnt - so : 0;                                                          \
+    const long long pc_ = (long long)(live_ ? s_i : i_any) * ddl.pitch + (lane < REM ? so + lane : 0); \
+    JM = dd_j[pc_];                                                                        \
+    SC = dd_s[pc_];                                                                        \
+    ROW = live_ ? sr : -1;                                                                 \
+    so += 64;                                                                              \
+    LAST = live_ && so >= s_cnt;                                                           \
+    if (LAST) { sr++; so = 0; POLAR_CURSOR_NORMALISE(); }                                  \
+  }
+#define POLAR_GATHER(JM, REM, P0, P1, P2, P3)                                              \
+  {                                                                                        \
+    const int jm_ = lane < REM ? JM : i_any; /* lanes past the end gather a harmless record */ \
+    const unsigned j0_ = __shfl(jm_, q4, 64), j1_ = __shfl(jm_, 16 + q4, 64);               \
+    const unsigned j2_ = __shfl(jm_, 32 + q4, 64), j3_ = __shfl(jm_, 48 + q4, 64);          \
+    P0 = *reinterpret_cast<const double2 *>(srcb + ((size_t)j0_ << 6));                     \
+    P1 = *reinterpret_cast<const double2 *>(srcb + ((size_t)j1_ << 6));                     \
+    P2 = *reinterpret_cast<const double2 *>(srcb + ((size_t)j2_ << 6));                     \
+    P3 = *reinterpret_cast<const double2 *>(srcb + ((size_t)j3_ << 6));                     \
+  }
+  int crow = -1;
+  double xi = 0, yi = 0, zi = 0, fx = 0, fy = 0, fz = 0;
+#define POLAR_COMPUTE(P0, P1, P2, P3, SCRAW, ROW, LAST, REM)                                 \
+  {                                                                                        \
+    if (ROW < 0) break;                                                                    \
+    const double2 SC = lane < REM ? SCRAW : make_double2(0.0, 0.0);                        \
+    if (ROW != crow) { crow = ROW; xi = info[crow][0]; yi = info[crow][1]; zi = info[crow][2]; } \
+    stage[q4 * 5 + k] = P0; stage[(16 + q4) * 5 + k] = P1;                                  \
+    stage[(32 + q4) * 5 + k] = P2; stage[(48 + q4) * 5 + k] = P3;                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                 \
+    __builtin_amdgcn_wave_barrier();                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                 \
+    const double2 a_ = stage[lane * 5], b_ = stage[lane * 5 + 1], c_ = stage[lane * 5 + 2]; \
+    __builtin_amdgcn_wave_barrier();                                                       \
+    double dx_ = xi - a_.x, dy_ = yi - b_.x, dz_ = zi - c_.x;                               \
+    if (allper) {                                                                          \
+      dx_ = fma(-box.prd[0], rint(dx_ * box.inv[0]), dx_);                                 \
+      dy_ = fma(-box.prd[1], rint(dy_ * box.inv[1]), dy_);                                 \
+      dz_ = fma(-box.prd[2], rint(dz_ * box.inv[2]), dz_);                                 \
+    } else {                                                                               \
+      if (box.periodic[0]) dx_ = fma(-box.prd[0], rint(dx_ * box.inv[0]), dx_);            \
+      if (box.periodic[1]) dy_ = fma(-box.prd[1], rint(dy_ * box.inv[1]), dy_);            \
+      if (box.periodic[2]) dz_ = fma(-box.prd[2], rint(dz_ * box.inv[2]), dz_);            \
+    }                                                                                      \
+    const double md_ = a_.y * dx_ + b_.y * dy_ + c_.y * dz_;                               \
+    const double cc_ = SC.y * md_;                                                         \
+    fx -= SC.x * a_.y - cc_ * dx_;                                                         \
+    fy -= SC.x * b_.y - cc_ * dy_;                                                         \
+    fz -= SC.x * c_.y - cc_ * dz_;                                                         \
+    if (LAST) { /* end of the row: reduce, update the dipole, restart the accumulators */   \
+      fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);                             \
+      if (lane == 0) {                                                                     \
+        const double al_ = info[crow][6];                                                  \
+        const double mx_ = al_ * (info[crow][7] + fx), my_ = al_ * (info[crow][8] + fy),    \
+                     mz_ = al_ * (info[crow][9] + fz);                                     \
+        const int ii_ = idx[crow][0];                                                      \
+        dst[ii_].mx = mx_; dst[ii_].my = my_; dst[ii_].mz = mz_;                            \
+        const double ax_ = mx_ - info[crow][3], ay_ = my_ - info[crow][4], az_ = mz_ - info[crow][5]; \
+        chg += ax_ * ax_ + ay_ * ay_ + az_ * az_;                                          \
+      }                                                                                    \
+      fx = fy = fz = 0.0;                                                                  \
+    }                                                                                      \
+  }
+#define POLAR_TRIP(SA, RA, LA, MA, JB, MB, JC, SC_, RC, LC, MC, GA0, GA1, GA2, GA3, GB0, GB1, GB2, GB3) \
+  {                                                                                        \
+    POLAR_LOAD_STREAM(JC, SC_, RC, LC, MC);                                                \
+    POLAR_GATHER(JB, MB, GB0, GB1, GB2, GB3);                                              \
+    POLAR_COMPUTE(GA0, GA1, GA2, GA3, SA, RA, LA, MA);                                     \
+  }
+  int j_0 = i_any, j_1 = i_any, j_2 = i_any, w_0 = -1, w_1 = -1, w_2 = -1, m_0 = 0, m_1 = 0, m_2 = 0;
+  bool l_0 = false, l_1 = false, l_2 = false;
+  const double2 z2 = make_double2(0.0, 0.0);
+  double2 s_0 = z2, s_1 = z2, s_2 = z2;
+  double2 ga0, ga1, ga2, ga3, gb0 = z2, gb1 = z2, gb2 = z2, gb3 = z2;
+  POLAR_LOAD_STREAM(j_0, s_0, w_0, l_0, m_0);
+  POLAR_LOAD_STREAM(j_1, s_1, w_1, l_1, m_1);
+  POLAR_GATHER(j_0, m_0, ga0, ga1, ga2, ga3);
+  for (;;) {
+    POLAR_TRIP(s_0, w_0, l_0, m_0, j_1, m_1, j_2, s_2, w_2, l_2, m_2, ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3);
+    POLAR_TRIP(s_1, w_1, l_1, m_1, j_2, m_2, j_0, s_0, w_0, l_0, m_0, gb0, gb1, gb2, gb3, ga0, ga1, ga2, ga3);
+    POLAR_TRIP(s_2, w_2, l_2, m_2, j_0, m_0, j_1, s_1, w_1, l_1, m_1, ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3);
+    POLAR_TRIP(s_0, w_0, l_0, m_0, j_1, m_1, j_2, s_2, w_2, l_2, m_2, gb0, gb1, gb2, gb3, ga0, ga1, ga2, ga3);
+    POLAR_TRIP(s_1, w_1, l_1, m_1, j_2, m_2, j_0, s_0, w_0, l_0, m_0, ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3);
+    POLAR_TRIP(s_2, w_2, l_2, m_2, j_0, m_0, j_1, s_1, w_1, l_1, m_1, gb0, gb1, gb2, gb3, ga0, ga1, ga2, ga3);
+  }
+#undef POLAR_TRIP
+#undef POLAR_COMPUTE
+#undef POLAR_GATHER
+#undef POLAR_LOAD_STREAM
+#undef POLAR_CURSOR_NORMALISE
+  if (lane == 0 && chg != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), chg);
 }
 
 // a6 for the list path: the damped tensor scalars of every listed pair, once per step

@@ -223,3 +223,24 @@ def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
     for k in ("eng_vdwl", "eng_coul", "eng_pol"):
         assert rel(tot[k], ref[k]) < max(tol, 1e-10)
     assert len({o["iterations"] for o in outs}) == 1
+
+
+@pytest.mark.parametrize("rpw", ["-1", "3"])
+def test_alternative_sweep_kernels_agree(rpw, wl, pkg, oracle, monkeypatch):
+    """The list sweep has two kernels (one row per wave / several rows streamed by one wave);
+    POLAR_ROWS_PER_WAVE selects them.  Both must reproduce the oracle (Jacobi sweep by sweep, GS
+    at the fixed point)."""
+    monkeypatch.setenv("POLAR_ROWS_PER_WAVE", rpw)
+    extra = ["use_previous", "no", "polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "4",
+             "dd_cutoff", "9.0"]
+    s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    out = pkg.pair_from_system(s).compute()
+    assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+    extra = ["use_previous", "no", "precision", "1e-13", "max_iterations", "200", "dd_cutoff", "9.0"]
+    s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"), extra_args=extra)
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    out = pkg.pair_from_system(s).compute()
+    assert out["status"] == 0
+    assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+    assert rel(out["eng_pol"], ref["eng_pol"]) < TOL
