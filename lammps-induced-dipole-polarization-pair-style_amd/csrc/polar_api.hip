@@ -197,7 +197,7 @@ void build_cells(polar_handle *h) {
   CellGrid &g = h->grid;
   long long ncell = 1;
   for (int k = 0; k < 3; k++) {
-    g.nc[k] = std::max(1, (int)std::floor(h->box.prd[k] / cutall));
+    g.nc[k] = std::max(1, (int)std::floor(h->box.prd[k] / (0.5 * cutall)));  // edge >= cutoff/2: +-2 stencil
     g.lo[k] = h->boxlo[k];
     g.inv[k] = g.nc[k] / h->box.prd[k];
     ncell *= g.nc[k];
