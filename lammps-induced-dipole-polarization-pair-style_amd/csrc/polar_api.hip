@@ -92,7 +92,7 @@ struct polar_handle {
   DBuf<int> d_cell_id, d_cell_cnt, d_cell_fill, d_nl_cnt, d_dd_cnt, d_nl_j, d_dd_j;
   DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
   DBuf<double2> d_dd_s;
-  DBuf<double4> d_xq;
+  DBuf<double4> d_xq, d_pos4;
   long long nl_pairs = 0, dd_pairs = 0;
   long long nl_pitch = 0, dd_pitch = 0;   // pitched row lists (see polar_kernels.hpp RowList)
   DBuf<int> d_overflow;
@@ -240,7 +240,7 @@ void build_lists(polar_handle *h) {
   HIPCHECK(hipMemsetAsync(h->d_overflow.p, 0, 16 * sizeof(int), s));
   HIPCHECK(hipMemsetAsync(h->d_ddtot.p, 0, 64 * 16 * sizeof(unsigned long long), s));
   k_nl_build<<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
-      rows, nr, h->d_rec0.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,
+      rows, nr, h->d_pos4.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,
       h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, h->d_overflow.p, h->d_ddtot.p);
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
   if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
@@ -524,9 +524,9 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     } else if (h->mu_resident) mu0 = h->d_mu.p;
   }
   h->sorted = false;
-  if (!ap) build_cells(h);  // cell order: perm / inv
+  if (!ap) { build_cells(h); h->d_pos4.ensure(n + 1); }  // cell order: perm / inv
   k_pack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_x.p, h->d_q.p, h->d_alpha.p, h->d_mol.p, mu0,
-                                      h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p);
+                                      h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p);
   if (!ap) {
     build_lists(h);
     if (h->colors_valid) map_color_rows(h);
@@ -705,7 +705,7 @@ int polar_destroy(polar_handle *h) {
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_nl_j.release(); h->d_dd_j.release();
-    h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release();
+    h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     if (h->h_ddtot) (void)hipHostFree(h->h_ddtot);

@@ -190,7 +190,8 @@ __device__ __forceinline__ void tensor_scalars(double r2, double pd, double &s3,
 // pack: x/q/alpha (+ initial mu) -> 64-byte records (both Jacobi buffers)
 __global__ void k_pack(int n, const int *__restrict__ perm, const double *__restrict__ x, const double *__restrict__ q,
                        const double *__restrict__ alpha, const int *__restrict__ mol, const double *__restrict__ mu0,
-                       AtomRec *__restrict__ r0, AtomRec *__restrict__ r1, int *__restrict__ mol_s) {
+                       AtomRec *__restrict__ r0, AtomRec *__restrict__ r1, int *__restrict__ mol_s,
+                       double4 *__restrict__ pos4) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int o = perm ? perm[i] : i;
@@ -201,6 +202,7 @@ __global__ void k_pack(int n, const int *__restrict__ perm, const double *__rest
   r0[i] = r;
   r1[i] = r;
   mol_s[i] = mol[o];
+  if (pos4) pos4[i] = make_double4(r.x, r.y, r.z, r.a);  // 32-byte {x,y,z,alpha} for the list build
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1249,7 +1251,7 @@ __global__ void k_map_range(int lo, int n, const int *__restrict__ inv, int *__r
 //   dd : alpha_i != 0, alpha_j != 0 and rsq < ddcutsq      (the dipole sweep stream)
 // cnt[] receives the TRUE counts; writes stop at the pitch and *overflow is raised.
 __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict__ rows, int nrows,
-                                                          const AtomRec *__restrict__ rec, Box box, CellGrid g,
+                                                          const double4 *__restrict__ pos4, Box box, CellGrid g,
                                                           const long long *__restrict__ cell_first, double cutallsq,
                                                           double ddcutsq, long long nl_pitch, long long dd_pitch,
                                                           int *__restrict__ nl_cnt, int *__restrict__ dd_cnt,
@@ -1260,7 +1262,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
   const int i = rows ? rows[row] : row;  // s space: the atoms of cell c are the indices [cell_first[c], cell_first[c+1])
-  const AtomRec ri = rec[i];
+  const double4 ri = pos4[i];            // {x, y, z, alpha}
   const int ci = cell_of(g, box, ri.x, ri.y, ri.z);
   const int c0 = ci % g.nc[0], c1 = (ci / g.nc[0]) % g.nc[1], c2 = ci / (g.nc[0] * g.nc[1]);
   const long long nl0 = (long long)i * nl_pitch, dd0 = (long long)i * dd_pitch;
@@ -1294,12 +1296,12 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
           bool in_nl = false, in_dd = false;
           const int j = (int)p;
           if (p < b && j != i) {
-            const AtomRec rj = rec[j];
+            const double4 rj = pos4[j];  // consecutive lanes read consecutive 32-byte entries
             double ex, ey, ez;
             min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
             const double rsq = ex * ex + ey * ey + ez * ez;
             in_nl = rsq <= cutallsq;
-            in_dd = (ri.a != 0.0) && (rj.a != 0.0) && (rsq < ddcutsq);
+            in_dd = (ri.w != 0.0) && (rj.w != 0.0) && (rsq < ddcutsq);
           }
           const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
           const int kn = ncount + __popcll(m_nl & below), kd = dcount + __popcll(m_dd & below);
