@@ -256,7 +256,7 @@ void build_lists(polar_handle *h) {
 // Atoms of one colour are >= color_dist apart, so the couplings treated Jacobi-style inside a
 // phase are weak and the splitting M = D + L_colour stays convergent for the SPD dipole system
 // (DESIGN.md "colour-phase Gauss-Seidel").  Visit order = ranked order when polar_gs_ranked.
-void build_colors(polar_handle *h, const std::vector<int> &visit) {
+void build_colors(polar_handle *h, const std::vector<double> &rank) {
   const int n = h->nlocal;
   const double dc = h->color_dist, dcsq = dc * dc;
   int nc[3];
@@ -269,16 +269,20 @@ void build_colors(polar_handle *h, const std::vector<int> &visit) {
       c[k] = std::min(nc[k] - 1, (int)(fr * nc[k]));
     }
   };
+  // 1. conflict graph: polarizable atoms closer than color_dist (cell grid of edge >= color_dist)
   std::vector<std::vector<int>> cells((size_t)ncell);
-  std::vector<int> color((size_t)n, -1);
-  int ncolors = 0;
-  std::vector<char> used;
-  for (int v = 0; v < n; v++) {
-    const int i = visit[v];
+  for (int i = 0; i < n; i++) {
     if (h->halpha[i] == 0.0) continue;  // never updated: needs no phase
     int c[3];
     cellof(i, c);
-    used.assign((size_t)ncolors + 1, 0);
+    cells[((size_t)c[2] * nc[1] + c[1]) * nc[0] + c[0]].push_back(i);
+  }
+  std::vector<std::vector<int>> adj((size_t)n);
+  for (int i = 0; i < n; i++) {
+    if (h->halpha[i] == 0.0) continue;
+    int c[3];
+    cellof(i, c);
+    int seen[27], nseen = 0;
     for (int dz = -1; dz <= 1; dz++)
       for (int dy = -1; dy <= 1; dy++)
         for (int dx = -1; dx <= 1; dx++) {
@@ -289,21 +293,76 @@ void build_colors(polar_handle *h, const std::vector<int> &visit) {
             else if (b[k] < 0 || b[k] >= nc[k]) ok = false;
           }
           if (!ok) continue;
-          for (int j : cells[((size_t)b[2] * nc[1] + b[1]) * nc[0] + b[0]]) {
+          const int cj = (int)(((size_t)b[2] * nc[1] + b[1]) * nc[0] + b[0]);
+          bool dup = false;
+          for (int t = 0; t < nseen; t++) dup |= seen[t] == cj;
+          if (dup) continue;  // tiny grids: a cell reached through two offsets
+          seen[nseen++] = cj;
+          for (int j : cells[cj]) {
+            if (j == i) continue;
             double rsq = 0;
             for (int k = 0; k < 3; k++) {
               double d = h->hx[3 * (size_t)i + k] - h->hx[3 * (size_t)j + k];
               if (h->box.periodic[k]) d -= h->box.prd[k] * std::nearbyint(d / h->box.prd[k]);
               rsq += d * d;
             }
-            if (rsq < dcsq) used[color[j]] = 1;
+            if (rsq < dcsq) adj[i].push_back(j);
           }
         }
+  }
+  // 2. DSATUR (Brelaz): always colour the vertex that sees the most distinct colours; ties by degree,
+  //    then by index (deterministic: every rank of a multi-GPU run derives the same colouring).
+  //    One colour fewer, and better balanced, than first-fit on the MOF test systems -> one launch
+  //    fewer per sweep.  Lazy max-heap: stale entries are skipped when popped.
+  std::vector<int> color((size_t)n, -1), satur((size_t)n, 0);
+  std::vector<unsigned long long> seenmask((size_t)n, 0ull);  // colours 0..63 seen by the neighbours
+  struct Key { int sat, deg, idx; };
+  auto lessk = [](const Key &a, const Key &b) {
+    if (a.sat != b.sat) return a.sat < b.sat;
+    if (a.deg != b.deg) return a.deg < b.deg;
+    return a.idx > b.idx;
+  };
+  std::vector<Key> heap;
+  heap.reserve((size_t)n * 2);
+  for (int i = 0; i < n; i++)
+    if (h->halpha[i] != 0.0) heap.push_back(Key{0, (int)adj[i].size(), i});
+  std::make_heap(heap.begin(), heap.end(), lessk);
+  int ncolors = 0;
+  while (!heap.empty()) {
+    std::pop_heap(heap.begin(), heap.end(), lessk);
+    const Key kx = heap.back();
+    heap.pop_back();
+    const int i = kx.idx;
+    if (color[i] >= 0 || kx.sat != satur[i]) continue;  // already coloured, or a stale entry
     int col = 0;
-    while (col < ncolors && used[col]) col++;
-    if (col == ncolors) ncolors++;
+    while (col < 64 && ((seenmask[i] >> col) & 1ull)) col++;
+    if (col >= 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
     color[i] = col;
-    cells[((size_t)c[2] * nc[1] + c[1]) * nc[0] + c[0]].push_back(i);
+    ncolors = std::max(ncolors, col + 1);
+    for (int j : adj[i]) {
+      if (color[j] >= 0) continue;
+      if (!((seenmask[j] >> col) & 1ull)) {
+        seenmask[j] |= 1ull << col;
+        satur[j]++;
+        heap.push_back(Key{satur[j], (int)adj[j].size(), j});
+        std::push_heap(heap.begin(), heap.end(), lessk);
+      }
+    }
+  }
+  // 3. phase order: "ranked" flavour = colours by descending mean rank metric (PS.cpp:192-227 ranks the
+  //    dipoles most likely to change first); otherwise by descending size.  Relabel accordingly.
+  {
+    std::vector<double> key((size_t)ncolors, 0.0);
+    std::vector<int> cnt((size_t)ncolors, 0), ord((size_t)ncolors), relabel((size_t)ncolors);
+    for (int i = 0; i < n; i++)
+      if (color[i] >= 0) { cnt[color[i]]++; key[color[i]] += rank.empty() ? 1.0 : rank[i]; }
+    if (!rank.empty())
+      for (int c = 0; c < ncolors; c++) key[c] /= std::max(cnt[c], 1);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] > key[b]; });
+    for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
+    for (int i = 0; i < n; i++)
+      if (color[i] >= 0) color[i] = relabel[color[i]];
   }
   std::vector<int> rows;
   rows.reserve(n);
@@ -421,19 +480,17 @@ void ensure_colors(polar_handle *h) {
   if (h->colors_valid) return;
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
-  std::vector<int> order(n);
-  std::iota(order.begin(), order.end(), 0);
-  const bool sharded = own_n(h) != n;
-  if (st.polar_gs_ranked && !sharded) {  // ranked visiting order (a sharded handle only knows its own rows' metric)
-    std::vector<double> rs(n), rk(n);
+  std::vector<double> rk;
+  if (st.polar_gs_ranked && !sharded(h)) {  // a sharded handle only knows its own rows' metric
+    std::vector<double> rs(n);
     std::vector<int> perm(n);
+    rk.assign(n, 0.0);
     HIPCHECK(hipMemcpyAsync(rs.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipMemcpyAsync(perm.data(), h->d_perm.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     for (int k = 0; k < n; k++) rk[perm[k]] = rs[k];  // rank metric was computed in s space
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rk[a] > rk[b]; });
   }
-  build_colors(h, order);
+  build_colors(h, rk);
 }
 // per step: the colour rows (orig ids) -> s space of this step's cell order
 void map_color_rows(polar_handle *h) {
