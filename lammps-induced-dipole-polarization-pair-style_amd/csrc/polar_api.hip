@@ -50,7 +50,8 @@ struct DBuf {
   }
 };
 
-inline int nblk(long long n, int per) { return (int)((n + per - 1) / per); }
+// at least one workgroup: every kernel bounds-checks its index, and a zero-sized grid is a launch error
+inline int nblk(long long n, int per) { return n <= 0 ? 1 : (int)((n + per - 1) / per); }
 
 }  // namespace
 
@@ -224,6 +225,7 @@ void build_lists(polar_handle *h) {
   const double cutall = std::max(st.cut_coul, st.dd_cutoff);
   hipStream_t s = h->stream;
   const CellGrid &g = h->grid;
+  if (h->nl_pitch == 0 && getenv("POLAR_INIT_PITCH")) h->nl_pitch = h->dd_pitch = std::max(64, atoi(getenv("POLAR_INIT_PITCH")));  // tests: force the overflow path
   if (h->nl_pitch == 0) {  // first build: 1.5x the mean sphere population, rounded to 64
     double vol = h->box.prd[0] * h->box.prd[1] * h->box.prd[2];
     double mean = n / vol * 4.18879020478639 * cutall * cutall * cutall;
@@ -471,6 +473,7 @@ void launch_force(polar_handle *h, int eflag, int vpair) {
 }
 
 void read_scal(polar_handle *h) {
+  HIPCHECK(hipGetLastError());  // a failed kernel launch must not go unnoticed
   HIPCHECK(hipMemcpyAsync(h->h_scal, h->d_scal.p, sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
 }

@@ -1,0 +1,127 @@
+"""Edge cases of the HIP path against the oracle: empty and tiny systems, no polarizable atoms,
+no charges, no ghosts, free (non-periodic) boundaries in list mode, unwrapped coordinates, and the
+pitched-list overflow retry."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLD, force_rel_err, rel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+
+
+def _mini(wl, n=40, seed=3, L=24.0, cut=9.0, extra=(), alpha_scale=1.0, q_scale=1.0, periodic=(1, 1, 1)):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(2.0, L - 2.0, (n, 3))
+    typ = rng.integers(1, 3, n).astype(np.int32)
+    q = rng.normal(0, 0.4, n) * q_scale
+    q -= q.mean()
+    alpha = np.where(rng.uniform(size=n) < 0.7, rng.uniform(0.3, 1.2, n), 0.0) * alpha_scale
+    mol = (np.arange(n) // 2 + 1).astype(np.int32)
+    st = wl.parse_pair_style_args(["8.0", repr(cut), "damp_type", "exponential", "precision", "1e-13",
+                                   "max_iterations", "200"] + list(extra))
+    rows = [["1", "1", "0.10", "3.0"], ["1", "2", "0.08", "3.2"], ["2", "2", "0.06", "3.4"]]
+    s = wl.make_system(x, q, alpha, typ, mol, np.zeros(3), np.array([L, L, L]), 2, rows, st, 0.25, name="mini")
+    return s
+
+
+def _check(pkg, oracle, s, tol=TOL, periodic=(1, 1, 1)):
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    p = pkg.pair_from_system(s)
+    out = p.compute()
+    if s.nlocal:
+        f = oracle.fold_ghost_forces(out["f"], s.owner, s.nlocal)
+        fr = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
+        if np.any(fr):
+            assert force_rel_err(f, fr) < tol
+        if np.any(ref["mu"]):
+            assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < tol
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert abs(out[k] - ref[k]) <= tol * max(abs(ref[k]), 1e-9)
+    assert out["status"] == ref["status"]
+    return out, ref
+
+
+@pytest.mark.parametrize("mode", ["exact", "list"])
+def test_small_random_system(mode, wl, pkg, oracle):
+    s = _mini(wl, extra=(["dd_cutoff", "9.0"] if mode == "list" else []))
+    out, ref = _check(pkg, oracle, s)
+    if mode == "exact":
+        assert out["iterations"] == ref["iterations"]
+
+
+@pytest.mark.parametrize("mode", ["exact", "list"])
+def test_no_polarizable_atoms(mode, wl, pkg, oracle):
+    s = _mini(wl, alpha_scale=0.0, extra=(["dd_cutoff", "9.0"] if mode == "list" else []))
+    out, ref = _check(pkg, oracle, s)
+    assert out["eng_pol"] == 0.0 and not np.any(out["mu"])
+    assert out["iterations"] == ref["iterations"] == 1
+
+
+def test_no_charges_gives_no_field(wl, pkg, oracle):
+    s = _mini(wl, q_scale=0.0)
+    out, ref = _check(pkg, oracle, s)
+    assert not np.any(out["ef_static"]) and out["eng_pol"] == 0.0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_tiny_systems(n, wl, pkg, oracle):
+    s = _mini(wl, n=n, seed=n)
+    _check(pkg, oracle, s)
+
+
+def test_empty_system(wl, pkg):
+    s = _mini(wl, n=2)
+    p = pkg.pair_from_system(s)
+    p.set_atoms(0, 0, np.zeros((0, 3)), np.zeros(0), np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    p.set_neighbors_csr(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int32))
+    out = p.compute()
+    assert out["eng_pol"] == 0.0 and out["eng_vdwl"] == 0.0 and out["f"].shape == (0, 3)
+
+
+def test_unwrapped_coordinates_list_mode(wl, pkg, oracle):
+    """LAMMPS atoms drift out of the box between reneighborings: shift some atoms by whole box lengths."""
+    s = _mini(wl, extra=["dd_cutoff", "9.0"])
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    s2 = copy.copy(s)
+    x = s.x.copy()
+    n = s.nlocal
+    x[:n:3, 0] += s.prd[0]
+    x[1:n:4, 2] -= s.prd[2]
+    s2.x = x
+    out = pkg.pair_from_system(s2).compute()
+    # polarization part is image-invariant; the LJ/coul half list refers to explicit ghosts, so compare
+    # dipoles and E_pol only
+    assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+    assert rel(out["eng_pol"], ref["eng_pol"]) < TOL
+
+
+def test_pitch_overflow_retry(wl, pkg, oracle, monkeypatch):
+    """A deliberately tiny list pitch must be detected and the step redone with a larger one."""
+    monkeypatch.setenv("POLAR_INIT_PITCH", "64")
+    s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=["use_previous", "no", "dd_cutoff", "9.0",
+                                                                            "precision", "1e-13", "max_iterations", "200"])
+    out, ref = _check(pkg, oracle, s)
+
+
+def test_two_consecutive_steps_reuse_lists_and_colours(wl, pkg, oracle):
+    """Second compute on moved coordinates without a new neighbor list (neighbor->ago > 0)."""
+    s = _mini(wl, n=60, extra=["dd_cutoff", "9.0"])
+    p = pkg.pair_from_system(s)
+    p.compute()
+    rng = np.random.default_rng(9)
+    s2 = copy.copy(s)
+    dx = rng.normal(0, 0.03, (s.nlocal, 3))
+    x2 = s.x.copy()
+    x2 += dx[s.owner]                      # ghosts move with their owners
+    s2.x = x2
+    p.set_atoms(s2.nlocal, s2.nghost, s2.x, s2.q, s2.alpha, s2.type, s2.molecule)   # no set_neighbors
+    out = p.compute()
+    ref = oracle.compute(s2, eflag=1, vflag=2)
+    f = oracle.fold_ghost_forces(out["f"], s.owner, s.nlocal)
+    fr = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
+    assert force_rel_err(f, fr) < TOL
+    assert rel(out["eng_pol"], ref["eng_pol"]) < TOL
