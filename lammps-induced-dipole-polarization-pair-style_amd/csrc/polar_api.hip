@@ -79,7 +79,8 @@ struct polar_handle {
   DBuf<double> d_x, d_q, d_alpha, d_f, d_ef, d_F, d_mu, d_rank, d_dmu, d_tab, d_lj;
   DBuf<int> d_type, d_mol, d_order, d_pos, d_ilist, d_numneigh, d_neigh, d_rows;
   DBuf<int> d_mol_s, d_perm, d_inv, d_rows_orig, d_ownrows;  // s-space bookkeeping (see polar_kernels.hpp)
-  DBuf<double> d_ef_s;
+  DBuf<double> d_ef_s, d_T6;
+  bool dense_gs = false;   // exact-order GS on the HBM-resident tensor (atoms in sweep order)
   CellGrid grid{};
   long long ncell = 0;
   bool sorted = false;  // true while the records are in cell order (list mode)
@@ -521,7 +522,23 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
         if (h->h_scal->done) break;
       }
     }
-  } else {  // exact-order blocked Gauss-Seidel (reference semantics)
+  } else if (h->dense_gs) {  // exact-order blocked Gauss-Seidel on the HBM-resident tensor
+    h->d_T6.ensure((size_t)n * n * 6 + 64); h->d_dmu.ensure(3 * 64);
+    if (expd) k_build_T6<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
+    else      k_build_T6<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
+    k_dense_field<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, h->d_T6.p, h->d_rec0.p, h->d_F.p);
+    for (int sw = 0; sw < max_sweeps; sw++) {
+      for (int b0 = 0; b0 < n; b0 += 64) {
+        k_gs_seq_T6<<<1, 64, 0, s>>>(n, b0, h->d_T6.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
+        k_gs_push_T6<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_T6.p, h->d_rec0.p, h->d_dmu.p, h->d_F.p, h->d_scal.p);
+      }
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr);
+      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
+        read_scal(h);
+        if (h->h_scal->done) break;
+      }
+    }
+  } else {  // exact-order blocked Gauss-Seidel, matrix-free (systems whose tensor does not fit)
     std::vector<int> order(n), pos(n);
     std::iota(order.begin(), order.end(), 0);
     if (st.polar_gs_ranked) {  // stable descending sort == the reference's bubble sort (PS.cpp:1130-1143)
@@ -584,6 +601,30 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     } else if (h->mu_resident) mu0 = h->d_mu.p;
   }
   h->sorted = false;
+  h->dense_gs = false;
+  const bool gs_mode = (st.polar_gs || st.polar_gs_ranked) && !st.zodid;
+  bool ranked_done = false;
+  if (ap && gs_mode && n > 0 && 48.0 * (double)n * (double)n <= 4.0e9 && !getenv("POLAR_NO_DENSE_GS")) {
+    // exact-order Gauss-Seidel on the HBM-resident tensor: put the atoms in SWEEP order first
+    // (s space = ranked order), so blocks of the sweep are contiguous rows/columns of T6
+    h->dense_gs = true;
+    if (st.polar_gs_ranked) {
+      launch_rank<true>(h, 1); launch_rank<true>(h, 2);  // a2 (orig space: needs only x/alpha/mol)
+      ranked_done = true;
+      std::vector<double> rk(n);
+      std::vector<int> order(n), pos(n);
+      HIPCHECK(hipMemcpyAsync(rk.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      std::iota(order.begin(), order.end(), 0);
+      // stable descending sort == the reference's bubble sort (PS.cpp:1130-1143)
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rk[a] > rk[b]; });
+      for (int k = 0; k < n; k++) pos[order[k]] = k;
+      h->d_perm.ensure(n + 1); h->d_inv.ensure(n + 1);
+      HIPCHECK(hipMemcpy(h->d_perm.p, order.data(), n * sizeof(int), hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy(h->d_inv.p, pos.data(), n * sizeof(int), hipMemcpyHostToDevice));
+      h->sorted = true;
+    }
+  }
   if (!ap) { build_cells(h); h->d_pos4.ensure(n + 1); }  // cell order: perm / inv
   k_pack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_x.p, h->d_q.p, h->d_alpha.p, h->d_mol.p, mu0,
                                       h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p);
@@ -594,7 +635,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   HIPCHECK(hipEventRecord(h->ev[1], s));
 
   // a2: every step in exact mode (reference); in cutoff mode only when the colour phases are rebuilt
-  if (st.polar_gs_ranked && (ap || !h->colors_valid)) {
+  if (st.polar_gs_ranked && (ap || !h->colors_valid) && !ranked_done) {
     if (ap) { launch_rank<true>(h, 1); launch_rank<true>(h, 2); }
     else    { launch_rank<false>(h, 1); launch_rank<false>(h, 2); }
   }
@@ -761,7 +802,7 @@ int polar_destroy(polar_handle *h) {
     h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();
     h->d_numneigh.release(); h->d_neigh.release(); h->d_rows.release(); h->d_first.release();
     h->d_sym_first.release(); h->d_sym_cnt.release(); h->d_sym_fill.release(); h->d_sym_j.release();
-    h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release();
+    h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release(); h->d_T6.release();
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_nl_j.release(); h->d_dd_j.release();

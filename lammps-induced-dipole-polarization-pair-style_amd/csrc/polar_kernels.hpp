@@ -930,6 +930,146 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_gs_block_push(int nlocal, int b
 }
 
 // ------------------------------------------------------------------------------------------
+// Exact mode with the tensor held in HBM, as the reference does (build_dipole_field_matrix,
+// PS.cpp:1243-1316) but packed: T6[i][j] = {Txx,Txy,Txz,Tyy,Tyz,Tzz}, 48 N^2 bytes (the reference's
+// dense matrix is 72 N^2).  Used by the exact-order Gauss-Seidel when it fits: the sequential chain
+// then has no exp / rsqrt / minimum image in it, only 9 FMAs per step.  Atoms are in RANKED order
+// here (s space = sweep order), so a block of 64 consecutive steps reads contiguous tensor rows.
+template <int DAMP>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_build_T6(int n, const AtomRec *__restrict__ rec, Box box, double pd,
+                                                          double *__restrict__ T6) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const AtomRec ri = rec[i];
+  for (int j = lane; j < n; j += 64) {
+    double t[6] = {0, 0, 0, 0, 0, 0};
+    if (j != i) {
+      const AtomRec rj = rec[j];
+      double dx, dy, dz;
+      min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+      double s3, s5;
+      tensor_scalars<DAMP>(dx * dx + dy * dy + dz * dz, pd, s3, s5);
+      t[0] = s3 - s5 * dx * dx; t[1] = -s5 * dx * dy; t[2] = -s5 * dx * dz;
+      t[3] = s3 - s5 * dy * dy; t[4] = -s5 * dy * dz; t[5] = s3 - s5 * dz * dz;
+    }
+    double *o = T6 + ((size_t)i * n + j) * 6;
+#pragma unroll
+    for (int c = 0; c < 6; c++) o[c] = t[c];
+  }
+}
+
+// F_i = - sum_j T_ij mu_j  (dense mat-vec; initial running field of the Gauss-Seidel)
+__global__ __launch_bounds__(POLAR_BLOCK) void k_dense_field(int n, const double *__restrict__ T6,
+                                                             const AtomRec *__restrict__ rec, double *__restrict__ F) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= n) return;
+  double fx = 0, fy = 0, fz = 0;
+  for (int j = lane; j < n; j += 64) {
+    const double *t = T6 + ((size_t)i * n + j) * 6;
+    const double mx = rec[j].mx, my = rec[j].my, mz = rec[j].mz;
+    fx -= t[0] * mx + t[1] * my + t[2] * mz;
+    fy -= t[1] * mx + t[3] * my + t[4] * mz;
+    fz -= t[2] * mx + t[4] * my + t[5] * mz;
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) { F[3 * i] = fx; F[3 * i + 1] = fy; F[3 * i + 2] = fz; }
+}
+
+__device__ __forceinline__ double readlane_d(double v, int k) {  // k wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+// ONE wave: the sequential recurrence over the 64 atoms b0..b0+63 of the sweep order
+// (PS.cpp:1158-1180).  Lane l owns atom b0+l; step k: mu_k <- alpha_k (E_k + F_k), and every lane
+// folds T_{l,k} dmu_k into its running field.  Tensor rows are prefetched four steps ahead.
+__global__ __launch_bounds__(64) void k_gs_seq_T6(int n, int b0, const double *__restrict__ T6,
+                                                  AtomRec *__restrict__ rec, const double *__restrict__ ef,
+                                                  double *__restrict__ F, double *__restrict__ dmu_blk,
+                                                  const Scal *scal, double *__restrict__ slots) {
+  if (scal->done) return;
+  const int lane = threadIdx.x;
+  const int cnt = min(64, n - b0);
+  const bool act = lane < cnt;
+  const int i = act ? b0 + lane : b0;
+  const AtomRec r = rec[i];
+  const double a = act ? r.a : 0.0;
+  double mx = r.mx, my = r.my, mz = r.mz;
+  const double mx0 = mx, my0 = my, mz0 = mz;
+  double Fx = F[3 * i], Fy = F[3 * i + 1], Fz = F[3 * i + 2];
+  const double Ex = ef[3 * i], Ey = ef[3 * i + 1], Ez = ef[3 * i + 2];
+  // T_{k,l} = T_{l,k}: read row (b0+k), columns b0..b0+63 -> consecutive lanes, contiguous 3 KB
+  const double *tcol = T6 + ((size_t)b0 * n + i) * 6;
+  const size_t rowstride = (size_t)n * 6;
+  double ta[4][6], tb[4][6];
+#define POLAR_LOADT(BUF, K0)                                                     \
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {                                \
+    const int kk = (K0) + u < cnt ? (K0) + u : cnt - 1;                          \
+    const double *t_ = tcol + (size_t)kk * rowstride;                            \
+    _Pragma("unroll") for (int c = 0; c < 6; c++) BUF[u][c] = t_[c];             \
+  }
+#define POLAR_STEPT(BUF, K0)                                                     \
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {                                \
+    const int k = (K0) + u;                                                      \
+    if (k < cnt) {                                                               \
+      const double nx = a * (Ex + Fx), ny = a * (Ey + Fy), nz = a * (Ez + Fz);   \
+      const double bdx = readlane_d(nx - mx, k), bdy = readlane_d(ny - my, k),   \
+                   bdz = readlane_d(nz - mz, k);                                 \
+      if (lane == k) { mx = nx; my = ny; mz = nz; }                              \
+      /* the diagonal block T_kk is stored as zero: lane k leaves its own field alone */ \
+      Fx -= BUF[u][0] * bdx + BUF[u][1] * bdy + BUF[u][2] * bdz;                 \
+      Fy -= BUF[u][1] * bdx + BUF[u][3] * bdy + BUF[u][4] * bdz;                 \
+      Fz -= BUF[u][2] * bdx + BUF[u][4] * bdy + BUF[u][5] * bdz;                 \
+    }                                                                            \
+  }
+  POLAR_LOADT(ta, 0);
+  for (int k0 = 0; k0 < cnt; k0 += 8) {
+    POLAR_LOADT(tb, k0 + 4);
+    POLAR_STEPT(ta, k0);
+    POLAR_LOADT(ta, k0 + 8);
+    POLAR_STEPT(tb, k0 + 4);
+  }
+#undef POLAR_LOADT
+#undef POLAR_STEPT
+  double dsq = 0.0;
+  if (act) {
+    const double tx = mx - mx0, ty = my - my0, tz = mz - mz0;
+    dsq = tx * tx + ty * ty + tz * tz;
+    rec[i].mx = mx; rec[i].my = my; rec[i].mz = mz;
+    F[3 * i] = Fx; F[3 * i + 1] = Fy; F[3 * i + 2] = Fz;
+    dmu_blk[3 * lane] = tx; dmu_blk[3 * lane + 1] = ty; dmu_blk[3 * lane + 2] = tz;
+  }
+  dsq = wave_sum(dsq);
+  if (lane == 0 && dsq != 0.0) atomicAdd(slots + (size_t)((b0 >> 6) & (POLAR_NSLOT - 1)) * POLAR_SLOT_STRIDE + SL_CHANGE, dsq);
+}
+
+// rows outside the block receive the block's dipole changes: F_j -= sum_k T_{j,b0+k} dmu_k
+__global__ __launch_bounds__(POLAR_BLOCK) void k_gs_push_T6(int n, int b0, const double *__restrict__ T6,
+                                                            const AtomRec *__restrict__ rec,
+                                                            const double *__restrict__ dmu_blk, double *__restrict__ F,
+                                                            const Scal *scal) {
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (j >= n || (j >= b0 && j < b0 + 64)) return;
+  if (rec[j].a == 0.0) return;  // mu_j stays 0: its field is never read
+  const int cnt = min(64, n - b0);
+  double fx = 0, fy = 0, fz = 0;
+  if (lane < cnt) {
+    const double *t = T6 + ((size_t)j * n + b0 + lane) * 6;
+    const double bdx = dmu_blk[3 * lane], bdy = dmu_blk[3 * lane + 1], bdz = dmu_blk[3 * lane + 2];
+    fx = -(t[0] * bdx + t[1] * bdy + t[2] * bdz);
+    fy = -(t[1] * bdx + t[3] * bdy + t[4] * bdz);
+    fz = -(t[2] * bdx + t[4] * bdy + t[5] * bdz);
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) { F[3 * j] += fx; F[3 * j + 1] += fy; F[3 * j + 2] += fz; }
+}
+
+// ------------------------------------------------------------------------------------------
 // a7 loop control, one thread: the reference's end-of-sweep logic (PS.cpp:1193-1236) kept on the
 // device so the host never has to look at ||dmu||^2 between sweeps.
 __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double *__restrict__ slots, int nlocal,
