@@ -280,7 +280,8 @@ class PolarPair:
         return args
 
     def set_system(self, sysm):
-        self.set_box(sysm.boxlo, sysm.prd)
+        self.set_box(sysm.boxlo, sysm.prd, tilt=getattr(sysm, "tilt", (0.0, 0.0, 0.0)),
+                     triclinic=int(getattr(sysm, "triclinic", 0)))
         self.set_atoms(sysm.nlocal, sysm.nghost, sysm.x, sysm.q, sysm.alpha, sysm.type, sysm.molecule)
         self.set_neighbors_csr(sysm.ilist, sysm.numneigh, sysm.firstneigh, sysm.neigh)
 

@@ -581,6 +581,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   const int n = h->nlocal, nall = h->nlocal + h->nghost;
   const bool ap = !(st.dd_cutoff > 0.0);
   if (ap && own_n(h) != n) throw InputError("row sharding needs dd_cutoff > 0 (exact all-pairs mode runs as replicas only)");
+  if (!ap && h->box.triclinic) throw InputError("dd_cutoff (list) mode needs an orthogonal box; triclinic boxes run in exact mode");
   const int vmode = vflag % 4;
   hipStream_t s = h->stream;
   h->warn.clear();
@@ -905,8 +906,13 @@ int polar_set_coul(polar_handle *h, double g_ewald, double qqrd2e, const double 
 int polar_set_box(polar_handle *h, const double boxlo[3], const double prd[3], const double tilt[3],
                   const int periodic[3], int triclinic) {
   return guarded(h, [&]() {
-    if (triclinic || (tilt && (tilt[0] != 0.0 || tilt[1] != 0.0 || tilt[2] != 0.0)))
-      return fail(h, POLAR_ERR_UNSUPPORTED, "triclinic boxes are not implemented (SURVEY 8(f) rank 3)");
+    // triclinic boxes: supported by the exact (all-pairs) kernels through the triclinic branch of
+    // closest_image; the list mode's cell grid is orthogonal only
+    const bool tri = triclinic != 0;
+    h->box.triclinic = tri ? 1 : 0;
+    h->box.xy = tri && tilt ? tilt[0] : 0.0;
+    h->box.xz = tri && tilt ? tilt[1] : 0.0;
+    h->box.yz = tri && tilt ? tilt[2] : 0.0;
     for (int k = 0; k < 3; k++) {
       if (!(prd[k] > 0.0) || !std::isfinite(prd[k])) throw InputError("box lengths must be positive and finite");
       h->box.prd[k] = prd[k]; h->box.half[k] = 0.5 * prd[k]; h->box.inv[k] = 1.0 / prd[k]; h->box.periodic[k] = periodic[k] ? 1 : 0;

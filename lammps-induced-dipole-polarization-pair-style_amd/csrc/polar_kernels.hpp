@@ -35,7 +35,9 @@ struct __attribute__((aligned(64))) AtomRec {
 
 struct Box {
   double prd[3], half[3], inv[3];
+  double xy, xz, yz;  // triclinic tilt factors (domain.cpp:1258-1305); zero for orthogonal boxes
   int periodic[3];
+  int triclinic;
 };
 
 // Device-resident solver/accumulator block (one per handle).
@@ -111,9 +113,35 @@ __device__ __forceinline__ double wrap_ci(double d, double L, double h, int peri
 // del = x_i - closest_image(x_j)
 __device__ __forceinline__ void min_image_del(const Box &b, double xi, double yi, double zi, double xj, double yj,
                                               double zj, double &dx, double &dy, double &dz) {
-  dx = -wrap_ci(xj - xi, b.prd[0], b.half[0], b.periodic[0]);
-  dy = -wrap_ci(yj - yi, b.prd[1], b.half[1], b.periodic[1]);
-  dz = -wrap_ci(zj - zi, b.prd[2], b.half[2], b.periodic[2]);
+  if (!b.triclinic) {
+    dx = -wrap_ci(xj - xi, b.prd[0], b.half[0], b.periodic[0]);
+    dy = -wrap_ci(yj - yi, b.prd[1], b.half[1], b.periodic[1]);
+    dz = -wrap_ci(zj - zi, b.prd[2], b.half[2], b.periodic[2]);
+    return;
+  }
+  // triclinic branch of Domain::closest_image (domain.cpp:1258-1305): z first (carrying yz, xz into
+  // y and x), then y (carrying xy into x), then x -- same add/subtract sequence as the reference
+  double ex = xj - xi, ey = yj - yi, ez = zj - zi;
+  if (b.periodic[2]) {
+    if (ez < 0.0) {
+      while (ez < 0.0) { ez += b.prd[2]; ey += b.yz; ex += b.xz; }
+      if (ez > b.half[2]) { ez -= b.prd[2]; ey -= b.yz; ex -= b.xz; }
+    } else {
+      while (ez > 0.0) { ez -= b.prd[2]; ey -= b.yz; ex -= b.xz; }
+      if (ez < -b.half[2]) { ez += b.prd[2]; ey += b.yz; ex += b.xz; }
+    }
+  }
+  if (b.periodic[1]) {
+    if (ey < 0.0) {
+      while (ey < 0.0) { ey += b.prd[1]; ex += b.xy; }
+      if (ey > b.half[1]) { ey -= b.prd[1]; ex -= b.xy; }
+    } else {
+      while (ey > 0.0) { ey -= b.prd[1]; ex -= b.xy; }
+      if (ey < -b.half[1]) { ey += b.prd[1]; ex += b.xy; }
+    }
+  }
+  ex = wrap_ci(ex, b.prd[0], b.half[0], b.periodic[0]);
+  dx = -ex; dy = -ey; dz = -ez;
 }
 
 // quad (4-lane) exchange through DPP quad_perm -- no LDS crossbar

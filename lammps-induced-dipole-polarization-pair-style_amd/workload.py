@@ -367,6 +367,8 @@ class PolarSystem:
     settings: PolarSettings
     owner: np.ndarray = None
     name: str = ""
+    tilt: tuple = (0.0, 0.0, 0.0)   # xy, xz, yz
+    triclinic: int = 0
     extra: dict = field(default_factory=dict)
 
 

@@ -96,9 +96,9 @@ def make_struct(sys, settings=None):
     s.type = _p(arr(sys.type, np.int32), C.c_int)
     s.molecule = _p(arr(sys.molecule, np.int32), C.c_int)
     s.prd[:] = list(sys.prd)
-    s.tilt[:] = [0.0, 0.0, 0.0]
+    s.tilt[:] = list(getattr(sys, "tilt", (0.0, 0.0, 0.0)))
     s.periodic[:] = [1, 1, 1]
-    s.triclinic = 0
+    s.triclinic = int(getattr(sys, "triclinic", 0))
     s.ntypes = sys.ntypes
     for k in ("lj1", "lj2", "lj3", "lj4", "offset", "cut_ljsq", "cutsq"):
         setattr(s, k, _p(arr(sys.tables[k], np.float64), C.c_double))

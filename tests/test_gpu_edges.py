@@ -125,3 +125,34 @@ def test_two_consecutive_steps_reuse_lists_and_colours(wl, pkg, oracle):
     fr = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
     assert force_rel_err(f, fr) < TOL
     assert rel(out["eng_pol"], ref["eng_pol"]) < TOL
+
+
+def test_triclinic_box_exact_mode(wl, pkg, oracle):
+    """Triclinic branch of Domain::closest_image (domain.cpp:1258-1305) in the all-pairs kernels.
+    No LJ/coul list here (inum = 0, no ghosts): the polarization loops are the ones that use the
+    minimum image.  Checker = the oracle's restatement of the triclinic branch."""
+    rng = np.random.default_rng(11)
+    n, L = 90, 16.0
+    s = _mini(wl, n=n, seed=11, L=L, cut=7.5)
+    s2 = copy.copy(s)
+    s2.tilt, s2.triclinic = (3.1, -2.2, 1.7), 1
+    # spread the atoms over the tilted cell: x = frac . (a, b, c)
+    fr = rng.uniform(0, 1, (n, 3))
+    xy, xz, yz = s2.tilt
+    x = np.stack([fr[:, 0] * L + fr[:, 1] * xy + fr[:, 2] * xz, fr[:, 1] * L + fr[:, 2] * yz, fr[:, 2] * L], axis=1)
+    s2.x = np.ascontiguousarray(x)
+    s2.nghost = 0
+    for k in ("q", "alpha", "type", "molecule"):
+        setattr(s2, k, np.ascontiguousarray(getattr(s, k)[:n]))
+    s2.owner = np.arange(n)
+    s2.ilist = np.zeros(0, np.int32); s2.numneigh = np.zeros(n, np.int32)
+    s2.firstneigh = np.zeros(n, np.int64); s2.neigh = np.zeros(0, np.int32)
+    for extra in ([], ["polar_gs_ranked", "no", "polar_gs", "yes"]):
+        s2.settings = wl.parse_pair_style_args(["8.0", "7.5", "damp_type", "exponential", "precision", "1e-13",
+                                                "max_iterations", "200"] + extra)
+        out, ref = _check(pkg, oracle, s2)
+        assert out["iterations"] == ref["iterations"]
+    # list mode refuses a tilted box instead of silently using an orthogonal grid
+    s2.settings = wl.parse_pair_style_args(["8.0", "7.5", "dd_cutoff", "7.5"])
+    with pytest.raises(pkg.PolarError):
+        pkg.pair_from_system(s2).compute()

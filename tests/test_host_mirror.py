@@ -139,8 +139,6 @@ def test_compute_fails_loudly_without_gpu_or_setup(pkg):
         p.compute_resident()
 
 
-def test_unsupported_features_are_reported(pkg):
+def test_triclinic_box_is_accepted_for_exact_mode(pkg):
     p = pkg.PolarPair(0)
-    with pytest.raises(pkg.PolarError) as e:
-        p.set_box([0, 0, 0], [10, 10, 10], tilt=(1.0, 0.0, 0.0), triclinic=1)
-    assert e.value.code == -4
+    p.set_box([0, 0, 0], [10, 10, 10], tilt=(1.0, 0.5, -0.5), triclinic=1)   # exact-mode kernels handle it
