@@ -120,15 +120,24 @@ int polar_set_neighbors_csr(polar_handle *h, int inum, const int *ilist, const i
 /* f[nall][3] is ACCUMULATED (+=) like atom->f; mu[nlocal][3] is atom->mu_induced (read when
  * use_previous, always written); ef_static[nlocal][3] (may be NULL) receives atom->ef_static.
  * eflag: 0 / 1 (global).  vflag: 0, 1 (pairwise global virial), 2 (fdotr global virial).
- * Per-atom energy/virial flags -> POLAR_ERR_UNSUPPORTED. */
+ * Per-atom flags (eflag & 2, vflag & 4) -> POLAR_ERR_INPUT here: use polar_compute_peratom. */
 int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, double *ef_static,
                   polar_result *out);
+/* The same step with LAMMPS' per-atom tallies (ev_setup: eflag_atom = eflag/2, vflag_atom = vflag/4,
+ * src/pair.cpp:760-764).  eatom[nall] (Pair::eatom) and vatom[nall][6] (Pair::vatom) are ACCUMULATED
+ * (+=) for locals and ghosts exactly as ev_tally (src/pair.cpp:881-885, 925-942) and ev_tally_xyz
+ * (src/pair.cpp:1065-1082) fill them: 1/2 of each LJ/Coulomb pair energy and of each pair virial to
+ * both atoms; the polarization pairs add to vatom only (PS.cpp:629 passes zero energies).
+ * eatom may be NULL unless eflag & 2, vatom may be NULL unless vflag & 4. */
+int polar_compute_peratom(polar_handle *h, int eflag, int vflag, double *f, double *mu, double *ef_static,
+                          double *eatom, double *vatom, polar_result *out);
 
 /* ---- device-resident variant (bench, multi-GPU driver): no host<->device traffic ---------- */
 /* Runs compute() on the atoms/lists already resident from polar_set_*; results stay on the
  * device (polar_dev_ptr) and only the scalars in polar_result come back. */
 int polar_compute_resident(polar_handle *h, int eflag, int vflag, polar_result *out);
-/* device pointers: "f" [nall][3], "mu" [nlocal][3], "ef_static" [nlocal][3], "x" [nall][3] */
+/* device pointers: "f" [nall][3], "mu" [nlocal][3], "ef_static" [nlocal][3], "x" [nall][3],
+ * "eatom" [nall], "vatom" [nall][6] (the last two are valid after a step run with eflag&2 / vflag&4) */
 void *polar_dev_ptr(polar_handle *h, const char *name);
 /* copy a device-resident per-atom array back: name as above, n doubles */
 int polar_download(polar_handle *h, const char *name, double *dst, long long n);

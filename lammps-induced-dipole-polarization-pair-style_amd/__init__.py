@@ -92,6 +92,7 @@ EXPORTS = {
     "polar_set_neighbors": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.POINTER(_ip)]),
     "polar_set_neighbors_csr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _llp, _ip]),
     "polar_compute": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Result)]),
+    "polar_compute_peratom": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.POINTER(Result)]),
     "polar_compute_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Result)]),
     "polar_dev_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
     "polar_download": (C.c_int, [C.c_void_p, C.c_char_p, _dp, C.c_longlong]),
@@ -292,10 +293,20 @@ class PolarPair:
         mu = np.zeros((n, 3)) if mu is None else np.array(mu, dtype=np.float64, copy=True)
         ef = np.zeros((n, 3))
         res = Result()
-        rc = self._ck(self.L.polar_compute(self.h, eflag, vflag, _dptr(f), _dptr(mu), _dptr(ef) if want_ef else None,
-                                           C.byref(res)))
+        eatom = vatom = None
+        if eflag // 2 or vflag // 4:  # per-atom tallies (Pair::eatom / Pair::vatom)
+            eatom = np.zeros(nall) if eflag // 2 else None
+            vatom = np.zeros((nall, 6)) if vflag // 4 else None
+            rc = self._ck(self.L.polar_compute_peratom(
+                self.h, eflag, vflag, _dptr(f), _dptr(mu), _dptr(ef) if want_ef else None,
+                _dptr(eatom) if eatom is not None else None, _dptr(vatom) if vatom is not None else None,
+                C.byref(res)))
+        else:
+            rc = self._ck(self.L.polar_compute(self.h, eflag, vflag, _dptr(f), _dptr(mu),
+                                               _dptr(ef) if want_ef else None, C.byref(res)))
         out = _result_dict(res)
-        out.update(f=f, mu=mu, ef_static=ef, status=rc, warning=self.L.polar_last_warning(self.h).decode())
+        out.update(f=f, mu=mu, ef_static=ef, status=rc, warning=self.L.polar_last_warning(self.h).decode(),
+                   eatom=eatom, vatom=vatom)
         return out
 
     def compute_resident(self, eflag=1, vflag=2):

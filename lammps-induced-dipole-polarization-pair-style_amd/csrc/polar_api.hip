@@ -79,7 +79,7 @@ struct polar_handle {
   DBuf<double> d_x, d_q, d_alpha, d_f, d_ef, d_F, d_mu, d_rank, d_dmu, d_tab, d_lj;
   DBuf<int> d_type, d_mol, d_order, d_pos, d_ilist, d_numneigh, d_neigh, d_rows;
   DBuf<int> d_mol_s, d_perm, d_inv, d_rows_orig, d_ownrows;  // s-space bookkeeping (see polar_kernels.hpp)
-  DBuf<double> d_ef_s, d_T6;
+  DBuf<double> d_ef_s, d_T6, d_eatom, d_vatom;
   bool dense_gs = false;   // exact-order GS on the HBM-resident tensor (atoms in sweep order)
   CellGrid grid{};
   long long ncell = 0;
@@ -460,14 +460,15 @@ void sweep_once(polar_handle *h, bool ap) {
 }
 
 template <bool AP, int DAMP>
-void launch_force(polar_handle *h, int eflag, int vpair) {
+void launch_force(polar_handle *h, int eflag, int vglobal, double *vatom) {
+  const bool vpair = vglobal || vatom;
   const polar_settings &st = h->ph.st;
   dim3 grid(nblk(own_n(h), POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
   const double ccs = st.cut_coul * st.cut_coul, dds = st.dd_cutoff * st.dd_cutoff, e2s = std::sqrt(h->P.qqrd2e);
 #define LF(E, V)                                                                                                    \
   k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(own_rows(h), own_n(h), h->sorted ? h->d_perm.p : nullptr, h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
                                                                h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p,  \
-                                                               ccs, dds, st.polar_damp, e2s, h->d_f.p, h->d_slots.p)
+                                                               ccs, dds, st.polar_damp, e2s, h->d_f.p, h->d_slots.p, vatom, vglobal)
   if (eflag) { if (vpair) LF(true, true); else LF(true, false); }
   else       { if (vpair) LF(false, true); else LF(false, false); }
 #undef LF
@@ -592,6 +593,11 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   h->d_ef_s.ensure(3 * (size_t)n); h->d_mol_s.ensure(n + 1);
   HIPCHECK(hipEventRecord(h->ev[0], s));
   HIPCHECK(hipMemsetAsync(h->d_f.p, 0, 3 * (size_t)nall * sizeof(double), s));
+  // per-atom tallies (eflag/2, vflag/4: src/pair.cpp:760-764), zeroed like ev_setup does (:789-806)
+  double *eatom = nullptr, *vatom = nullptr;
+  if (eflag / 2) { h->d_eatom.ensure(nall + 1); eatom = h->d_eatom.p; HIPCHECK(hipMemsetAsync(eatom, 0, (size_t)nall * sizeof(double), s)); }
+  if (vflag / 4) { h->d_vatom.ensure(6 * (size_t)nall + 6); vatom = h->d_vatom.p; HIPCHECK(hipMemsetAsync(vatom, 0, 6 * (size_t)nall * sizeof(double), s)); }
+  if ((eatom || vatom) && own_n(h) != n) throw InputError("per-atom tallies are not available on a row-sharded handle");
   k_zero_scal<<<1, 1, 0, s>>>(h->d_scal.p, 0);
   k_zero_slots<<<nblk(POLAR_NSLOT, 256), 256, 0, s>>>(h->d_slots.p);
   const double *mu0 = nullptr;
@@ -651,6 +657,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     if (ljlds > 64 * 1024) throw InputError("too many atom types for the LDS-resident LJ table (max 31)");
     dim3 block(POLAR_BLOCK);
     const bool symmetrise = !h->full_list && !getenv("POLAR_LJ_ATOMICS");
+    if ((eatom || vatom) && !symmetrise && !h->full_list) throw InputError("per-atom tallies need the row-complete pair list (unset POLAR_LJ_ATOMICS)");
     if (symmetrise && !h->sym_valid && h->inum > 0) {  // once per uploaded list (reneighbor steps)
       dim3 g0(nblk(h->inum, POLAR_ROWS_PER_BLOCK));
       h->d_sym_cnt.ensure(nall + 1); h->d_sym_fill.ensure(nall + 1); h->d_sym_first.ensure(nall + 2);
@@ -671,9 +678,10 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     const long long *fi = symmetrise ? h->d_sym_first.p : h->d_first.p;
     const int *nj = symmetrise ? h->d_sym_j.p : h->d_neigh.p;
     if (h->inum > 0) {
-#define LJ(E, V) k_ljcoul<E, V><<<grid, block, ljlds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p)
-      if (eflag) { if (vmode == 1) LJ(true, true); else LJ(true, false); }
-      else       { if (vmode == 1) LJ(false, true); else LJ(false, false); }
+#define LJ(E, V) k_ljcoul<E, V><<<grid, block, ljlds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1)
+      const bool vrow = vmode == 1 || vatom;
+      if (eflag) { if (vrow) LJ(true, true); else LJ(true, false); }
+      else       { if (vrow) LJ(false, true); else LJ(false, false); }
 #undef LJ
     }
   }
@@ -698,8 +706,9 @@ int phase_finish(polar_handle *h, polar_result *out) {
   hipStream_t s = h->stream;
   k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p);
   HIPCHECK(hipEventRecord(h->ev[5], s));
-  if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1); else launch_force<true, 1>(h, eflag, vmode == 1); }
-  else    { if (expd) launch_force<false, 0>(h, eflag, vmode == 1); else launch_force<false, 1>(h, eflag, vmode == 1); }
+  double *vatom = (h->step_vflag / 4) ? h->d_vatom.p : nullptr;
+  if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1, vatom); else launch_force<true, 1>(h, eflag, vmode == 1, vatom); }
+  else    { if (expd) launch_force<false, 0>(h, eflag, vmode == 1, vatom); else launch_force<false, 1>(h, eflag, vmode == 1, vatom); }
   if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_slots.p);  // a10
   k_unpack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p, h->d_mu.p, h->d_ef.p);
   k_fold_scal<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, 0);
@@ -731,7 +740,6 @@ int phase_finish(polar_handle *h, polar_result *out) {
 }
 
 int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, polar_result *out) {
-  if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not implemented (SURVEY 8(f) rank 3)");
   memset(out, 0, sizeof(*out));
   const bool ap = !(h->ph.st.dd_cutoff > 0.0);
   int rc = 0;
@@ -1009,6 +1017,7 @@ int polar_set_neighbors(polar_handle *h, int inum, const int *ilist, const int *
 int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, double *ef_static, polar_result *out) {
   return guarded(h, [&]() {
     if (!f || !mu || !out) throw std::runtime_error("polar_compute: null output pointer");
+    if (eflag / 2 || vflag / 4) throw InputError("per-atom tallies (eflag & 2, vflag & 4) are returned by polar_compute_peratom");
     need_device(h);
     HIPCHECK(hipSetDevice(h->device));
     int rc = do_compute(h, eflag, vflag, mu, out);
@@ -1017,6 +1026,30 @@ int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, 
     h->h_tmp.resize(3 * nall);
     HIPCHECK(hipMemcpy(h->h_tmp.data(), h->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < 3 * nall; k++) f[k] += h->h_tmp[k];
+    HIPCHECK(hipMemcpy(mu, h->d_mu.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (ef_static) HIPCHECK(hipMemcpy(ef_static, h->d_ef.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    return rc;
+  });
+}
+
+int polar_compute_peratom(polar_handle *h, int eflag, int vflag, double *f, double *mu, double *ef_static,
+                          double *eatom, double *vatom, polar_result *out) {
+  return guarded(h, [&]() {
+    if (!f || !mu || !out) throw std::runtime_error("polar_compute_peratom: null output pointer");
+    if ((eflag / 2 && !eatom) || (vflag / 4 && !vatom)) throw InputError("polar_compute_peratom: eflag & 2 needs eatom, vflag & 4 needs vatom");
+    need_device(h);
+    HIPCHECK(hipSetDevice(h->device));
+    int rc = do_compute(h, eflag, vflag, mu, out);
+    if (rc < 0) return rc;
+    const size_t n = h->nlocal, nall = (size_t)h->nlocal + h->nghost;
+    auto add_from = [&](const double *dev, double *host, size_t cnt) {
+      h->h_tmp.resize(cnt);
+      HIPCHECK(hipMemcpy(h->h_tmp.data(), dev, cnt * sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < cnt; k++) host[k] += h->h_tmp[k];
+    };
+    add_from(h->d_f.p, f, 3 * nall);
+    if (eflag / 2) add_from(h->d_eatom.p, eatom, nall);
+    if (vflag / 4) add_from(h->d_vatom.p, vatom, 6 * nall);
     HIPCHECK(hipMemcpy(mu, h->d_mu.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
     if (ef_static) HIPCHECK(hipMemcpy(ef_static, h->d_ef.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
     return rc;
@@ -1038,6 +1071,8 @@ void *polar_dev_ptr(polar_handle *h, const char *name) {
   if (strcmp(name, "mu") == 0) return h->d_mu.p;
   if (strcmp(name, "ef_static") == 0) return h->d_ef.p;
   if (strcmp(name, "x") == 0) return h->d_x.p;
+  if (strcmp(name, "eatom") == 0) return h->d_eatom.p;
+  if (strcmp(name, "vatom") == 0) return h->d_vatom.p;
   return nullptr;
 }
 int polar_download(polar_handle *h, const char *name, double *dst, long long n) {
@@ -1084,7 +1119,7 @@ int polar_set_list_style(polar_handle *h, int full) {
 int polar_step_begin(polar_handle *h, int eflag, int vflag) {
   return guarded(h, [&]() {
     HIPCHECK(hipSetDevice(h->device));
-    if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not implemented");
+    if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not available in the stepwise (sharded) interface");
     h->h_flags[0] = 0;
     phase_begin(h, eflag, vflag, nullptr);
     const polar_settings &st = h->ph.st;

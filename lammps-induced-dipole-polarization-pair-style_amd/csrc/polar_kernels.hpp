@@ -376,7 +376,9 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
                                                         const long long *__restrict__ first,
                                                         const int *__restrict__ neigh,
                                                         const double4 *__restrict__ xq, const int *__restrict__ type,
-                                                        double *__restrict__ f, double *__restrict__ slots) {
+                                                        double *__restrict__ f, double *__restrict__ slots,
+                                                        double *__restrict__ eatom, double *__restrict__ vatom,
+                                                        int vglobal) {
   const double EWALD_F = 1.12837917, EWALD_P = 0.3275911, A1 = 0.254829592, A2 = -0.284496736, A3 = 1.421413741,
                A4 = -1.453152027, A5 = 1.061405429;  // PS.cpp:43-49
   extern __shared__ double lj_lds[];
@@ -470,13 +472,24 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
   }
   if (EFLAG) {
     ev = wave_sum(ev); ec = wave_sum(ec);
-    if (lane == 0) { atomicAdd(slot_ptr(slots, SL_EVDWL), ev); atomicAdd(slot_ptr(slots, SL_ECOUL), ec); }
+    if (lane == 0) {
+      atomicAdd(slot_ptr(slots, SL_EVDWL), ev); atomicAdd(slot_ptr(slots, SL_ECOUL), ec);
+      // per-atom energy, src/pair.cpp:881-885: every pair of a full row carries weight 1/2, so the
+      // row total IS eatom[i] (one wave per row: plain store-add, no atomics)
+      if (eatom) eatom[i] += ev + ec;
+    }
   }
   if (VPAIR) {
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
     if (lane == 0) {
-      atomicAdd(slot_ptr(slots, SL_V0), v0); atomicAdd(slot_ptr(slots, SL_V1), v1); atomicAdd(slot_ptr(slots, SL_V2), v2);
-      atomicAdd(slot_ptr(slots, SL_V3), v3); atomicAdd(slot_ptr(slots, SL_V4), v4); atomicAdd(slot_ptr(slots, SL_V5), v5);
+      if (vglobal) {
+        atomicAdd(slot_ptr(slots, SL_V0), v0); atomicAdd(slot_ptr(slots, SL_V1), v1); atomicAdd(slot_ptr(slots, SL_V2), v2);
+        atomicAdd(slot_ptr(slots, SL_V3), v3); atomicAdd(slot_ptr(slots, SL_V4), v4); atomicAdd(slot_ptr(slots, SL_V5), v5);
+      }
+      if (vatom) {  // src/pair.cpp:925-942
+        double *va = vatom + 6 * (size_t)i;
+        va[0] += v0; va[1] += v1; va[2] += v2; va[3] += v3; va[4] += v4; va[5] += v5;
+      }
     }
   }
 }
@@ -1218,7 +1231,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
                                                              RowList nl,
                                                              const int *__restrict__ nl_j, double cut_coulsq,
                                                              double ddcutsq, double pd, double e2s,
-                                                             double *__restrict__ f, double *__restrict__ slots) {
+                                                             double *__restrict__ f, double *__restrict__ slots,
+                                                             double *__restrict__ vatom, int vglobal) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -1319,8 +1333,14 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
   if (VPAIR) {
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
     if (lane == 0) {
-      atomicAdd(slot_ptr(slots, SL_V0), v0); atomicAdd(slot_ptr(slots, SL_V1), v1); atomicAdd(slot_ptr(slots, SL_V2), v2);
-      atomicAdd(slot_ptr(slots, SL_V3), v3); atomicAdd(slot_ptr(slots, SL_V4), v4); atomicAdd(slot_ptr(slots, SL_V5), v5);
+      if (vglobal) {
+        atomicAdd(slot_ptr(slots, SL_V0), v0); atomicAdd(slot_ptr(slots, SL_V1), v1); atomicAdd(slot_ptr(slots, SL_V2), v2);
+        atomicAdd(slot_ptr(slots, SL_V3), v3); atomicAdd(slot_ptr(slots, SL_V4), v4); atomicAdd(slot_ptr(slots, SL_V5), v5);
+      }
+      if (vatom) {  // per-atom part of ev_tally_xyz, src/pair.cpp:1065-1082 (the row total is vatom[i])
+        double *va = vatom + 6 * (size_t)(perm ? perm[i] : i);
+        va[0] += v0; va[1] += v1; va[2] += v2; va[3] += v3; va[4] += v4; va[5] += v5;
+      }
     }
   }
 }

@@ -68,9 +68,6 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
 {
   if (eflag || vflag) ev_setup(eflag,vflag);
   else evflag = vflag_fdotr = 0;
-  if (eflag_atom || vflag_atom)
-    error->all(FLERR,"Pair style lj/cut/coul/long/polarization (MI355X): per-atom energy/virial not supported yet");
-
   // what compute() reads through domain->, atom-> and list-> (PS.cpp:125-188)
   double tilt[3] = {domain->xy,domain->xz,domain->yz};
   int periodic[3] = {domain->xperiodic,domain->yperiodic,domain->zperiodic};
@@ -82,9 +79,17 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
 
   // global virial: fdotr is left to the base class (it needs the reverse-communicated ghosts'
   // x, which LAMMPS owns); a pairwise global virial (vflag_global == 1) is tallied on the device
+  // per-atom tallies go straight into Pair::eatom / Pair::vatom, which ev_setup has just zeroed
+  // (src/pair.cpp:789-806); both are contiguous (src/memory.h:118-131)
   polar_result res;
-  int rc = polar_compute(h,eflag_either ? 1 : 0,vflag_global ? 1 : 0,&atom->f[0][0],
-                         &atom->mu_induced[0][0],&atom->ef_static[0][0],&res);
+  const int ef = (eflag_either ? 1 : 0) | (eflag_atom ? 2 : 0);
+  const int vf = (vflag_global ? 1 : 0) | (vflag_atom ? 4 : 0);
+  int rc;
+  if (eflag_atom || vflag_atom)
+    rc = polar_compute_peratom(h,ef,vf,&atom->f[0][0],&atom->mu_induced[0][0],&atom->ef_static[0][0],
+                               eflag_atom ? eatom : NULL,vflag_atom ? &vatom[0][0] : NULL,&res);
+  else
+    rc = polar_compute(h,ef,vf,&atom->f[0][0],&atom->mu_induced[0][0],&atom->ef_static[0][0],&res);
   check(rc);
 
   if (eflag_global) {

@@ -67,6 +67,8 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_compute.restype = C.c_int
         _LIB.orc_compute.argtypes = [C.POINTER(OrcSystem), C.c_int, C.c_int, dp, dp, dp, C.POINTER(OrcResult), dp]
+        _LIB.orc_compute_peratom.restype = C.c_int
+        _LIB.orc_compute_peratom.argtypes = _LIB.orc_compute.argtypes + [dp, dp]
         _LIB.orc_init_tables.restype = C.c_int
         _LIB.orc_init_tables.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, ip, ip, dp, dp]
         _LIB.orc_rank_metric.argtypes = [C.POINTER(OrcSystem), dp, dp]
@@ -135,9 +137,13 @@ def compute(sys, eflag=1, vflag=2, mu0=None, settings=None, trace=False):
     ef = np.zeros((sys.nlocal, 3))
     res = OrcResult()
     ut = np.zeros(st.iterations_max + 8) if trace else None
-    rc = L.orc_compute(C.byref(s), eflag, vflag, _p(f, C.c_double), _p(mu, C.c_double), _p(ef, C.c_double),
-                       C.byref(res), _p(ut, C.c_double) if trace else None)
-    out = dict(f=f, mu=mu, ef_static=ef, status=rc, utrace=ut)
+    eatom = np.zeros(nall) if eflag // 2 else None
+    vatom = np.zeros((nall, 6)) if vflag // 4 else None
+    rc = L.orc_compute_peratom(C.byref(s), eflag, vflag, _p(f, C.c_double), _p(mu, C.c_double),
+                               _p(ef, C.c_double), C.byref(res), _p(ut, C.c_double) if trace else None,
+                               _p(eatom, C.c_double) if eatom is not None else None,
+                               _p(vatom, C.c_double) if vatom is not None else None)
+    out = dict(f=f, mu=mu, ef_static=ef, status=rc, utrace=ut, eatom=eatom, vatom=vatom)
     for name, _ in OrcResult._fields_:
         v = getattr(res, name)
         out[name] = np.array(list(v)) if name == "virial" else v
@@ -147,6 +153,6 @@ def compute(sys, eflag=1, vflag=2, mu0=None, settings=None, trace=False):
 def fold_ghost_forces(f, owner, nlocal):
     """What LAMMPS' reverse_comm does after pair->compute (reference src/verlet.cpp:335):
     add ghost forces onto their owners."""
-    out = np.zeros((nlocal, 3))
+    out = np.zeros((nlocal,) + f.shape[1:])
     np.add.at(out, owner, f)
     return out

@@ -404,7 +404,7 @@ void orc_rank_metric(const orc_system *s, double *rank_metric, double *rmin_out)
 /* ------------------------------------------------------------------ a3 --
  * PS.cpp:232-321: stock lj/cut/coul/long half-list loop.                   */
 void orc_ljcoul(const orc_system *s, int eflag, int vflag_pairwise, double *f, double *eng_vdwl,
-                double *eng_coul, double *virial) {
+                double *eng_coul, double *virial, double *eatom, double *vatom) {
   const int w = s->ntypes + 1, nlocal = s->nlocal;
   const double *x = s->x, *q = s->q;
   const double cut_coulsq = s->cut_coul * s->cut_coul;
@@ -495,6 +495,18 @@ void orc_ljcoul(const orc_system *s, int eflag, int vflag_pairwise, double *f, d
             if (i < nlocal) for (int k = 0; k < 6; k++) virial[k] += 0.5 * v[k];
             if (j < nlocal) for (int k = 0; k < 6; k++) virial[k] += 0.5 * v[k];
           }
+        }
+        /* per-atom parts of ev_tally, pair.cpp:881-885 (eatom) and 925-942 (vatom) */
+        if (eatom) {
+          double epairhalf = 0.5 * (evdwl + ecoul);
+          if (s->newton_pair || i < nlocal) eatom[i] += epairhalf;
+          if (s->newton_pair || j < nlocal) eatom[j] += epairhalf;
+        }
+        if (vatom) {
+          double v[6] = {delx * delx * fpair, dely * dely * fpair, delz * delz * fpair,
+                         delx * dely * fpair, delx * delz * fpair, dely * delz * fpair};
+          if (s->newton_pair || i < nlocal) for (int k = 0; k < 6; k++) vatom[6 * i + k] += 0.5 * v[k];
+          if (s->newton_pair || j < nlocal) for (int k = 0; k < 6; k++) vatom[6 * j + k] += 0.5 * v[k];
         }
       }
     }
@@ -779,8 +791,14 @@ static void polar_pair(const orc_system *s, int eflag, int i, int j, double delx
   fout[0] = fx; fout[1] = fy; fout[2] = fz;
 }
 
+/* per-atom part of ev_tally_xyz, pair.cpp:1065-1082 (newton or both local: every pair here) */
+static void vatom_xyz(double *vatom, int i, int j, const double *d, const double *fo) {
+  double v[6] = {d[0] * fo[0], d[1] * fo[1], d[2] * fo[2], d[0] * fo[1], d[0] * fo[2], d[1] * fo[2]};
+  for (int k = 0; k < 6; k++) { vatom[6 * i + k] += 0.5 * v[k]; vatom[6 * j + k] += 0.5 * v[k]; }
+}
+
 void orc_polar_forces(const orc_system *s, int eflag, int vflag_pairwise, const double *mu, double *f,
-                      orc_result *res) {
+                      orc_result *res, double *vatom) {
   const int nlocal = s->nlocal;
   const double *x = s->x, *alpha = s->alpha;
   const double cut_coulsq = s->cut_coul * s->cut_coul;
@@ -807,6 +825,7 @@ void orc_polar_forces(const orc_system *s, int eflag, int vflag_pairwise, const 
           res->virial[0] += d[0] * fo[0]; res->virial[1] += d[1] * fo[1]; res->virial[2] += d[2] * fo[2];
           res->virial[3] += d[0] * fo[1]; res->virial[4] += d[0] * fo[2]; res->virial[5] += d[1] * fo[2];
         }
+        if (vatom) vatom_xyz(vatom, i, j, &L.d[3 * p], fo);
       }
     }
     nbr_free(&L);
@@ -825,6 +844,7 @@ void orc_polar_forces(const orc_system *s, int eflag, int vflag_pairwise, const 
           res->virial[0] += delx * fo[0]; res->virial[1] += dely * fo[1]; res->virial[2] += delz * fo[2];
           res->virial[3] += delx * fo[1]; res->virial[4] += delx * fo[2]; res->virial[5] += dely * fo[2];
         }
+        if (vatom) { double d[3] = {delx, dely, delz}; vatom_xyz(vatom, i, j, d, fo); }
       }
     }
   }
@@ -850,6 +870,13 @@ void orc_virial_fdotr(const orc_system *s, const double *f, double *virial) {
  * PS.cpp:125-645 in order.                                               */
 int orc_compute(const orc_system *s, int eflag, int vflag, double *f, double *mu, double *ef_static,
                 orc_result *res, double *utrace) {
+  return orc_compute_peratom(s, eflag, vflag, f, mu, ef_static, res, utrace, NULL, NULL);
+}
+
+/* eflag/2 -> eatom[nall], vflag/4 -> vatom[nall][6] (pair.cpp:760-764); the caller zeroes them
+ * like ev_setup does (pair.cpp:789-806).                                                    */
+int orc_compute_peratom(const orc_system *s, int eflag, int vflag, double *f, double *mu, double *ef_static,
+                        orc_result *res, double *utrace, double *eatom, double *vatom) {
   const int nlocal = s->nlocal;
   double t0;
   memset(res, 0, sizeof(*res));
@@ -861,7 +888,9 @@ int orc_compute(const orc_system *s, int eflag, int vflag, double *f, double *mu
   res->t_rank = now_s() - t0;
 
   t0 = now_s();
-  orc_ljcoul(s, eflag, vpair, f, &res->eng_vdwl, &res->eng_coul, res->virial); /* a3 */
+  if (!(eflag / 2)) eatom = NULL;
+  if (!(vflag / 4)) vatom = NULL;
+  orc_ljcoul(s, eflag, vpair, f, &res->eng_vdwl, &res->eng_coul, res->virial, eatom, vatom); /* a3 */
   res->t_ljcoul = now_s() - t0;
 
   t0 = now_s();
@@ -921,7 +950,7 @@ int orc_compute(const orc_system *s, int eflag, int vflag, double *f, double *mu
   res->iterations = iterations;
 
   t0 = now_s();
-  orc_polar_forces(s, eflag, vpair, mu, f, res); /* a8 */
+  orc_polar_forces(s, eflag, vpair, mu, f, res, vatom); /* a8 */
   res->t_force = now_s() - t0;
 
   if ((vflag % 4) == 2) orc_virial_fdotr(s, f, res->virial); /* a10; f must hold pair forces only */

@@ -100,7 +100,8 @@ void orc_init_one_all(int ntypes, const int *setflag, double *eps, double *sig, 
 void orc_rank_metric(const orc_system *s, double *rank_metric, double *rmin);
 /* a3: PS.cpp:232-321 (+ ev_tally pair.cpp:854-950 when vflag_global==1) */
 void orc_ljcoul(const orc_system *s, int eflag, int vflag_pairwise, double *f,
-                double *eng_vdwl, double *eng_coul, double *virial);
+                double *eng_vdwl, double *eng_coul, double *virial, double *eatom,
+                double *vatom); /* eatom/vatom may be NULL: ev_tally per-atom parts, pair.cpp:881-942 */
 /* a4: PS.cpp:324-361 */
 void orc_static_field(const orc_system *s, double *ef_static);
 /* a6: PS.cpp:1243-1316 ; matrix is [3N][3N] row-major */
@@ -110,7 +111,7 @@ int orc_dipole_solver(const orc_system *s, const double *matrix, const double *e
                       const double *rank_metric, double *mu, orc_result *res, double *utrace);
 /* a8: PS.cpp:406-641 */
 void orc_polar_forces(const orc_system *s, int eflag, int vflag_pairwise, const double *mu,
-                      double *f, orc_result *res);
+                      double *f, orc_result *res, double *vatom /* may be NULL; pair.cpp:1065-1082 */);
 /* a10: pair.cpp:1495-1540 */
 void orc_virial_fdotr(const orc_system *s, const double *f, double *virial);
 
@@ -120,6 +121,11 @@ void orc_virial_fdotr(const orc_system *s, const double *f, double *virial);
  * eflag: 0/1 global energy; vflag: 0 none, 1 pairwise global virial, 2 fdotr virial. */
 int orc_compute(const orc_system *s, int eflag, int vflag, double *f, double *mu,
                 double *ef_static, orc_result *res, double *utrace);
+/* Same, plus the per-atom tallies of ev_tally / ev_tally_xyz: eflag & 2 -> eatom[nall] +=,
+ * vflag & 4 -> vatom[nall][6] += (zeroed by the caller, as ev_setup does, pair.cpp:789-806). */
+int orc_compute_peratom(const orc_system *s, int eflag, int vflag, double *f, double *mu,
+                        double *ef_static, orc_result *res, double *utrace, double *eatom,
+                        double *vatom);
 
 #ifdef __cplusplus
 }

@@ -32,22 +32,28 @@ VARIANTS = {
     "vpair": (["use_previous", "no"], [], 1, 1, 1),
     "notable": (["use_previous", "no"], ["table", "0"], 1, 2, 1),
     "prec1e6": (["use_previous", "no", "precision", "1e-6"], [], 1, 2, 1),
+    # per-atom tallies: eflag 3 = global + atom; vflag 6 = fdotr + atom, 5 = pairwise + atom
+    "peratom": (["use_previous", "no"], [], 3, 6, 1),
+    "peratom_vpair": (["use_previous", "no"], [], 3, 5, 1),
 }
 PLAN = {
     "mof5_h2": list(VARIANTS),
-    "bulk_h2": ["ranked", "gs", "zodid", "notable"],
+    "bulk_h2": ["ranked", "gs", "zodid", "notable", "peratom"],
     "mof5_methane": ["ranked"],
     "sifsix_co2": ["ranked", "nodamp_fallback30"],
 }
 
 
 def main():
+    only = set(sys.argv[1:])  # optional: regenerate just these variants
     for case, variants in PLAN.items():
         z = np.load(os.path.join(GOLD, case + ".npz"))
         meta = json.loads(str(z["meta"]))
         rows = [" ".join([str(int(r[0])), str(int(r[1])), repr(float(r[2])), repr(float(r[3])), repr(float(r[4]))])
                 for r in z["pair_coeff"]]
         for var in variants:
+            if only and var not in only:
+                continue
             extra, modify, eflag, vflag, ncalls = VARIANTS[var]
             nbits = 0 if "table" in modify else 12
             s, _ = wl.load_fixture(os.path.join(GOLD, case + ".npz"), extra_args=extra, ncoultablebits=nbits)
@@ -58,7 +64,12 @@ def main():
             info = dict(case=case, variant=var, extra_args=extra, modify_args=modify, eflag=eflag, vflag=vflag,
                         ncalls=ncalls, warnings=int(ref["warnings"]), message=ref["message"],
                         ncoultablebits=nbits)
-            np.savez_compressed(os.path.join(GOLD, f"ref_{case}__{var}.npz"),
+            peratom = {}
+            if ref["eatom"] is not None:  # ghost tallies go to the owner (Comm::reverse_comm_pair role)
+                peratom["eatom"] = oracle.fold_ghost_forces(ref["eatom"], s.owner, s.nlocal)
+            if ref["vatom"] is not None:
+                peratom["vatom"] = oracle.fold_ghost_forces(ref["vatom"], s.owner, s.nlocal)
+            np.savez_compressed(os.path.join(GOLD, f"ref_{case}__{var}.npz"), **peratom,
                                 f=f_fold, mu=ref["mu"], ef_static=ref["ef_static"],
                                 energies=np.array([ref["eng_vdwl"], ref["eng_coul"], ref["eng_pol"]]),
                                 virial=ref["virial"], info=np.array(json.dumps(info)))

@@ -27,7 +27,8 @@ class SeamInput(C.Structure):
 class SeamOutput(C.Structure):
     _fields_ = [("f", dp), ("mu", dp), ("ef_static", dp),
                 ("eng_vdwl", C.c_double), ("eng_coul", C.c_double), ("eng_pol", C.c_double),
-                ("virial", C.c_double * 6), ("warnings", C.c_int), ("message", C.c_char * 256)]
+                ("virial", C.c_double * 6), ("warnings", C.c_int), ("message", C.c_char * 256),
+                ("eatom", dp), ("vatom", dp)]
 
 
 def available():
@@ -75,6 +76,10 @@ def run(sysm, style_args, coeff_rows, modify_args=(), eflag=1, vflag=2, ncalls=1
     ef = np.zeros((sysm.nlocal, 3))
     so = SeamOutput()
     so.f, so.mu, so.ef_static = f.ctypes.data_as(dp), mu.ctypes.data_as(dp), ef.ctypes.data_as(dp)
+    eatom = np.zeros(nall) if eflag // 2 else None
+    vatom = np.zeros((nall, 6)) if vflag // 4 else None
+    if eatom is not None: so.eatom = eatom.ctypes.data_as(dp)
+    if vatom is not None: so.vatom = vatom.ctypes.data_as(dp)
     rc = lib.seam_run(C.byref(si), C.byref(so))
-    return dict(rc=rc, f=f, mu=mu, ef_static=ef, eng_vdwl=so.eng_vdwl, eng_coul=so.eng_coul, eng_pol=so.eng_pol,
+    return dict(eatom=eatom, vatom=vatom, rc=rc, f=f, mu=mu, ef_static=ef, eng_vdwl=so.eng_vdwl, eng_coul=so.eng_coul, eng_pol=so.eng_pol,
                 virial=np.array(list(so.virial)), warnings=so.warnings, message=so.message.decode())

@@ -45,6 +45,40 @@ def test_hip_matches_reference_golden(path, info, wl, pkg, oracle):
     assert (out["status"] == 1) == bool(info["warnings"])
     if info["warnings"]:
         assert out["warning"] == info["message"]
+    # per-atom tallies (Pair::eatom / Pair::vatom), ghost entries folded onto their owners
+    if "eatom" in z.files:
+        ea = oracle.fold_ghost_forces(out["eatom"], s.owner, s.nlocal)
+        assert np.max(np.abs(ea - z["eatom"])) < TOL * np.max(np.abs(z["eatom"]))
+    if "vatom" in z.files:
+        va = oracle.fold_ghost_forces(out["vatom"], s.owner, s.nlocal)
+        assert np.max(np.abs(va - z["vatom"])) < TOL * np.max(np.abs(z["vatom"]))
+
+
+def test_peratom_tallies_in_cutoff_mode_and_flag_errors(wl, pkg, oracle):
+    """eflag & 2 / vflag & 4 in list mode against the oracle; the per-atom sums reproduce the
+    global tallies (sum eatom = E_vdwl + E_coul; sum vatom = pairwise virial)."""
+    s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"),
+                           extra_args=["use_previous", "no", "dd_cutoff", "12.8345"])
+    ref = oracle.compute(s, eflag=3, vflag=5)
+    p = pkg.pair_from_system(s)
+    out = p.compute(eflag=3, vflag=5)
+    assert np.max(np.abs(out["eatom"] - ref["eatom"])) < TOL * np.max(np.abs(ref["eatom"]))
+    assert np.max(np.abs(out["vatom"] - ref["vatom"])) < TOL * np.max(np.abs(ref["vatom"]))
+    assert rel(out["eatom"].sum(), out["eng_vdwl"] + out["eng_coul"], 1e-9) < 1e-9
+    assert np.max(np.abs(out["vatom"].sum(axis=0) - out["virial"])) < 1e-9 * np.max(np.abs(out["virial"]))
+    # eflag = 2 alone (atom without global) still fills eatom
+    out2 = p.compute(eflag=2, vflag=2)
+    assert np.max(np.abs(out2["eatom"] - out["eatom"])) < 1e-12 * np.max(np.abs(out["eatom"]))
+    assert out2["vatom"] is None
+    # the plain entry point refuses the flags instead of dropping them
+    n, nall = s.nlocal, s.nlocal + s.nghost
+    import ctypes as C
+    f, mu = np.zeros((nall, 3)), np.zeros((n, 3))
+    res = pkg.Result()
+    dp = C.POINTER(C.c_double)
+    rc = p.L.polar_compute(p.h, 3, 2, f.ctypes.data_as(dp), mu.ctypes.data_as(dp), None, C.byref(res))
+    assert rc == -1 and b"polar_compute_peratom" in p.L.polar_last_error(p.h)  # POLAR_ERR_INPUT
+    p.close()
 
 
 def test_iteration_count_matches_reference_knife_edge(wl, pkg):
