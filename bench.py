@@ -97,19 +97,25 @@ def main():
     n = s.nlocal
     ms_step = 1e3 * dt / args.steps
     value = n * args.steps / dt
-    # dominant kernel: k_field_rows (dipole-field sweep).  One sweep = ncolors launches.
+    # dominant kernel: k_field_quad (dipole-field sweep).  One sweep = ncolors launches.
     launches = out["sweeps"] * max(out["ncolors"], 1)
     rows = int(np.count_nonzero(s.alpha[:n]))
-    # per pair: int32 j + cached tensor scalars (s3,s5: 16 B); per row: offset 8 + x 24 + mu 24 + E 24 + alpha 8 + mu_new 24
-    bytes_sweep = 20.0 * out["dd_pairs"] + rows * 112.0
+    # ALGORITHMIC bytes of one sweep, SURVEY.md 8(d): N*(4*K + 8) + N*104 -- int32 neighbor index per
+    # pair, int64 row offset, and the per-row streams (x 24, mu 24, E 24, alpha 8, mu_new 24).  Gathers
+    # of x_j / mu_j are not counted.  K*N = dd_pairs (the directed polarizable pairs the launch walks).
+    bytes_sweep = 4.0 * out["dd_pairs"] + rows * 112.0
     bytes_launch = bytes_sweep / max(out["ncolors"], 1)
     ms_launch = (ms_solve / args.steps) / launches      # HIP events on the library's stream around the solve
     achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
+    # What the kernel actually streams by design: + the cached r^2 of every pair (8 B), a deliberate
+    # bytes-for-flops trade: 12 B/pair.
+    stream_launch = (12.0 * out["dd_pairs"] + rows * 112.0) / max(out["ncolors"], 1)
     # HBM bytes per launch from PMC counters cannot be read inside this process; the value below was
     # collected with tools/pmc_traffic.sh on this exact workload (separate --pmc passes, per launch:
-    # FETCH_SIZE 31,254 KB -> x2 on gfx950 for 16-B/lane streams, WRITE_SIZE 413 KB;
-    # profiles/r01_v10_kfield_traffic_pmc.txt) and is reported only for that workload.
-    traffic = 64.4e6 if (tuple(args.reps) == (3, 3, 3) and not args.extra) else None
+    # FETCH_SIZE 26,658 KB -> x2 on gfx950 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE 496 KB;
+    # profiles/r01_v17_kfield_quad_traffic_pmc.txt) and is reported only for that workload.  It exceeds
+    # the streamed bytes by ~8 x 2.3 MB: every launch re-reads the 64-byte atom records into each XCD's L2.
+    traffic = 53.8e6 if (tuple(args.reps) == (3, 3, 3) and not args.extra) else None
     line = {
         "metric": "atom-steps/sec", "value": value, "unit": "atom-steps/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
@@ -122,8 +128,10 @@ def main():
                    "ms_static": out["ms_static"], "ms_list": out["ms_list"], "ms_rank": out["ms_rank"],
                    "rms_dmu_last_sweep": out["rms_dmu"], "eng_pol": out["eng_pol"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_field_rows (dipole-field sweep, one launch per colour phase)",
-                     "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_field_quad (dipole-field sweep, one launch per colour phase)",
+                     "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch,
+                     "streamed_bytes_per_launch": stream_launch,
+                     "streamed_frac": stream_launch / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"], _ = cpu_baseline(wl)

@@ -79,7 +79,7 @@ struct polar_handle {
   DBuf<double> d_x, d_q, d_alpha, d_f, d_ef, d_F, d_mu, d_rank, d_dmu, d_tab, d_lj;
   DBuf<int> d_type, d_mol, d_order, d_pos, d_ilist, d_numneigh, d_neigh, d_rows;
   DBuf<int> d_mol_s, d_perm, d_inv, d_rows_orig, d_ownrows;  // s-space bookkeeping (see polar_kernels.hpp)
-  DBuf<double> d_ef_s, d_T6, d_eatom, d_vatom;
+  DBuf<double> d_ef_s, d_T6, d_eatom, d_vatom, d_dd_r2;
   bool dense_gs = false;   // exact-order GS on the HBM-resident tensor (atoms in sweep order)
   CellGrid grid{};
   long long ncell = 0;
@@ -110,6 +110,8 @@ struct polar_handle {
   bool colors_valid = false;
   double color_dist = 2.6;
   int field_block = 256;
+  int cache_r2 = 1;       // 1: the sweep streams r^2 (12 B/pair) and rebuilds (s3,s5); 0: streams cached (s3,s5) (POLAR_CACHE_R2)
+  int sweep_kernel = 0;   // 0: k_field_quad (component-per-lane); 1: lane-per-pair kernels (POLAR_SWEEP_KERNEL)
   int rows_per_wave = 0;  // 0: automatic; >0: forced; <0: use the one-row-per-wave kernel (POLAR_ROWS_PER_WAVE)
   int ablate = 0;  // lab switches for k_field (POLAR_ABLATE), 0 in production
   Scal *h_scal = nullptr;  // pinned
@@ -226,7 +228,7 @@ void build_lists(polar_handle *h) {
   const double cutall = std::max(st.cut_coul, st.dd_cutoff);
   hipStream_t s = h->stream;
   const CellGrid &g = h->grid;
-  if (h->nl_pitch == 0 && getenv("POLAR_INIT_PITCH")) h->nl_pitch = h->dd_pitch = std::max(64, atoi(getenv("POLAR_INIT_PITCH")));  // tests: force the overflow path
+  if (h->nl_pitch == 0 && getenv("POLAR_INIT_PITCH")) h->nl_pitch = h->dd_pitch = ((std::max(64, atoi(getenv("POLAR_INIT_PITCH"))) + 63) / 64) * 64;  // tests: force the overflow path
   if (h->nl_pitch == 0) {  // first build: 1.5x the mean sphere population, rounded to 64
     double vol = h->box.prd[0] * h->box.prd[1] * h->box.prd[2];
     double mean = n / vol * 4.18879020478639 * cutall * cutall * cutall;
@@ -234,7 +236,10 @@ void build_lists(polar_handle *h) {
   }
   h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1);
   h->d_nl_j.ensure((size_t)n * h->nl_pitch + 64); h->d_dd_j.ensure((size_t)n * h->dd_pitch + 64);
-  h->d_dd_s.ensure((size_t)n * h->dd_pitch + 64);
+  const bool r2c = h->cache_r2 && h->sweep_kernel == 0;
+  if (r2c) h->d_dd_r2.ensure((size_t)n * h->dd_pitch + 64);
+  else h->d_dd_s.ensure((size_t)n * h->dd_pitch + 64);
+  double *r2p = r2c ? h->d_dd_r2.p : nullptr;
   const double cutallsq = cutall * cutall, ddsq = st.dd_cutoff * st.dd_cutoff;
   const int nr = own_n(h);
   const int *rows = own_rows(h);
@@ -247,9 +252,9 @@ void build_lists(polar_handle *h) {
       h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, h->d_overflow.p, h->d_ddtot.p);
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
   if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
-    k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
+    k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p, r2p);
   else
-    k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p);
+    k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p, r2p);
   // overflow flag and dd total come back with the end-of-step read (no sync here)
   HIPCHECK(hipMemcpyAsync(h->h_flags, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -440,11 +445,32 @@ void launch_field_rows(polar_handle *h, int nrows, const int *rows) {
       h->d_ef_s.p, h->d_scal.p, h->d_slots.p);
 }
 
+// list-mode production sweep: component-per-lane quads (k_field_quad), one wave per row
+template <int EP>
+void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
+  if (nrows <= 0) return;
+  const polar_settings &st = h->ph.st;
+#define FQ(M) k_field_quad<EP, M><<<nblk(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(                 \
+      nrows, rows, h->d_rec0.p, h->d_rec1.p, h->box, RowList{h->d_dd_cnt.p, h->dd_pitch}, h->d_dd_j.p, h->d_dd_s.p, \
+      h->d_dd_r2.p, st.polar_damp, h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
+  if (!h->cache_r2) FQ(0);
+  else if (st.damping_type == POLAR_DAMP_EXPONENTIAL) FQ(1);
+  else FQ(2);
+#undef FQ
+}
+
 // one sweep over the rows this handle owns (Jacobi, or the colour phases)
 void sweep_once(polar_handle *h, bool ap) {
   const polar_settings &st = h->ph.st;
   const bool gs = st.polar_gs || st.polar_gs_ranked;
   const bool stream_rows = !ap && !h->ablate && h->rows_per_wave >= 0;  // lab switches fall back to k_field
+  if (!ap && h->sweep_kernel == 0) {
+    if (!gs) { launch_field_quad<EP_JACOBI>(h, own_n(h), own_rows(h)); return; }
+    const int ncol = (int)h->color_off.size() - 1;
+    for (int c = 0; c < ncol; c++)
+      launch_field_quad<EP_INPLACE>(h, h->color_off[c + 1] - h->color_off[c], h->d_rows.p + h->color_off[c]);
+    return;
+  }
   if (!gs) {
     if (stream_rows && h->rows_per_wave > 0) launch_field_rows<EP_JACOBI>(h, own_n(h), own_rows(h));
     else launch_field_dyn<EP_JACOBI>(h, ap, own_n(h), own_rows(h));
@@ -778,7 +804,9 @@ int polar_create(int device, polar_handle **out) {
   h->device = device;
   if (const char *e = getenv("POLAR_COLOR_DIST")) h->color_dist = atof(e);
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
-  if (const char *e = getenv("POLAR_ROWS_PER_WAVE")) h->rows_per_wave = atoi(e);
+  if (const char *e = getenv("POLAR_ROWS_PER_WAVE")) { h->rows_per_wave = atoi(e); h->sweep_kernel = 1; }
+  if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
+  if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);  // 0 quad (default), 1 lane-per-pair kernels
   if (const char *e = getenv("POLAR_FIELD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->field_block = v; }
   int n = polar_device_count();
   if (n <= 0 || device < 0 || device >= n) {

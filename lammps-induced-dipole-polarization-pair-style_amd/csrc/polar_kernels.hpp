@@ -75,16 +75,24 @@ __device__ __forceinline__ double dpp_get(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// full-mask permutations (every lane has a source): bound_ctrl lets the compiler skip the
+// zero-initialisation of the destination that dpp_get needs for its masked rows
+template <int CTRL>
+__device__ __forceinline__ double dpp_full(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double lane63(double v) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_get<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v += dpp_get<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v += dpp_get<0x141, 0xF>(v);  // row_half_mirror
-  v += dpp_get<0x140, 0xF>(v);  // row_mirror: all 16 lanes of a row hold the row total
+  v += dpp_full<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_full<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_full<0x141>(v);  // row_half_mirror
+  v += dpp_full<0x140>(v);  // row_mirror: all 16 lanes of a row hold the row total
   v += dpp_get<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
   v += dpp_get<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
   return lane63(v);
@@ -856,14 +864,111 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field_rows(int nrows, const int
   if (lane == 0 && chg != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), chg);
 }
 
+// ------------------------------------------------------------------------------------------
+// List-mode sweep, component-per-lane form (production).
+// k_field / k_field_rows give every LANE one pair, so the 64-byte records fetched quad-wise have to
+// be transposed through LDS and the indices shuffled to the quads: ~180 of the ~200 VALU slots of a
+// 64-pair trip were bookkeeping, and the kernel was VALU-issue bound on it.  Here the quad that
+// fetches a record also does its arithmetic: lane k of a quad owns COMPONENT k of the pair
+//     d_k = x_ik - x_jk (wrapped),  dot = sum_k mu_jk d_k (quad DPP),  E_k -= s3 mu_jk - s5 dot d_k
+// so nothing is transposed, no LDS is used, and the three field components are three lanes of one
+// accumulator.  A gather instruction covers 16 pairs (one 64-byte access per quad for the record
+// pieces {x_k, mu_k}).  Lane 3 of each quad rides along on component z (its results are unused).
+// Rows are padded to whole 64-pair trips by k_dd_scalars (j = i, s = 0), so a trip needs no masks.
+// SMODE 0: stream the cached (s3,s5) (20 B/pair); 1 / 2: stream the cached r^2 (12 B/pair) and
+// rebuild (s3,s5) with exponential / no damping -- lane L for ITS pair, before the quad hand-round.
+template <int EP, int SMODE>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_field_quad(int nrows, const int *__restrict__ rows,
+                                                            AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
+                                                            Box box, RowList ddl, const int *__restrict__ dd_j,
+                                                            const double2 *__restrict__ dd_s,
+                                                            const double *__restrict__ dd_r2, double pd,
+                                                            const double *__restrict__ ef, const Scal *scal,
+                                                            double *__restrict__ slots, int ablate) {
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + wv;
+  if (row >= nrows) return;
+  const int i = __builtin_amdgcn_readfirstlane(rows ? rows[row] : row);
+  const int cur = scal->cur;
+  const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+  const int k = lane & 3, kk = k < 3 ? k : 2;
+  const double *ri = reinterpret_cast<const double *>(src + i);
+  const double xi = ri[2 * kk], mi = ri[2 * kk + 1], ai = ri[7];
+  long long c = ddl.cnt[i];
+  if (c > ddl.pitch) c = ddl.pitch;
+  if (ai == 0.0) c = 0;
+  int T = __builtin_amdgcn_readfirstlane((int)((c + 63) >> 6));
+  if (ablate & 1) T = 0;             // lab switches (POLAR_ABLATE): timing only, wrong numbers
+  if ((ablate & 8) && T > 1) T = 1;
+  const double prd = box.periodic[kk] ? box.prd[kk] : 0.0, inv = box.inv[kk];
+  const char *srcb = reinterpret_cast<const char *>(src) + kk * 16;
+  // stream: lane L reads pair L of the trip (ONE coalesced instruction each for j and (s3,s5): the
+  // vector-memory address unit spends ~16 cycles per wave instruction however little it fetches, and
+  // it is the unit this kernel saturates).  Pair 4q+r of a trip belongs to quad q, step r, so the
+  // quad already holds its four pairs' stream values and hands them round with quad_perm DPP moves.
+  const int *pj = dd_j + (size_t)i * ddl.pitch + lane;
+  const double2 *ps = dd_s + (size_t)i * ddl.pitch + lane;
+  const double *pr = dd_r2 + (size_t)i * ddl.pitch + lane;
+  double acc = 0.0;
+  // One trip per iteration; only the NEXT trip's indices are prefetched.  A deeper software pipeline
+  // (gathers one trip ahead) was measured and bought nothing: with <= 64 VGPRs eight waves per SIMD
+  // hide the latencies, and the kernel sits on the stream bandwidth and the VALU rate instead.
+  int jn = pj[0];  // the pitch keeps this in bounds even for an empty row
+  for (int t = 0; t < T; t++) {
+    const int jv = (ablate & 2) ? i : jn;
+    double2 P[4];
+#define POLAR_QGATHER(R)                                                                        \
+  {                                                                                            \
+    const unsigned j_ = (unsigned)__builtin_amdgcn_update_dpp(0, jv, (R) * 0x55, 0xF, 0xF, true); \
+    P[R] = *reinterpret_cast<const double2 *>(srcb + ((size_t)j_ << 6));                        \
+  }
+    POLAR_QGATHER(0) POLAR_QGATHER(1) POLAR_QGATHER(2) POLAR_QGATHER(3)
+#undef POLAR_QGATHER
+    double2 Sv = make_double2(0.0, 0.0);
+    double r2v = 0.0;
+    if (SMODE == 0) Sv = (ablate & 4) ? make_double2(1e-3, 1e-4) : ps[64 * t];
+    else r2v = (ablate & 4) ? 30.0 : pr[64 * t];
+    if (t + 1 < T) jn = pj[64 * (t + 1)];  // wave-uniform: the next trip's indices travel during the math
+    if (SMODE != 0) tensor_scalars<SMODE == 1 ? 0 : 1>(r2v, pd, Sv.x, Sv.y);  // lane L: pair L of the trip
+#define POLAR_QSTEP(R)                                                                          \
+  {                                                                                            \
+    const double s3_ = dpp_full<(R) * 0x55>(Sv.x), s5_ = dpp_full<(R) * 0x55>(Sv.y);             \
+    double d = xi - P[R].x;                                                                     \
+    d = fma(-prd, rint(d * inv), d);                                                            \
+    const double m = P[R].y * d;                                                                \
+    /* dot over the quad's three component lanes (lane 3 gets a don't-care) */                  \
+    const double dot = m + dpp_full<0xC9>(m) + dpp_full<0xD2>(m); /* quad_perm [1,2,0,3], [2,0,1,3] */ \
+    const double cc = s5_ * dot;                                                                \
+    acc = fma(-s3_, P[R].y, acc);                                                               \
+    acc = fma(cc, d, acc);                                                                      \
+  }
+    POLAR_QSTEP(0) POLAR_QSTEP(1) POLAR_QSTEP(2) POLAR_QSTEP(3)
+#undef POLAR_QSTEP
+  }
+  // sum the 16 quads: rotate-adds inside the 16-lane rows, then across the four rows
+  acc += dpp_full<0x124>(acc);  // row_ror:4
+  acc += dpp_full<0x128>(acc);  // row_ror:8
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  const double mu_new = ai * (ef[3 * i + kk] + acc);
+  const double dm = mu_new - mi;
+  double chg = (k < 3) ? dm * dm : 0.0;
+  chg = chg + dpp_full<0xC9>(chg) + dpp_full<0xD2>(chg);
+  if (lane < 3) reinterpret_cast<double *>(dst + i)[2 * lane + 1] = mu_new;
+  if (lane == 0 && chg != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), chg);
+}
+
 // a6 for the list path: the damped tensor scalars of every listed pair, once per step
 // (the sparse, matrix-free-storage analog of build_dipole_field_matrix, PS.cpp:1273-1306).
 template <int DAMP>
 __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restrict__ rows, int nrows, const AtomRec *__restrict__ rec,
                                                             Box box,
                                                             RowList ddl,
-                                                            const int *__restrict__ dd_j, double pd,
-                                                            double2 *__restrict__ dd_s) {
+                                                            int *__restrict__ dd_j, double pd,
+                                                            double2 *__restrict__ dd_s, double *__restrict__ dd_r2) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -876,8 +981,20 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restric
     double dx, dy, dz;
     min_image_rint(box, xi, yi, zi, rec[j].x, rec[j].y, rec[j].z, dx, dy, dz);
     double s3, s5;
-    tensor_scalars<DAMP>(dx * dx + dy * dy + dz * dz, pd, s3, s5);
-    dd_s[p] = make_double2(s3, s5);
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    if (dd_r2) dd_r2[p] = r2;
+    else {
+      tensor_scalars<DAMP>(r2, pd, s3, s5);
+      dd_s[p] = make_double2(s3, s5);
+    }
+  }
+  // pad the row to whole 64-pair trips with inert entries (the atom itself, zero tensor): the
+  // component-per-lane sweep then runs without lane masks.  The pitch is a multiple of 64.
+  const long long pad_end = beg + (((end - beg) + 63) & ~63ll);
+  for (long long p = end + lane; p < pad_end; p += 64) {
+    dd_j[p] = i;
+    if (dd_r2) dd_r2[p] = 1e60;  // s3 ~ 1e-90, and d = 0 kills the s5 term: contributes nothing
+    else dd_s[p] = make_double2(0.0, 0.0);
   }
 }
 
