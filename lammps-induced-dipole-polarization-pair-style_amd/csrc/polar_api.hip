@@ -116,6 +116,12 @@ struct polar_handle {
   int ablate = 0;  // lab switches for k_field (POLAR_ABLATE), 0 in production
   Scal *h_scal = nullptr;  // pinned
   hipEvent_t ev[8] = {};
+  // a3 runs on its own stream beside the list build / static field / dipole solve (it only shares the
+  // force and tally accumulators with them): fork after the accumulators are zeroed, join before they are read
+  hipStream_t lj_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_lj0 = nullptr, ev_lj1 = nullptr;
+  bool overlap_lj = true;  // POLAR_NO_OVERLAP=1 keeps a3 on the main stream
+  bool lj_forked = false;
   std::vector<double> h_tmp;
 };
 
@@ -626,6 +632,54 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   if ((eatom || vatom) && own_n(h) != n) throw InputError("per-atom tallies are not available on a row-sharded handle");
   k_zero_scal<<<1, 1, 0, s>>>(h->d_scal.p, 0);
   k_zero_slots<<<nblk(POLAR_NSLOT, 256), 256, 0, s>>>(h->d_slots.p);
+  {  // a3 -- on a low-priority side stream when overlap is on: it depends on nothing below, and fills
+    // whatever the list build, the static field and the latency-bound solver launches leave idle
+    hipStream_t ms = s;
+    h->lj_forked = h->overlap_lj && h->inum > 0;
+    if (h->lj_forked) {
+      HIPCHECK(hipEventRecord(h->ev_fork, ms));
+      HIPCHECK(hipStreamWaitEvent(h->lj_stream, h->ev_fork, 0));
+    }
+    hipStream_t s = h->lj_forked ? h->lj_stream : ms;  // shadows the main stream inside this block
+    HIPCHECK(hipEventRecord(h->ev_lj0, s));
+    LJCoulParams P = h->P;
+    P.newton_pair = 1; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list; P.ablate = h->ablate;
+    h->d_xq.ensure(nall + 1);
+    k_pack_lj<<<nblk(nall, 256), 256, 0, s>>>(nall, h->d_x.p, h->d_q.p, h->d_xq.p);
+    const size_t ljlds = (size_t)(h->ntypes + 1) * (h->ntypes + 1) * 8 * sizeof(double);
+    if (ljlds > 64 * 1024) throw InputError("too many atom types for the LDS-resident LJ table (max 31)");
+    dim3 block(POLAR_BLOCK);
+    const bool symmetrise = !h->full_list && !getenv("POLAR_LJ_ATOMICS");
+    if ((eatom || vatom) && !symmetrise && !h->full_list) throw InputError("per-atom tallies need the row-complete pair list (unset POLAR_LJ_ATOMICS)");
+    if (symmetrise && !h->sym_valid && h->inum > 0) {  // once per uploaded list (reneighbor steps)
+      dim3 g0(nblk(h->inum, POLAR_ROWS_PER_BLOCK));
+      h->d_sym_cnt.ensure(nall + 1); h->d_sym_fill.ensure(nall + 1); h->d_sym_first.ensure(nall + 2);
+      h->d_sym_j.ensure(2 * (size_t)h->nneigh + 64);
+      HIPCHECK(hipMemsetAsync(h->d_sym_cnt.p, 0, (nall + 1) * sizeof(int), s));
+      HIPCHECK(hipMemsetAsync(h->d_sym_fill.p, 0, (nall + 1) * sizeof(int), s));
+      k_sym_count<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_cnt.p);
+      k_exclusive_scan<int><<<1, 1024, 0, s>>>(nall, h->d_sym_cnt.p, h->d_sym_first.p);
+      k_sym_fill<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_first.p,
+                                      h->d_sym_fill.p, h->d_sym_j.p);
+      h->sym_valid = true;
+    }
+    const int nrows_lj = symmetrise ? nall : h->inum;
+    dim3 grid(nblk(nrows_lj, POLAR_ROWS_PER_BLOCK));
+    if (symmetrise) P.full_list = 1;  // rows of the symmetrised list: force on the row atom only, tallies halved
+    const int *il = symmetrise ? nullptr : h->d_ilist.p;
+    const int *nn = symmetrise ? nullptr : h->d_numneigh.p;
+    const long long *fi = symmetrise ? h->d_sym_first.p : h->d_first.p;
+    const int *nj = symmetrise ? h->d_sym_j.p : h->d_neigh.p;
+    if (h->inum > 0) {
+#define LJ(E, V) k_ljcoul<E, V><<<grid, block, ljlds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1)
+      const bool vrow = vmode == 1 || vatom;
+      if (eflag) { if (vrow) LJ(true, true); else LJ(true, false); }
+      else       { if (vrow) LJ(false, true); else LJ(false, false); }
+#undef LJ
+    }
+    HIPCHECK(hipEventRecord(h->ev_lj1, s));
+    if (h->lj_forked) HIPCHECK(hipEventRecord(h->ev_join, s));
+  }
   const double *mu0 = nullptr;
   if (st.use_previous) {
     if (mu_host) {
@@ -674,43 +728,6 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   }
   HIPCHECK(hipEventRecord(h->ev[2], s));
 
-  {  // a3
-    LJCoulParams P = h->P;
-    P.newton_pair = 1; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list; P.ablate = h->ablate;
-    h->d_xq.ensure(nall + 1);
-    k_pack_lj<<<nblk(nall, 256), 256, 0, s>>>(nall, h->d_x.p, h->d_q.p, h->d_xq.p);
-    const size_t ljlds = (size_t)(h->ntypes + 1) * (h->ntypes + 1) * 8 * sizeof(double);
-    if (ljlds > 64 * 1024) throw InputError("too many atom types for the LDS-resident LJ table (max 31)");
-    dim3 block(POLAR_BLOCK);
-    const bool symmetrise = !h->full_list && !getenv("POLAR_LJ_ATOMICS");
-    if ((eatom || vatom) && !symmetrise && !h->full_list) throw InputError("per-atom tallies need the row-complete pair list (unset POLAR_LJ_ATOMICS)");
-    if (symmetrise && !h->sym_valid && h->inum > 0) {  // once per uploaded list (reneighbor steps)
-      dim3 g0(nblk(h->inum, POLAR_ROWS_PER_BLOCK));
-      h->d_sym_cnt.ensure(nall + 1); h->d_sym_fill.ensure(nall + 1); h->d_sym_first.ensure(nall + 2);
-      h->d_sym_j.ensure(2 * (size_t)h->nneigh + 64);
-      HIPCHECK(hipMemsetAsync(h->d_sym_cnt.p, 0, (nall + 1) * sizeof(int), s));
-      HIPCHECK(hipMemsetAsync(h->d_sym_fill.p, 0, (nall + 1) * sizeof(int), s));
-      k_sym_count<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_cnt.p);
-      k_exclusive_scan<int><<<1, 1024, 0, s>>>(nall, h->d_sym_cnt.p, h->d_sym_first.p);
-      k_sym_fill<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_first.p,
-                                      h->d_sym_fill.p, h->d_sym_j.p);
-      h->sym_valid = true;
-    }
-    const int nrows_lj = symmetrise ? nall : h->inum;
-    dim3 grid(nblk(nrows_lj, POLAR_ROWS_PER_BLOCK));
-    if (symmetrise) P.full_list = 1;  // rows of the symmetrised list: force on the row atom only, tallies halved
-    const int *il = symmetrise ? nullptr : h->d_ilist.p;
-    const int *nn = symmetrise ? nullptr : h->d_numneigh.p;
-    const long long *fi = symmetrise ? h->d_sym_first.p : h->d_first.p;
-    const int *nj = symmetrise ? h->d_sym_j.p : h->d_neigh.p;
-    if (h->inum > 0) {
-#define LJ(E, V) k_ljcoul<E, V><<<grid, block, ljlds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1)
-      const bool vrow = vmode == 1 || vatom;
-      if (eflag) { if (vrow) LJ(true, true); else LJ(true, false); }
-      else       { if (vrow) LJ(false, true); else LJ(false, false); }
-#undef LJ
-    }
-  }
   HIPCHECK(hipEventRecord(h->ev[3], s));
 
   {  // a4 + a5
@@ -733,8 +750,13 @@ int phase_finish(polar_handle *h, polar_result *out) {
   k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p);
   HIPCHECK(hipEventRecord(h->ev[5], s));
   double *vatom = (h->step_vflag / 4) ? h->d_vatom.p : nullptr;
+  // join a3: before the force kernel when both write the (non-atomic) per-atom virial rows,
+  // otherwise only before the accumulators are read
+  auto join_lj = [&]() { if (h->lj_forked) { HIPCHECK(hipStreamWaitEvent(s, h->ev_join, 0)); h->lj_forked = false; } };
+  if (vatom) join_lj();
   if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1, vatom); else launch_force<true, 1>(h, eflag, vmode == 1, vatom); }
   else    { if (expd) launch_force<false, 0>(h, eflag, vmode == 1, vatom); else launch_force<false, 1>(h, eflag, vmode == 1, vatom); }
+  join_lj();
   if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_slots.p);  // a10
   k_unpack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p, h->d_mu.p, h->d_ef.p);
   k_fold_scal<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, 0);
@@ -759,7 +781,9 @@ int phase_finish(polar_handle *h, polar_result *out) {
   out->dd_pairs = ap ? (long long)n * (n - 1) : h->dd_pairs;
   float ms;
   auto el = [&](int a, int b) { HIPCHECK(hipEventElapsedTime(&ms, h->ev[a], h->ev[b])); return (double)ms; };
-  out->ms_list = el(0, 1); out->ms_rank = el(1, 2); out->ms_ljcoul = el(2, 3); out->ms_static = el(3, 4);
+  out->ms_list = el(0, 1); out->ms_rank = el(1, 2); out->ms_static = el(3, 4);
+  HIPCHECK(hipEventElapsedTime(&ms, h->ev_lj0, h->ev_lj1));
+  out->ms_ljcoul = ms;  // on its own stream: overlaps the other phases, so the parts no longer add up to ms_total
   out->ms_solve = el(4, 5); out->ms_force = el(5, 6); out->ms_total = el(0, 6);
   if (sc.status) h->warn = "Number of iterations exceeding max_iterations, setting dipoles to alpha*E";  // PS.cpp:1233
   return out->status;
@@ -818,6 +842,14 @@ int polar_create(int device, polar_handle **out) {
     HIPCHECK(hipSetDevice(device));
     HIPCHECK(hipStreamCreate(&h->stream));
     for (auto &e : h->ev) HIPCHECK(hipEventCreate(&e));
+    {
+      int prio_lo = 0, prio_hi = 0;  // numerically greatest = lowest priority
+      HIPCHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      HIPCHECK(hipStreamCreateWithPriority(&h->lj_stream, hipStreamNonBlocking, prio_lo));
+    }
+    HIPCHECK(hipEventCreate(&h->ev_fork)); HIPCHECK(hipEventCreate(&h->ev_join));
+    HIPCHECK(hipEventCreate(&h->ev_lj0)); HIPCHECK(hipEventCreate(&h->ev_lj1));
+    if (getenv("POLAR_NO_OVERLAP")) h->overlap_lj = false;
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
     HIPCHECK(hipHostMalloc((void **)&h->h_flags, 16 * sizeof(int)));
     HIPCHECK(hipHostMalloc((void **)&h->h_ddtot, 64 * 16 * sizeof(unsigned long long)));
@@ -834,6 +866,9 @@ int polar_destroy(polar_handle *h) {
   if (h->have_device) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->lj_stream) { (void)hipStreamSynchronize(h->lj_stream); (void)hipStreamDestroy(h->lj_stream); }
+    for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1}) if (e) (void)hipEventDestroy(e);
+    h->d_eatom.release(); h->d_vatom.release(); h->d_dd_r2.release();
     h->d_x.release(); h->d_q.release(); h->d_alpha.release(); h->d_f.release(); h->d_ef.release(); h->d_F.release();
     h->d_mu.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
     h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();
