@@ -52,6 +52,8 @@ struct DBuf {
 
 // at least one workgroup: every kernel bounds-checks its index, and a zero-sized grid is a launch error
 inline int nblk(long long n, int per) { return n <= 0 ? 1 : (int)((n + per - 1) / per); }
+// grid of a kernel that places its workgroups with xcd_block(): 8 * ceil(nblocks / 8)
+inline int nblk_xcd(long long n, int per) { return ((nblk(n, per) + 7) / 8) * 8; }
 
 }  // namespace
 
@@ -456,7 +458,7 @@ template <int EP>
 void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
   if (nrows <= 0) return;
   const polar_settings &st = h->ph.st;
-#define FQ(M) k_field_quad<EP, M><<<nblk(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(                 \
+#define FQ(M) k_field_quad<EP, M><<<nblk_xcd(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(                 \
       nrows, rows, h->d_rec0.p, h->d_rec1.p, h->box, RowList{h->d_dd_cnt.p, h->dd_pitch}, h->d_dd_j.p, h->d_dd_s.p, \
       h->d_dd_r2.p, st.polar_damp, h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
   if (!h->cache_r2) FQ(0);

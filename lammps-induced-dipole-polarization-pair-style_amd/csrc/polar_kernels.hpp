@@ -75,6 +75,17 @@ __device__ __forceinline__ double dpp_get(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// XCD-aware row placement.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with
+// its own 4 MB L2.  Rows are in cell order (spatially sorted), so giving XCD x the x-th contiguous
+// eighth of the launch's workgroups keeps each L2's gather working set to one slab of the box plus
+// its cutoff halo instead of the whole record table (8.6 MB at 135k atoms).  The grid is
+// 8 * ceil(nblocks / 8) workgroups; returns -1 for the padding workgroups.
+__device__ __forceinline__ int xcd_block(int b, int nblocks) {
+  const int chunk = (nblocks + 7) >> 3;
+  const int lb = (b & 7) * chunk + (b >> 3);
+  return lb < nblocks ? lb : -1;
+}
+
 // full-mask permutations (every lane has a source): bound_ctrl lets the compiler skip the
 // zero-initialisation of the destination that dpp_get needs for its masked rows
 template <int CTRL>
@@ -888,7 +899,9 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field_quad(int nrows, const int
   if (scal->done) return;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + wv;
+  const int lb = xcd_block(blockIdx.x, (nrows + POLAR_ROWS_PER_BLOCK - 1) / POLAR_ROWS_PER_BLOCK);
+  if (lb < 0) return;
+  const int row = lb * POLAR_ROWS_PER_BLOCK + wv;
   if (row >= nrows) return;
   const int i = __builtin_amdgcn_readfirstlane(rows ? rows[row] : row);
   const int cur = scal->cur;
