@@ -25,7 +25,7 @@ extern "C" {
 #define POLAR_ERR_INPUT -1         /* reference error->all() conditions; message = reference text */
 #define POLAR_ERR_NO_DEVICE -2
 #define POLAR_ERR_HIP -3
-#define POLAR_ERR_UNSUPPORTED -4   /* feature on the SURVEY 8(f) "next" list (triclinic, per-atom tallies) */
+#define POLAR_ERR_UNSUPPORTED -4   /* not offered in this mode (e.g. per-atom tallies through the stepwise/sharded entry points) */
 #define POLAR_ERR_STATE -5         /* call order (e.g. compute before set_atoms) */
 
 enum { POLAR_DAMP_EXPONENTIAL = 0, POLAR_DAMP_NONE = 1 }; /* PS.cpp:51 */
