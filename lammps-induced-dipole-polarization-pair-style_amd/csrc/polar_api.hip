@@ -549,9 +549,14 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
 
   if (!gs || !ap) {  // Jacobi (reference "polar_gs no") or colour-phase Gauss-Seidel over the dd list
     if (gs) { if (!h->colors_valid) { ensure_colors(h); map_color_rows(h); } out->ncolors = (int)h->color_off.size() - 1; }
+    // fixed-iteration GS takes no decision between sweeps: its end-of-sweep logic is applied in two
+    // launches (all sweeps but the last, then the last one, whose sum |dmu|^2 is the one reported)
+    const bool lazy = st.fixed_iteration && gs;
     for (int sw = 0; sw < max_sweeps; sw++) {
       sweep_once(h, ap);
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr);
+      if (lazy && sw < max_sweeps - 2) continue;
+      const int count = (lazy && sw == max_sweeps - 2) ? max_sweeps - 1 : 1;
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
@@ -567,7 +572,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
         k_gs_seq_T6<<<1, 64, 0, s>>>(n, b0, h->d_T6.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
         k_gs_push_T6<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_T6.p, h->d_rec0.p, h->d_dmu.p, h->d_F.p, h->d_scal.p);
       }
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
@@ -598,7 +603,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
           k_gs_block_push<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_order.p, h->d_pos.p, h->d_rec0.p, h->box, st.polar_damp, h->d_dmu.p, h->d_F.p, h->d_scal.p);
         }
       }
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
@@ -1206,7 +1211,7 @@ int polar_step_sweep_end(polar_handle *h, const double *dev_global_change) {
     const polar_settings &st = h->ph.st;
     const bool gs = st.polar_gs || st.polar_gs_ranked;
     k_solver_step<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, h->nlocal, st.fixed_iteration, st.iterations_max, st.polar_precision,
-                                          gs ? 0 : 1, dev_global_change);
+                                          gs ? 0 : 1, dev_global_change, 1);
     return POLAR_OK;
   });
 }

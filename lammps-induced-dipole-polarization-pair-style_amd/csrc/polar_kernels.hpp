@@ -1245,7 +1245,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_gs_push_T6(int n, int b0, const
 // device so the host never has to look at ||dmu||^2 between sweeps.
 __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double *__restrict__ slots, int nlocal,
                                                            int fixed_iteration, int iterations_max, double precision,
-                                                           int jacobi, const double *__restrict__ global_change) {
+                                                           int jacobi, const double *__restrict__ global_change,
+                                                           int count) {
   if (scal->done) return;
   __shared__ double red[POLAR_NSLOT / 64];
   double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
@@ -1260,14 +1261,18 @@ __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double 
   // multi-GPU: the all-reduced sum over ranks arrives through global_change (device memory)
   const double change = (global_change ? *global_change : sum) / ((double)nlocal * 3.0);
   scal->last_change = change;
-  scal->sweeps += 1;
-  int keep = 1;
-  if (!fixed_iteration) keep = change > precision * precision;
-  else if (scal->iterations >= iterations_max) { scal->done = 1; return; }  // returns BEFORE the copy
-  if (jacobi) scal->cur ^= 1;  // "mu = mu_new"
-  scal->iterations += 1;
-  if (scal->iterations > iterations_max) { scal->status = 1; scal->done = 1; return; }
-  if (!keep) scal->done = 1;
+  // `count` > 1: the end-of-sweep logic of several sweeps at once (fixed-iteration Gauss-Seidel takes
+  // no decision between sweeps, so the host launches this only before and after the last one)
+  for (int c = 0; c < count; c++) {
+    scal->sweeps += 1;
+    int keep = 1;
+    if (!fixed_iteration) keep = change > precision * precision;
+    else if (scal->iterations >= iterations_max) { scal->done = 1; return; }  // returns BEFORE the copy
+    if (jacobi) scal->cur ^= 1;  // "mu = mu_new"
+    scal->iterations += 1;
+    if (scal->iterations > iterations_max) { scal->status = 1; scal->done = 1; return; }
+    if (!keep) { scal->done = 1; return; }
+  }
 }
 
 // fold the change slots into scal->change without touching the loop state (multi-GPU export)
