@@ -81,7 +81,7 @@ struct polar_handle {
   DBuf<double> d_x, d_q, d_alpha, d_f, d_ef, d_F, d_mu, d_rank, d_dmu, d_tab, d_lj;
   DBuf<int> d_type, d_mol, d_order, d_pos, d_ilist, d_numneigh, d_neigh, d_rows;
   DBuf<int> d_mol_s, d_perm, d_inv, d_rows_orig, d_ownrows;  // s-space bookkeeping (see polar_kernels.hpp)
-  DBuf<double> d_ef_s, d_T6, d_eatom, d_vatom, d_dd_r2;
+  DBuf<double> d_ef_s, d_T6, d_eatom, d_vatom, d_dd_r2, d_fpol;
   bool dense_gs = false;   // exact-order GS on the HBM-resident tensor (atoms in sweep order)
   CellGrid grid{};
   long long ncell = 0;
@@ -494,7 +494,7 @@ void sweep_once(polar_handle *h, bool ap) {
 }
 
 template <bool AP, int DAMP>
-void launch_force(polar_handle *h, int eflag, int vglobal, double *vatom) {
+void launch_force(polar_handle *h, int eflag, int vglobal, double *vatom, double *fdst) {
   const bool vpair = vglobal || vatom;
   const polar_settings &st = h->ph.st;
   dim3 grid(nblk(own_n(h), POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
@@ -502,7 +502,7 @@ void launch_force(polar_handle *h, int eflag, int vglobal, double *vatom) {
 #define LF(E, V)                                                                                                    \
   k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(own_rows(h), own_n(h), h->sorted ? h->d_perm.p : nullptr, h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
                                                                h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p,  \
-                                                               ccs, dds, st.polar_damp, e2s, h->d_f.p, h->d_slots.p, vatom, vglobal)
+                                                               ccs, dds, st.polar_damp, e2s, fdst, h->d_slots.p, vatom, vglobal)
   if (eflag) { if (vpair) LF(true, true); else LF(true, false); }
   else       { if (vpair) LF(false, true); else LF(false, false); }
 #undef LF
@@ -657,6 +657,10 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     if (ljlds > 64 * 1024) throw InputError("too many atom types for the LDS-resident LJ table (max 31)");
     dim3 block(POLAR_BLOCK);
     const bool symmetrise = !h->full_list && !getenv("POLAR_LJ_ATOMICS");
+    // A full (newton-off) list puts no force on ghosts, so sum f.x over locals+ghosts (fdotr) would miss
+    // the image terms: the LJ/Coulomb virial is then tallied pairwise (the same number), and only the
+    // polarization forces -- local atoms, minimum-image displacements -- go through f.x (phase_finish)
+    const bool lj_pairwise_virial = h->full_list && vmode == 2;
     if ((eatom || vatom) && !symmetrise && !h->full_list) throw InputError("per-atom tallies need the row-complete pair list (unset POLAR_LJ_ATOMICS)");
     if (symmetrise && !h->sym_valid && h->inum > 0) {  // once per uploaded list (reneighbor steps)
       dim3 g0(nblk(h->inum, POLAR_ROWS_PER_BLOCK));
@@ -678,8 +682,8 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     const long long *fi = symmetrise ? h->d_sym_first.p : h->d_first.p;
     const int *nj = symmetrise ? h->d_sym_j.p : h->d_neigh.p;
     if (h->inum > 0) {
-#define LJ(E, V) k_ljcoul<E, V><<<grid, block, ljlds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1)
-      const bool vrow = vmode == 1 || vatom;
+#define LJ(E, V) k_ljcoul<E, V><<<grid, block, ljlds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1 || lj_pairwise_virial)
+      const bool vrow = vmode == 1 || vatom || lj_pairwise_virial;
       if (eflag) { if (vrow) LJ(true, true); else LJ(true, false); }
       else       { if (vrow) LJ(false, true); else LJ(false, false); }
 #undef LJ
@@ -761,10 +765,22 @@ int phase_finish(polar_handle *h, polar_result *out) {
   // otherwise only before the accumulators are read
   auto join_lj = [&]() { if (h->lj_forked) { HIPCHECK(hipStreamWaitEvent(s, h->ev_join, 0)); h->lj_forked = false; } };
   if (vatom) join_lj();
-  if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1, vatom); else launch_force<true, 1>(h, eflag, vmode == 1, vatom); }
-  else    { if (expd) launch_force<false, 0>(h, eflag, vmode == 1, vatom); else launch_force<false, 1>(h, eflag, vmode == 1, vatom); }
+  // full-list mode with an fdotr virial: the polarization forces go to their own array first, so that
+  // sum f_pol . x can be formed without the LJ forces (whose virial was tallied pairwise)
+  const bool split_f = h->full_list && vmode == 2;
+  double *fdst = h->d_f.p;
+  if (split_f) {
+    h->d_fpol.ensure(3 * (size_t)n + 3);
+    HIPCHECK(hipMemsetAsync(h->d_fpol.p, 0, 3 * (size_t)n * sizeof(double), s));
+    fdst = h->d_fpol.p;
+  }
+  if (ap) { if (expd) launch_force<true, 0>(h, eflag, vmode == 1, vatom, fdst); else launch_force<true, 1>(h, eflag, vmode == 1, vatom, fdst); }
+  else    { if (expd) launch_force<false, 0>(h, eflag, vmode == 1, vatom, fdst); else launch_force<false, 1>(h, eflag, vmode == 1, vatom, fdst); }
   join_lj();
-  if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_slots.p);  // a10
+  if (split_f) {
+    k_virial_fdotr<<<std::min(1024, nblk(n, 256)), 256, 0, s>>>(n, h->d_x.p, h->d_fpol.p, h->d_slots.p);
+    k_add_into<<<nblk(3 * (long long)n, 256), 256, 0, s>>>(3 * (long long)n, h->d_fpol.p, h->d_f.p);
+  } else if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_slots.p);  // a10
   k_unpack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p, h->d_mu.p, h->d_ef.p);
   k_fold_scal<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, 0);
   HIPCHECK(hipEventRecord(h->ev[6], s));
@@ -875,7 +891,7 @@ int polar_destroy(polar_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->lj_stream) { (void)hipStreamSynchronize(h->lj_stream); (void)hipStreamDestroy(h->lj_stream); }
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1}) if (e) (void)hipEventDestroy(e);
-    h->d_eatom.release(); h->d_vatom.release(); h->d_dd_r2.release();
+    h->d_eatom.release(); h->d_vatom.release(); h->d_dd_r2.release(); h->d_fpol.release();
     h->d_x.release(); h->d_q.release(); h->d_alpha.release(); h->d_f.release(); h->d_ef.release(); h->d_F.release();
     h->d_mu.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
     h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();

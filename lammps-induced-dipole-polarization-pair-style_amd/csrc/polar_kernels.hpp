@@ -1480,6 +1480,11 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
   }
 }
 
+__global__ void k_add_into(long long n, const double *__restrict__ src, double *__restrict__ dst) {
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
 // a10  virial_fdotr_compute, src/pair.cpp:1495-1540: sum over locals AND ghosts of f_i x_i
 __global__ __launch_bounds__(POLAR_BLOCK) void k_virial_fdotr(int nall, const double *__restrict__ x,
                                                               const double *__restrict__ f, double *__restrict__ slots) {

@@ -257,6 +257,10 @@ def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
     for k in ("eng_vdwl", "eng_coul", "eng_pol"):
         assert rel(tot[k], ref[k]) < max(tol, 1e-10)
     assert len({o["iterations"] for o in outs}) == 1
+    # virial: the shards run on full (newton-off) lists, where the LJ/Coulomb part is tallied pairwise
+    # and only the polarization forces go through f.x -- the sum must equal the half-list fdotr virial
+    vir = sum(o["virial"] for o in outs)
+    assert np.max(np.abs(vir - ref["virial"])) < max(tol, 1e-9) * np.max(np.abs(ref["virial"]))
 
 
 @pytest.mark.parametrize("rpw", ["-1", "3"])
