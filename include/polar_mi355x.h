@@ -45,6 +45,9 @@ typedef struct {
    *                  polarization loops run over a device-built cell/neighbor list (O(N K)).
    *                  Identical to the reference when dd_cutoff >= sqrt(3)/2 * L.               */
   double dd_cutoff;
+  /* device_neigh yes|no (extension keyword): the LAMMPS shim lets the library build the LJ/Coulomb
+   * neighbor list on the device (polar_build_neighbors) instead of uploading Neighbor's list. */
+  int device_neigh;
 } polar_settings;
 
 typedef struct {
@@ -115,6 +118,25 @@ int polar_set_neighbors(polar_handle *h, int inum, const int *ilist, const int *
 /* same list already flattened: firstneigh[i] = offset of atom i's entries in neigh[] */
 int polar_set_neighbors_csr(polar_handle *h, int inum, const int *ilist, const int *numneigh,
                             const long long *firstneigh, const int *neigh);
+
+/* Device-side neighbor build for the LJ + Ewald-real loop, INSTEAD of polar_set_neighbors when
+ * neighbor->ago == 0.  Replaces what Neighbor builds for this style
+ * (src/neighbor.cpp, src/npair_half_bin_newton.cpp) with the rules of NPair::exclusion() and
+ * NPair::find_special() (src/npair.cpp): pairs with rsq <= cutneighsq[itype][jtype] among the atoms of
+ * the last polar_set_atoms (locals + ghosts); same-molecule pairs dropped when exclude_molecule_intra
+ * (neigh_modify exclude molecule/intra all); special partners dropped / kept plain / kept with their
+ * 1-2,1-3,1-4 code in bits 30-31 according to special_flag[1..3] = neighbor->special_flag
+ * (src/neighbor.cpp: 0, 1, 2), except images beyond half a box (Domain::minimum_image_check).
+ * The result is a FULL list for the local rows (newton off): such steps leave no force on ghosts,
+ * and the LJ/Coulomb part of a vflag = 2 virial is tallied pairwise (the same number as LAMMPS'
+ * fdotr over locals + ghosts) -- a shim using this entry point sets Pair::no_virial_fdotr_compute = 1 (src/pair.h:53).
+ *   cutneighsq[(ntypes+1)^2]  neighbor->cutneighsq (cut_ij + skin)^2, 1-based types
+ *   tag[nall]                 atom->tag (may be NULL when special is NULL)
+ *   nspecial[nlocal][3], special[nlocal][maxspecial]   atom->nspecial (cumulative counts) and
+ *                             atom->special (partner tags); both NULL for systems without bonds */
+int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *tag, const int *nspecial,
+                          const int *special, int maxspecial, const int special_flag[4],
+                          int exclude_molecule_intra);
 
 /* ---- the hot path: PairLJCutCoulLongPolarization::compute(eflag,vflag), PS.cpp:125-645 ---- */
 /* f[nall][3] is ACCUMULATED (+=) like atom->f; mu[nlocal][3] is atom->mu_induced (read when

@@ -11,6 +11,7 @@ is missing, ``PolarPair.compute`` raises.
 from __future__ import annotations
 
 import ctypes as C
+import importlib
 import os
 import subprocess
 
@@ -54,7 +55,8 @@ class Settings(C.Structure):
     _fields_ = [("cut_lj_global", C.c_double), ("cut_coul", C.c_double), ("polar_precision", C.c_double),
                 ("polar_damp", C.c_double), ("polar_gamma", C.c_double), ("iterations_max", C.c_int),
                 ("damping_type", C.c_int), ("zodid", C.c_int), ("fixed_iteration", C.c_int), ("polar_gs", C.c_int),
-                ("polar_gs_ranked", C.c_int), ("use_previous", C.c_int), ("debug", C.c_int), ("dd_cutoff", C.c_double)]
+                ("polar_gs_ranked", C.c_int), ("use_previous", C.c_int), ("debug", C.c_int), ("dd_cutoff", C.c_double),
+                ("device_neigh", C.c_int)]
 
 
 class Result(C.Structure):
@@ -91,6 +93,7 @@ EXPORTS = {
     "polar_set_atoms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _ip, _ip]),
     "polar_set_neighbors": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.POINTER(_ip)]),
     "polar_set_neighbors_csr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _llp, _ip]),
+    "polar_build_neighbors": (C.c_int, [C.c_void_p, _dp, _ip, _ip, _ip, C.c_int, _ip, C.c_int]),
     "polar_compute": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Result)]),
     "polar_compute_peratom": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.POINTER(Result)]),
     "polar_compute_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Result)]),
@@ -285,6 +288,31 @@ class PolarPair:
                      triclinic=int(getattr(sysm, "triclinic", 0)))
         self.set_atoms(sysm.nlocal, sysm.nghost, sysm.x, sysm.q, sysm.alpha, sysm.type, sysm.molecule)
         self.set_neighbors_csr(sysm.ilist, sysm.numneigh, sysm.firstneigh, sysm.neigh)
+
+    def build_neighbors(self, cutneighsq, tag=None, nspecial=None, special=None, special_flag=(1, 2, 2, 2),
+                        exclude_molecule_intra=False):
+        """Device-side neighbor build for the LJ + Ewald-real loop (instead of set_neighbors_*)."""
+        cn = np.ascontiguousarray(cutneighsq, dtype=np.float64)
+        keep = [cn]
+        ip = lambda a: None if a is None else (keep.append(np.ascontiguousarray(a, dtype=np.int32)) or
+                                               keep[-1].ctypes.data_as(_ip))
+        sf = np.ascontiguousarray(special_flag, dtype=np.int32)
+        maxspecial = 0 if special is None else int(np.asarray(special).shape[1])
+        self._ck(self.L.polar_build_neighbors(self.h, _dptr(cn), ip(tag), ip(nspecial), ip(special), maxspecial,
+                                              sf.ctypes.data_as(_ip), int(bool(exclude_molecule_intra))))
+
+    def build_neighbors_from_system(self, sysm, skin=None):
+        """The same list make_system built on the host (same cutoff, exclusions, special bonds)."""
+        wlm = importlib.import_module(__name__ + ".workload")
+        w = sysm.ntypes + 1
+        cutneigh = sysm.extra["cutneigh"] if skin is None else float(np.sqrt(sysm.tables["cutsq"][1:, 1:].max())) + skin
+        cn = np.full((w, w), cutneigh * cutneigh)
+        nsp = sp = None
+        if sysm.extra.get("special"):
+            nsp, sp = wlm.lammps_special_arrays(sysm.nlocal, sysm.extra["special"])
+        tag = (np.asarray(sysm.owner) + 1).astype(np.int32)
+        self.build_neighbors(cn, tag, nsp, sp, wlm.neighbor_special_flag(sysm.special_lj, sysm.special_coul),
+                             sysm.extra.get("exclude_intra", False))
 
     # ---- the hot path ----
     def compute(self, eflag=1, vflag=2, mu=None, want_ef=True):

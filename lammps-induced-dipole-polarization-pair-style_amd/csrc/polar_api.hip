@@ -112,6 +112,11 @@ struct polar_handle {
   bool colors_valid = false;
   double color_dist = 2.6;
   int field_block = 256;
+  double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // locals + ghosts, recorded by polar_set_atoms
+  bool device_list = false;  // the a3 list was built by polar_build_neighbors (always a full list)
+  int user_full_list = 0;    // polar_set_list_style for uploaded lists
+  long long lj_pitch = 0;
+  DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
   int cache_r2 = 1;       // 1: the sweep streams r^2 (12 B/pair) and rebuilds (s3,s5); 0: streams cached (s3,s5) (POLAR_CACHE_R2)
   int sweep_kernel = 0;   // 0: k_field_quad (component-per-lane); 1: lane-per-pair kernels (POLAR_SWEEP_KERNEL)
   int rows_per_wave = 0;  // 0: automatic; >0: forced; <0: use the one-row-per-wave kernel (POLAR_ROWS_PER_WAVE)
@@ -891,6 +896,8 @@ int polar_destroy(polar_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->lj_stream) { (void)hipStreamSynchronize(h->lj_stream); (void)hipStreamDestroy(h->lj_stream); }
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1}) if (e) (void)hipEventDestroy(e);
+    h->d_ljpos.release(); h->d_ljaux.release(); h->d_tag.release(); h->d_nspecial.release(); h->d_special.release();
+    h->d_ljcell_id.release(); h->d_ljcell_cnt.release(); h->d_ljcell_fill.release(); h->d_ljcell_first.release(); h->d_cutneighsq.release();
     h->d_eatom.release(); h->d_vatom.release(); h->d_dd_r2.release(); h->d_fpol.release();
     h->d_x.release(); h->d_q.release(); h->d_alpha.release(); h->d_f.release(); h->d_ef.release(); h->d_F.release();
     h->d_mu.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
@@ -1040,6 +1047,12 @@ int polar_set_atoms(polar_handle *h, int nlocal, int nghost, const double *x, co
     HIPCHECK(hipMemcpyAsync(h->d_mol.p, molecule, nall * sizeof(int), hipMemcpyHostToDevice, s));
     h->hx.assign(x, x + 3 * (size_t)nlocal);
     h->halpha.assign(alpha, alpha + nlocal);
+    for (int k = 0; k < 3; k++) { h->bbox_lo[k] = 1e300; h->bbox_hi[k] = -1e300; }
+    for (size_t a = 0; a < nall; a++)
+      for (int k = 0; k < 3; k++) {
+        h->bbox_lo[k] = std::min(h->bbox_lo[k], x[3 * a + k]);
+        h->bbox_hi[k] = std::max(h->bbox_hi[k], x[3 * a + k]);
+      }
     HIPCHECK(hipStreamSynchronize(s));
     h->atoms_set = true;
     return POLAR_OK;
@@ -1075,6 +1088,87 @@ int polar_set_neighbors_csr(polar_handle *h, int inum, const int *ilist, const i
     h->neigh_set = true;
     h->sym_valid = false;
     h->colors_valid = false;  // reneighbor step: refresh the colour phases too
+    h->device_list = false;
+    h->full_list = h->user_full_list;
+    return POLAR_OK;
+  });
+}
+
+int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *tag, const int *nspecial,
+                          const int *special, int maxspecial, const int special_flag[4], int exclude_molecule_intra) {
+  return guarded(h, [&]() {
+    need_device(h);
+    HIPCHECK(hipSetDevice(h->device));
+    if (!h->atoms_set || !h->box_set) throw std::runtime_error("polar_build_neighbors before polar_set_box/polar_set_atoms");
+    if (!h->types_set) throw std::runtime_error("polar_build_neighbors before the pair tables were set");
+    if (!cutneighsq || !special_flag) throw InputError("polar_build_neighbors: null cutneighsq/special_flag");
+    if ((nspecial == nullptr) != (special == nullptr) || (special && maxspecial <= 0)) throw InputError("polar_build_neighbors: nspecial/special/maxspecial are inconsistent");
+    const int n = h->nlocal, nall = h->nlocal + h->nghost, w = h->ntypes + 1;
+    hipStream_t s = h->stream;
+    double cutmax2 = 0.0;
+    for (int a = 1; a < w; a++) for (int b = 1; b < w; b++) cutmax2 = std::max(cutmax2, cutneighsq[a * w + b]);
+    if (!(cutmax2 > 0.0)) throw InputError("polar_build_neighbors: no positive neighbor cutoff");
+    const double cutmax = std::sqrt(cutmax2);
+    // grid over the bounding box of locals + ghosts (recorded by polar_set_atoms), cell edge >= cutmax / 2
+    LJGrid g;
+    long long ncell = 1;
+    for (int k = 0; k < 3; k++) {
+      const double ext = std::max(h->bbox_hi[k] - h->bbox_lo[k], 1e-9);
+      int nc = (int)std::floor(ext / (0.5 * cutmax));
+      nc = std::max(1, std::min(nc, 512));
+      g.nc[k] = nc; g.lo[k] = h->bbox_lo[k]; g.inv[k] = nc / ext;
+      ncell *= nc;
+    }
+    h->d_ljcell_id.ensure(nall + 1); h->d_ljcell_cnt.ensure(ncell + 1); h->d_ljcell_fill.ensure(ncell + 1); h->d_ljcell_first.ensure(ncell + 2);
+    h->d_ljpos.ensure(nall + 1); h->d_ljaux.ensure(nall + 1); h->d_cutneighsq.ensure((size_t)w * w);
+    HIPCHECK(hipMemcpyAsync(h->d_cutneighsq.p, cutneighsq, (size_t)w * w * sizeof(double), hipMemcpyHostToDevice, s));
+    const int *d_tag = nullptr, *d_nsp = nullptr, *d_sp = nullptr;
+    if (tag) { h->d_tag.ensure(nall + 1); HIPCHECK(hipMemcpyAsync(h->d_tag.p, tag, (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s)); d_tag = h->d_tag.p; }
+    if (special) {
+      if (!tag) throw InputError("polar_build_neighbors: special lists need the atom tags");
+      h->d_nspecial.ensure(3 * (size_t)n + 3); h->d_special.ensure((size_t)n * maxspecial + 1);
+      HIPCHECK(hipMemcpyAsync(h->d_nspecial.p, nspecial, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+      HIPCHECK(hipMemcpyAsync(h->d_special.p, special, (size_t)n * maxspecial * sizeof(int), hipMemcpyHostToDevice, s));
+      d_nsp = h->d_nspecial.p; d_sp = h->d_special.p;
+    }
+    HIPCHECK(hipMemsetAsync(h->d_ljcell_cnt.p, 0, (ncell + 1) * sizeof(int), s));
+    HIPCHECK(hipMemsetAsync(h->d_ljcell_fill.p, 0, (ncell + 1) * sizeof(int), s));
+    k_lj_cell_count<<<nblk(nall, 256), 256, 0, s>>>(nall, h->d_x.p, g, h->d_ljcell_id.p, h->d_ljcell_cnt.p);
+    k_exclusive_scan<int><<<1, 1024, 0, s>>>(ncell, h->d_ljcell_cnt.p, h->d_ljcell_first.p);
+    k_lj_cell_fill<<<nblk(nall, 256), 256, 0, s>>>(nall, h->d_ljcell_id.p, h->d_ljcell_first.p, h->d_ljcell_fill.p, h->d_x.p,
+                                                    h->d_type.p, h->d_mol.p, d_tag, h->d_ljpos.p, h->d_ljaux.p);
+    if (h->lj_pitch == 0 && getenv("POLAR_INIT_PITCH")) h->lj_pitch = ((std::max(64, atoi(getenv("POLAR_INIT_PITCH"))) + 63) / 64) * 64;  // tests: force the overflow path
+    if (h->lj_pitch == 0) {  // first build: 1.3x the mean sphere population, rounded to 64
+      const double vol = std::max((h->bbox_hi[0] - h->bbox_lo[0]) * (h->bbox_hi[1] - h->bbox_lo[1]) * (h->bbox_hi[2] - h->bbox_lo[2]), 1e-9);
+      const double mean = 4.18879 * cutmax * cutmax2 * nall / vol;
+      h->lj_pitch = (((long long)(1.3 * mean) + 64) / 64 + 1) * 64;
+    }
+    h->d_numneigh.ensure(n + 1); h->d_ilist.ensure(n + 1); h->d_first.ensure(n + 1);
+    const size_t lds = (size_t)w * w * sizeof(double);
+    if (lds > 64 * 1024) throw InputError("too many atom types for the LDS-resident cutoff table");
+    for (int attempt = 0;; attempt++) {
+      h->d_neigh.ensure((size_t)std::max(n, 1) * h->lj_pitch + 64);
+      HIPCHECK(hipMemsetAsync(h->d_overflow.p, 0, 16 * sizeof(int), s));
+      HIPCHECK(hipMemsetAsync(h->d_ddtot.p, 0, 64 * 16 * sizeof(unsigned long long), s));
+      k_lj_nl_build<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, lds, s>>>(
+          n, h->ntypes, h->d_x.p, h->d_type.p, h->d_mol.p, h->d_ljpos.p, h->d_ljaux.p, g, h->d_ljcell_first.p,
+          h->d_cutneighsq.p, h->box, exclude_molecule_intra, d_nsp, d_sp, maxspecial, special_flag[1], special_flag[2],
+          special_flag[3], h->lj_pitch, h->d_numneigh.p, h->d_neigh.p, h->d_overflow.p, h->d_ddtot.p);
+      HIPCHECK(hipMemcpyAsync(h->h_flags, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      HIPCHECK(hipGetLastError());
+      if (h->h_flags[0] == 0) break;
+      if (attempt >= 3) throw std::runtime_error("polar_build_neighbors: row pitch overflow persists");
+      h->lj_pitch = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
+    }
+    unsigned long long tot = 0;
+    for (int k = 0; k < 64; k++) tot += h->h_ddtot[16 * k];
+    h->h_flags[0] = 0;
+    k_lj_rows<<<nblk(n, 256), 256, 0, s>>>(n, h->lj_pitch, h->d_ilist.p, h->d_first.p);
+    h->inum = n; h->nneigh = (long long)tot;
+    h->neigh_set = true; h->sym_valid = false; h->colors_valid = false;
+    h->device_list = true; h->full_list = 1;
     return POLAR_OK;
   });
 }
@@ -1199,7 +1293,8 @@ int polar_set_row_range(polar_handle *h, int lo, int hi) {
 }
 int polar_set_list_style(polar_handle *h, int full) {
   if (!h) return POLAR_ERR_STATE;
-  h->full_list = full ? 1 : 0;
+  h->user_full_list = full ? 1 : 0;
+  if (!h->device_list) h->full_list = h->user_full_list;
   return POLAR_OK;
 }
 int polar_step_begin(polar_handle *h, int eflag, int vflag) {

@@ -1648,6 +1648,138 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Device-side neighbor build for a3: what Neighbor hands this style --
+// src/neighbor.cpp + src/npair_half_bin_newton.cpp, with NPair::exclusion() (molecule/intra) and
+// NPair::find_special() (src/npair.cpp) -- as a FULL list over locals + ghosts for the local rows.
+// Ghosts are explicit periodic images, so the grid is a plain (non-periodic) binning of the
+// bounding box of all atoms.
+struct LJGrid {
+  int nc[3];
+  double lo[3], inv[3];  // cell = clamp(floor((x - lo) * inv))
+};
+__device__ __forceinline__ int lj_cell_of(const LJGrid &g, double x, double y, double z) {
+  const double p[3] = {x, y, z};
+  int c[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int ck = (int)floor((p[k] - g.lo[k]) * g.inv[k]);
+    c[k] = ck < 0 ? 0 : (ck >= g.nc[k] ? g.nc[k] - 1 : ck);
+  }
+  return (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
+}
+__global__ void k_lj_cell_count(int nall, const double *__restrict__ x, LJGrid g, int *__restrict__ cell_id,
+                                int *__restrict__ cell_cnt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nall) return;
+  const int c = lj_cell_of(g, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
+  cell_id[i] = c;
+  atomicAdd(&cell_cnt[c], 1);
+}
+// s order = cell order: pos[s] = {x, y, z, (type, molecule)}, aux[s] = {atom index, tag}
+__global__ void k_lj_cell_fill(int nall, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
+                               int *__restrict__ fill, const double *__restrict__ x, const int *__restrict__ type,
+                               const int *__restrict__ mol, const int *__restrict__ tag, double4 *__restrict__ pos,
+                               int2 *__restrict__ aux) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nall) return;
+  const int c = cell_id[i];
+  const int s = (int)cell_first[c] + atomicAdd(&fill[c], 1);
+  pos[s] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], __hiloint2double(mol[i], type[i]));
+  aux[s] = make_int2(i, tag ? tag[i] : i + 1);
+}
+
+// One wave per local row i; lanes stride the atoms of the +-2 stencil of half-cutoff cells
+// (contiguous x-runs), ballot + popcount compacts in order into the pitched row.
+// Pair rules, in LAMMPS' order (npair_half_bin_newton.cpp):
+//   rsq <= cutneighsq[itype][jtype]; exclusion: same molecule with molecule/intra;
+//   special: which = find_special(special[i], nspecial[i], tag[j]) mapped through special_flag
+//            (0: drop the pair, 1: keep plain, 2: keep with `which` in bits 30-31), except that a
+//            pair farther apart than half a periodic box length is an image and kept plain
+//            (Domain::minimum_image_check).
+__global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int nlocal, int ntypes, const double *__restrict__ x,
+                                                             const int *__restrict__ type, const int *__restrict__ mol,
+                                                             const double4 *__restrict__ pos, const int2 *__restrict__ aux,
+                                                             LJGrid g, const long long *__restrict__ cell_first,
+                                                             const double *__restrict__ cutneighsq, Box box,
+                                                             int exclude_intra, const int *__restrict__ nspecial,
+                                                             const int *__restrict__ special, int maxspecial, int sf1,
+                                                             int sf2, int sf3, long long pitch, int *__restrict__ cnt,
+                                                             int *__restrict__ out_j, int *__restrict__ overflow,
+                                                             unsigned long long *__restrict__ total) {
+  extern __shared__ double cn_lds[];
+  const int w = ntypes + 1;
+  for (int t = threadIdx.x; t < w * w; t += blockDim.x) cn_lds[t] = cutneighsq[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= nlocal) return;
+  const double xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+  const int itype = type[i], imol = mol[i];
+  const double *cn = cn_lds + itype * w;
+  int n1 = 0, n2 = 0, n3 = 0;
+  if (nspecial) { n1 = nspecial[3 * i]; n2 = nspecial[3 * i + 1]; n3 = nspecial[3 * i + 2]; }
+  const int *sp = special ? special + (size_t)i * maxspecial : nullptr;
+  const int ci = lj_cell_of(g, xi, yi, zi);
+  const int n0 = g.nc[0], n1c = g.nc[1], n2c = g.nc[2];
+  const int c0 = ci % n0, c1 = (ci / n0) % n1c, c2 = ci / (n0 * n1c);
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const long long row0 = (long long)i * pitch;
+  int count = 0;
+  for (int zz = max(c2 - 2, 0); zz <= min(c2 + 2, n2c - 1); zz++)
+    for (int yy = max(c1 - 2, 0); yy <= min(c1 + 2, n1c - 1); yy++) {
+      const long long rb = ((long long)zz * n1c + yy) * n0;
+      const long long a = cell_first[rb + max(c0 - 2, 0)], b = cell_first[rb + min(c0 + 2, n0 - 1) + 1];
+      for (long long base = a; base < b; base += 64) {
+        const long long p = base + lane;
+        bool keep = false;
+        int entry = 0;
+        if (p < b) {
+          const double4 pj = pos[p];
+          const int2 aj = aux[p];
+          const int jtype = __double2loint(pj.w), jmol = __double2hiint(pj.w);
+          const double dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+          const double rsq = dx * dx + dy * dy + dz * dz;
+          keep = aj.x != i && rsq <= cn[jtype];
+          if (keep && exclude_intra && imol == jmol) keep = false;
+          entry = aj.x;
+          if (keep && n3 > 0) {
+            int which = 0;
+            for (int k = 0; k < n3; k++)
+              if (sp[k] == aj.y) {
+                const int cls = k < n1 ? 1 : (k < n2 ? 2 : 3);
+                const int flag = cls == 1 ? sf1 : (cls == 2 ? sf2 : sf3);
+                which = flag == 0 ? -1 : (flag == 1 ? 0 : cls);
+                break;
+              }
+            if (which > 0) {  // minimum_image_check: a partner more than half a box away is an image
+              if ((box.periodic[0] && fabs(dx) > box.half[0]) || (box.periodic[1] && fabs(dy) > box.half[1]) ||
+                  (box.periodic[2] && fabs(dz) > box.half[2]))
+                which = 0;
+            }
+            if (which < 0) keep = false;
+            else entry |= which << 30;
+          }
+        }
+        const unsigned long long m = __ballot(keep);
+        const int k = count + __popcll(m & below);
+        if (keep && k < pitch) out_j[row0 + k] = entry;
+        count += __popcll(m);
+      }
+    }
+  if (lane == 0) {
+    cnt[i] = count < pitch ? count : (int)pitch;
+    if (count > pitch) atomicMax(overflow, count);
+    atomicAdd(total + (blockIdx.x & 63) * 16, (unsigned long long)count);
+  }
+}
+__global__ void k_lj_rows(int nlocal, long long pitch, int *__restrict__ ilist, long long *__restrict__ first) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  ilist[i] = i;
+  first[i] = (long long)i * pitch;
+}
+
 // multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers
 __global__ void k_mu_gather(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
                             const AtomRec *__restrict__ recA, const AtomRec *__restrict__ recB,

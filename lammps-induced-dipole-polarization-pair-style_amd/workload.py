@@ -339,6 +339,7 @@ class PolarSettings:
     use_previous: int = 0
     debug: int = 0
     dd_cutoff: float = 0.0  # extension: <=0 exact all-pairs (reference), >0 truncated
+    device_neigh: int = 0   # extension: the LAMMPS shim builds the LJ/coul list on the device
 
 
 @dataclass
@@ -396,7 +397,41 @@ def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings,
         tables=tables, coul=coul, g_ewald=g_ewald, qqrd2e=QQR2E_REAL,
         special_lj=np.asarray(special_lj, dtype=np.float64), special_coul=np.asarray(special_coul, dtype=np.float64),
         ilist=ilist, numneigh=numneigh, firstneigh=first, neigh=neigh, settings=settings, owner=owner, name=name,
-        extra={"coeff_rows": [list(map(str, r)) for r in coeff_rows]})
+        extra={"coeff_rows": [list(map(str, r)) for r in coeff_rows], "special": special, "cutneigh": cutneigh,
+               "exclude_intra": bool(exclude_intra)})
+
+
+def lammps_special_arrays(n, special):
+    """{(i,j): which} -> atom->nspecial [n][3] (cumulative 1-2, 1-3, 1-4 counts) and atom->special
+    [n][maxspecial] (partner TAGS = index + 1, ordered 1-2 | 1-3 | 1-4), the layout
+    NPair::find_special reads (reference src/npair.cpp)."""
+    per = [[[], [], []] for _ in range(n)]
+    for (i, j), which in (special or {}).items():
+        per[i][which - 1].append(j + 1)
+    maxspecial = max([sum(len(c) for c in p) for p in per] + [1])
+    nspecial = np.zeros((n, 3), dtype=np.int32)
+    arr = np.zeros((n, maxspecial), dtype=np.int32)
+    for i, p in enumerate(per):
+        flat = sorted(p[0]) + sorted(p[1]) + sorted(p[2])
+        arr[i, :len(flat)] = flat
+        nspecial[i] = np.cumsum([len(p[0]), len(p[1]), len(p[2])])
+    return nspecial, arr
+
+
+def neighbor_special_flag(special_lj, special_coul, kspace=True):
+    """neighbor->special_flag (reference src/neighbor.cpp init): 0 drop, 1 keep plain, 2 keep with bits;
+    with a KSpace style every special pair is kept with its bits."""
+    flag = [1, 0, 0, 0]
+    for k in (1, 2, 3):
+        if special_lj[k] == 0.0 and special_coul[k] == 0.0:
+            flag[k] = 0
+        elif special_lj[k] == 1.0 and special_coul[k] == 1.0:
+            flag[k] = 1
+        else:
+            flag[k] = 2
+        if kspace:
+            flag[k] = 2
+    return np.asarray(flag, dtype=np.int32)
 
 
 # --------------------------------------------------------------------------- synthetic boxes
@@ -517,6 +552,8 @@ def parse_pair_style_args(args, base=None):
             st.use_previous = yn[v]
         elif k == "dd_cutoff":  # extension keyword (not in the reference)
             st.dd_cutoff = float(v)
+        elif k == "device_neigh":  # extension keyword (not in the reference)
+            st.device_neigh = yn[v]
         else:
             raise ValueError("Illegal pair_style command")
         i += 2

@@ -16,6 +16,7 @@
 #include "kspace.h"
 #include "memory.h"
 #include "neigh_list.h"
+#include "neigh_request.h"
 #include "neighbor.h"
 #include "update.h"
 
@@ -36,6 +37,7 @@ PairLJCutCoulLongPolarizationMI355X::PairLJCutCoulLongPolarizationMI355X(LAMMPS 
   ftable = NULL;
   epsilon = sigma = cut_lj = NULL;
   pair_inited = 0;
+  device_neigh = 0;
   cut_lj_global = cut_coul = 0.0;
   h = NULL;
   const char *dev = getenv("POLAR_DEVICE");
@@ -74,8 +76,15 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
   check(polar_set_box(h,domain->boxlo,domain->prd,tilt,periodic,domain->triclinic));
   check(polar_set_atoms(h,atom->nlocal,atom->nghost,&atom->x[0][0],atom->q,atom->static_polarizability,
                         atom->type,(const int *) atom->molecule));
-  if (neighbor->ago == 0)
-    check(polar_set_neighbors(h,list->inum,list->ilist,list->numneigh,list->firstneigh));
+  if (neighbor->ago == 0) {
+    if (device_neigh)
+      check(polar_build_neighbors(h,&neighbor->cutneighsq[0][0],(const int *) atom->tag,
+                                  atom->molecular ? &atom->nspecial[0][0] : NULL,
+                                  atom->molecular ? (const int *) &atom->special[0][0] : NULL,atom->maxspecial,
+                                  neighbor->special_flag,neighbor->nex_mol > 0));
+    else
+      check(polar_set_neighbors(h,list->inum,list->ilist,list->numneigh,list->firstneigh));
+  }
 
   // global virial: fdotr is left to the base class (it needs the reverse-communicated ghosts'
   // x, which LAMMPS owns); a pairwise global virial (vflag_global == 1) is tallied on the device
@@ -83,7 +92,9 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
   // (src/pair.cpp:789-806); both are contiguous (src/memory.h:118-131)
   polar_result res;
   const int ef = (eflag_either ? 1 : 0) | (eflag_atom ? 2 : 0);
-  const int vf = (vflag_global ? 1 : 0) | (vflag_atom ? 4 : 0);
+  // with device_neigh, no_virial_fdotr_compute leaves vflag_global = 2 for an fdotr-style request: the library
+  // then tallies the LJ/Coulomb part pairwise and the polarization part as sum f.x, like the reference
+  const int vf = (device_neigh ? vflag_global : (vflag_global ? 1 : 0)) | (vflag_atom ? 4 : 0);
   int rc;
   if (eflag_atom || vflag_atom)
     rc = polar_compute_peratom(h,ef,vf,&atom->f[0][0],&atom->mu_induced[0][0],&atom->ef_static[0][0],
@@ -168,7 +179,23 @@ void PairLJCutCoulLongPolarizationMI355X::init_style()
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization requires atom attribute polarizability");
   if (strstr(update->integrate_style,"respa"))
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization does not support rRESPA");  // respa_enable = 0
-  neighbor->request(this,instance_me);     // default half list, newton on
+  int irequest = neighbor->request(this,instance_me);     // default half list, newton on
+  polar_settings pst;
+  check(polar_get_settings(h,&pst));
+  device_neigh = pst.device_neigh;
+  if (device_neigh) {
+    // extension keyword `device_neigh yes`: the library bins locals + ghosts and builds the (full) list
+    // itself (polar_build_neighbors), so Neighbor never builds this request -- it still decides WHEN to
+    // reneighbor (neighbor->ago) and provides cutneighsq / special_flag / the exclusion settings.
+    // A full list puts no force on ghosts: the base class must not form the fdotr virial.
+    neighbor->requests[irequest]->occasional = 1;
+    no_virial_fdotr_compute = 1;
+    if (neighbor->nex_type || neighbor->nex_group)
+      error->all(FLERR,"Pair style lj/cut/coul/long/polarization device_neigh supports only neigh_modify exclude molecule/intra all");
+    for (int k = 0; k < neighbor->nex_mol; k++)
+      if (!neighbor->ex_mol_intra[k])
+        error->all(FLERR,"Pair style lj/cut/coul/long/polarization device_neigh supports only neigh_modify exclude molecule/intra all");
+  }
   if (force->kspace == NULL) error->all(FLERR,"Pair style requires a KSpace style");
 
   // pair_modify state lives in the Pair base class; mirror it into the library, then let it build

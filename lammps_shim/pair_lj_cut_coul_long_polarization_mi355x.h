@@ -48,6 +48,7 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   double cut_lj_global, cut_coul;
   double **epsilon, **sigma, **cut_lj;   // row-pointer views into the library's tables (extract())
   int pair_inited;
+  int device_neigh;                      // extension keyword: list built by polar_build_neighbors
   virtual void allocate();
   void check(int rc);                    // C-ABI status -> error->all / error->warning
   void sync_views();

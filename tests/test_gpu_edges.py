@@ -156,3 +156,51 @@ def test_triclinic_box_exact_mode(wl, pkg, oracle):
     s2.settings = wl.parse_pair_style_args(["8.0", "7.5", "dd_cutoff", "7.5"])
     with pytest.raises(pkg.PolarError):
         pkg.pair_from_system(s2).compute()
+
+
+def _filter_csr(s, wl, keep_fn):
+    """Rebuild the uploaded half list keeping entries for which keep_fn(i, j_owner, code) -> new code or None."""
+    first = np.zeros_like(s.firstneigh)
+    nn = np.zeros_like(s.numneigh)
+    out = []
+    pos = 0
+    for i in s.ilist:
+        row = s.neigh[s.firstneigh[i]:s.firstneigh[i] + s.numneigh[i]].view(np.uint32)
+        new = []
+        for e in row:
+            j, code = int(e & 0x3FFFFFFF), int(e >> 30)
+            c = keep_fn(int(i), int(s.owner[j]), code)
+            if c is not None:
+                new.append(j | (c << 30))
+        first[i], nn[i] = pos, len(new)
+        pos += len(new)
+        out.extend(new)
+    return nn, first, np.asarray(out, dtype=np.uint32).view(np.int32)
+
+
+@pytest.mark.parametrize("flag", [0, 1])
+def test_device_neighbor_build_special_flag_drop_and_plain(flag, wl, pkg, oracle, monkeypatch):
+    """neighbor->special_flag 0 (special partners are not listed at all) and 1 (listed as ordinary
+    pairs) in polar_build_neighbors, each against an uploaded list edited the same way; plus a
+    per-type-pair cutneighsq and a forced row-pitch overflow inside the build."""
+    if flag == 1:
+        monkeypatch.setenv("POLAR_INIT_PITCH", "64")  # first build overflows its rows and is redone
+    s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=["use_previous", "no"])
+    assert s.extra["special"], "fixture is expected to carry bonds"
+    nn, first, neigh = _filter_csr(s, wl, (lambda i, j, c: (None if c else 0)) if flag == 0 else (lambda i, j, c: 0))
+    p = pkg.pair_from_system(s)
+    p.set_neighbors_csr(s.ilist, nn, first, neigh)
+    ref = p.compute()
+    fref = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
+    nsp, sp = wl.lammps_special_arrays(s.nlocal, s.extra["special"])
+    w = s.ntypes + 1
+    # per-type-pair neighbor cutoffs: (cut_ij + skin)^2 exactly as neighbor->cutneighsq holds them
+    cn = (np.sqrt(s.tables["cutsq"]) + 2.0) ** 2
+    cn[0, :] = cn[:, 0] = 0.0
+    p.build_neighbors(cn, (np.asarray(s.owner) + 1).astype(np.int32), nsp, sp, special_flag=(1, flag, flag, flag),
+                      exclude_molecule_intra=s.extra["exclude_intra"])
+    out = p.compute()
+    assert force_rel_err(out["f"][:s.nlocal], fref) < 1e-10
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert rel(out[k], ref[k], 1e-9) < 1e-10
+    p.close()

@@ -41,6 +41,7 @@ ARG_CASES = [
     ["9.0", "9.0", "polar_gs_ranked", "no", "zodid", "yes"],
     ["9.0", "9.0", "fixed_iteration", "yes", "max_iterations", "7", "damp_type", "none"],
     ["9.0", "9.0", "dd_cutoff", "8.5"],
+    ["9.0", "9.0", "dd_cutoff", "8.5", "device_neigh", "yes"],
 ]
 
 
@@ -51,7 +52,8 @@ def test_settings_parser_agrees_with_python_mirror(args, pkg, wl):
     s = p.get_settings()
     ref = wl.parse_pair_style_args(args)
     for k in ("cut_lj_global", "cut_coul", "iterations_max", "damping_type", "zodid", "fixed_iteration", "polar_gs",
-              "polar_gs_ranked", "use_previous", "debug", "polar_damp", "polar_precision", "polar_gamma", "dd_cutoff"):
+              "polar_gs_ranked", "use_previous", "debug", "polar_damp", "polar_precision", "polar_gamma", "dd_cutoff",
+              "device_neigh"):
         assert getattr(s, k) == getattr(ref, k), k
 
 
@@ -64,6 +66,7 @@ ERR_CASES = [
     (["9", "9", "precision"], "Illegal pair_style command"),
     (["9", "9", "damp_type", "thole"], "Illegal pair_style command"),
     (["9", "9", "debug", "maybe"], "Illegal pair_style command"),
+    (["9", "9", "device_neigh", "1"], "Illegal pair_style command"),
     (["9", "9", "nonsense", "1"], "Illegal pair_style command"),
     (["9", "precision", "1e-8"], "Expected floating point parameter in input script or data file"),  # scan starts at arg 2
 ]
