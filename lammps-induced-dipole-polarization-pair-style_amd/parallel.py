@@ -150,6 +150,72 @@ class HaloPlan:
         self.world = world
 
 
+class P2PHaloPlan:
+    """The same visibility rule, kept PER PAIR of ranks: ``send[q][r]`` = the atoms of rank q that lie
+    within ``reach`` of rank r's extent.  With z slabs only the two neighbouring slabs are peers, so
+    a rank exchanges two face layers point-to-point (xGMI is point-to-point: 2 x ~145 KB per sweep at
+    36k atoms per GPU) instead of taking part in an all-gather of every rank's whole halo."""
+
+    def __init__(self, x, prd, offs, reach):
+        world = len(offs) - 1
+        x = np.asarray(x, dtype=np.float64)
+        lo = np.array([x[offs[r]:offs[r + 1]].min(axis=0) for r in range(world)])
+        hi = np.array([x[offs[r]:offs[r + 1]].max(axis=0) for r in range(world)])
+        self.world = world
+        self.send = [[np.zeros(0, dtype=np.int32) for _ in range(world)] for _ in range(world)]
+        for q in range(world):
+            xq = x[offs[q]:offs[q + 1]]
+            for r in range(world):
+                if r == q or len(xq) == 0 or offs[r + 1] == offs[r]:
+                    continue
+                d2 = np.zeros(len(xq))
+                for k in range(3):
+                    c = 0.5 * (lo[r, k] + hi[r, k])
+                    h = 0.5 * (hi[r, k] - lo[r, k])
+                    d = xq[:, k] - c
+                    d -= prd[k] * np.round(d / prd[k])
+                    d2 += np.maximum(np.abs(d) - h, 0.0) ** 2
+                self.send[q][r] = (np.nonzero(d2 < reach * reach)[0] + offs[q]).astype(np.int32)
+        self.counts = [int(sum(len(a) for a in self.send[q])) for q in range(world)]
+
+    def peers(self, rank):
+        return [r for r in range(self.world) if r != rank and (len(self.send[rank][r]) or len(self.send[r][rank]))]
+
+
+def p2p_buffers(backend, plan, rank):
+    """Device index lists and packed buffers of one rank: segments ordered by peer."""
+    peers = plan.peers(rank)
+    out_idx = np.concatenate([plan.send[rank][r] for r in peers]) if peers else np.zeros(0, dtype=np.int32)
+    in_idx = np.concatenate([plan.send[r][rank] for r in peers]) if peers else np.zeros(0, dtype=np.int32)
+    seg_out = np.concatenate([[0], np.cumsum([len(plan.send[rank][r]) for r in peers])]).astype(int)
+    seg_in = np.concatenate([[0], np.cumsum([len(plan.send[r][rank]) for r in peers])]).astype(int)
+    return dict(peers=peers, seg_out=seg_out, seg_in=seg_in,
+                idx_out=backend.index_tensor(out_idx if len(out_idx) else np.full(1, -1, dtype=np.int32)),
+                idx_in=backend.index_tensor(in_idx if len(in_idx) else np.full(1, -1, dtype=np.int32)),
+                send=backend.new_buffer(max(len(out_idx), 1) * 3), recv=backend.new_buffer(max(len(in_idx), 1) * 3))
+
+
+def exchange_halo_p2p(backend, dist, plan, rank, bufs):
+    """Send each peer the face layer it can see and take in its layer: one grouped batch of
+    isend/irecv (ncclGroupStart/End under RCCL), one pack kernel before, one unpack kernel after."""
+    peers = bufs["peers"]
+    if not peers:
+        return
+    backend.gather_idx(bufs["idx_out"], bufs["send"])
+    ops = []
+    for k, r in enumerate(peers):
+        a, b = 3 * bufs["seg_in"][k], 3 * bufs["seg_in"][k + 1]
+        if b > a:
+            ops.append(dist.P2POp(dist.irecv, bufs["recv"][a:b], r))
+    for k, r in enumerate(peers):
+        a, b = 3 * bufs["seg_out"][k], 3 * bufs["seg_out"][k + 1]
+        if b > a:
+            ops.append(dist.P2POp(dist.isend, bufs["send"][a:b], r))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    backend.scatter_idx(bufs["idx_in"], bufs["recv"])
+
+
 def exchange_halo(backend, dist, plan, rank, bufs):
     """Publish this rank's halo dipoles and take in everybody else's (one all-gather per call)."""
     if plan.world == 1:
@@ -197,9 +263,13 @@ def run_step(backend, dist, rank, world, counts, offs, eflag=1, vflag=2, check_e
     maxc = max(counts)
     if halo is not None:
         plan, hb = halo
+        p2p = isinstance(plan, P2PHaloPlan)
 
         def exchange_mu(backend, dist, counts, offs, rank, gather_buf):  # noqa: F811 (local override)
-            exchange_halo(backend, dist, plan, rank, hb)
+            if p2p:
+                exchange_halo_p2p(backend, dist, plan, rank, hb)
+            else:
+                exchange_halo(backend, dist, plan, rank, hb)
     else:
         exchange_mu = globals()["exchange_mu"]
         if gather_buf is None:
@@ -261,8 +331,13 @@ def bench_distributed(args, rank, world, local_rank):
     p = pkg.pair_from_system(s, device=local_rank)
     be = HipShardBackend(p, lo, hi, local_rank)
     # halo plan from the replicated coordinates: reach = list cutoff + the neighbor skin
-    plan = HaloPlan(s.x[:s.nlocal], s.prd, offs, cut + 2.0)
-    halo = (plan, halo_buffers(be, plan, rank)) if world > 1 else None
+    # point-to-point face layers between slab neighbours (default) or one all-gather of every halo
+    if os.environ.get("POLAR_HALO_MODE", "p2p") == "allgather":
+        plan = HaloPlan(s.x[:s.nlocal], s.prd, offs, cut + 2.0)
+        halo = (plan, halo_buffers(be, plan, rank)) if world > 1 else None
+    else:
+        plan = P2PHaloPlan(s.x[:s.nlocal], s.prd, offs, cut + 2.0)
+        halo = (plan, p2p_buffers(be, plan, rank)) if world > 1 else None
     gbuf = None
     for _ in range(args.warmup):
         out = run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo)
@@ -283,7 +358,7 @@ def bench_distributed(args, rank, world, local_rank):
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"MOF5+H2 cell replicated {reps[0]}x{reps[1]}x{reps[2]} = {n_total} atoms "
                                    f"({n_total // world} per GPU, z slabs), exponential damping, fixed_iteration 30 "
-                                   f"(31 sweeps), colour-phase GS per rank + all-gather of the halo dipoles per sweep (RCCL), "
+                                   f"(31 sweeps), colour-phase GS per rank + {'all-gather' if isinstance(plan, HaloPlan) else 'point-to-point exchange'} of the halo dipoles per sweep (RCCL), "
                                    f"dd_cutoff=cut_coul={cut}",
                        "natoms": n_total, "sweeps": out["sweeps"], "colors": out["ncolors"],
                        "dd_pairs": out["dd_pairs"], "eng_pol": out["eng_pol"],

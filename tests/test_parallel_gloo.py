@@ -150,7 +150,11 @@ def _worker(rank, world, port, extra, gs, q, use_halo=False):
     be = NumpyShardBackend(T, E, s.alpha[:s.nlocal].copy(), int(offs[rank]), int(offs[rank + 1]), gs,
                            bool(st.fixed_iteration), st.iterations_max, st.polar_precision, st.polar_gamma)
     halo = None
-    if use_halo:  # dense tensor here: every atom sees every atom, so the plan must select all rows
+    if use_halo == "p2p":  # point-to-point form: every other rank is a peer and gets all owned rows
+        plan = par.P2PHaloPlan(s.x[:s.nlocal], s.prd, offs, reach=1.0e9)
+        assert plan.counts == [c * (world - 1) for c in counts] and plan.peers(rank) == [r for r in range(world) if r != rank]
+        halo = (plan, par.p2p_buffers(be, plan, rank))
+    elif use_halo:  # dense tensor here: every atom sees every atom, so the plan must select all rows
         plan = par.HaloPlan(s.x[:s.nlocal], s.prd, offs, reach=1.0e9)
         assert plan.counts == counts
         halo = (plan, par.halo_buffers(be, plan, rank))
@@ -226,6 +230,43 @@ def test_halo_exchange_path_matches_full_exchange():
     half = 3 * ((n3 // 3 + 1) // 2)
     assert np.max(np.abs(mu0[:half] - muref[:half])) < 1e-12 * np.max(np.abs(muref))
     assert np.max(np.abs(mu1[half:] - muref[half:])) < 1e-12 * np.max(np.abs(muref))
+
+
+def test_p2p_halo_exchange_three_ranks_matches_the_oracle():
+    """The point-to-point exchange (batch of isend/irecv per sweep, one segment per peer) on three
+    ranks: fixed-iteration Jacobi must reproduce the serial iteration on every rank's rows."""
+    res = _run(["polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "5"], gs=False, world=3,
+               use_halo="p2p")
+    par = importlib.import_module(PKG + ".parallel")
+    muref = res[0][6]
+    n = len(muref) // 3
+    counts, offs = par.split_rows(n, 3)
+    for (rank, mu, e, it, sw, st, _, itref, swref) in res:
+        assert it == itref == 5 and sw == swref == 6 and st == 0
+        sl = slice(3 * int(offs[rank]), 3 * int(offs[rank + 1]))
+        assert np.max(np.abs(mu[sl] - muref[sl])) < 1e-12 * np.max(np.abs(muref))
+    assert max(abs(r[2] - res[0][2]) for r in res) < 1e-12 * abs(res[0][2])
+
+
+def test_p2p_plan_of_slabs_has_two_peers_and_covers_all_visible_atoms():
+    par = importlib.import_module(PKG + ".parallel")
+    rng = np.random.default_rng(1)
+    L = np.array([20.0, 20.0, 120.0])
+    n, world = 6000, 6
+    x = rng.uniform(0, 1, (n, 3)) * L
+    x = x[np.argsort(x[:, 2])]
+    counts, offs = par.split_rows(n, world)
+    plan = par.P2PHaloPlan(x, L, offs, reach=5.0)
+    for q in range(world):
+        assert sorted(plan.peers(q)) == sorted({(q - 1) % world, (q + 1) % world})
+        own = np.arange(offs[q], offs[q + 1])
+        for r in plan.peers(q):
+            other = np.arange(offs[r], offs[r + 1])
+            d = x[own][:, None, :] - x[other][None, :, :]
+            d -= L * np.round(d / L)
+            near = own[(np.sum(d * d, axis=2) < 25.0).any(axis=1)]
+            assert set(near.tolist()) <= set(plan.send[q][r].tolist())
+            assert len(plan.send[q][r]) < 0.5 * len(own)
 
 
 def test_halo_plan_selects_boundary_layers_of_slabs():
