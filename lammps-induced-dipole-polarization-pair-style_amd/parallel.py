@@ -256,8 +256,29 @@ def exchange_mu(backend, dist, counts, offs, rank, gather_buf):
         backend.set_mu(int(offs[r]), int(offs[r + 1]), seg)
 
 
+class SweepTimer:
+    """HIP events (torch's current stream = the library's stream) around every sweep of a step, read
+    after the timed region: the per-launch time of the dominant kernel for bench.py's roofline."""
+
+    def __init__(self, torch):
+        self.torch, self.pairs = torch, []
+
+    def start(self):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._a = e
+
+    def stop(self):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.pairs.append((self._a, e))
+
+    def total_ms(self):
+        return float(sum(a.elapsed_time(b) for a, b in self.pairs))
+
+
 def run_step(backend, dist, rank, world, counts, offs, eflag=1, vflag=2, check_every=4, gather_buf=None,
-             halo=None):
+             halo=None, timer=None):
     """One Pair::compute across ``world`` ranks.  Returns the globally reduced result dict.
     ``halo`` = (HaloPlan, buffers) switches the dipole exchange from "all owned rows" to halo rows."""
     maxc = max(counts)
@@ -279,7 +300,11 @@ def run_step(backend, dist, rank, world, counts, offs, eflag=1, vflag=2, check_e
     sweeps = 0
     if not backend.zodid:
         for sw in range(backend.max_it + 1):
+            if timer is not None:
+                timer.start()
             backend.sweep()
+            if timer is not None:
+                timer.stop()
             if world > 1 and not backend.fixed:
                 chg = backend.local_change()
                 dist.all_reduce(chg)
@@ -343,14 +368,23 @@ def bench_distributed(args, rank, world, local_rank):
         out = run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo)
     dist.barrier()
     torch.cuda.synchronize()
+    timer = SweepTimer(torch)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo)
+        out = run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo, timer=timer)
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    # roofline of the dominant kernel on this rank (same accounting as the single-GPU line, bench.py)
+    launches = max(len(timer.pairs), 1) * max(out["ncolors"], 1)
+    ms_launch = timer.total_ms() / launches
+    rows_own = int(np.count_nonzero(s.alpha[lo:hi]))
+    pairs_rank = out["dd_pairs"] / world          # dd_pairs was all-reduced; weak scaling: equal shares
+    bytes_launch = (4.0 * pairs_rank + 112.0 * rows_own) / max(out["ncolors"], 1)
+    stream_launch = (12.0 * pairs_rank + 112.0 * rows_own) / max(out["ncolors"], 1)
+    achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
     if rank == 0:
         line = {
             "metric": "atom-steps/sec", "value": n_total * args.steps / dt, "unit": "atom-steps/s", "n_gpus": world,
@@ -363,6 +397,11 @@ def bench_distributed(args, rank, world, local_rank):
                        "natoms": n_total, "sweeps": out["sweeps"], "colors": out["ncolors"],
                        "dd_pairs": out["dd_pairs"], "eng_pol": out["eng_pol"],
                        "halo_rows_per_rank": plan.counts, "rows_per_rank": counts},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "kernel": "k_field_quad (dipole-field sweep, one launch per colour phase; rank 0)",
+                         "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch,
+                         "streamed_bytes_per_launch": stream_launch,
+                         "streamed_frac": stream_launch / (ms_launch * 1e-3) / 1e9 / 8000.0},
         }
         print(json.dumps(line))
     dist.destroy_process_group()
