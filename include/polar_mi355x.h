@@ -22,6 +22,8 @@ extern "C" {
 
 #define POLAR_OK 0
 #define POLAR_WARN_NOT_CONVERGED 1 /* PS.cpp:1227-1235: mu reset to alpha*E, warning text in polar_last_warning */
+#define POLAR_RETRY_STEP 2         /* polar_step_finish only: a list row outgrew its pitch; the pitch was enlarged, the
+                                      results of this step are void and the driver repeats the step (all ranks together) */
 #define POLAR_ERR_INPUT -1         /* reference error->all() conditions; message = reference text */
 #define POLAR_ERR_NO_DEVICE -2
 #define POLAR_ERR_HIP -3

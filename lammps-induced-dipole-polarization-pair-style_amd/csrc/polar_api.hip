@@ -243,7 +243,28 @@ void build_lists(polar_handle *h) {
   const CellGrid &g = h->grid;
   if (h->nl_pitch == 0 && getenv("POLAR_INIT_PITCH")) h->nl_pitch = h->dd_pitch = ((std::max(64, atoi(getenv("POLAR_INIT_PITCH"))) + 63) / 64) * 64;  // tests: force the overflow path
   if (h->nl_pitch == 0) {  // first build: 1.5x the mean sphere population, rounded to 64
+    // density over the OCCUPIED part of the box (a shard handle holds one slab plus its halo, not the
+    // whole box): count the non-empty cells of a coarse host grid with edge ~cutoff
     double vol = h->box.prd[0] * h->box.prd[1] * h->box.prd[2];
+    {
+      int nc[3];
+      long long tot = 1;
+      for (int k = 0; k < 3; k++) { nc[k] = std::max(1, std::min(64, (int)(h->box.prd[k] / cutall))); tot *= nc[k]; }
+      std::vector<char> occ((size_t)tot, 0);
+      for (int a = 0; a < n; a++) {
+        long long c = 0, mul = 1;
+        for (int k = 0; k < 3; k++) {
+          double fr = (h->hx[3 * (size_t)a + k] - h->grid.lo[k]) / h->box.prd[k];
+          fr -= std::floor(fr);
+          c += mul * std::min(nc[k] - 1, (int)(fr * nc[k]));
+          mul *= nc[k];
+        }
+        occ[(size_t)c] = 1;
+      }
+      long long filled = 0;
+      for (char v : occ) filled += v;
+      if (filled > 0) vol *= (double)filled / (double)tot;
+    }
     double mean = n / vol * 4.18879020478639 * cutall * cutall * cutall;
     h->nl_pitch = h->dd_pitch = (((long long)(1.5 * mean) + 64) / 64 + 1) * 64;
   }
@@ -1346,7 +1367,9 @@ int polar_step_finish(polar_handle *h, polar_result *out) {
     if (h->h_flags[0] != 0) {  // the driver must redo the step (all ranks see their own flag)
       const long long need = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
       h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
-      return fail(h, POLAR_ERR_STATE, "neighbor list pitch overflow: pitch enlarged, repeat the step");
+      out->status = POLAR_RETRY_STEP;
+      h->warn = "neighbor list pitch overflow: pitch enlarged, repeat the step";
+      return POLAR_RETRY_STEP;
     }
     return rc;
   });

@@ -181,12 +181,23 @@ class P2PHaloPlan:
     def peers(self, rank):
         return [r for r in range(self.world) if r != rank and (len(self.send[rank][r]) or len(self.send[r][rank]))]
 
+    def halo_of(self, rank):
+        """Global ids of the atoms rank ``rank`` receives, in the order the exchange delivers them."""
+        peers = self.peers(rank)
+        return np.concatenate([self.send[r][rank] for r in peers]) if peers else np.zeros(0, dtype=np.int32)
 
-def p2p_buffers(backend, plan, rank):
-    """Device index lists and packed buffers of one rank: segments ordered by peer."""
+
+def p2p_buffers(backend, plan, rank, compact_lo=None):
+    """Device index lists and packed buffers of one rank: segments ordered by peer.
+    ``compact_lo``: the handle holds only [own | halo | ghosts] (workload.compact_shard) -- own atom g
+    is row g - compact_lo and the received atoms are rows n_own, n_own + 1, ... in delivery order."""
     peers = plan.peers(rank)
     out_idx = np.concatenate([plan.send[rank][r] for r in peers]) if peers else np.zeros(0, dtype=np.int32)
     in_idx = np.concatenate([plan.send[r][rank] for r in peers]) if peers else np.zeros(0, dtype=np.int32)
+    if compact_lo is not None:
+        n_own = backend.hi - backend.lo
+        out_idx = (out_idx - compact_lo).astype(np.int32)
+        in_idx = (n_own + np.arange(len(in_idx))).astype(np.int32)
     seg_out = np.concatenate([[0], np.cumsum([len(plan.send[rank][r]) for r in peers])]).astype(int)
     seg_in = np.concatenate([[0], np.cumsum([len(plan.send[r][rank]) for r in peers])]).astype(int)
     return dict(peers=peers, seg_out=seg_out, seg_in=seg_in,
@@ -277,10 +288,31 @@ class SweepTimer:
         return float(sum(a.elapsed_time(b) for a, b in self.pairs))
 
 
+POLAR_RETRY_STEP = 2  # include/polar_mi355x.h
+
+
 def run_step(backend, dist, rank, world, counts, offs, eflag=1, vflag=2, check_every=4, gather_buf=None,
              halo=None, timer=None):
     """One Pair::compute across ``world`` ranks.  Returns the globally reduced result dict.
-    ``halo`` = (HaloPlan, buffers) switches the dipole exchange from "all owned rows" to halo rows."""
+    A rank whose neighbor rows outgrew their pitch reports POLAR_RETRY_STEP; the flag is max-reduced so
+    that ALL ranks repeat the step together (collectives stay matched)."""
+    for attempt in range(5):
+        out = _run_step_once(backend, dist, rank, world, counts, offs, eflag, vflag, check_every, gather_buf, halo,
+                             timer)
+        retry = 1.0 if out.get("status") == POLAR_RETRY_STEP else 0.0
+        if world > 1:
+            t = backend.scalars_tensor([retry])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            retry = float(t.cpu().numpy()[0])
+        if retry == 0.0:
+            return out
+        if timer is not None:
+            timer.pairs.clear()
+    raise RuntimeError("neighbor list pitch overflow persists")
+
+
+def _run_step_once(backend, dist, rank, world, counts, offs, eflag, vflag, check_every, gather_buf, halo, timer):
+    """``halo`` = (HaloPlan | P2PHaloPlan, buffers) switches the dipole exchange from "all owned rows" to halo rows."""
     maxc = max(counts)
     if halo is not None:
         plan, hb = halo
@@ -351,18 +383,29 @@ def bench_distributed(args, rank, world, local_rank):
     n_total = 1349 * reps[0] * reps[1] * reps[2]
     counts, offs = split_rows(n_total, world)
     lo, hi = int(offs[rank]), int(offs[rank + 1])
-    s = wl.replicate_fixture(os.path.join(root, "tests", "golden", "mof5_h2.npz"), *reps, extra_args=extra,
-                             rows=np.arange(lo, hi), full=True)
-    p = pkg.pair_from_system(s, device=local_rank)
-    be = HipShardBackend(p, lo, hi, local_rank)
-    # halo plan from the replicated coordinates: reach = list cutoff + the neighbor skin
-    # point-to-point face layers between slab neighbours (default) or one all-gather of every halo
-    if os.environ.get("POLAR_HALO_MODE", "p2p") == "allgather":
-        plan = HaloPlan(s.x[:s.nlocal], s.prd, offs, cut + 2.0)
+    sg = wl.replicate_fixture(os.path.join(root, "tests", "golden", "mof5_h2.npz"), *reps, extra_args=extra,
+                              rows=np.arange(lo, hi), full=True)
+    # reach = the neighbor-list cutoff of the LJ/Coulomb rows (max cut + skin) -- it covers the dd cutoff
+    reach = float(sg.extra["cutneigh"]) + 1e-6
+    mode = os.environ.get("POLAR_HALO_MODE", "p2p")
+    if mode == "allgather" or world == 1:
+        # every rank holds ALL atoms and owns the rows [lo, hi); one all-gather of the halos per sweep
+        s = sg
+        p = pkg.pair_from_system(s, device=local_rank)
+        be = HipShardBackend(p, lo, hi, local_rank)
+        plan = HaloPlan(s.x[:s.nlocal], s.prd, offs, reach)
         halo = (plan, halo_buffers(be, plan, rank)) if world > 1 else None
+        rows_own = int(np.count_nonzero(s.alpha[lo:hi]))
     else:
-        plan = P2PHaloPlan(s.x[:s.nlocal], s.prd, offs, cut + 2.0)
-        halo = (plan, p2p_buffers(be, plan, rank)) if world > 1 else None
+        # default: every rank holds only [own | halo | ghosts] (per-step cost independent of the number of
+        # ranks) and exchanges face layers point-to-point with its slab neighbours
+        plan = P2PHaloPlan(sg.x[:sg.nlocal], sg.prd, offs, reach)
+        s = wl.compact_shard(sg, np.arange(lo, hi), plan.halo_of(rank))
+        p = pkg.pair_from_system(s, device=local_rank)
+        be = HipShardBackend(p, 0, hi - lo, local_rank)
+        halo = (plan, p2p_buffers(be, plan, rank, compact_lo=lo))
+        rows_own = int(np.count_nonzero(s.alpha[:hi - lo]))
+    del sg
     gbuf = None
     for _ in range(args.warmup):
         out = run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo)
@@ -381,7 +424,6 @@ def bench_distributed(args, rank, world, local_rank):
     # roofline of the dominant kernel on this rank (same accounting as the single-GPU line, bench.py)
     launches = max(len(timer.pairs), 1) * max(out["ncolors"], 1)
     ms_launch = timer.total_ms() / launches
-    rows_own = int(np.count_nonzero(s.alpha[lo:hi]))
     pairs_rank = out["dd_pairs"] / world          # dd_pairs was all-reduced; weak scaling: equal shares
     bytes_launch = (4.0 * pairs_rank + 112.0 * rows_own) / max(out["ncolors"], 1)
     stream_launch = (12.0 * pairs_rank + 112.0 * rows_own) / max(out["ncolors"], 1)

@@ -401,6 +401,43 @@ def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings,
                "exclude_intra": bool(exclude_intra)})
 
 
+def compact_shard(s, own, halo):
+    """The part of a replicated system ONE rank needs: its own atoms (rows), the halo atoms other
+    ranks own but its rows can see, and the ghost images its LJ/Coulomb rows reference -- in that
+    order, with the neighbor rows of ``own`` re-indexed.  The global box is kept (minimum image
+    still resolves the periodic wrap between the first and the last slab).
+    ``s`` must carry list rows for ``own`` (replicate_fixture(rows=own, full=True))."""
+    own = np.asarray(own, dtype=np.int64)
+    halo = np.asarray(halo, dtype=np.int64)
+    n, nall = s.nlocal, s.nlocal + s.nghost
+    seg = [(int(s.firstneigh[i]), int(s.numneigh[i])) for i in own]
+    flat = np.concatenate([s.neigh[a:a + c] for a, c in seg]) if seg else np.zeros(0, dtype=np.int32)
+    u = flat.view(np.uint32)
+    jm = (u & np.uint32(NEIGHMASK)).astype(np.int64)
+    bits = u & np.uint32(0xC0000000)
+    ghosts = np.unique(jm[jm >= n])
+    lut = np.full(nall, -1, dtype=np.int64)
+    lut[own] = np.arange(len(own))
+    lut[halo] = len(own) + np.arange(len(halo))
+    lut[ghosts] = len(own) + len(halo) + np.arange(len(ghosts))
+    jc = lut[jm]
+    if np.any(jc < 0):
+        raise ValueError("a neighbor of an owned row is neither owned, halo nor ghost: halo reach too small")
+    neigh = (jc.astype(np.uint32) | bits).view(np.int32)
+    keep = np.concatenate([own, halo, ghosts])
+    nloc = len(own) + len(halo)
+    numneigh = np.zeros(nloc, dtype=np.int32)
+    numneigh[:len(own)] = [c for _, c in seg]
+    first = np.zeros(nloc, dtype=np.int64)
+    first[:len(own)] = np.concatenate([[0], np.cumsum(numneigh[:len(own)])])[:-1]
+    return PolarSystem(
+        nlocal=nloc, nghost=len(ghosts), x=np.ascontiguousarray(s.x[keep]), q=s.q[keep].copy(), alpha=s.alpha[keep].copy(),
+        type=s.type[keep].copy(), molecule=s.molecule[keep].copy(), boxlo=s.boxlo, prd=s.prd, ntypes=s.ntypes,
+        tables=s.tables, coul=s.coul, g_ewald=s.g_ewald, qqrd2e=s.qqrd2e, special_lj=s.special_lj,
+        special_coul=s.special_coul, ilist=np.arange(len(own), dtype=np.int32), numneigh=numneigh, firstneigh=first,
+        neigh=neigh, settings=s.settings, owner=None, name=s.name + "_shard", extra=dict(s.extra, n_own=len(own)))
+
+
 def lammps_special_arrays(n, special):
     """{(i,j): which} -> atom->nspecial [n][3] (cumulative 1-2, 1-3, 1-4 counts) and atom->special
     [n][maxspecial] (partner TAGS = index + 1, ordered 1-2 | 1-3 | 1-4), the layout

@@ -3,6 +3,7 @@
   (b) the CPU oracle on the same inputs.
 Bar (BASELINE.json north_star): per-atom forces and energies within 1e-5 relative of the
 reference.  The asserts below use 1e-7 -- FP64 kernels should clear the bar by two orders."""
+import copy
 import os
 
 import numpy as np
@@ -309,3 +310,74 @@ def test_device_neighbor_build_matches_uploaded_list(case, wl, pkg, oracle):
     again = p.compute(eflag=1, vflag=2)
     assert np.max(np.abs(again["f"] - ref["f"])) < 1e-9 * np.max(np.abs(ref["f"]))
     p.close()
+
+
+def test_compact_shards_with_point_to_point_halos_match_single_handle(wl, pkg, oracle):
+    """The default multi-GPU layout on ONE GPU: three handles that each hold only [own | halo | ghosts]
+    (workload.compact_shard), stepped in lock-step with the point-to-point index lists of
+    parallel.p2p_buffers (loopback in place of isend/irecv), against the unsharded handle."""
+    import importlib
+    import torch
+    par = importlib.import_module(pkg.__name__ + ".parallel")
+    extra = ["use_previous", "no", "dd_cutoff", "12.8345", "precision", "1e-13", "max_iterations", "200"]
+    path = os.path.join(GOLD, "mof5_h2.npz")
+    s = wl.replicate_fixture(path, 1, 1, 4, extra_args=extra)            # 5,396 atoms, z slabs of one cell each
+    ref = pkg.pair_from_system(s).compute()
+    fref = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
+    world = 4
+    counts, offs = par.split_rows(s.nlocal, world)
+    sfull = wl.replicate_fixture(path, 1, 1, 4, extra_args=extra, rows=np.arange(s.nlocal), full=True)
+    reach = float(sfull.extra["cutneigh"]) + 1e-6
+    plan = par.P2PHaloPlan(s.x[:s.nlocal], s.prd, offs, reach)
+    bes, bufs, shards = [], [], []
+    for r in range(world):
+        lo, hi = int(offs[r]), int(offs[r + 1])
+        sc = wl.compact_shard(sfull, np.arange(lo, hi), plan.halo_of(r))
+        p = pkg.pair_from_system(sc)
+        be = par.HipShardBackend(p, 0, hi - lo, 0)
+        bes.append(be); shards.append(sc)
+        bufs.append(par.p2p_buffers(be, plan, r, compact_lo=lo))
+
+    def exchange():
+        for r, be in enumerate(bes):
+            be.gather_idx(bufs[r]["idx_out"], bufs[r]["send"])
+        for r in range(world):           # loopback delivery: segment k of rank r's recv <- peer's segment for r
+            for k, q in enumerate(bufs[r]["peers"]):
+                kq = bufs[q]["peers"].index(r)
+                a, b = 3 * bufs[r]["seg_in"][k], 3 * bufs[r]["seg_in"][k + 1]
+                c, d = 3 * bufs[q]["seg_out"][kq], 3 * bufs[q]["seg_out"][kq + 1]
+                assert b - a == d - c
+                bufs[r]["recv"][a:b] = bufs[q]["send"][c:d]
+        for r, be in enumerate(bes):
+            be.scatter_idx(bufs[r]["idx_in"], bufs[r]["recv"])
+
+    for be in bes:
+        be.begin(1, 2)
+    exchange()
+    for sw in range(bes[0].max_it + 1):
+        for be in bes:
+            be.sweep()
+        tot = sum(be.local_change().clone() for be in bes)
+        for be in bes:
+            be.sweep_end(tot)
+        exchange()
+        if sw % 4 == 3 and all(be.state()[0] for be in bes):
+            break
+    outs = [be.finish() for be in bes]
+    torch.cuda.synchronize()
+    f = np.zeros((s.nlocal, 3)); mu = np.zeros((s.nlocal, 3))
+    assert all(sc.nlocal < 0.9 * s.nlocal for sc in shards)      # the shards really are compact
+    for r, be in enumerate(bes):
+        lo, hi = int(offs[r]), int(offs[r + 1])
+        nloc = shards[r].nlocal
+        fr = be.pair.download("f", 3 * (nloc + shards[r].nghost)).reshape(-1, 3)
+        f[lo:hi] = fr[:hi - lo]
+        assert np.all(fr[hi - lo:] == 0)                       # halo and ghost atoms receive no force
+        mu[lo:hi] = be.pair.download("mu", 3 * nloc).reshape(-1, 3)[:hi - lo]
+    assert np.max(np.abs(mu - ref["mu"])) / np.max(np.abs(ref["mu"])) < 1e-8
+    assert force_rel_err(f, fref) < 1e-8
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert rel(sum(o[k] for o in outs), ref[k]) < 1e-9
+    vir = sum(o["virial"] for o in outs)
+    assert np.max(np.abs(vir - ref["virial"])) < 1e-8 * np.max(np.abs(ref["virial"]))
+    assert len({o["iterations"] for o in outs}) == 1

@@ -105,6 +105,10 @@ class NumpyShardBackend:
         return self.done, self.iterations, self.status
 
     def finish(self):
+        if getattr(self, "retry_once", False):   # emulate POLAR_RETRY_STEP (a list row outgrew its pitch)
+            self.retry_once = False
+            return dict(eng_vdwl=0.0, eng_coul=0.0, eng_pol=0.0, u_self=0.0, u_ef=0.0, u_dd=0.0, virial=np.zeros(6),
+                        dd_pairs=0, iterations=0, sweeps=0, status=2, ncolors=0)
         s = slice(3 * self.lo, 3 * self.hi)
         u = -0.5 * float(self.E[s] @ self.mu[s])
         return dict(eng_vdwl=0.0, eng_coul=0.0, eng_pol=u, u_self=0.0, u_ef=0.0, u_dd=0.0, virial=np.zeros(6),
@@ -150,6 +154,9 @@ def _worker(rank, world, port, extra, gs, q, use_halo=False):
     be = NumpyShardBackend(T, E, s.alpha[:s.nlocal].copy(), int(offs[rank]), int(offs[rank + 1]), gs,
                            bool(st.fixed_iteration), st.iterations_max, st.polar_precision, st.polar_gamma)
     halo = None
+    if use_halo == "retry":   # rank 1 alone reports an overflow on its first attempt: both ranks must repeat
+        be.retry_once = rank == 1
+        use_halo = False
     if use_halo == "p2p":  # point-to-point form: every other rank is a peer and gets all owned rows
         plan = par.P2PHaloPlan(s.x[:s.nlocal], s.prd, offs, reach=1.0e9)
         assert plan.counts == [c * (world - 1) for c in counts] and plan.peers(rank) == [r for r in range(world) if r != rank]
@@ -230,6 +237,17 @@ def test_halo_exchange_path_matches_full_exchange():
     half = 3 * ((n3 // 3 + 1) // 2)
     assert np.max(np.abs(mu0[:half] - muref[:half])) < 1e-12 * np.max(np.abs(muref))
     assert np.max(np.abs(mu1[half:] - muref[half:])) < 1e-12 * np.max(np.abs(muref))
+
+
+def test_one_rank_asking_for_a_retry_makes_every_rank_repeat_the_step():
+    res = _run(["polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "5"], gs=False, use_halo="retry")
+    (r0, mu0, e0, it0, sw0, st0, muref, itref, swref), (r1, mu1, e1, it1, sw1, st1, _, _, _) = res
+    assert st0 == st1 == 0 and it0 == it1 == itref == 5
+    n3 = len(muref)
+    half = 3 * ((n3 // 3 + 1) // 2)
+    assert np.max(np.abs(mu0[:half] - muref[:half])) < 1e-12 * np.max(np.abs(muref))
+    assert np.max(np.abs(mu1[half:] - muref[half:])) < 1e-12 * np.max(np.abs(muref))
+    assert abs(e0 - e1) < 1e-12 * abs(e0)
 
 
 def test_p2p_halo_exchange_three_ranks_matches_the_oracle():
