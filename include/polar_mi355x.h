@@ -176,6 +176,9 @@ int polar_upload_mu(polar_handle *h, const double *mu, long long n);
 /* run all kernels on this HIP stream (e.g. torch's current stream) instead of the private one */
 int polar_set_stream(polar_handle *h, void *hip_stream);
 int polar_set_row_range(polar_handle *h, int lo, int hi); /* hi < 0: all rows */
+/* the N of the stop rule sum(dmu^2)/(3N) <= precision^2 (PS.cpp:1194-1210) when the handle holds only a
+ * part of the system (own + halo atoms): the global atom count, identical on every rank; 0 = nlocal */
+int polar_set_global_count(polar_handle *h, long long natoms);
 /* 1: the LJ/coul list is a LAMMPS *full* list (each pair in both rows): force on i only, tallies halved */
 int polar_set_list_style(polar_handle *h, int full);
 /* compute() split at the exchange points: begin = list build, LJ+coul, static field, initial guess */
@@ -194,6 +197,17 @@ int polar_mu_scatter(polar_handle *h, long long lo, long long hi, const double *
 int polar_mu_gather_idx(polar_handle *h, const int *dev_idx, long long n, double *dev_dst);
 int polar_mu_scatter_idx(polar_handle *h, const int *dev_idx, long long n, const double *dev_src);
 int polar_change_export(polar_handle *h, double *dev_dst); /* this handle's running sum of (dmu)^2 */
+/* Host-pointer forms of the exchange, for a host whose communication layer works on host arrays
+ * (LAMMPS: Comm::forward_comm_pair -> Pair::pack_forward_comm / unpack_forward_comm, src/pair.h:165-166,
+ * one MPI rank per GPU; lammps_shim/ uses them):
+ *   polar_step_mu_get      dipoles of the rows [lo,hi) -> mu_host [(hi-lo)][3]      (synchronises)
+ *   polar_step_mu_put_idx  mu_host [n][3] -> the atoms idx[0..n) (handle-local indices, host array)
+ *   polar_step_change_get  this handle's sum of (dmu)^2 of the sweep -> *sum        (synchronises)
+ *   polar_step_sweep_end_host  end-of-sweep control with the globally reduced sum passed by value */
+int polar_step_mu_get(polar_handle *h, long long lo, long long hi, double *mu_host);
+int polar_step_mu_put_idx(polar_handle *h, long long n, const int *idx_host, const double *mu_host);
+int polar_step_change_get(polar_handle *h, double *sum);
+int polar_step_sweep_end_host(polar_handle *h, double global_change);
 
 #ifdef __cplusplus
 }

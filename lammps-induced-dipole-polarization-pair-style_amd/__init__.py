@@ -102,6 +102,11 @@ EXPORTS = {
     "polar_upload_mu": (C.c_int, [C.c_void_p, _dp, C.c_longlong]),
     "polar_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "polar_set_row_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "polar_set_global_count": (C.c_int, [C.c_void_p, C.c_longlong]),
+    "polar_step_mu_get": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, _dp]),
+    "polar_step_mu_put_idx": (C.c_int, [C.c_void_p, C.c_longlong, _ip, _dp]),
+    "polar_step_change_get": (C.c_int, [C.c_void_p, _dp]),
+    "polar_step_sweep_end_host": (C.c_int, [C.c_void_p, C.c_double]),
     "polar_set_list_style": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_step_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "polar_step_sweep": (C.c_int, [C.c_void_p]),

@@ -113,6 +113,8 @@ struct polar_handle {
   double color_dist = 2.6;
   int field_block = 256;
   double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // locals + ghosts, recorded by polar_set_atoms
+  long long global_count = 0;  // N of the stop rule when the handle holds a part of the system (0: nlocal)
+  DBuf<double> d_xchg; DBuf<int> d_xidx;  // staging of the host-pointer exchange forms
   bool device_list = false;  // the a3 list was built by polar_build_neighbors (always a full list)
   int user_full_list = 0;    // polar_set_list_style for uploaded lists
   long long lj_pitch = 0;
@@ -200,6 +202,7 @@ void upload_coul(polar_handle *h, double g_ewald, double qqrd2e, const double *s
 // ---- cutoff-mode: cell sort (perm/inv), then CSR lists in s space, all on the device ----------
 inline int own_lo(const polar_handle *h) { return h->row_lo; }
 inline int own_n(const polar_handle *h) { return (h->row_hi < 0 ? h->nlocal : h->row_hi) - h->row_lo; }
+inline int norm_count(const polar_handle *h) { return (int)(h->global_count > 0 ? h->global_count : h->nlocal); }
 inline bool sharded(const polar_handle *h) { return own_n(h) != h->nlocal; }
 // rows a per-row kernel should visit: nullptr = all rows 0..n-1 (identity)
 inline const int *own_rows(const polar_handle *h) { return (h->sorted && sharded(h)) ? h->d_ownrows.p : nullptr; }
@@ -582,7 +585,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
       sweep_once(h, ap);
       if (lazy && sw < max_sweeps - 2) continue;
       const int count = (lazy && sw == max_sweeps - 2) ? max_sweeps - 1 : 1;
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
@@ -598,7 +601,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
         k_gs_seq_T6<<<1, 64, 0, s>>>(n, b0, h->d_T6.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
         k_gs_push_T6<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_T6.p, h->d_rec0.p, h->d_dmu.p, h->d_F.p, h->d_scal.p);
       }
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
@@ -629,7 +632,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
           k_gs_block_push<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_order.p, h->d_pos.p, h->d_rec0.p, h->box, st.polar_damp, h->d_dmu.p, h->d_F.p, h->d_scal.p);
         }
       }
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, n, st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
@@ -919,6 +922,7 @@ int polar_destroy(polar_handle *h) {
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1}) if (e) (void)hipEventDestroy(e);
     h->d_ljpos.release(); h->d_ljaux.release(); h->d_tag.release(); h->d_nspecial.release(); h->d_special.release();
     h->d_ljcell_id.release(); h->d_ljcell_cnt.release(); h->d_ljcell_fill.release(); h->d_ljcell_first.release(); h->d_cutneighsq.release();
+    h->d_xchg.release(); h->d_xidx.release();
     h->d_eatom.release(); h->d_vatom.release(); h->d_dd_r2.release(); h->d_fpol.release();
     h->d_x.release(); h->d_q.release(); h->d_alpha.release(); h->d_f.release(); h->d_ef.release(); h->d_F.release();
     h->d_mu.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
@@ -1312,6 +1316,12 @@ int polar_set_row_range(polar_handle *h, int lo, int hi) {
     return POLAR_OK;
   });
 }
+int polar_set_global_count(polar_handle *h, long long natoms) {
+  if (!h) return POLAR_ERR_STATE;
+  if (natoms < 0 || natoms > 2147483647LL) return fail(h, POLAR_ERR_INPUT, "bad global atom count");
+  h->global_count = natoms;
+  return POLAR_OK;
+}
 int polar_set_list_style(polar_handle *h, int full) {
   if (!h) return POLAR_ERR_STATE;
   h->user_full_list = full ? 1 : 0;
@@ -1342,7 +1352,7 @@ int polar_step_sweep_end(polar_handle *h, const double *dev_global_change) {
     if (!h->in_step) throw std::runtime_error("polar_step_sweep_end outside polar_step_begin/finish");
     const polar_settings &st = h->ph.st;
     const bool gs = st.polar_gs || st.polar_gs_ranked;
-    k_solver_step<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, h->nlocal, st.fixed_iteration, st.iterations_max, st.polar_precision,
+    k_solver_step<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
                                           gs ? 0 : 1, dev_global_change, 1);
     return POLAR_OK;
   });
@@ -1408,6 +1418,58 @@ int polar_change_export(polar_handle *h, double *dev_dst) {
     k_fold_change<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, dev_dst);
     return POLAR_OK;
   });
+}
+
+int polar_step_mu_get(polar_handle *h, long long lo, long long hi, double *mu_host) {
+  return guarded(h, [&]() {
+    need_device(h);
+    if (!mu_host || lo < 0 || hi < lo || hi > h->nlocal) throw InputError("polar_step_mu_get: bad range or null pointer");
+    const size_t cnt = 3 * (size_t)(hi - lo);
+    if (cnt == 0) return (int)POLAR_OK;
+    h->d_xchg.ensure(cnt);
+    k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_xchg.p);
+    HIPCHECK(hipMemcpyAsync(mu_host, h->d_xchg.p, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return (int)POLAR_OK;
+  });
+}
+int polar_step_mu_put_idx(polar_handle *h, long long n, const int *idx_host, const double *mu_host) {
+  return guarded(h, [&]() {
+    need_device(h);
+    if (n < 0 || (n > 0 && (!idx_host || !mu_host))) throw InputError("polar_step_mu_put_idx: null pointer");
+    if (n == 0) return (int)POLAR_OK;
+    for (long long k = 0; k < n; k++)
+      if (idx_host[k] >= h->nlocal) throw InputError("polar_step_mu_put_idx: atom index out of range");
+    h->d_xchg.ensure(3 * (size_t)n); h->d_xidx.ensure((size_t)n);
+    HIPCHECK(hipMemcpyAsync(h->d_xidx.p, idx_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->d_xchg.p, mu_host, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    k_mu_scatter_idx<<<nblk(n, 256), 256, 0, h->stream>>>(n, h->d_xidx.p, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_xchg.p, own_lo(h), own_lo(h) + own_n(h));
+    HIPCHECK(hipStreamSynchronize(h->stream));  // the host buffers may be reused by the caller
+    return (int)POLAR_OK;
+  });
+}
+int polar_step_change_get(polar_handle *h, double *sum) {
+  return guarded(h, [&]() {
+    need_device(h);
+    if (!sum) throw InputError("polar_step_change_get: null pointer");
+    h->d_xchg.ensure(8);
+    k_fold_change<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, h->d_xchg.p);
+    HIPCHECK(hipMemcpyAsync(sum, h->d_xchg.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return (int)POLAR_OK;
+  });
+}
+int polar_step_sweep_end_host(polar_handle *h, double global_change) {
+  if (!h) return POLAR_ERR_STATE;
+  int rc = guarded(h, [&]() {
+    need_device(h);
+    h->d_xchg.ensure(8);
+    HIPCHECK(hipMemcpyAsync(h->d_xchg.p + 4, &global_change, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));  // global_change lives on the caller's stack
+    return (int)POLAR_OK;
+  });
+  if (rc < 0) return rc;
+  return polar_step_sweep_end(h, h->d_xchg.p + 4);
 }
 
 }  // extern "C"

@@ -42,7 +42,9 @@ def split_rows(n, world):
 class HipShardBackend:
     """Product backend: the HIP library driven step-wise on torch's current stream."""
 
-    def __init__(self, pair, lo, hi, device):
+    def __init__(self, pair, lo, hi, device, global_count=0):
+        """``global_count``: the atom count of the WHOLE system when the handle holds only a part of it
+        (compact shards) -- it is the N of the stop rule sum(dmu^2)/(3N) and must agree on all ranks."""
         import torch
 
         self.torch = torch
@@ -50,6 +52,7 @@ class HipShardBackend:
         self.dev = torch.device("cuda", device)
         L, h = pair.L, pair.h
         pair._ck(L.polar_set_row_range(h, lo, hi))
+        pair._ck(L.polar_set_global_count(h, int(global_count)))
         pair._ck(L.polar_set_list_style(h, 1))
         pair._ck(L.polar_set_stream(h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
         self.n = pair.nlocal
@@ -402,7 +405,7 @@ def bench_distributed(args, rank, world, local_rank):
         plan = P2PHaloPlan(sg.x[:sg.nlocal], sg.prd, offs, reach)
         s = wl.compact_shard(sg, np.arange(lo, hi), plan.halo_of(rank))
         p = pkg.pair_from_system(s, device=local_rank)
-        be = HipShardBackend(p, 0, hi - lo, local_rank)
+        be = HipShardBackend(p, 0, hi - lo, local_rank, global_count=n_total)
         halo = (plan, p2p_buffers(be, plan, rank, compact_lo=lo))
         rows_own = int(np.count_nonzero(s.alpha[:hi - lo]))
     del sg

@@ -312,7 +312,8 @@ def test_device_neighbor_build_matches_uploaded_list(case, wl, pkg, oracle):
     p.close()
 
 
-def test_compact_shards_with_point_to_point_halos_match_single_handle(wl, pkg, oracle):
+@pytest.mark.parametrize("comm", ["device", "host"])
+def test_compact_shards_with_point_to_point_halos_match_single_handle(comm, wl, pkg, oracle):
     """The default multi-GPU layout on ONE GPU: three handles that each hold only [own | halo | ghosts]
     (workload.compact_shard), stepped in lock-step with the point-to-point index lists of
     parallel.p2p_buffers (loopback in place of isend/irecv), against the unsharded handle."""
@@ -334,7 +335,7 @@ def test_compact_shards_with_point_to_point_halos_match_single_handle(wl, pkg, o
         lo, hi = int(offs[r]), int(offs[r + 1])
         sc = wl.compact_shard(sfull, np.arange(lo, hi), plan.halo_of(r))
         p = pkg.pair_from_system(sc)
-        be = par.HipShardBackend(p, 0, hi - lo, 0)
+        be = par.HipShardBackend(p, 0, hi - lo, 0, global_count=s.nlocal)
         bes.append(be); shards.append(sc)
         bufs.append(par.p2p_buffers(be, plan, r, compact_lo=lo))
 
