@@ -7,6 +7,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mpi.h>
+#include <map>
+#include <vector>
+#include <algorithm>
 #include "pair_lj_cut_coul_long_polarization_mi355x.h"
 #include "atom.h"
 #include "comm.h"
@@ -40,8 +44,14 @@ PairLJCutCoulLongPolarizationMI355X::PairLJCutCoulLongPolarizationMI355X(LAMMPS 
   device_neigh = 0;
   cut_lj_global = cut_coul = 0.0;
   h = NULL;
+  // one MPI rank per GPU: the dipoles of ghost atoms travel through
+  // Comm::forward_comm_pair -> pack_forward_comm / unpack_forward_comm, 3 doubles per atom.
+  // (The reference declares pack_comm/unpack_comm but never calls them: it is single-process only.)
+  comm_forward = 3;
+  nhalo = 0;
   const char *dev = getenv("POLAR_DEVICE");
-  int rc = polar_create(dev ? atoi(dev) : 0, &h);
+  int ndev = polar_device_count();
+  int rc = polar_create(dev ? atoi(dev) : (ndev > 0 ? comm->me % ndev : 0), &h);
   if (rc < 0 || polar_device_count() < 1)
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization (MI355X) found no usable HIP device");
 }
@@ -70,6 +80,7 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
 {
   if (eflag || vflag) ev_setup(eflag,vflag);
   else evflag = vflag_fdotr = 0;
+  if (comm->nprocs > 1) { compute_sharded(eflag,vflag); return; }
   // what compute() reads through domain->, atom-> and list-> (PS.cpp:125-188)
   double tilt[3] = {domain->xy,domain->xz,domain->yz};
   int periodic[3] = {domain->xperiodic,domain->yperiodic,domain->zperiodic};
@@ -110,6 +121,174 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
   force->pair->eng_pol = res.eng_pol;   // PS.cpp:641 (zero on steps without eflag)
   if (vflag_global) for (int k = 0; k < 6; k++) virial[k] += res.virial[k];
   if (vflag_fdotr) virial_fdotr_compute();
+}
+
+/* ----------------------------------------------------------------------
+   More than one MPI rank (one rank per GPU).  The reference cannot do this at all: its
+   polarization loops run over local atoms only (PS.cpp:330-641).  Here every rank hands the library
+   [own atoms | halo atoms | remaining ghosts]: halo = one ghost per foreign atom (distinct tag not
+   owned by this rank); inside the GLOBAL periodic box the minimum image of an (own, halo) pair is the
+   image LAMMPS' ghost shell carries, provided the box is at least twice the cutoff (list mode,
+   keyword dd_cutoff).  The library sweeps the own rows (polar_set_row_range) and between sweeps the
+   dipoles make the round trip  device -> atom->mu_induced -> Comm::forward_comm_pair -> device.
+------------------------------------------------------------------------- */
+
+void PairLJCutCoulLongPolarizationMI355X::build_halo_map()
+{
+  const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
+  if (atom->map_style == 0)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization on several MPI ranks needs an atom map");
+  lib_of_lammps.assign(nall,-1);
+  halo_ghost.clear();
+  for (int i = 0; i < nlocal; i++) lib_of_lammps[i] = i;
+  std::map<tagint,int> seen;
+  std::vector<int> rest;
+  for (int g = nlocal; g < nall; g++) {
+    const int owner = atom->map(atom->tag[g]);           // closest image; an index < nlocal means "mine"
+    if (owner >= 0 && owner < nlocal) { rest.push_back(g); continue; }
+    if (seen.insert(std::make_pair(atom->tag[g],g)).second) halo_ghost.push_back(g);
+    else rest.push_back(g);
+  }
+  nhalo = (int) halo_ghost.size();
+  for (int k = 0; k < nhalo; k++) lib_of_lammps[halo_ghost[k]] = nlocal + k;
+  for (size_t k = 0; k < rest.size(); k++) lib_of_lammps[rest[k]] = nlocal + nhalo + (int) k;
+  lammps_of_lib.assign(nall,0);
+  for (int a = 0; a < nall; a++) lammps_of_lib[lib_of_lammps[a]] = a;
+
+  // the half list with its indices in library order (special bits kept), rows = own atoms
+  const int inum = list->inum;
+  std::vector<int> nn(nlocal + nhalo,0);
+  std::vector<long long> first(nlocal + nhalo,0);
+  long long total = 0;
+  for (int ii = 0; ii < inum; ii++) { const int i = list->ilist[ii]; first[i] = total; nn[i] = list->numneigh[i]; total += nn[i]; }
+  std::vector<int> flat((size_t) total + 1);
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = list->ilist[ii];
+    const int *jl = list->firstneigh[i];
+    for (int k = 0; k < nn[i]; k++)
+      flat[first[i] + k] = lib_of_lammps[jl[k] & NEIGHMASK] | (jl[k] & ~NEIGHMASK);
+  }
+  sh_n = nlocal + nhalo;
+  sh_nn.swap(nn); sh_first.swap(first); sh_flat.swap(flat);
+}
+
+void PairLJCutCoulLongPolarizationMI355X::exchange_dipoles()
+{
+  const int nlocal = atom->nlocal;
+  check(polar_step_mu_get(h,0,nlocal,&atom->mu_induced[0][0]));
+  comm->forward_comm_pair(this);                       // ghosts of atom->mu_induced now hold their owners' dipoles
+  sh_mu.resize(3 * (size_t) nhalo + 3);
+  sh_idx.resize((size_t) nhalo + 1);
+  for (int k = 0; k < nhalo; k++) {
+    const double *m = atom->mu_induced[halo_ghost[k]];
+    sh_mu[3*k] = m[0]; sh_mu[3*k+1] = m[1]; sh_mu[3*k+2] = m[2];
+    sh_idx[k] = nlocal + k;
+  }
+  check(polar_step_mu_put_idx(h,nhalo,sh_idx.data(),sh_mu.data()));
+}
+
+void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
+{
+  polar_settings pst;
+  check(polar_get_settings(h,&pst));
+  if (!(pst.dd_cutoff > 0.0))
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization on several MPI ranks needs the dd_cutoff keyword (list mode)");
+  if (device_neigh)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization: device_neigh is not available on several MPI ranks yet");
+  if (eflag_atom || vflag_atom)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization: per-atom tallies are not available on several MPI ranks yet");
+  const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
+  if (neighbor->ago == 0 || (int) lib_of_lammps.size() != nall) build_halo_map();
+
+  // per-atom inputs in library order
+  sh_x.resize(3 * (size_t) nall); sh_q.resize(nall); sh_a.resize(nall); sh_t.resize(nall); sh_m.resize(nall);
+  for (int k = 0; k < nall; k++) {
+    const int a = lammps_of_lib[k];
+    sh_x[3*k] = atom->x[a][0]; sh_x[3*k+1] = atom->x[a][1]; sh_x[3*k+2] = atom->x[a][2];
+    sh_q[k] = atom->q[a]; sh_a[k] = atom->static_polarizability[a];
+    sh_t[k] = atom->type[a]; sh_m[k] = (int) atom->molecule[a];
+  }
+  double tilt[3] = {domain->xy,domain->xz,domain->yz};
+  int periodic[3] = {domain->xperiodic,domain->yperiodic,domain->zperiodic};
+  check(polar_set_box(h,domain->boxlo,domain->prd,tilt,periodic,domain->triclinic));
+  check(polar_set_atoms(h,sh_n,nall - sh_n,sh_x.data(),sh_q.data(),sh_a.data(),sh_t.data(),sh_m.data()));
+  if (neighbor->ago == 0) {
+    std::vector<int> il(list->inum);
+    for (int ii = 0; ii < list->inum; ii++) il[ii] = list->ilist[ii];
+    check(polar_set_neighbors_csr(h,list->inum,il.data(),sh_nn.data(),sh_first.data(),sh_flat.data()));
+  }
+  check(polar_set_row_range(h,0,nlocal));
+  check(polar_set_global_count(h,(long long) atom->natoms));
+
+  const int ef = eflag_either ? 1 : 0, vf = vflag_global ? 1 : 0;
+  polar_result res;
+  for (int attempt = 0;; attempt++) {
+    check(polar_step_begin(h,ef,vf));
+    exchange_dipoles();                                // the other ranks' initial guess
+    if (!pst.zodid)
+      for (int sw = 0; sw <= pst.iterations_max; sw++) {
+        check(polar_step_sweep(h));
+        if (!pst.fixed_iteration) {                    // PS.cpp:1194-1210 with the sum over all ranks
+          double mine = 0.0, all = 0.0;
+          check(polar_step_change_get(h,&mine));
+          MPI_Allreduce(&mine,&all,1,MPI_DOUBLE,MPI_SUM,world);
+          check(polar_step_sweep_end_host(h,all));
+        } else check(polar_step_sweep_end(h,NULL));
+        exchange_dipoles();
+        if (!pst.fixed_iteration) {
+          int done = 0, it = 0, st = 0;
+          check(polar_step_state(h,&done,&it,&st));    // identical on every rank: same global sum
+          if (done) break;
+        }
+      }
+    int rc = polar_step_finish(h,&res);
+    int retry = rc == POLAR_RETRY_STEP ? 1 : 0, any = 0;
+    MPI_Allreduce(&retry,&any,1,MPI_INT,MPI_MAX,world);  // a row outgrew its pitch somewhere: all repeat
+    if (!any) { check(rc); break; }
+    if (attempt >= 4) error->all(FLERR,"Pair style lj/cut/coul/long/polarization: neighbor row pitch overflow persists");
+  }
+
+  // results back in LAMMPS order: forces on locals AND ghosts (newton on), dipoles / static field of the own atoms
+  sh_f.resize(3 * (size_t) nall);
+  check(polar_download(h,"f",sh_f.data(),3 * (long long) nall));
+  for (int k = 0; k < nall; k++) {
+    double *fa = atom->f[lammps_of_lib[k]];
+    fa[0] += sh_f[3*k]; fa[1] += sh_f[3*k+1]; fa[2] += sh_f[3*k+2];
+  }
+  sh_x.resize(3 * (size_t) std::max(sh_n,nall));
+  check(polar_download(h,"mu",sh_x.data(),3 * (long long) sh_n));
+  memcpy(&atom->mu_induced[0][0],sh_x.data(),3 * (size_t) nlocal * sizeof(double));
+  check(polar_download(h,"ef_static",sh_x.data(),3 * (long long) sh_n));
+  memcpy(&atom->ef_static[0][0],sh_x.data(),3 * (size_t) nlocal * sizeof(double));
+
+  if (eflag_global) {
+    eng_vdwl += res.eng_vdwl;
+    eng_coul += res.eng_coul;
+  }
+  force->pair->eng_pol = res.eng_pol;   // this rank's share; compute pe / thermo sum over ranks
+  if (vflag_global) for (int k = 0; k < 6; k++) virial[k] += res.virial[k];
+  if (vflag_fdotr) virial_fdotr_compute();
+}
+
+/* ---------------------------------------------------------------------- */
+
+int PairLJCutCoulLongPolarizationMI355X::pack_forward_comm(int n, int *list_, double *buf, int /*pbc_flag*/, int * /*pbc*/)
+{
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const double *mu = atom->mu_induced[list_[i]];
+    buf[m++] = mu[0]; buf[m++] = mu[1]; buf[m++] = mu[2];
+  }
+  return m;
+}
+
+void PairLJCutCoulLongPolarizationMI355X::unpack_forward_comm(int n, int first, double *buf)
+{
+  int m = 0;
+  for (int i = first; i < first + n; i++) {
+    double *mu = atom->mu_induced[i];
+    mu[0] = buf[m++]; mu[1] = buf[m++]; mu[2] = buf[m++];
+  }
 }
 
 /* ---------------------------------------------------------------------- */

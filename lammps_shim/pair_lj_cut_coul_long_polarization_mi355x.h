@@ -20,6 +20,7 @@ PairStyle(lj/cut/coul/long/polarization,PairLJCutCoulLongPolarizationMI355X)
 #define LMP_PAIR_LJ_CUT_COUL_LONG_POLARIZATION_MI355X_H
 
 #include "pair.h"
+#include <vector>
 
 struct polar_handle;
 
@@ -42,6 +43,8 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   void write_data_all(FILE *);
   virtual double single(int, int, int, int, double, double, double, double &);
   virtual void *extract(const char *, int &);
+  virtual int pack_forward_comm(int, int *, double *, int, int *);
+  virtual void unpack_forward_comm(int, int, double *);
 
  protected:
   polar_handle *h;
@@ -49,6 +52,14 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   double **epsilon, **sigma, **cut_lj;   // row-pointer views into the library's tables (extract())
   int pair_inited;
   int device_neigh;                      // extension keyword: list built by polar_build_neighbors
+  // one MPI rank per GPU: library order = [own | halo (one ghost per foreign tag) | other ghosts]
+  int nhalo, sh_n;
+  std::vector<int> lib_of_lammps, lammps_of_lib, halo_ghost, sh_nn, sh_flat, sh_idx, sh_t, sh_m;
+  std::vector<long long> sh_first;
+  std::vector<double> sh_x, sh_q, sh_a, sh_f, sh_mu;
+  void compute_sharded(int, int);
+  void build_halo_map();
+  void exchange_dipoles();
   virtual void allocate();
   void check(int rc);                    // C-ABI status -> error->all / error->warning
   void sync_views();
