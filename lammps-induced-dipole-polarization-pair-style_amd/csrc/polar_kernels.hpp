@@ -211,6 +211,34 @@ __device__ __forceinline__ void pair_del(const Box &b, double xi, double yi, dou
   else min_image_rint(b, xi, yi, zi, xj, yj, zj, dx, dy, dz);
 }
 
+#define POLAR_NL_SAMEMOL 0x40000000
+#define POLAR_NL_MASK 0x3FFFFFFF
+
+// Wave-cooperative gather of 64 atom records for the lane-per-pair row kernels (list mode).  A
+// scattered load costs the vector-memory address unit one 64-byte line per LANE; here lane k of quad
+// q loads piece k of the records of lanes q, 16+q, 32+q, 48+q (4 instructions, one line per quad
+// each), a per-wave LDS tile (80-byte pitch: conflict-free b128 reads) transposes them, and every
+// lane gets ITS record back.  All 64 lanes call it (idle lanes pass any valid index).
+struct RecQuad { double2 a, b, c, d; };  // {x,mx} {y,my} {z,mz} {q,alpha}
+__device__ __forceinline__ RecQuad fetch_records(const AtomRec *__restrict__ rec, int j, double2 *stage, int lane) {
+  const int q4 = lane >> 2, k = lane & 3;
+  const char *base = reinterpret_cast<const char *>(rec) + k * 16;
+  const unsigned j0 = __shfl(j, q4, 64), j1 = __shfl(j, 16 + q4, 64), j2 = __shfl(j, 32 + q4, 64), j3 = __shfl(j, 48 + q4, 64);
+  const double2 p0 = *reinterpret_cast<const double2 *>(base + ((size_t)j0 << 6));
+  const double2 p1 = *reinterpret_cast<const double2 *>(base + ((size_t)j1 << 6));
+  const double2 p2 = *reinterpret_cast<const double2 *>(base + ((size_t)j2 << 6));
+  const double2 p3 = *reinterpret_cast<const double2 *>(base + ((size_t)j3 << 6));
+  stage[q4 * 5 + k] = p0; stage[(16 + q4) * 5 + k] = p1;
+  stage[(32 + q4) * 5 + k] = p2; stage[(48 + q4) * 5 + k] = p3;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  RecQuad r;
+  r.a = stage[lane * 5]; r.b = stage[lane * 5 + 1]; r.c = stage[lane * 5 + 2]; r.d = stage[lane * 5 + 3];
+  __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next trip
+  return r;
+}
+
 // Dipole field tensor scalars of build_dipole_field_matrix (PS.cpp:1284-1306):
 //   T_pq = delta_pq * s3 - d_p d_q * s5,  s3 = damp1 / r^3,  s5 = 3 damp2 / r^5
 template <int DAMP>
@@ -249,7 +277,8 @@ __global__ void k_pack(int n, const int *__restrict__ perm, const double *__rest
   r0[i] = r;
   r1[i] = r;
   mol_s[i] = mol[o];
-  if (pos4) pos4[i] = make_double4(r.x, r.y, r.z, r.a);  // 32-byte {x,y,z,alpha} for the list build
+  // 32-byte {x, y, z, (molecule id, alpha != 0)} for the list build
+  if (pos4) pos4[i] = make_double4(r.x, r.y, r.z, __hiloint2double(mol[o], r.a != 0.0 ? 1 : 0));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -281,7 +310,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, co
     bool hit = false;
     double term = 0.0;
     if (p < end) {
-      const int j = ALLPAIRS ? (int)p : nl_j[p];
+      const int j = ALLPAIRS ? (int)p : (nl_j[p] & POLAR_NL_MASK);
       if (j != i) {
         double dx, dy, dz, aj;
         int mj;
@@ -536,17 +565,37 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restr
   double ex = 0, ey = 0, ez = 0;
   long long beg = 0, end = nlocal;
   if (!ALLPAIRS) row_range(nl, i, beg, end);
-  for (long long p = beg + lane; p < end; p += 64) {
-    const int j = ALLPAIRS ? (int)p : nl_j[p];
-    if (j == i) continue;
-    const AtomRec rj = rec[j];
-    double dx, dy, dz;
-    pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
-    const double rsq = dx * dx + dy * dy + dz * dz;
-    if (rsq <= cut_coulsq && ((mi != mol[j]) || mi == 0)) {  // note <=, PS.cpp:342
-      const double rinv = rsqrt(rsq);
-      const double ef_temp = (rinv * rinv + f_shift) * rinv * rj.q;
-      ex += ef_temp * dx; ey += ef_temp * dy; ez += ef_temp * dz;
+  if (ALLPAIRS) {
+    for (long long p = beg + lane; p < end; p += 64) {
+      const int j = (int)p;
+      if (j == i) continue;
+      const AtomRec rj = rec[j];
+      double dx, dy, dz;
+      pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq <= cut_coulsq && ((mi != mol[j]) || mi == 0)) {  // note <=, PS.cpp:342
+        const double rinv = rsqrt(rsq);
+        const double ef_temp = (rinv * rinv + f_shift) * rinv * rj.q;
+        ex += ef_temp * dx; ey += ef_temp * dy; ez += ef_temp * dz;
+      }
+    }
+  } else {
+    __shared__ double2 s_stage[POLAR_ROWS_PER_BLOCK][64 * 5];
+    double2 *stage = s_stage[threadIdx.x >> 6];
+    for (long long base = beg; base < end; base += 64) {  // wave-uniform trip count: the fetch is cooperative
+      const long long p = base + lane;
+      const bool valid = p < end;
+      const int e = valid ? nl_j[p] : i;
+      const int j = e & POLAR_NL_MASK;
+      const RecQuad rj = fetch_records(rec, j, stage, lane);
+      double dx, dy, dz;
+      pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.a.x, rj.b.x, rj.c.x, dx, dy, dz);
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (valid && j != i && rsq <= cut_coulsq && !(e & POLAR_NL_SAMEMOL)) {  // note <=, PS.cpp:342
+        const double rinv = rsqrt(rsq);
+        const double ef_temp = (rinv * rinv + f_shift) * rinv * rj.d.x;
+        ex += ef_temp * dx; ey += ef_temp * dy; ez += ef_temp * dz;
+      }
     }
   }
   ex = wave_sum(ex); ey = wave_sum(ey); ez = wave_sum(ez);
@@ -1380,10 +1429,14 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
   double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
   long long beg = 0, end = nlocal;
   if (!ALLPAIRS) row_range(nl, i, beg, end);
+  // (the cooperative record fetch of k_static_field was tried here too: this kernel is bound by its FP64
+  //  arithmetic, not by the gathers, and got 7 % slower)
   for (long long p = beg + lane; p < end; p += 64) {
-    const int j = ALLPAIRS ? (int)p : nl_j[p];
+    const int e = ALLPAIRS ? (int)p : nl_j[p];
+    const int j = ALLPAIRS ? e : (e & POLAR_NL_MASK);
     if (j == i) continue;
     const AtomRec rj = rec[j];
+    const bool molok = ALLPAIRS ? ((mi != mol[j]) || mi == 0) : !(e & POLAR_NL_SAMEMOL);
     double dx, dy, dz;
     pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
     const double xsq = dx * dx, ysq = dy * dy, zsq = dz * dz;
@@ -1393,7 +1446,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
     const double r = rsq * rinv;
     const double r3inv = r2inv * rinv;
     double px = 0, py = 0, pz = 0;
-    if (rsq < cut_coulsq && ((mi != mol[j]) || mi == 0)) {  // note <, PS.cpp:454
+    if (rsq < cut_coulsq && molok) {  // note <, PS.cpp:454
       // shifted-force charge-dipole tensor G_pq = delta_pq (r^-2 + f_shift) r^2 ... written as the
       // reference does: M_pp = (-2 p^2 + q^2 + s^2) r2inv + f_shift (q^2 + s^2), M_pq = -pq (3 r2inv + f_shift)
       const double mxx = (-2.0 * xsq + ysq + zsq) * r2inv + f_shift * (ysq + zsq);
@@ -1590,7 +1643,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
   const int i = rows ? rows[row] : row;  // s space: the atoms of cell c are the indices [cell_first[c], cell_first[c+1])
-  const double4 ri = pos4[i];            // {x, y, z, alpha}
+  const double4 ri = pos4[i];            // {x, y, z, (molecule, polarizable)}
+  const int imol = __double2hiint(ri.w), ipol = __double2loint(ri.w);
   const int ci = cell_of(g, box, ri.x, ri.y, ri.z);
   const int c0 = ci % g.nc[0], c1 = (ci / g.nc[0]) % g.nc[1], c2 = ci / (g.nc[0] * g.nc[1]);
   const long long nl0 = (long long)i * nl_pitch, dd0 = (long long)i * dd_pitch;
@@ -1623,17 +1677,21 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
           const long long p = base + lane;
           bool in_nl = false, in_dd = false;
           const int j = (int)p;
+          int same = 0;
           if (p < b && j != i) {
             const double4 rj = pos4[j];  // consecutive lanes read consecutive 32-byte entries
             double ex, ey, ez;
             min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
             const double rsq = ex * ex + ey * ey + ez * ez;
             in_nl = rsq <= cutallsq;
-            in_dd = (ri.w != 0.0) && (rj.w != 0.0) && (rsq < ddcutsq);
+            in_dd = ipol && __double2loint(rj.w) && (rsq < ddcutsq);
+            same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;
           }
           const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
           const int kn = ncount + __popcll(m_nl & below), kd = dcount + __popcll(m_dd & below);
-          if (in_nl && kn < nl_pitch) nl_j[nl0 + kn] = j;
+          // bit 30 of an nl entry: "same non-zero molecule" -- the static field and the charge-dipole terms
+          // skip such pairs (PS.cpp:342,454), so those kernels need no molecule gather
+          if (in_nl && kn < nl_pitch) nl_j[nl0 + kn] = j | same;
           if (in_dd && kd < dd_pitch) dd_j[dd0 + kd] = j;
           ncount += __popcll(m_nl);
           dcount += __popcll(m_dd);
