@@ -668,7 +668,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   if ((eatom || vatom) && own_n(h) != n) throw InputError("per-atom tallies are not available on a row-sharded handle");
   k_zero_scal<<<1, 1, 0, s>>>(h->d_scal.p, 0);
   k_zero_slots<<<nblk(POLAR_NSLOT, 256), 256, 0, s>>>(h->d_slots.p);
-  {  // a3 -- on a low-priority side stream when overlap is on: it depends on nothing below, and fills
+  auto launch_lj = [&]() {  // a3 -- on a low-priority side stream when overlap is on: it depends on nothing below, and fills
     // whatever the list build, the static field and the latency-bound solver launches leave idle
     hipStream_t ms = s;
     h->lj_forked = h->overlap_lj && h->inum > 0;
@@ -719,7 +719,9 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     }
     HIPCHECK(hipEventRecord(h->ev_lj1, s));
     if (h->lj_forked) HIPCHECK(hipEventRecord(h->ev_join, s));
-  }
+  };
+  const bool lj_late = getenv("POLAR_LJ_LATE") != nullptr;  // lab: fork a3 after the static field instead
+  if (!lj_late) launch_lj();
   const double *mu0 = nullptr;
   if (st.use_previous) {
     if (mu_host) {
@@ -777,6 +779,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
   }
   HIPCHECK(hipEventRecord(h->ev[4], s));
+  if (lj_late) launch_lj();
 }
 
 // PS.cpp:406-645: everything after the solve
