@@ -119,7 +119,9 @@ struct polar_handle {
   int user_full_list = 0;    // polar_set_list_style for uploaded lists
   long long lj_pitch = 0;
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
-  int cache_r2 = 1;       // 1: the sweep streams r^2 (12 B/pair) and rebuilds (s3,s5); 0: streams cached (s3,s5) (POLAR_CACHE_R2)
+  int cache_r2 = -1;      // sweep stream (POLAR_CACHE_R2): 0 cached (s3,s5), 20 B/pair; 1 cached r^2, 12 B/pair; 2 nothing,
+                          // 4 B/pair (r^2 rebuilt from the gathered positions); -1: 1 or 2 by size, see build_lists
+  int stream_mode = 1;    // the choice in force for the current lists
   int sweep_kernel = 0;   // 0: k_field_quad (component-per-lane); 1: lane-per-pair kernels (POLAR_SWEEP_KERNEL)
   int rows_per_wave = 0;  // 0: automatic; >0: forced; <0: use the one-row-per-wave kernel (POLAR_ROWS_PER_WAVE)
   int ablate = 0;  // lab switches for k_field (POLAR_ABLATE), 0 in production
@@ -273,10 +275,22 @@ void build_lists(polar_handle *h) {
   }
   h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1);
   h->d_nl_j.ensure((size_t)n * h->nl_pitch + 64); h->d_dd_j.ensure((size_t)n * h->dd_pitch + 64);
-  const bool r2c = h->cache_r2 && h->sweep_kernel == 0;
-  if (r2c) h->d_dd_r2.ensure((size_t)n * h->dd_pitch + 64);
-  else h->d_dd_s.ensure((size_t)n * h->dd_pitch + 64);
+  // What the sweep streams per pair.  Measured (tools/exp_nocache.sh): while index + r^2 of all pairs
+  // (12 B/pair) stay resident in the 256 MB Infinity Cache between sweeps the cached r^2 wins (36k atoms,
+  // 160 MB: 99 vs 107 us/sweep); beyond that the stream comes from HBM every sweep and rebuilding r^2 from
+  // the gathered positions wins (135k atoms, 595 MB: 320 vs 350 us/sweep).
+  int mode = h->cache_r2;
+  if (h->sweep_kernel != 0) mode = 0;
+  if (mode < 0) {
+    const double est_pairs = h->dd_pairs > 0 ? (double)h->dd_pairs : 0.35 * (double)own_n(h) * (double)h->dd_pitch;
+    mode = (12.0 * est_pairs < 200.0e6) ? 1 : 2;
+  }
+  h->stream_mode = mode;
+  const bool r2c = mode == 1;
+  if (mode == 1) h->d_dd_r2.ensure((size_t)n * h->dd_pitch + 64);
+  else if (mode == 0) h->d_dd_s.ensure((size_t)n * h->dd_pitch + 64);
   double *r2p = r2c ? h->d_dd_r2.p : nullptr;
+  double2 *sp = mode == 0 ? h->d_dd_s.p : nullptr;
   const double cutallsq = cutall * cutall, ddsq = st.dd_cutoff * st.dd_cutoff;
   const int nr = own_n(h);
   const int *rows = own_rows(h);
@@ -289,9 +303,9 @@ void build_lists(polar_handle *h) {
       h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, h->d_overflow.p, h->d_ddtot.p);
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
   if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
-    k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p, r2p);
+    k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, sp, r2p);
   else
-    k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, h->d_dd_s.p, r2p);
+    k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, sp, r2p);
   // overflow flag and dd total come back with the end-of-step read (no sync here)
   HIPCHECK(hipMemcpyAsync(h->h_flags, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -490,8 +504,10 @@ void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
 #define FQ(M) k_field_quad<EP, M><<<nblk_xcd(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(                 \
       nrows, rows, h->d_rec0.p, h->d_rec1.p, h->box, RowList{h->d_dd_cnt.p, h->dd_pitch}, h->d_dd_j.p, h->d_dd_s.p, \
       h->d_dd_r2.p, st.polar_damp, h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
-  if (!h->cache_r2) FQ(0);
-  else if (st.damping_type == POLAR_DAMP_EXPONENTIAL) FQ(1);
+  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  if (h->stream_mode == 0) FQ(0);
+  else if (h->stream_mode == 2) { if (expd) FQ(3); else FQ(4); }
+  else if (expd) FQ(1);
   else FQ(2);
 #undef FQ
 }

@@ -992,14 +992,35 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field_quad(int nrows, const int
     double2 Sv = make_double2(0.0, 0.0);
     double r2v = 0.0;
     if (SMODE == 0) Sv = (ablate & 4) ? make_double2(1e-3, 1e-4) : ps[64 * t];
-    else r2v = (ablate & 4) ? 30.0 : pr[64 * t];
+    else if (SMODE <= 2) r2v = (ablate & 4) ? 30.0 : pr[64 * t];
     if (t + 1 < T) jn = pj[64 * (t + 1)];  // wave-uniform: the next trip's indices travel during the math
-    if (SMODE != 0) tensor_scalars<SMODE == 1 ? 0 : 1>(r2v, pd, Sv.x, Sv.y);  // lane L: pair L of the trip
+    double D[4];
+#define POLAR_QDEL(R)                                  \
+  {                                                   \
+    double d = xi - P[R].x;                            \
+    D[R] = fma(-prd, rint(d * inv), d);                \
+  }
+    POLAR_QDEL(0) POLAR_QDEL(1) POLAR_QDEL(2) POLAR_QDEL(3)
+#undef POLAR_QDEL
+    if (SMODE >= 3) {
+      // no per-pair stream value at all (4 B/pair; chosen when the stream would not stay in the 256 MB
+      // Infinity Cache, see build_lists) -- r^2 from the quad's three
+      // component lanes (lane 3 rides on z, so [1,2,0,0] / [2,0,1,1] give ALL four lanes the sum), and
+      // lane r of the quad keeps the r^2 of step r: its own pair, as in the cached forms
+      double r2s[4];
+#pragma unroll
+      for (int R = 0; R < 4; R++) {
+        const double q = D[R] * D[R];
+        r2s[R] = q + dpp_full<0x09>(q) + dpp_full<0x52>(q);  // quad_perm [1,2,0,0], [2,0,1,1]
+      }
+      r2v = k == 0 ? r2s[0] : (k == 1 ? r2s[1] : (k == 2 ? r2s[2] : r2s[3]));
+      r2v = r2v > 0.0 ? r2v : 1e60;  // padding entries (the atom itself): an inert pair
+    }
+    if (SMODE != 0) tensor_scalars<(SMODE == 1 || SMODE == 3) ? 0 : 1>(r2v, pd, Sv.x, Sv.y);  // lane L: pair L of the trip
 #define POLAR_QSTEP(R)                                                                          \
   {                                                                                            \
     const double s3_ = dpp_full<(R) * 0x55>(Sv.x), s5_ = dpp_full<(R) * 0x55>(Sv.y);             \
-    double d = xi - P[R].x;                                                                     \
-    d = fma(-prd, rint(d * inv), d);                                                            \
+    const double d = D[R];                                                                      \
     const double m = P[R].y * d;                                                                \
     /* dot over the quad's three component lanes (lane 3 gets a don't-care) */                  \
     const double dot = m + dpp_full<0xC9>(m) + dpp_full<0xD2>(m); /* quad_perm [1,2,0,3], [2,0,1,3] */ \
@@ -1038,25 +1059,26 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restric
   const double xi = rec[i].x, yi = rec[i].y, zi = rec[i].z;
   long long beg, end;
   row_range(ddl, i, beg, end);
-  for (long long p = beg + lane; p < end; p += 64) {
-    const int j = dd_j[p];
-    double dx, dy, dz;
-    min_image_rint(box, xi, yi, zi, rec[j].x, rec[j].y, rec[j].z, dx, dy, dz);
-    double s3, s5;
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    if (dd_r2) dd_r2[p] = r2;
-    else {
-      tensor_scalars<DAMP>(r2, pd, s3, s5);
-      dd_s[p] = make_double2(s3, s5);
+  if (dd_r2 || dd_s)
+    for (long long p = beg + lane; p < end; p += 64) {
+      const int j = dd_j[p];
+      double dx, dy, dz;
+      min_image_rint(box, xi, yi, zi, rec[j].x, rec[j].y, rec[j].z, dx, dy, dz);
+      double s3, s5;
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      if (dd_r2) dd_r2[p] = r2;
+      else {
+        tensor_scalars<DAMP>(r2, pd, s3, s5);
+        dd_s[p] = make_double2(s3, s5);
+      }
     }
-  }
   // pad the row to whole 64-pair trips with inert entries (the atom itself, zero tensor): the
   // component-per-lane sweep then runs without lane masks.  The pitch is a multiple of 64.
   const long long pad_end = beg + (((end - beg) + 63) & ~63ll);
   for (long long p = end + lane; p < pad_end; p += 64) {
     dd_j[p] = i;
     if (dd_r2) dd_r2[p] = 1e60;  // s3 ~ 1e-90, and d = 0 kills the s5 term: contributes nothing
-    else dd_s[p] = make_double2(0.0, 0.0);
+    else if (dd_s) dd_s[p] = make_double2(0.0, 0.0);
   }
 }
 

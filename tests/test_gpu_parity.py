@@ -264,12 +264,15 @@ def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
     assert np.max(np.abs(vir - ref["virial"])) < max(tol, 1e-9) * np.max(np.abs(ref["virial"]))
 
 
-@pytest.mark.parametrize("rpw", ["-1", "3"])
-def test_alternative_sweep_kernels_agree(rpw, wl, pkg, oracle, monkeypatch):
-    """The list sweep has two kernels (one row per wave / several rows streamed by one wave);
-    POLAR_ROWS_PER_WAVE selects them.  Both must reproduce the oracle (Jacobi sweep by sweep, GS
-    at the fixed point)."""
-    monkeypatch.setenv("POLAR_ROWS_PER_WAVE", rpw)
+@pytest.mark.parametrize("knob", ["POLAR_ROWS_PER_WAVE=-1", "POLAR_ROWS_PER_WAVE=3", "POLAR_CACHE_R2=0", "POLAR_CACHE_R2=1",
+                                  "POLAR_CACHE_R2=2"])
+def test_alternative_sweep_kernels_agree(knob, wl, pkg, oracle, monkeypatch):
+    """The list sweep exists in several forms: the lane-per-pair kernels (one row per wave / several rows
+    streamed by one wave, POLAR_ROWS_PER_WAVE) and the component-per-lane kernel with its three stream
+    modes (POLAR_CACHE_R2: cached (s3,s5), cached r^2, nothing cached -- normally chosen by size).  All
+    must reproduce the oracle (Jacobi sweep by sweep, GS at the fixed point; both damping types)."""
+    name, val = knob.split("=")
+    monkeypatch.setenv(name, val)
     extra = ["use_previous", "no", "polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "4",
              "dd_cutoff", "9.0"]
     s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
@@ -281,6 +284,14 @@ def test_alternative_sweep_kernels_agree(rpw, wl, pkg, oracle, monkeypatch):
     ref = oracle.compute(s, eflag=1, vflag=2)
     out = pkg.pair_from_system(s).compute()
     assert out["status"] == 0
+    assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+    assert rel(out["eng_pol"], ref["eng_pol"]) < TOL
+    # undamped tensor (the other template instance of every stream mode): Jacobi, sweep by sweep
+    extra = ["use_previous", "no", "polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "3",
+             "dd_cutoff", "9.0", "damp_type", "none"]
+    s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    out = pkg.pair_from_system(s).compute()
     assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
     assert rel(out["eng_pol"], ref["eng_pol"]) < TOL
 
