@@ -119,6 +119,7 @@ struct polar_handle {
   int user_full_list = 0;    // polar_set_list_style for uploaded lists
   long long lj_pitch = 0;
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
+  int quad_block = POLAR_BLOCK;  // workgroup size of k_field_quad (POLAR_QUAD_BLOCK)
   int cache_r2 = -1;      // sweep stream (POLAR_CACHE_R2): 0 cached (s3,s5), 20 B/pair; 1 cached r^2, 12 B/pair; 2 nothing,
                           // 4 B/pair (r^2 rebuilt from the gathered positions); -1: 1 or 2 by size, see build_lists
   int stream_mode = 1;    // the choice in force for the current lists
@@ -501,7 +502,8 @@ template <int EP>
 void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
   if (nrows <= 0) return;
   const polar_settings &st = h->ph.st;
-#define FQ(M) k_field_quad<EP, M><<<nblk_xcd(nrows, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(                 \
+  const int qb = h->quad_block;
+#define FQ(M) k_field_quad<EP, M><<<nblk_xcd(nrows, qb / 64), qb, 0, h->stream>>>(                 \
       nrows, rows, h->d_rec0.p, h->d_rec1.p, h->box, RowList{h->d_dd_cnt.p, h->dd_pitch}, h->d_dd_j.p, h->d_dd_s.p, \
       h->d_dd_r2.p, st.polar_damp, h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
@@ -901,7 +903,8 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_ROWS_PER_WAVE")) { h->rows_per_wave = atoi(e); h->sweep_kernel = 1; }
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
-  if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);  // 0 quad (default), 1 lane-per-pair kernels
+  if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
+  if (const char *e = getenv("POLAR_QUAD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->quad_block = v; }  // 0 quad (default), 1 lane-per-pair kernels
   if (const char *e = getenv("POLAR_FIELD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->field_block = v; }
   int n = polar_device_count();
   if (n <= 0 || device < 0 || device >= n) {

@@ -938,7 +938,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field_rows(int nrows, const int
 // SMODE 0: stream the cached (s3,s5) (20 B/pair); 1 / 2: stream the cached r^2 (12 B/pair) and
 // rebuild (s3,s5) with exponential / no damping -- lane L for ITS pair, before the quad hand-round.
 template <int EP, int SMODE>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_field_quad(int nrows, const int *__restrict__ rows,
+__global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__restrict__ rows,
                                                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
                                                             Box box, RowList ddl, const int *__restrict__ dd_j,
                                                             const double2 *__restrict__ dd_s,
@@ -948,9 +948,10 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_field_quad(int nrows, const int
   if (scal->done) return;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lb = xcd_block(blockIdx.x, (nrows + POLAR_ROWS_PER_BLOCK - 1) / POLAR_ROWS_PER_BLOCK);
+  const int rpb = blockDim.x >> 6;  // rows (waves) per workgroup
+  const int lb = xcd_block(blockIdx.x, (nrows + rpb - 1) / rpb);
   if (lb < 0) return;
-  const int row = lb * POLAR_ROWS_PER_BLOCK + wv;
+  const int row = lb * rpb + wv;
   if (row >= nrows) return;
   const int i = __builtin_amdgcn_readfirstlane(rows ? rows[row] : row);
   const int cur = scal->cur;

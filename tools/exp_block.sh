@@ -1,8 +1,5 @@
-for fb in 64 128 256 512 1024; do
-  for mode in "jac:--extra polar_gs_ranked no" "gs:"; do
-    name=${mode%%:*}; args=${mode#*:}
-    POLAR_FIELD_BLOCK=$fb python bench.py --steps 5 --warmup 2 --no-cpu-baseline $args 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); c=d['config']; print('fb=$fb $name ms/step %.2f solve %.2f per-iter %.3f'%(d['ms_per_step'], c['ms_solve'], c['ms_per_dipole_iteration']))" | tee -a gpurun_out/exp_block.log
-  done
+#!/bin/bash
+for v in 256 64 128 512 1024 256; do
+  POLAR_QUAD_BLOCK=$v timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/qb_$v.log 2>&1
+  echo "quad_block=$v"; python tools/show_line.py gpurun_out/qb_$v.log
 done
