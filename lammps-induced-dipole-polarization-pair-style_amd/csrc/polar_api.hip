@@ -124,7 +124,6 @@ struct polar_handle {
                           // 4 B/pair (r^2 rebuilt from the gathered positions); -1: 1 or 2 by size, see build_lists
   int stream_mode = 1;    // the choice in force for the current lists
   int sweep_kernel = 0;   // 0: k_field_quad (component-per-lane); 1: lane-per-pair kernels (POLAR_SWEEP_KERNEL)
-  int rows_per_wave = 0;  // 0: automatic; >0: forced; <0: use the one-row-per-wave kernel (POLAR_ROWS_PER_WAVE)
   int ablate = 0;  // lab switches for k_field (POLAR_ABLATE), 0 in production
   Scal *h_scal = nullptr;  // pinned
   hipEvent_t ev[8] = {};
@@ -482,21 +481,6 @@ void launch_field_dyn(polar_handle *h, bool ap, int nrows, const int *rows) {
   else    { if (expd) launch_field<false, 0, EP>(h, nrows, rows); else launch_field<false, 1, EP>(h, nrows, rows); }
 }
 
-// list-mode production sweep: a wave streams `rpw` rows (k_field_rows)
-template <int EP>
-void launch_field_rows(polar_handle *h, int nrows, const int *rows) {
-  if (nrows <= 0) return;
-  // enough waves to fill the chip (256 CUs x 16), at most POLAR_RPW rows per wave
-  // measured on MI355X (profiles/r01_lab_rows_per_wave.txt): the sweep is bound by the dependent
-  // instruction chain of a wave, so MORE waves beat longer pipelines -- one row per wave unless forced
-  int rpw = h->rows_per_wave > 0 ? h->rows_per_wave : 1;
-  rpw = std::max(1, std::min(rpw, POLAR_RPW));
-  const int nwaves = (nrows + rpw - 1) / rpw;
-  k_field_rows<EP><<<nblk(nwaves, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, h->stream>>>(
-      nrows, rows, rpw, h->d_rec0.p, h->d_rec1.p, h->box, RowList{h->d_dd_cnt.p, h->dd_pitch}, h->d_dd_j.p, h->d_dd_s.p,
-      h->d_ef_s.p, h->d_scal.p, h->d_slots.p);
-}
-
 // list-mode production sweep: component-per-lane quads (k_field_quad), one wave per row
 template <int EP>
 void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
@@ -518,7 +502,6 @@ void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
 void sweep_once(polar_handle *h, bool ap) {
   const polar_settings &st = h->ph.st;
   const bool gs = st.polar_gs || st.polar_gs_ranked;
-  const bool stream_rows = !ap && !h->ablate && h->rows_per_wave >= 0;  // lab switches fall back to k_field
   if (!ap && h->sweep_kernel == 0) {
     if (!gs) { launch_field_quad<EP_JACOBI>(h, own_n(h), own_rows(h)); return; }
     const int ncol = (int)h->color_off.size() - 1;
@@ -527,16 +510,14 @@ void sweep_once(polar_handle *h, bool ap) {
     return;
   }
   if (!gs) {
-    if (stream_rows && h->rows_per_wave > 0) launch_field_rows<EP_JACOBI>(h, own_n(h), own_rows(h));
-    else launch_field_dyn<EP_JACOBI>(h, ap, own_n(h), own_rows(h));
+    launch_field_dyn<EP_JACOBI>(h, ap, own_n(h), own_rows(h));
     return;
   }
   const int ncol = (int)h->color_off.size() - 1;
   for (int c = 0; c < ncol; c++) {
     const int cnt = h->color_off[c + 1] - h->color_off[c];
     if (cnt <= 0) continue;
-    if (stream_rows) launch_field_rows<EP_INPLACE>(h, cnt, h->d_rows.p + h->color_off[c]);
-    else launch_field_dyn<EP_INPLACE>(h, false, cnt, h->d_rows.p + h->color_off[c]);
+    launch_field_dyn<EP_INPLACE>(h, false, cnt, h->d_rows.p + h->color_off[c]);
   }
 }
 
@@ -901,7 +882,6 @@ int polar_create(int device, polar_handle **out) {
   h->device = device;
   if (const char *e = getenv("POLAR_COLOR_DIST")) h->color_dist = atof(e);
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
-  if (const char *e = getenv("POLAR_ROWS_PER_WAVE")) { h->rows_per_wave = atoi(e); h->sweep_kernel = 1; }
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
   if (const char *e = getenv("POLAR_QUAD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->quad_block = v; }  // 0 quad (default), 1 lane-per-pair kernels

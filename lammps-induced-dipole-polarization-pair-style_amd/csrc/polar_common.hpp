@@ -1,0 +1,250 @@
+// polar_common.hpp -- types, slot accumulators, wave/DPP helpers, minimum-image rules, tensor scalars, record fetch.
+// Part of the hand-written HIP kernels (gfx950 / CDNA4, wave64) of the lj/cut/coul/long/polarization
+// hot path; see polar_kernels.hpp for the mapping and the index spaces.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace polar {
+
+
+// 64-byte atom record: one L2 line-half per gathered neighbor.
+struct __attribute__((aligned(64))) AtomRec {
+  // component-interleaved: 16-byte piece k (k = 0,1,2) holds (position_k, dipole_k); piece 3 = (q, alpha).
+  // A QUAD of lanes reads one whole record with one coalesced 64-byte access (see k_field, list mode).
+  double x, mx;
+  double y, my;
+  double z, mz;
+  double q, a;
+};
+
+struct Box {
+  double prd[3], half[3], inv[3];
+  double xy, xz, yz;  // triclinic tilt factors (domain.cpp:1258-1305); zero for orthogonal boxes
+  int periodic[3];
+  int triclinic;
+};
+
+// Device-resident solver/accumulator block (one per handle).
+struct Scal {
+  double eng_vdwl, eng_coul, u_self, u_ef, u_dd;
+  double virial[6];
+  double change;           // sum (mu_new - mu_old)^2 of the running sweep
+  double last_change;      // change / (3N) of the last finished sweep
+  unsigned long long rmin_bits;  // double bits of rmin (positive doubles order like uint64)
+  int iterations, done, status, cur, sweeps, pad;
+};
+
+// Contended accumulators (energies, virial, sum dmu^2, rmin) are spread over NSLOT cache lines:
+// every wave adds into the line picked by its workgroup id, a single-workgroup kernel folds the
+// lines.  (One shared address costs ~12 ns per atomic on MI355X: 36k rows -> 0.4 ms per launch.)
+#define POLAR_NSLOT 1024
+#define POLAR_SLOT_STRIDE 16
+enum { SL_EVDWL = 0, SL_ECOUL, SL_USELF, SL_UEF, SL_UDD, SL_V0, SL_V1, SL_V2, SL_V3, SL_V4, SL_V5, SL_CHANGE, SL_RMIN };
+__device__ __forceinline__ double *slot_ptr(double *slots, int field) {
+  return slots + (size_t)(blockIdx.x & (POLAR_NSLOT - 1)) * POLAR_SLOT_STRIDE + field;
+}
+
+#define POLAR_WAVE 64
+#define POLAR_BLOCK 256
+#define POLAR_ROWS_PER_BLOCK (POLAR_BLOCK / POLAR_WAVE)
+
+// Wave-wide reductions through DPP (data-parallel primitives: no LDS crossbar round trips).
+// quad_perm xor1, xor2 -> row_half_mirror -> row_mirror give every lane its 16-lane row total;
+// row_bcast15 / row_bcast31 (GFX9/CDNA) carry row totals into the following rows, so lane 63 ends
+// with the wave total, which readlane broadcasts.  ~18 short VALU ops per double instead of 12
+// dependent ds_bpermute round trips.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_get(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// XCD-aware row placement.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with
+// its own 4 MB L2.  Rows are in cell order (spatially sorted), so giving XCD x the x-th contiguous
+// eighth of the launch's workgroups keeps each L2's gather working set to one slab of the box plus
+// its cutoff halo instead of the whole record table (8.6 MB at 135k atoms).  The grid is
+// 8 * ceil(nblocks / 8) workgroups; returns -1 for the padding workgroups.
+__device__ __forceinline__ int xcd_block(int b, int nblocks) {
+  const int chunk = (nblocks + 7) >> 3;
+  const int lb = (b & 7) * chunk + (b >> 3);
+  return lb < nblocks ? lb : -1;
+}
+
+// full-mask permutations (every lane has a source): bound_ctrl lets the compiler skip the
+// zero-initialisation of the destination that dpp_get needs for its masked rows
+template <int CTRL>
+__device__ __forceinline__ double dpp_full(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_full<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_full<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_full<0x141>(v);  // row_half_mirror
+  v += dpp_full<0x140>(v);  // row_mirror: all 16 lanes of a row hold the row total
+  v += dpp_get<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp_get<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+  return lane63(v);
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Domain::closest_image wrap of one component d = xj - xi (domain.cpp:1231-1257): the reference's
+// add/subtract sequence, not a rint() wrap, so that pairs at exactly L/2 pick the same image.
+__device__ __forceinline__ double wrap_ci(double d, double L, double h, int periodic) {
+  if (periodic) {
+    if (d < 0.0) {
+      while (d < 0.0) d += L;
+      if (d > h) d -= L;
+    } else {
+      while (d > 0.0) d -= L;
+      if (d < -h) d += L;
+    }
+  }
+  return d;
+}
+
+// del = x_i - closest_image(x_j)
+__device__ __forceinline__ void min_image_del(const Box &b, double xi, double yi, double zi, double xj, double yj,
+                                              double zj, double &dx, double &dy, double &dz) {
+  if (!b.triclinic) {
+    dx = -wrap_ci(xj - xi, b.prd[0], b.half[0], b.periodic[0]);
+    dy = -wrap_ci(yj - yi, b.prd[1], b.half[1], b.periodic[1]);
+    dz = -wrap_ci(zj - zi, b.prd[2], b.half[2], b.periodic[2]);
+    return;
+  }
+  // triclinic branch of Domain::closest_image (domain.cpp:1258-1305): z first (carrying yz, xz into
+  // y and x), then y (carrying xy into x), then x -- same add/subtract sequence as the reference
+  double ex = xj - xi, ey = yj - yi, ez = zj - zi;
+  if (b.periodic[2]) {
+    if (ez < 0.0) {
+      while (ez < 0.0) { ez += b.prd[2]; ey += b.yz; ex += b.xz; }
+      if (ez > b.half[2]) { ez -= b.prd[2]; ey -= b.yz; ex -= b.xz; }
+    } else {
+      while (ez > 0.0) { ez -= b.prd[2]; ey -= b.yz; ex -= b.xz; }
+      if (ez < -b.half[2]) { ez += b.prd[2]; ey += b.yz; ex += b.xz; }
+    }
+  }
+  if (b.periodic[1]) {
+    if (ey < 0.0) {
+      while (ey < 0.0) { ey += b.prd[1]; ex += b.xy; }
+      if (ey > b.half[1]) { ey -= b.prd[1]; ex -= b.xy; }
+    } else {
+      while (ey > 0.0) { ey -= b.prd[1]; ex -= b.xy; }
+      if (ey < -b.half[1]) { ey += b.prd[1]; ex += b.xy; }
+    }
+  }
+  ex = wrap_ci(ex, b.prd[0], b.half[0], b.periodic[0]);
+  dx = -ex; dy = -ey; dz = -ez;
+}
+
+// quad (4-lane) exchange through DPP quad_perm -- no LDS crossbar
+__device__ __forceinline__ double quad_xor(double v, const int which) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if (which == 1) {  // lanes 0<->1, 2<->3   quad_perm [1,0,3,2]
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+  } else {           // lanes 0<->2, 1<->3   quad_perm [2,3,0,1]
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+  }
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  v += quad_xor(v, 1);
+  v += quad_xor(v, 2);
+  return v;
+}
+
+// Pitched row lists (list mode): row i owns the slots [i*pitch, i*pitch + cnt[i]).  A fixed pitch lets
+// k_nl_build emit both lists in ONE pass (no count pass, no prefix scans, no host sync for the
+// totals); a row that would overflow sets a flag and the step is redone with a larger pitch.
+struct RowList {
+  const int *cnt;
+  long long pitch;
+};
+__device__ __forceinline__ void row_range(const RowList &L, int i, long long &beg, long long &end) {
+  beg = (long long)i * L.pitch;
+  const long long c = L.cnt[i];
+  end = beg + (c < L.pitch ? c : L.pitch);
+}
+
+// Branch-free minimum image for the LIST kernels (dd_cutoff extension): d - L*rint(d/L).
+// Equals closest_image except for pairs at exactly L/2, which lie outside every cutoff there
+// (the list path requires L >= 2*cutoff).  The all-pairs (reference-exact) kernels keep wrap_ci.
+__device__ __forceinline__ void min_image_rint(const Box &b, double xi, double yi, double zi, double xj, double yj,
+                                               double zj, double &dx, double &dy, double &dz) {
+  dx = xi - xj; dy = yi - yj; dz = zi - zj;
+  if (b.periodic[0]) dx = fma(-b.prd[0], rint(dx * b.inv[0]), dx);
+  if (b.periodic[1]) dy = fma(-b.prd[1], rint(dy * b.inv[1]), dy);
+  if (b.periodic[2]) dz = fma(-b.prd[2], rint(dz * b.inv[2]), dz);
+}
+template <bool EXACT>
+__device__ __forceinline__ void pair_del(const Box &b, double xi, double yi, double zi, double xj, double yj,
+                                         double zj, double &dx, double &dy, double &dz) {
+  if (EXACT) min_image_del(b, xi, yi, zi, xj, yj, zj, dx, dy, dz);
+  else min_image_rint(b, xi, yi, zi, xj, yj, zj, dx, dy, dz);
+}
+
+#define POLAR_NL_SAMEMOL 0x40000000
+#define POLAR_NL_MASK 0x3FFFFFFF
+
+// Wave-cooperative gather of 64 atom records for the lane-per-pair row kernels (list mode).  A
+// scattered load costs the vector-memory address unit one 64-byte line per LANE; here lane k of quad
+// q loads piece k of the records of lanes q, 16+q, 32+q, 48+q (4 instructions, one line per quad
+// each), a per-wave LDS tile (80-byte pitch: conflict-free b128 reads) transposes them, and every
+// lane gets ITS record back.  All 64 lanes call it (idle lanes pass any valid index).
+struct RecQuad { double2 a, b, c, d; };  // {x,mx} {y,my} {z,mz} {q,alpha}
+__device__ __forceinline__ RecQuad fetch_records(const AtomRec *__restrict__ rec, int j, double2 *stage, int lane) {
+  const int q4 = lane >> 2, k = lane & 3;
+  const char *base = reinterpret_cast<const char *>(rec) + k * 16;
+  const unsigned j0 = __shfl(j, q4, 64), j1 = __shfl(j, 16 + q4, 64), j2 = __shfl(j, 32 + q4, 64), j3 = __shfl(j, 48 + q4, 64);
+  const double2 p0 = *reinterpret_cast<const double2 *>(base + ((size_t)j0 << 6));
+  const double2 p1 = *reinterpret_cast<const double2 *>(base + ((size_t)j1 << 6));
+  const double2 p2 = *reinterpret_cast<const double2 *>(base + ((size_t)j2 << 6));
+  const double2 p3 = *reinterpret_cast<const double2 *>(base + ((size_t)j3 << 6));
+  stage[q4 * 5 + k] = p0; stage[(16 + q4) * 5 + k] = p1;
+  stage[(32 + q4) * 5 + k] = p2; stage[(48 + q4) * 5 + k] = p3;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  RecQuad r;
+  r.a = stage[lane * 5]; r.b = stage[lane * 5 + 1]; r.c = stage[lane * 5 + 2]; r.d = stage[lane * 5 + 3];
+  __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next trip
+  return r;
+}
+
+// Dipole field tensor scalars of build_dipole_field_matrix (PS.cpp:1284-1306):
+//   T_pq = delta_pq * s3 - d_p d_q * s5,  s3 = damp1 / r^3,  s5 = 3 damp2 / r^5
+template <int DAMP>
+__device__ __forceinline__ void tensor_scalars(double r2, double pd, double &s3, double &s5) {
+  double rinv = rsqrt(r2);
+  double r = r2 * rinv;
+  double rinv2 = rinv * rinv;
+  double r3 = rinv * rinv2;
+  double r5 = r3 * rinv2;
+  if (DAMP == 0) {  // exponential (Thole-like) damping
+    double ar = pd * r;
+    double e = exp(-ar);
+    double p2 = 1.0 + ar + 0.5 * ar * ar;
+    double p3 = p2 + ar * ar * ar * (1.0 / 6.0);
+    s3 = (1.0 - e * p2) * r3;
+    s5 = 3.0 * (1.0 - e * p3) * r5;
+  } else {
+    s3 = r3;
+    s5 = 3.0 * r5;
+  }
+}
+
+}  // namespace polar

@@ -1,0 +1,346 @@
+// polar_lists.hpp -- list mode: cell binning, pitched neighbor lists, device-side neighbor build for a3, dipole exchange and small utilities.
+// Part of the hand-written HIP kernels (gfx950 / CDNA4, wave64) of the lj/cut/coul/long/polarization
+// hot path; see polar_kernels.hpp for the mapping and the index spaces.
+#pragma once
+
+#include "polar_common.hpp"
+
+namespace polar {
+
+// ------------------------------------------------------------------------------------------
+// Cutoff-mode lists (extension): cell binning + CSR full lists over LOCAL atoms, minimum image.
+struct CellGrid {
+  int nc[3];
+  double lo[3], inv[3];  // cell index = floor((x - lo) * inv) wrapped
+};
+
+__device__ __forceinline__ int cell_of(const CellGrid &g, const Box &b, double x, double y, double z) {
+  int c[3];
+  const double p[3] = {x, y, z};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double fr = (p[k] - g.lo[k]) / b.prd[k];
+    fr -= floor(fr);
+    int ck = (int)(fr * g.nc[k]);
+    c[k] = ck >= g.nc[k] ? g.nc[k] - 1 : ck;
+  }
+  return (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
+}
+
+__global__ void k_cell_count(int n, const double *__restrict__ x, CellGrid g, Box b, int *__restrict__ cell_id,
+                             int *__restrict__ cell_cnt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int c = cell_of(g, b, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
+  cell_id[i] = c;
+  atomicAdd(&cell_cnt[c], 1);
+}
+
+// single-workgroup exclusive scan (n up to a few million; run once per list build)
+template <typename T>
+__global__ __launch_bounds__(1024) void k_exclusive_scan(long long n, const T *__restrict__ in,
+                                                         long long *__restrict__ out) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x;
+  const long long chunk = (n + 1023) / 1024;
+  const long long a = t * chunk, bnd = (a + chunk < n) ? a + chunk : n;
+  long long s = 0;
+  for (long long k = a; k < bnd; k++) s += (long long)in[k];
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    long long run = 0;
+    for (int k = 0; k < 1024; k++) { long long v = part[k]; part[k] = run; run += v; }
+    out[n] = run;
+  }
+  __syncthreads();
+  long long run = part[t];
+  for (long long k = a; k < bnd; k++) { out[k] = run; run += (long long)in[k]; }
+}
+
+// counting-sort fill: perm[s] = orig index of the atom stored at sorted position s, inv = inverse.
+// (Order inside a cell follows the atomics, i.e. it only permutes floating-point summation order.)
+__global__ void k_cell_fill(int n, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
+                            int *__restrict__ fill, int *__restrict__ perm, int *__restrict__ inv) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell_id[i];
+  const int s = (int)cell_first[c] + atomicAdd(&fill[c], 1);
+  perm[s] = i;
+  inv[i] = s;
+}
+__global__ void k_map_rows(int n, const int *__restrict__ inv, const int *__restrict__ in, int *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = inv[in[i]];
+}
+__global__ void k_map_range(int lo, int n, const int *__restrict__ inv, int *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = inv[lo + i];
+}
+
+// One wave per atom row; lanes stride the atoms of the <=27 distinct neighbor cells (contiguous s
+// ranges); ballot + popcount compacts in order.  Single pass into the pitched lists:
+//   nl : every j with rsq <= cutallsq                      (static field, forces, rank metric)
+//   dd : alpha_i != 0, alpha_j != 0 and rsq < ddcutsq      (the dipole sweep stream)
+// cnt[] receives the TRUE counts; writes stop at the pitch and *overflow is raised.
+__global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict__ rows, int nrows,
+                                                          const double4 *__restrict__ pos4, Box box, CellGrid g,
+                                                          const long long *__restrict__ cell_first, double cutallsq,
+                                                          double ddcutsq, long long nl_pitch, long long dd_pitch,
+                                                          int *__restrict__ nl_cnt, int *__restrict__ dd_cnt,
+                                                          int *__restrict__ nl_j, int *__restrict__ dd_j,
+                                                          int *__restrict__ overflow,
+                                                          unsigned long long *__restrict__ dd_total) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = rows ? rows[row] : row;  // s space: the atoms of cell c are the indices [cell_first[c], cell_first[c+1])
+  const double4 ri = pos4[i];            // {x, y, z, (molecule, polarizable)}
+  const int imol = __double2hiint(ri.w), ipol = __double2loint(ri.w);
+  const int ci = cell_of(g, box, ri.x, ri.y, ri.z);
+  const int c0 = ci % g.nc[0], c1 = (ci / g.nc[0]) % g.nc[1], c2 = ci / (g.nc[0] * g.nc[1]);
+  const long long nl0 = (long long)i * nl_pitch, dd0 = (long long)i * dd_pitch;
+  int ncount = 0, dcount = 0;
+  // Cells have an edge >= cutoff/2, so the stencil reaches +-2 cells (125 cells hold 42 % fewer
+  // candidates than 27 cells of edge >= cutoff).  Cells are stored x-fastest, so the 5 cells of a
+  // stencil row are ONE contiguous run of atoms (two runs when the row wraps around the box): the
+  // lanes stride runs of ~100 atoms instead of single small cells.  Dimensions with fewer than 5
+  // cells visit every cell exactly once.
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int n0 = g.nc[0], n1 = g.nc[1], n2 = g.nc[2];
+  const int zlo = n2 >= 5 ? c2 - 2 : 0, zhi = n2 >= 5 ? c2 + 2 : n2 - 1;
+  const int ylo = n1 >= 5 ? c1 - 2 : 0, yhi = n1 >= 5 ? c1 + 2 : n1 - 1;
+  const int xlo = n0 >= 5 ? c0 - 2 : 0, xhi = n0 >= 5 ? c0 + 2 : n0 - 1;
+  for (int zz = zlo; zz <= zhi; zz++) {
+    int b2 = zz;
+    if (b2 < 0 || b2 >= n2) { if (!box.periodic[2]) continue; b2 = (b2 + n2) % n2; }
+    for (int yy = ylo; yy <= yhi; yy++) {
+      int b1 = yy;
+      if (b1 < 0 || b1 >= n1) { if (!box.periodic[1]) continue; b1 = (b1 + n1) % n1; }
+      const long long rowbase = ((long long)b2 * n1 + b1) * n0;
+      // the x-run [xlo, xhi] as at most three pieces: below 0 (wrapped), inside, above n0-1 (wrapped)
+      for (int piece = 0; piece < 3; piece++) {
+        int xa, xb;
+        if (piece == 0) { if (xlo >= 0) continue; if (!box.periodic[0]) continue; xa = xlo + n0; xb = n0 - 1; }
+        else if (piece == 1) { xa = xlo < 0 ? 0 : xlo; xb = xhi >= n0 ? n0 - 1 : xhi; }
+        else { if (xhi < n0) continue; if (!box.periodic[0]) continue; xa = 0; xb = xhi - n0; }
+        const long long a = cell_first[rowbase + xa], b = cell_first[rowbase + xb + 1];
+        for (long long base = a; base < b; base += 64) {
+          const long long p = base + lane;
+          bool in_nl = false, in_dd = false;
+          const int j = (int)p;
+          int same = 0;
+          if (p < b && j != i) {
+            const double4 rj = pos4[j];  // consecutive lanes read consecutive 32-byte entries
+            double ex, ey, ez;
+            min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
+            const double rsq = ex * ex + ey * ey + ez * ez;
+            in_nl = rsq <= cutallsq;
+            in_dd = ipol && __double2loint(rj.w) && (rsq < ddcutsq);
+            same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;
+          }
+          const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
+          const int kn = ncount + __popcll(m_nl & below), kd = dcount + __popcll(m_dd & below);
+          // bit 30 of an nl entry: "same non-zero molecule" -- the static field and the charge-dipole terms
+          // skip such pairs (PS.cpp:342,454), so those kernels need no molecule gather
+          if (in_nl && kn < nl_pitch) nl_j[nl0 + kn] = j | same;
+          if (in_dd && kd < dd_pitch) dd_j[dd0 + kd] = j;
+          ncount += __popcll(m_nl);
+          dcount += __popcll(m_dd);
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    nl_cnt[i] = ncount; dd_cnt[i] = dcount;
+    if (ncount > nl_pitch || dcount > dd_pitch) atomicMax(overflow, ncount > dcount ? ncount : dcount);
+    if (dcount) atomicAdd(dd_total + (blockIdx.x & 63) * 16, (unsigned long long)(dcount < dd_pitch ? dcount : (int)dd_pitch));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Device-side neighbor build for a3: what Neighbor hands this style --
+// src/neighbor.cpp + src/npair_half_bin_newton.cpp, with NPair::exclusion() (molecule/intra) and
+// NPair::find_special() (src/npair.cpp) -- as a FULL list over locals + ghosts for the local rows.
+// Ghosts are explicit periodic images, so the grid is a plain (non-periodic) binning of the
+// bounding box of all atoms.
+struct LJGrid {
+  int nc[3];
+  double lo[3], inv[3];  // cell = clamp(floor((x - lo) * inv))
+};
+__device__ __forceinline__ int lj_cell_of(const LJGrid &g, double x, double y, double z) {
+  const double p[3] = {x, y, z};
+  int c[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int ck = (int)floor((p[k] - g.lo[k]) * g.inv[k]);
+    c[k] = ck < 0 ? 0 : (ck >= g.nc[k] ? g.nc[k] - 1 : ck);
+  }
+  return (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
+}
+__global__ void k_lj_cell_count(int nall, const double *__restrict__ x, LJGrid g, int *__restrict__ cell_id,
+                                int *__restrict__ cell_cnt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nall) return;
+  const int c = lj_cell_of(g, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
+  cell_id[i] = c;
+  atomicAdd(&cell_cnt[c], 1);
+}
+// s order = cell order: pos[s] = {x, y, z, (type, molecule)}, aux[s] = {atom index, tag}
+__global__ void k_lj_cell_fill(int nall, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
+                               int *__restrict__ fill, const double *__restrict__ x, const int *__restrict__ type,
+                               const int *__restrict__ mol, const int *__restrict__ tag, double4 *__restrict__ pos,
+                               int2 *__restrict__ aux) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nall) return;
+  const int c = cell_id[i];
+  const int s = (int)cell_first[c] + atomicAdd(&fill[c], 1);
+  pos[s] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], __hiloint2double(mol[i], type[i]));
+  aux[s] = make_int2(i, tag ? tag[i] : i + 1);
+}
+
+// One wave per local row i; lanes stride the atoms of the +-2 stencil of half-cutoff cells
+// (contiguous x-runs), ballot + popcount compacts in order into the pitched row.
+// Pair rules, in LAMMPS' order (npair_half_bin_newton.cpp):
+//   rsq <= cutneighsq[itype][jtype]; exclusion: same molecule with molecule/intra;
+//   special: which = find_special(special[i], nspecial[i], tag[j]) mapped through special_flag
+//            (0: drop the pair, 1: keep plain, 2: keep with `which` in bits 30-31), except that a
+//            pair farther apart than half a periodic box length is an image and kept plain
+//            (Domain::minimum_image_check).
+__global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int nlocal, int ntypes, const double *__restrict__ x,
+                                                             const int *__restrict__ type, const int *__restrict__ mol,
+                                                             const double4 *__restrict__ pos, const int2 *__restrict__ aux,
+                                                             LJGrid g, const long long *__restrict__ cell_first,
+                                                             const double *__restrict__ cutneighsq, Box box,
+                                                             int exclude_intra, const int *__restrict__ nspecial,
+                                                             const int *__restrict__ special, int maxspecial, int sf1,
+                                                             int sf2, int sf3, long long pitch, int *__restrict__ cnt,
+                                                             int *__restrict__ out_j, int *__restrict__ overflow,
+                                                             unsigned long long *__restrict__ total) {
+  extern __shared__ double cn_lds[];
+  const int w = ntypes + 1;
+  for (int t = threadIdx.x; t < w * w; t += blockDim.x) cn_lds[t] = cutneighsq[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= nlocal) return;
+  const double xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+  const int itype = type[i], imol = mol[i];
+  const double *cn = cn_lds + itype * w;
+  int n1 = 0, n2 = 0, n3 = 0;
+  if (nspecial) { n1 = nspecial[3 * i]; n2 = nspecial[3 * i + 1]; n3 = nspecial[3 * i + 2]; }
+  const int *sp = special ? special + (size_t)i * maxspecial : nullptr;
+  const int ci = lj_cell_of(g, xi, yi, zi);
+  const int n0 = g.nc[0], n1c = g.nc[1], n2c = g.nc[2];
+  const int c0 = ci % n0, c1 = (ci / n0) % n1c, c2 = ci / (n0 * n1c);
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const long long row0 = (long long)i * pitch;
+  int count = 0;
+  for (int zz = max(c2 - 2, 0); zz <= min(c2 + 2, n2c - 1); zz++)
+    for (int yy = max(c1 - 2, 0); yy <= min(c1 + 2, n1c - 1); yy++) {
+      const long long rb = ((long long)zz * n1c + yy) * n0;
+      const long long a = cell_first[rb + max(c0 - 2, 0)], b = cell_first[rb + min(c0 + 2, n0 - 1) + 1];
+      for (long long base = a; base < b; base += 64) {
+        const long long p = base + lane;
+        bool keep = false;
+        int entry = 0;
+        if (p < b) {
+          const double4 pj = pos[p];
+          const int2 aj = aux[p];
+          const int jtype = __double2loint(pj.w), jmol = __double2hiint(pj.w);
+          const double dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+          const double rsq = dx * dx + dy * dy + dz * dz;
+          keep = aj.x != i && rsq <= cn[jtype];
+          if (keep && exclude_intra && imol == jmol) keep = false;
+          entry = aj.x;
+          if (keep && n3 > 0) {
+            int which = 0;
+            for (int k = 0; k < n3; k++)
+              if (sp[k] == aj.y) {
+                const int cls = k < n1 ? 1 : (k < n2 ? 2 : 3);
+                const int flag = cls == 1 ? sf1 : (cls == 2 ? sf2 : sf3);
+                which = flag == 0 ? -1 : (flag == 1 ? 0 : cls);
+                break;
+              }
+            if (which > 0) {  // minimum_image_check: a partner more than half a box away is an image
+              if ((box.periodic[0] && fabs(dx) > box.half[0]) || (box.periodic[1] && fabs(dy) > box.half[1]) ||
+                  (box.periodic[2] && fabs(dz) > box.half[2]))
+                which = 0;
+            }
+            if (which < 0) keep = false;
+            else entry |= which << 30;
+          }
+        }
+        const unsigned long long m = __ballot(keep);
+        const int k = count + __popcll(m & below);
+        if (keep && k < pitch) out_j[row0 + k] = entry;
+        count += __popcll(m);
+      }
+    }
+  if (lane == 0) {
+    cnt[i] = count < pitch ? count : (int)pitch;
+    if (count > pitch) atomicMax(overflow, count);
+    atomicAdd(total + (blockIdx.x & 63) * 16, (unsigned long long)count);
+  }
+}
+__global__ void k_lj_rows(int nlocal, long long pitch, int *__restrict__ ilist, long long *__restrict__ first) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  ilist[i] = i;
+  first[i] = (long long)i * pitch;
+}
+
+// multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers
+__global__ void k_mu_gather(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
+                            const AtomRec *__restrict__ recA, const AtomRec *__restrict__ recB,
+                            double *__restrict__ dst) {
+  long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  const long long s = inv ? inv[i] : i;
+  const AtomRec *r = scal->cur ? recB : recA;
+  dst[3 * (i - lo)] = r[s].mx; dst[3 * (i - lo) + 1] = r[s].my; dst[3 * (i - lo) + 2] = r[s].mz;
+}
+__global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
+                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src) {
+  long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  const long long s = inv ? inv[i] : i;
+  AtomRec *r = scal->cur ? recB : recA;
+  r[s].mx = src[3 * (i - lo)]; r[s].my = src[3 * (i - lo) + 1]; r[s].mz = src[3 * (i - lo) + 2];
+}
+
+// halo exchange by index list (orig ids; negative entries are padding and skipped)
+__global__ void k_mu_gather_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
+                                const AtomRec *__restrict__ recA, const AtomRec *__restrict__ recB,
+                                double *__restrict__ dst) {
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int o = idx[t];
+  if (o < 0) return;
+  const AtomRec *r = scal->cur ? recB : recA;
+  const int s = inv ? inv[o] : o;
+  dst[3 * t] = r[s].mx; dst[3 * t + 1] = r[s].my; dst[3 * t + 2] = r[s].mz;
+}
+__global__ void k_mu_scatter_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
+                                 AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src,
+                                 int own_lo, int own_hi) {
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int o = idx[t];
+  if (o < 0 || (o >= own_lo && o < own_hi)) return;  // padding, or a row this handle owns itself
+  AtomRec *r = scal->cur ? recB : recA;
+  const int s = inv ? inv[o] : o;
+  r[s].mx = src[3 * t]; r[s].my = src[3 * t + 1]; r[s].mz = src[3 * t + 2];
+}
+
+// small utilities
+__global__ void k_zero_scal(Scal *s, int keep_solver) {
+  s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;
+  for (int k = 0; k < 6; k++) s->virial[k] = 0.0;
+  s->change = 0.0; s->last_change = 0.0; s->pad = 0;
+  s->rmin_bits = (unsigned long long)__double_as_longlong(1000.0);
+  if (!keep_solver) { s->iterations = 0; s->done = 0; s->status = 0; s->cur = 0; s->sweeps = 0; }
+}
+__global__ void k_set_done(Scal *s, int done) { s->done = done; }
+
+}  // namespace polar

@@ -1,0 +1,514 @@
+// polar_rows.hpp -- per-row kernels of the step: pack, rank metric (a2), LJ + Ewald-real (a3), static field (a4/a5), polarization forces (a8), fdotr virial (a10).
+// Part of the hand-written HIP kernels (gfx950 / CDNA4, wave64) of the lj/cut/coul/long/polarization
+// hot path; see polar_kernels.hpp for the mapping and the index spaces.
+#pragma once
+
+#include "polar_common.hpp"
+
+namespace polar {
+
+// ------------------------------------------------------------------------------------------
+// pack: x/q/alpha (+ initial mu) -> 64-byte records (both Jacobi buffers)
+__global__ void k_pack(int n, const int *__restrict__ perm, const double *__restrict__ x, const double *__restrict__ q,
+                       const double *__restrict__ alpha, const int *__restrict__ mol, const double *__restrict__ mu0,
+                       AtomRec *__restrict__ r0, AtomRec *__restrict__ r1, int *__restrict__ mol_s,
+                       double4 *__restrict__ pos4) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = perm ? perm[i] : i;
+  AtomRec r;
+  r.x = x[3 * o]; r.y = x[3 * o + 1]; r.z = x[3 * o + 2]; r.q = q[o];
+  r.mx = mu0 ? mu0[3 * o] : 0.0; r.my = mu0 ? mu0[3 * o + 1] : 0.0; r.mz = mu0 ? mu0[3 * o + 2] : 0.0;
+  r.a = alpha[o];
+  r0[i] = r;
+  r1[i] = r;
+  mol_s[i] = mol[o];
+  // 32-byte {x, y, z, (molecule id, alpha != 0)} for the list build
+  if (pos4) pos4[i] = make_double4(r.x, r.y, r.z, __hiloint2double(mol[o], r.a != 0.0 ? 1 : 0));
+}
+
+// ------------------------------------------------------------------------------------------
+// a2  rank metric, PS.cpp:192-227.  Pass 1: rmin; pass 2: rank_metric.
+// ALLPAIRS: raw (non-minimum-image) distances to locals AND ghosts, exactly as the reference.
+// list mode (extension): minimum-image distances over the library's full list.
+template <bool ALLPAIRS, int PASS>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, const double *__restrict__ x,
+                                                      const double *__restrict__ alpha, const int *__restrict__ mol,
+                                                      Box box, RowList nl,
+                                                      const int *__restrict__ nl_j,
+                                                      const AtomRec *__restrict__ rec,
+                                                      const int *__restrict__ mol_s, Scal *scal,
+                                                      double *__restrict__ slots,
+                                                      double *__restrict__ rank_metric) {
+  // ALLPAIRS: orig space (x/alpha/mol incl. ghosts).  List mode: s space (records, mol_s).
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= nlocal) return;
+  const double xi = ALLPAIRS ? x[3 * i] : rec[i].x, yi = ALLPAIRS ? x[3 * i + 1] : rec[i].y,
+               zi = ALLPAIRS ? x[3 * i + 2] : rec[i].z, ai = ALLPAIRS ? alpha[i] : rec[i].a;
+  const int mi = ALLPAIRS ? mol[i] : mol_s[i];
+  double rmin = (PASS == 1) ? 1000.0 : __longlong_as_double((long long)scal->rmin_bits);
+  double acc = 0.0;
+  long long beg = 0, end = ntotal;
+  if (!ALLPAIRS) row_range(nl, i, beg, end);
+  for (long long base = beg; base < end; base += 64) {
+    const long long p = base + lane;
+    bool hit = false;
+    double term = 0.0;
+    if (p < end) {
+      const int j = ALLPAIRS ? (int)p : (nl_j[p] & POLAR_NL_MASK);
+      if (j != i) {
+        double dx, dy, dz, aj;
+        int mj;
+        if (ALLPAIRS) {
+          dx = xi - x[3 * j]; dy = yi - x[3 * j + 1]; dz = zi - x[3 * j + 2];
+          aj = alpha[j]; mj = mol[j];
+        } else {
+          const AtomRec rj = rec[j];
+          min_image_rint(box, xi, yi, zi, rj.x, rj.y, rj.z, dx, dy, dz);
+          aj = rj.a; mj = mol_s[j];
+        }
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const bool molok = (mi != mj) || mi == 0;
+        if (PASS == 1) {
+          if (ai > 0 && aj > 0 && molok) rmin = fmin(rmin, r);
+        } else if (rmin * 1.5 > r && molok) {
+          hit = true;
+          term = ai * aj;
+        }
+      }
+    }
+    if (PASS == 2) {
+      // add the (few) qualifying terms in ascending j, like the reference's serial loop, so that
+      // ties in rank_metric -- and with them the ranked sweep order -- come out bit-identical
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        acc += __shfl(term, b, 64);
+        m &= m - 1;
+      }
+    }
+  }
+  if (PASS == 1) {
+    rmin = wave_min(rmin);
+    if (lane == 0)
+      atomicMin((unsigned long long *)slot_ptr(slots, SL_RMIN), (unsigned long long)__double_as_longlong(rmin));
+  } else {
+    if (lane == 0) rank_metric[i] = acc;  // identical in every lane
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a3  LJ + real-space Ewald Coulomb over the LAMMPS half list, PS.cpp:232-321.
+// One wave per listed atom i; -F is deposited on j (local or ghost) with FP64 atomics so that
+// ghost forces come back exactly as LAMMPS' reverse_comm expects.
+struct LJCoulParams {
+  int ntypes, newton_pair, nlocal;
+  int full_list;  // 1: LAMMPS full list (each pair in both rows): force on i only, tallies halved
+  int ncoultablebits, ncoulmask, ncoulshiftbits;
+  int ablate;     // lab switch (POLAR_ABLATE & 32: no deposit on j)
+  double tabinnersq, cut_coulsq, g_ewald, qqrd2e;
+  double special_lj[4], special_coul[4];
+  const double *ljpack;   // [(ntypes+1)^2][8] = cutsq, cut_ljsq, lj1, lj2, lj3, lj4, offset, pad
+  const double *ctab;     // [ntable][8]      = r, dr, f, df, e, de, c, dc  (one 64-byte line per bin)
+};
+
+// per-atom pack for the half-list loop: 32-byte {x,y,z,q} + type, locals AND ghosts, orig order
+__global__ void k_pack_lj(int nall, const double *__restrict__ x, const double *__restrict__ q, double4 *__restrict__ xq) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nall) xq[i] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], q[i]);
+}
+
+// Symmetrised copy of LAMMPS' half list, built on the device when the list is uploaded: every pair
+// (i,j) of the half list appears in the row of i AND in the row of j (ghost atoms get rows too), so
+// the force loop needs no atomics on j -- the three scattered FP64 atomics per pair were 85 % of
+// the kernel.  Each row then accumulates the full force on its atom; pair tallies count 1/2 per row.
+__global__ __launch_bounds__(POLAR_BLOCK) void k_sym_count(int inum, const int *__restrict__ ilist,
+                                                           const int *__restrict__ numneigh,
+                                                           const long long *__restrict__ first,
+                                                           const int *__restrict__ neigh, int *__restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  const int ii = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ii >= inum) return;
+  const int i = ilist[ii];
+  const int *jl = neigh + first[i];
+  const int jn = numneigh[i];
+  for (int jj = lane; jj < jn; jj += 64) atomicAdd(&cnt[jl[jj] & 0x3FFFFFFF], 1);
+  if (lane == 0) atomicAdd(&cnt[i], jn);
+}
+__global__ __launch_bounds__(POLAR_BLOCK) void k_sym_fill(int inum, const int *__restrict__ ilist,
+                                                          const int *__restrict__ numneigh,
+                                                          const long long *__restrict__ first,
+                                                          const int *__restrict__ neigh,
+                                                          const long long *__restrict__ sfirst, int *__restrict__ fill,
+                                                          int *__restrict__ sj) {
+  const int lane = threadIdx.x & 63;
+  const int ii = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ii >= inum) return;
+  const int i = ilist[ii];
+  const int *jl = neigh + first[i];
+  const int jn = numneigh[i];
+  // own row: one slot range per wave, entries in list order
+  long long base = 0;
+  if (lane == 0) base = sfirst[i] + atomicAdd(&fill[i], jn);
+  base = __shfl(base, 0, 64);
+  for (int jj = lane; jj < jn; jj += 64) {
+    const int e = jl[jj];
+    const int j = e & 0x3FFFFFFF;
+    sj[base + jj] = e;                                                 // j with its special bits
+    sj[sfirst[j] + atomicAdd(&fill[j], 1)] = i | (e & 0xC0000000);     // reverse entry, same bits
+  }
+}
+
+// One wave per listed atom i.  Per pair: 1 coalesced index load, two 16-byte gathers of {x,y,z,q},
+// one 4-byte gather of the type, the type-pair parameters out of LDS, and the Coulomb bin as one
+// 64-byte line -- the loop is bound by L1 transactions and by the three FP64 atomics that deposit
+// -F on j (LAMMPS' newton-on contract: ghosts are folded back by reverse_comm).
+template <bool EFLAG, bool VPAIR>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum, const int *__restrict__ ilist,
+                                                        const int *__restrict__ numneigh,
+                                                        const long long *__restrict__ first,
+                                                        const int *__restrict__ neigh,
+                                                        const double4 *__restrict__ xq, const int *__restrict__ type,
+                                                        double *__restrict__ f, double *__restrict__ slots,
+                                                        double *__restrict__ eatom, double *__restrict__ vatom,
+                                                        int vglobal) {
+  const double EWALD_F = 1.12837917, EWALD_P = 0.3275911, A1 = 0.254829592, A2 = -0.284496736, A3 = 1.421413741,
+               A4 = -1.453152027, A5 = 1.061405429;  // PS.cpp:43-49
+  extern __shared__ double lj_lds[];
+  const int w = P.ntypes + 1;
+  for (int t = threadIdx.x; t < w * w * 8; t += blockDim.x) lj_lds[t] = P.ljpack[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int ii = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ii >= inum) return;
+  const int i = ilist ? ilist[ii] : ii;
+  const double4 pi = xq[i];
+  const double qtmp = pi.w, xtmp = pi.x, ytmp = pi.y, ztmp = pi.z;
+  const int itype = type[i];
+  const int *jlist = neigh + first[i];
+  const int jnum = numneigh ? numneigh[i] : (int)(first[i + 1] - first[i]);
+  if (jnum == 0) return;
+  double fx = 0, fy = 0, fz = 0, ev = 0, ec = 0;
+  double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  for (int jj = lane; jj < jnum; jj += 64) {
+    int j = jlist[jj];
+    const int sb = (j >> 30) & 3;  // sbmask, src/pair.h:241
+    const double factor_lj = P.special_lj[sb], factor_coul = P.special_coul[sb];
+    j &= 0x3FFFFFFF;  // NEIGHMASK
+    const double4 pj = xq[j];
+    const double delx = xtmp - pj.x, dely = ytmp - pj.y, delz = ztmp - pj.z;
+    const double rsq = delx * delx + dely * dely + delz * delz;
+    const double *lj = lj_lds + (itype * w + type[j]) * 8;
+    if (rsq < lj[0]) {
+      const double r2inv = 1.0 / rsq;
+      const double qiqj = qtmp * pj.w;
+      double forcecoul = 0.0, forcelj = 0.0, prefactor = 0.0, erfc_ = 0.0, fraction = 0.0, r6inv = 0.0;
+      double2 tab_e = make_double2(0.0, 0.0);
+      bool direct = true;
+      if (rsq < P.cut_coulsq) {
+        direct = (!P.ncoultablebits) || (rsq <= P.tabinnersq);
+        if (direct) {
+          const double r = sqrt(rsq), grij = P.g_ewald * r, expm2 = exp(-grij * grij);
+          const double t = 1.0 / (1.0 + EWALD_P * grij);
+          erfc_ = t * (A1 + t * (A2 + t * (A3 + t * (A4 + t * A5)))) * expm2;
+          prefactor = P.qqrd2e * qiqj / r;
+          forcecoul = prefactor * (erfc_ + EWALD_F * grij * expm2);
+          if (factor_coul < 1.0) forcecoul -= (1.0 - factor_coul) * prefactor;
+        } else {
+          const float rsqf = (float)rsq;  // union_int_float_t lookup, PS.cpp:268-272
+          const int itable = (__float_as_int(rsqf) & P.ncoulmask) >> P.ncoulshiftbits;
+          const double2 *bin = reinterpret_cast<const double2 *>(P.ctab + (size_t)itable * 8);
+          const double2 rdr = bin[0], fdf = bin[1];
+          if (EFLAG) tab_e = bin[2];
+          fraction = ((double)rsqf - rdr.x) * rdr.y;
+          forcecoul = qiqj * (fdf.x + fraction * fdf.y);
+          if (factor_coul < 1.0) {
+            const double2 cdc = bin[3];
+            prefactor = qiqj * (cdc.x + fraction * cdc.y);
+            forcecoul -= (1.0 - factor_coul) * prefactor;
+          }
+        }
+      }
+      if (rsq < lj[1]) {
+        r6inv = r2inv * r2inv * r2inv;
+        forcelj = r6inv * (lj[2] * r6inv - lj[3]);
+      }
+      const double fpair = (forcecoul + factor_lj * forcelj) * r2inv;
+      fx += delx * fpair; fy += dely * fpair; fz += delz * fpair;
+      if (!P.full_list && (P.newton_pair || j < P.nlocal) && !(P.ablate & 32)) {
+        atomicAdd(&f[3 * j], -delx * fpair);
+        atomicAdd(&f[3 * j + 1], -dely * fpair);
+        atomicAdd(&f[3 * j + 2], -delz * fpair);
+      }
+      double wgt = 1.0;  // ev_tally, src/pair.cpp:854-950
+      if (P.full_list) wgt = 0.5;  // ev_tally_full, src/pair.cpp:957-995
+      else if (!P.newton_pair) wgt = 0.5 * ((i < P.nlocal) + (j < P.nlocal));
+      if (EFLAG) {
+        if (rsq < P.cut_coulsq) {
+          double ecoul;
+          if (direct) ecoul = prefactor * erfc_;
+          else ecoul = qiqj * (tab_e.x + fraction * tab_e.y);
+          if (factor_coul < 1.0) ecoul -= (1.0 - factor_coul) * prefactor;
+          ec += wgt * ecoul;
+        }
+        if (rsq < lj[1]) ev += wgt * factor_lj * (r6inv * (lj[4] * r6inv - lj[5]) - lj[6]);
+      }
+      if (VPAIR) {
+        v0 += wgt * delx * delx * fpair; v1 += wgt * dely * dely * fpair; v2 += wgt * delz * delz * fpair;
+        v3 += wgt * delx * dely * fpair; v4 += wgt * delx * delz * fpair; v5 += wgt * dely * delz * fpair;
+      }
+    }
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) {
+    atomicAdd(&f[3 * i], fx); atomicAdd(&f[3 * i + 1], fy); atomicAdd(&f[3 * i + 2], fz);
+  }
+  if (EFLAG) {
+    ev = wave_sum(ev); ec = wave_sum(ec);
+    if (lane == 0) {
+      atomicAdd(slot_ptr(slots, SL_EVDWL), ev); atomicAdd(slot_ptr(slots, SL_ECOUL), ec);
+      // per-atom energy, src/pair.cpp:881-885: every pair of a full row carries weight 1/2, so the
+      // row total IS eatom[i] (one wave per row: plain store-add, no atomics)
+      if (eatom) eatom[i] += ev + ec;
+    }
+  }
+  if (VPAIR) {
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
+    if (lane == 0) {
+      if (vglobal) {
+        atomicAdd(slot_ptr(slots, SL_V0), v0); atomicAdd(slot_ptr(slots, SL_V1), v1); atomicAdd(slot_ptr(slots, SL_V2), v2);
+        atomicAdd(slot_ptr(slots, SL_V3), v3); atomicAdd(slot_ptr(slots, SL_V4), v4); atomicAdd(slot_ptr(slots, SL_V5), v5);
+      }
+      if (vatom) {  // src/pair.cpp:925-942
+        double *va = vatom + 6 * (size_t)i;
+        va[0] += v0; va[1] += v1; va[2] += v2; va[3] += v3; va[4] += v4; va[5] += v5;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a4 + a5  static field (shifted-force Coulomb, PS.cpp:324-361), unit scale and initial guess
+// (PS.cpp:363-386).  Full-row evaluation: E_i = sum_j ef_temp * q_j * del_ij, which is the
+// reference's i<j scatter seen from row i (del is antisymmetric under the image rule).
+template <bool ALLPAIRS>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restrict__ rows, int nrows, int nlocal,
+                                                              const AtomRec *__restrict__ rec,
+                                                              const int *__restrict__ mol, Box box,
+                                                              RowList nl,
+                                                              const int *__restrict__ nl_j, double cut_coulsq,
+                                                              double e2s, double gamma, int use_previous,
+                                                              double *__restrict__ ef, AtomRec *__restrict__ rec0,
+                                                              AtomRec *__restrict__ rec1) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = rows ? rows[row] : row;
+  const AtomRec ri = rec[i];
+  const int mi = mol[i];
+  const double f_shift = -1.0 / cut_coulsq;
+  double ex = 0, ey = 0, ez = 0;
+  long long beg = 0, end = nlocal;
+  if (!ALLPAIRS) row_range(nl, i, beg, end);
+  if (ALLPAIRS) {
+    for (long long p = beg + lane; p < end; p += 64) {
+      const int j = (int)p;
+      if (j == i) continue;
+      const AtomRec rj = rec[j];
+      double dx, dy, dz;
+      pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq <= cut_coulsq && ((mi != mol[j]) || mi == 0)) {  // note <=, PS.cpp:342
+        const double rinv = rsqrt(rsq);
+        const double ef_temp = (rinv * rinv + f_shift) * rinv * rj.q;
+        ex += ef_temp * dx; ey += ef_temp * dy; ez += ef_temp * dz;
+      }
+    }
+  } else {
+    __shared__ double2 s_stage[POLAR_ROWS_PER_BLOCK][64 * 5];
+    double2 *stage = s_stage[threadIdx.x >> 6];
+    for (long long base = beg; base < end; base += 64) {  // wave-uniform trip count: the fetch is cooperative
+      const long long p = base + lane;
+      const bool valid = p < end;
+      const int e = valid ? nl_j[p] : i;
+      const int j = e & POLAR_NL_MASK;
+      const RecQuad rj = fetch_records(rec, j, stage, lane);
+      double dx, dy, dz;
+      pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.a.x, rj.b.x, rj.c.x, dx, dy, dz);
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (valid && j != i && rsq <= cut_coulsq && !(e & POLAR_NL_SAMEMOL)) {  // note <=, PS.cpp:342
+        const double rinv = rsqrt(rsq);
+        const double ef_temp = (rinv * rinv + f_shift) * rinv * rj.d.x;
+        ex += ef_temp * dx; ey += ef_temp * dy; ez += ef_temp * dz;
+      }
+    }
+  }
+  ex = wave_sum(ex); ey = wave_sum(ey); ez = wave_sum(ez);
+  if (lane == 0) {
+    ex *= e2s; ey *= e2s; ez *= e2s;
+    ef[3 * i] = ex; ef[3 * i + 1] = ey; ef[3 * i + 2] = ez;
+    if (!use_previous) {  // mu = gamma * alpha * E
+      const double a = ri.a;
+      double mx = a * ex, my = a * ey, mz = a * ez;
+      mx *= gamma; my *= gamma; mz *= gamma;
+      rec0[i].mx = mx; rec0[i].my = my; rec0[i].mz = mz;
+      rec1[i].mx = mx; rec1[i].my = my; rec1[i].mz = mz;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a8  polarization forces and energies, PS.cpp:406-641, evaluated per row (force on i from every j).
+// The pair force is antisymmetric, so summing rows reproduces the reference's i<j scatter;
+// pair energies are counted from both rows and halved.
+template <bool ALLPAIRS, int DAMP, bool EFLAG, bool VPAIR>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restrict__ rows, int nrows, const int *__restrict__ perm,
+                                                             int nlocal, const Scal *scal_in,
+                                                             const AtomRec *__restrict__ recA,
+                                                             const AtomRec *__restrict__ recB,
+                                                             const int *__restrict__ mol, Box box,
+                                                             RowList nl,
+                                                             const int *__restrict__ nl_j, double cut_coulsq,
+                                                             double ddcutsq, double pd, double e2s,
+                                                             double *__restrict__ f, double *__restrict__ slots,
+                                                             double *__restrict__ vatom, int vglobal) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = rows ? rows[row] : row;
+  const AtomRec *__restrict__ rec = scal_in->cur ? recB : recA;
+  const AtomRec ri = rec[i];
+  const int mi = mol[i];
+  const double f_shift = -1.0 / cut_coulsq;
+  double fx = 0, fy = 0, fz = 0, uef = 0, udd = 0;
+  double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  long long beg = 0, end = nlocal;
+  if (!ALLPAIRS) row_range(nl, i, beg, end);
+  // (the cooperative record fetch of k_static_field was tried here too: this kernel is bound by its FP64
+  //  arithmetic, not by the gathers, and got 7 % slower)
+  for (long long p = beg + lane; p < end; p += 64) {
+    const int e = ALLPAIRS ? (int)p : nl_j[p];
+    const int j = ALLPAIRS ? e : (e & POLAR_NL_MASK);
+    if (j == i) continue;
+    const AtomRec rj = rec[j];
+    const bool molok = ALLPAIRS ? ((mi != mol[j]) || mi == 0) : !(e & POLAR_NL_SAMEMOL);
+    double dx, dy, dz;
+    pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+    const double xsq = dx * dx, ysq = dy * dy, zsq = dz * dz;
+    const double rsq = xsq + ysq + zsq;
+    const double rinv = rsqrt(rsq);
+    const double r2inv = rinv * rinv;
+    const double r = rsq * rinv;
+    const double r3inv = r2inv * rinv;
+    double px = 0, py = 0, pz = 0;
+    if (rsq < cut_coulsq && molok) {  // note <, PS.cpp:454
+      // shifted-force charge-dipole tensor G_pq = delta_pq (r^-2 + f_shift) r^2 ... written as the
+      // reference does: M_pp = (-2 p^2 + q^2 + s^2) r2inv + f_shift (q^2 + s^2), M_pq = -pq (3 r2inv + f_shift)
+      const double mxx = (-2.0 * xsq + ysq + zsq) * r2inv + f_shift * (ysq + zsq);
+      const double myy = (-2.0 * ysq + xsq + zsq) * r2inv + f_shift * (xsq + zsq);
+      const double mzz = (-2.0 * zsq + xsq + ysq) * r2inv + f_shift * (xsq + ysq);
+      const double k = -(3.0 * r2inv + f_shift);
+      const double mxy = k * dx * dy, mxz = k * dx * dz, myz = k * dy * dz;
+      const double ef_temp = (r2inv + f_shift) * rinv * e2s;
+      if (ri.a != 0.0 && rj.q != 0.0) {  // dipole on i, charge on j
+        const double cf = rj.q * e2s * r3inv;
+        px += cf * (ri.mx * mxx + ri.my * mxy + ri.mz * mxz);
+        py += cf * (ri.mx * mxy + ri.my * myy + ri.mz * myz);
+        pz += cf * (ri.mx * mxz + ri.my * myz + ri.mz * mzz);
+        if (EFLAG) uef -= ef_temp * rj.q * (ri.mx * dx + ri.my * dy + ri.mz * dz);
+      }
+      if (rj.a != 0.0 && ri.q != 0.0) {  // dipole on j, charge on i
+        const double cf = ri.q * e2s * r3inv;
+        px -= cf * (rj.mx * mxx + rj.my * mxy + rj.mz * mxz);
+        py -= cf * (rj.mx * mxy + rj.my * myy + rj.mz * myz);
+        pz -= cf * (rj.mx * mxz + rj.my * myz + rj.mz * mzz);
+        if (EFLAG) uef += ef_temp * ri.q * (rj.mx * dx + rj.my * dy + rj.mz * dz);
+      }
+    }
+    if (ri.a != 0.0 && rj.a != 0.0 && (ALLPAIRS || rsq < ddcutsq)) {  // dipole-dipole, PS.cpp:512-602
+      const double r5inv = r3inv * r2inv, r7inv = r5inv * r2inv;
+      const double pdotp = ri.mx * rj.mx + ri.my * rj.my + ri.mz * rj.mz;
+      const double pidotr = ri.mx * dx + ri.my * dy + ri.mz * dz;
+      const double pjdotr = rj.mx * dx + rj.my * dy + rj.mz * dz;
+      double pre_r, pre2, pre3;
+      if (DAMP == 0) {
+        const double t1 = exp(-pd * r);
+        const double t2 = 1.0 + pd * r + 0.5 * pd * pd * r * r;
+        const double t3 = t2 + (1.0 / 6.0) * pd * pd * pd * r * r * r;
+        const double g2 = 1.0 - t1 * t2, g3 = 1.0 - t1 * t3;
+        const double pre1 = 3.0 * r5inv * pdotp * g2 - 15.0 * r7inv * pidotr * pjdotr * g3;
+        pre2 = 3.0 * r5inv * pjdotr * g3;
+        pre3 = 3.0 * r5inv * pidotr * g3;
+        const double pre4 = -pdotp * r3inv * (-t1 * (pd * rinv + pd * pd) + t1 * pd * t2 * rinv);
+        const double pre5 = 3.0 * pidotr * pjdotr * r5inv *
+                            (-t1 * (pd * rinv + pd * pd + 0.5 * r * pd * pd * pd) + t1 * pd * t3 * rinv);
+        pre_r = pre1 + pre4 + pre5;
+        if (EFLAG) udd += r3inv * pdotp * g2 - 3.0 * r5inv * pidotr * pjdotr * g3;
+      } else {
+        pre_r = 3.0 * r5inv * pdotp - 15.0 * r7inv * pidotr * pjdotr;
+        pre2 = 3.0 * r5inv * pjdotr;
+        pre3 = 3.0 * r5inv * pidotr;
+        if (EFLAG) udd += r3inv * pdotp - 3.0 * r5inv * pidotr * pjdotr;
+      }
+      px += pre_r * dx + pre2 * ri.mx + pre3 * rj.mx;
+      py += pre_r * dy + pre2 * ri.my + pre3 * rj.my;
+      pz += pre_r * dz + pre2 * ri.mz + pre3 * rj.mz;
+    }
+    fx += px; fy += py; fz += pz;
+    if (VPAIR) {  // ev_tally_xyz, src/pair.cpp:1001-1075 (each pair seen from both rows -> 0.5)
+      v0 += 0.5 * dx * px; v1 += 0.5 * dy * py; v2 += 0.5 * dz * pz;
+      v3 += 0.5 * dx * py; v4 += 0.5 * dx * pz; v5 += 0.5 * dy * pz;
+    }
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) {
+    const int o = perm ? perm[i] : i;  // forces leave in LAMMPS' order
+    atomicAdd(&f[3 * o], fx); atomicAdd(&f[3 * o + 1], fy); atomicAdd(&f[3 * o + 2], fz);
+  }
+  if (EFLAG) {
+    uef = wave_sum(uef); udd = wave_sum(udd);
+    if (lane == 0) {
+      if (ri.a != 0.0) atomicAdd(slot_ptr(slots, SL_USELF), 0.5 * (ri.mx * ri.mx + ri.my * ri.my + ri.mz * ri.mz) / ri.a);
+      atomicAdd(slot_ptr(slots, SL_UEF), 0.5 * uef);
+      atomicAdd(slot_ptr(slots, SL_UDD), 0.5 * udd);
+    }
+  }
+  if (VPAIR) {
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
+    if (lane == 0) {
+      if (vglobal) {
+        atomicAdd(slot_ptr(slots, SL_V0), v0); atomicAdd(slot_ptr(slots, SL_V1), v1); atomicAdd(slot_ptr(slots, SL_V2), v2);
+        atomicAdd(slot_ptr(slots, SL_V3), v3); atomicAdd(slot_ptr(slots, SL_V4), v4); atomicAdd(slot_ptr(slots, SL_V5), v5);
+      }
+      if (vatom) {  // per-atom part of ev_tally_xyz, src/pair.cpp:1065-1082 (the row total is vatom[i])
+        double *va = vatom + 6 * (size_t)(perm ? perm[i] : i);
+        va[0] += v0; va[1] += v1; va[2] += v2; va[3] += v3; va[4] += v4; va[5] += v5;
+      }
+    }
+  }
+}
+
+__global__ void k_add_into(long long n, const double *__restrict__ src, double *__restrict__ dst) {
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+// a10  virial_fdotr_compute, src/pair.cpp:1495-1540: sum over locals AND ghosts of f_i x_i
+__global__ __launch_bounds__(POLAR_BLOCK) void k_virial_fdotr(int nall, const double *__restrict__ x,
+                                                              const double *__restrict__ f, double *__restrict__ slots) {
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nall; i += gridDim.x * blockDim.x) {
+    const double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
+    const double xx = x[3 * i], yy = x[3 * i + 1], zz = x[3 * i + 2];
+    v[0] += fx * xx; v[1] += fy * yy; v[2] += fz * zz; v[3] += fy * xx; v[4] += fz * xx; v[5] += fz * yy;
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double s = wave_sum(v[k]);
+    if (lane == 0 && s != 0.0) atomicAdd(slot_ptr(slots, SL_V0 + k), s);
+  }
+}
+
+}  // namespace polar

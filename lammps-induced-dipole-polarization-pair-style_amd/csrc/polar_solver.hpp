@@ -1,0 +1,648 @@
+// polar_solver.hpp -- the dipole solver (a6/a7): matrix-free field kernels, component-per-lane list sweep, exact-order Gauss-Seidel (matrix-free and on the packed tensor), device-resident loop control.
+// Part of the hand-written HIP kernels (gfx950 / CDNA4, wave64) of the lj/cut/coul/long/polarization
+// hot path; see polar_kernels.hpp for the mapping and the index spaces.
+#pragma once
+
+#include "polar_common.hpp"
+
+namespace polar {
+
+// ------------------------------------------------------------------------------------------
+// a6 + a7  the dipole-field sweep (matrix-free): for row i
+//     ef_ind_i = - sum_j T_ij mu_j ,   mu_new_i = alpha_i (E_static_i + ef_ind_i)
+// (PS.cpp:1158-1180 with the tensor of PS.cpp:1273-1306 recomputed per pair).
+// Epilogues:
+//   EP_JACOBI : read rec[cur], write rec[1-cur] (reference "polar_gs no")
+//   EP_INPLACE: write mu into the same buffer (colour-phase Gauss-Seidel; rows of one colour do
+//               not read each other's NEW values by construction of the phases)
+//   EP_FIELD  : store ef_ind only (initial field of the blocked sequential Gauss-Seidel)
+enum { EP_JACOBI = 0, EP_INPLACE = 1, EP_FIELD = 2 };
+
+template <bool ALLPAIRS, int DAMP, int EP>
+__global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict__ rows, int nlocal,
+                                                       AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, Box box,
+                                                       RowList ddl,
+                                                       const int *__restrict__ dd_j,
+                                                       const double2 *__restrict__ dd_s, double ddcutsq, double pd,
+                                                       const double *__restrict__ ef, double *__restrict__ Fout,
+                                                       const Scal *scal, double *__restrict__ slots, int ablate) {
+  if (scal->done) return;  // device-resident loop control: finished solves turn later launches into no-ops
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // blockDim.x/64 rows per workgroup
+  if (row >= nrows) return;
+  const int i = rows ? rows[row] : row;
+  const int cur = scal->cur;
+  const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+  const AtomRec ri = src[i];
+  double fx = 0, fy = 0, fz = 0;
+  if (ri.a != 0.0 || EP == EP_FIELD) {
+    long long beg = 0, end = nlocal;
+    if (!ALLPAIRS) row_range(ddl, i, beg, end);
+    if (ALLPAIRS) {
+      for (long long p = beg + lane; p < end; p += 64) {
+        const int j = (int)p;
+        if (j == i) continue;
+        const AtomRec rj = src[j];
+        double dx, dy, dz;
+        min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        double s3, s5;
+        tensor_scalars<DAMP>(r2, pd, s3, s5);
+        const double md = rj.mx * dx + rj.my * dy + rj.mz * dz;
+        const double c = s5 * md;
+        fx -= s3 * rj.mx - c * dx;
+        fy -= s3 * rj.my - c * dy;
+        fz -= s3 * rj.mz - c * dz;
+      }
+    } else {
+      // list mode.  The damped tensor scalars (s3, s5) were cached per pair by k_dd_scalars, so a
+      // sweep streams 20 B per pair (int32 j + two doubles) and gathers one 64-byte record.
+      //   gather : scattered 16-byte loads cost one L1 (TCP) transaction per LANE, so the records of
+      //            a trip's 64 pairs are fetched QUAD-cooperatively -- lane k of quad q loads piece k
+      //            of record (r*16+q): 4 load instructions, each quad one coalesced 64-byte access;
+      //   LDS    : the pieces are written to a per-wave staging tile (80-byte pitch: conflict-free
+      //            b128 reads) and every lane reads back ITS pair's record: a wave-local transpose,
+      //            no workgroup barrier (rows have different trip counts);
+      //   math   : lane-per-pair, 64 pairs per VALU instruction.
+      if (ablate & 1) end = beg;  // lab: no pair loop at all
+      extern __shared__ double2 stage_all[];
+      double2 *stage = stage_all + (size_t)(threadIdx.x >> 6) * (64 * 5);
+      const int q4 = lane >> 2, k = lane & 3;
+      // Three trips in flight (software pipeline): while trip t is transposed and computed, the
+      // records of trip t+1 are being gathered and the index/scalar stream of trip t+2 is being read,
+      // so a row pays its memory latencies once instead of twice per 64 pairs.
+#define POLAR_LOAD_STREAM(BASE, JM, SC)                                   \
+  {                                                                      \
+    const long long p_ = (BASE) + lane;                                  \
+    const bool ok_ = p_ < end;                                           \
+    JM = (ok_ && !(ablate & 8)) ? dd_j[p_] : i;                          \
+    SC = (ok_ && !(ablate & 4)) ? dd_s[p_] : make_double2(0.0, 0.0);     \
+  }
+#define POLAR_GATHER(JM, P0, P1, P2, P3)                                                   \
+  {                                                                                        \
+    int j0_, j1_, j2_, j3_;                                                                 \
+    if (ablate & 128) { j0_ = JM; j1_ = JM ^ 1; j2_ = JM ^ 2; j3_ = JM ^ 3; } /* lab: no bpermute */ \
+    else { j0_ = __shfl(JM, q4, 64); j1_ = __shfl(JM, 16 + q4, 64);                         \
+           j2_ = __shfl(JM, 32 + q4, 64); j3_ = __shfl(JM, 48 + q4, 64); }                  \
+    if (ablate & 2) j0_ = j1_ = j2_ = j3_ = i;                                             \
+    P0 = reinterpret_cast<const double2 *>(src + j0_)[k];                                   \
+    P1 = reinterpret_cast<const double2 *>(src + j1_)[k];                                   \
+    P2 = reinterpret_cast<const double2 *>(src + j2_)[k];                                   \
+    P3 = reinterpret_cast<const double2 *>(src + j3_)[k];                                   \
+  }
+      int jm0 = i, jm1 = i, jm2 = i;
+      double2 sc0 = make_double2(0.0, 0.0), sc1 = sc0, sc2 = sc0;
+      double2 pa0 = sc0, pa1 = sc0, pa2 = sc0, pa3 = sc0, pb0 = sc0, pb1 = sc0, pb2 = sc0, pb3 = sc0;
+      if (beg < end) {
+        POLAR_LOAD_STREAM(beg, jm0, sc0);
+        POLAR_LOAD_STREAM(beg + 64, jm1, sc1);
+        POLAR_GATHER(jm0, pa0, pa1, pa2, pa3);
+      }
+      for (long long base = beg; base < end; base += 64) {
+        POLAR_LOAD_STREAM(base + 128, jm2, sc2);   // trip t+2 (predicated off past the row's end)
+        POLAR_GATHER(jm1, pb0, pb1, pb2, pb3);     // trip t+1
+        double2 a, b, c2;
+        if (ablate & 64) {  // lab: no LDS transpose (wrong numbers, timing only)
+          a = pa0; b = pa1; c2 = make_double2(pa2.x + pa3.x, pa2.y + pa3.y);
+        } else {
+        stage[(q4)*5 + k] = pa0; stage[(16 + q4) * 5 + k] = pa1;  // trip t
+        stage[(32 + q4) * 5 + k] = pa2; stage[(48 + q4) * 5 + k] = pa3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        a = stage[lane * 5]; b = stage[lane * 5 + 1]; c2 = stage[lane * 5 + 2];
+        __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next trip
+        }
+        double dx, dy, dz;
+        min_image_rint(box, ri.x, ri.y, ri.z, a.x, b.x, c2.x, dx, dy, dz);
+        const double md = a.y * dx + b.y * dy + c2.y * dz;
+        const double c = sc0.y * md;
+        fx -= sc0.x * a.y - c * dx;
+        fy -= sc0.x * b.y - c * dy;
+        fz -= sc0.x * c2.y - c * dz;
+        jm1 = jm2; sc0 = sc1; sc1 = sc2;
+        pa0 = pb0; pa1 = pb1; pa2 = pb2; pa3 = pb3;
+      }
+#undef POLAR_LOAD_STREAM
+#undef POLAR_GATHER
+      fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+    }
+    if (ALLPAIRS) { fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz); }
+  }
+  if (lane == 0) {
+    if (EP == EP_FIELD) {
+      Fout[3 * i] = fx; Fout[3 * i + 1] = fy; Fout[3 * i + 2] = fz;
+    } else {
+      const double a = ri.a;
+      const double mx = a * (ef[3 * i] + fx), my = a * (ef[3 * i + 1] + fy), mz = a * (ef[3 * i + 2] + fz);
+      const double ddx = mx - ri.mx, ddy = my - ri.my, ddz = mz - ri.mz;
+      dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz;
+      const double c = ddx * ddx + ddy * ddy + ddz * ddz;
+      if (c != 0.0 && !(ablate & 16)) atomicAdd(slot_ptr(slots, SL_CHANGE), c);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// List-mode sweep, component-per-lane form (production).
+// The lane-per-pair kernel (k_field) gives every LANE one pair, so the 64-byte records fetched quad-wise have to
+// be transposed through LDS and the indices shuffled to the quads: ~180 of the ~200 VALU slots of a
+// 64-pair trip were bookkeeping, and the kernel was VALU-issue bound on it.  Here the quad that
+// fetches a record also does its arithmetic: lane k of a quad owns COMPONENT k of the pair
+//     d_k = x_ik - x_jk (wrapped),  dot = sum_k mu_jk d_k (quad DPP),  E_k -= s3 mu_jk - s5 dot d_k
+// so nothing is transposed, no LDS is used, and the three field components are three lanes of one
+// accumulator.  A gather instruction covers 16 pairs (one 64-byte access per quad for the record
+// pieces {x_k, mu_k}).  Lane 3 of each quad rides along on component z (its results are unused).
+// Rows are padded to whole 64-pair trips by k_dd_scalars (j = i, s = 0), so a trip needs no masks.
+// SMODE 0: stream the cached (s3,s5) (20 B/pair); 1 / 2: stream the cached r^2 (12 B/pair) and
+// rebuild (s3,s5) with exponential / no damping -- lane L for ITS pair, before the quad hand-round.
+template <int EP, int SMODE>
+__global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__restrict__ rows,
+                                                            AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
+                                                            Box box, RowList ddl, const int *__restrict__ dd_j,
+                                                            const double2 *__restrict__ dd_s,
+                                                            const double *__restrict__ dd_r2, double pd,
+                                                            const double *__restrict__ ef, const Scal *scal,
+                                                            double *__restrict__ slots, int ablate) {
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rpb = blockDim.x >> 6;  // rows (waves) per workgroup
+  const int lb = xcd_block(blockIdx.x, (nrows + rpb - 1) / rpb);
+  if (lb < 0) return;
+  const int row = lb * rpb + wv;
+  if (row >= nrows) return;
+  const int i = __builtin_amdgcn_readfirstlane(rows ? rows[row] : row);
+  const int cur = scal->cur;
+  const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+  const int k = lane & 3, kk = k < 3 ? k : 2;
+  const double *ri = reinterpret_cast<const double *>(src + i);
+  const double xi = ri[2 * kk], mi = ri[2 * kk + 1], ai = ri[7];
+  long long c = ddl.cnt[i];
+  if (c > ddl.pitch) c = ddl.pitch;
+  if (ai == 0.0) c = 0;
+  int T = __builtin_amdgcn_readfirstlane((int)((c + 63) >> 6));
+  if (ablate & 1) T = 0;             // lab switches (POLAR_ABLATE): timing only, wrong numbers
+  if ((ablate & 8) && T > 1) T = 1;
+  const double prd = box.periodic[kk] ? box.prd[kk] : 0.0, inv = box.inv[kk];
+  const char *srcb = reinterpret_cast<const char *>(src) + kk * 16;
+  // stream: lane L reads pair L of the trip (ONE coalesced instruction each for j and (s3,s5): the
+  // vector-memory address unit spends ~16 cycles per wave instruction however little it fetches, and
+  // it is the unit this kernel saturates).  Pair 4q+r of a trip belongs to quad q, step r, so the
+  // quad already holds its four pairs' stream values and hands them round with quad_perm DPP moves.
+  const int *pj = dd_j + (size_t)i * ddl.pitch + lane;
+  const double2 *ps = dd_s + (size_t)i * ddl.pitch + lane;
+  const double *pr = dd_r2 + (size_t)i * ddl.pitch + lane;
+  double acc = 0.0;
+  // One trip per iteration; only the NEXT trip's indices are prefetched.  A deeper software pipeline
+  // (gathers one trip ahead) was measured and bought nothing: with <= 64 VGPRs eight waves per SIMD
+  // hide the latencies, and the kernel sits on the stream bandwidth and the VALU rate instead.
+  int jn = pj[0];  // the pitch keeps this in bounds even for an empty row
+  for (int t = 0; t < T; t++) {
+    const int jv = (ablate & 2) ? i : jn;
+    double2 P[4];
+#define POLAR_QGATHER(R)                                                                        \
+  {                                                                                            \
+    const unsigned j_ = (unsigned)__builtin_amdgcn_update_dpp(0, jv, (R) * 0x55, 0xF, 0xF, true); \
+    P[R] = *reinterpret_cast<const double2 *>(srcb + ((size_t)j_ << 6));                        \
+  }
+    POLAR_QGATHER(0) POLAR_QGATHER(1) POLAR_QGATHER(2) POLAR_QGATHER(3)
+#undef POLAR_QGATHER
+    double2 Sv = make_double2(0.0, 0.0);
+    double r2v = 0.0;
+    if (SMODE == 0) Sv = (ablate & 4) ? make_double2(1e-3, 1e-4) : ps[64 * t];
+    else if (SMODE <= 2) r2v = (ablate & 4) ? 30.0 : pr[64 * t];
+    if (t + 1 < T) jn = pj[64 * (t + 1)];  // wave-uniform: the next trip's indices travel during the math
+    double D[4];
+#define POLAR_QDEL(R)                                  \
+  {                                                   \
+    double d = xi - P[R].x;                            \
+    D[R] = fma(-prd, rint(d * inv), d);                \
+  }
+    POLAR_QDEL(0) POLAR_QDEL(1) POLAR_QDEL(2) POLAR_QDEL(3)
+#undef POLAR_QDEL
+    if (SMODE >= 3) {
+      // no per-pair stream value at all (4 B/pair; chosen when the stream would not stay in the 256 MB
+      // Infinity Cache, see build_lists) -- r^2 from the quad's three
+      // component lanes (lane 3 rides on z, so [1,2,0,0] / [2,0,1,1] give ALL four lanes the sum), and
+      // lane r of the quad keeps the r^2 of step r: its own pair, as in the cached forms
+      double r2s[4];
+#pragma unroll
+      for (int R = 0; R < 4; R++) {
+        const double q = D[R] * D[R];
+        r2s[R] = q + dpp_full<0x09>(q) + dpp_full<0x52>(q);  // quad_perm [1,2,0,0], [2,0,1,1]
+      }
+      r2v = k == 0 ? r2s[0] : (k == 1 ? r2s[1] : (k == 2 ? r2s[2] : r2s[3]));
+      r2v = r2v > 0.0 ? r2v : 1e60;  // padding entries (the atom itself): an inert pair
+    }
+    if (SMODE != 0) tensor_scalars<(SMODE == 1 || SMODE == 3) ? 0 : 1>(r2v, pd, Sv.x, Sv.y);  // lane L: pair L of the trip
+#define POLAR_QSTEP(R)                                                                          \
+  {                                                                                            \
+    const double s3_ = dpp_full<(R) * 0x55>(Sv.x), s5_ = dpp_full<(R) * 0x55>(Sv.y);             \
+    const double d = D[R];                                                                      \
+    const double m = P[R].y * d;                                                                \
+    /* dot over the quad's three component lanes (lane 3 gets a don't-care) */                  \
+    const double dot = m + dpp_full<0xC9>(m) + dpp_full<0xD2>(m); /* quad_perm [1,2,0,3], [2,0,1,3] */ \
+    const double cc = s5_ * dot;                                                                \
+    acc = fma(-s3_, P[R].y, acc);                                                               \
+    acc = fma(cc, d, acc);                                                                      \
+  }
+    POLAR_QSTEP(0) POLAR_QSTEP(1) POLAR_QSTEP(2) POLAR_QSTEP(3)
+#undef POLAR_QSTEP
+  }
+  // sum the 16 quads: rotate-adds inside the 16-lane rows, then across the four rows
+  acc += dpp_full<0x124>(acc);  // row_ror:4
+  acc += dpp_full<0x128>(acc);  // row_ror:8
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  const double mu_new = ai * (ef[3 * i + kk] + acc);
+  const double dm = mu_new - mi;
+  double chg = (k < 3) ? dm * dm : 0.0;
+  chg = chg + dpp_full<0xC9>(chg) + dpp_full<0xD2>(chg);
+  if (lane < 3) reinterpret_cast<double *>(dst + i)[2 * lane + 1] = mu_new;
+  if (lane == 0 && chg != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), chg);
+}
+
+// a6 for the list path: the damped tensor scalars of every listed pair, once per step
+// (the sparse, matrix-free-storage analog of build_dipole_field_matrix, PS.cpp:1273-1306).
+template <int DAMP>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restrict__ rows, int nrows, const AtomRec *__restrict__ rec,
+                                                            Box box,
+                                                            RowList ddl,
+                                                            int *__restrict__ dd_j, double pd,
+                                                            double2 *__restrict__ dd_s, double *__restrict__ dd_r2) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = rows ? rows[row] : row;
+  const double xi = rec[i].x, yi = rec[i].y, zi = rec[i].z;
+  long long beg, end;
+  row_range(ddl, i, beg, end);
+  if (dd_r2 || dd_s)
+    for (long long p = beg + lane; p < end; p += 64) {
+      const int j = dd_j[p];
+      double dx, dy, dz;
+      min_image_rint(box, xi, yi, zi, rec[j].x, rec[j].y, rec[j].z, dx, dy, dz);
+      double s3, s5;
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      if (dd_r2) dd_r2[p] = r2;
+      else {
+        tensor_scalars<DAMP>(r2, pd, s3, s5);
+        dd_s[p] = make_double2(s3, s5);
+      }
+    }
+  // pad the row to whole 64-pair trips with inert entries (the atom itself, zero tensor): the
+  // component-per-lane sweep then runs without lane masks.  The pitch is a multiple of 64.
+  const long long pad_end = beg + (((end - beg) + 63) & ~63ll);
+  for (long long p = end + lane; p < pad_end; p += 64) {
+    dd_j[p] = i;
+    if (dd_r2) dd_r2[p] = 1e60;  // s3 ~ 1e-90, and d = 0 kills the s5 term: contributes nothing
+    else if (dd_s) dd_s[p] = make_double2(0.0, 0.0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a7  sequential (ranked) Gauss-Seidel, exact-order, blocked for the GPU.
+// F_j = -sum_k T_jk mu_k is kept current for every atom.  For a block of 64 consecutive atoms of
+// the ranked order:
+//   k_gs_block_seq  (ONE wave): in order k = 0..63   mu_k <- alpha_k (E_k + F_k), then every
+//                   other lane of the block applies  F_l -= T_lk dmu_k  (wave broadcast) --
+//                   exactly the reference's "use the newest mu" recurrence (PS.cpp:1158-1180)
+//   k_gs_block_push (all rows outside the block): F_j -= sum_k T_jk dmu_k
+// so atoms later in the order see the new dipoles, atoms earlier keep a current field for the
+// next sweep.  Arithmetic differs from the reference only in summation order.
+template <int DAMP>
+__global__ __launch_bounds__(64) void k_gs_block_seq(int nlocal, int b0, const int *__restrict__ order,
+                                                     AtomRec *__restrict__ rec, Box box, double pd,
+                                                     const double *__restrict__ ef, double *__restrict__ F,
+                                                     double *__restrict__ dmu_blk, const Scal *scal,
+                                                     double *__restrict__ slots) {
+  if (scal->done) return;
+  const int lane = threadIdx.x;
+  const int cnt = min(64, nlocal - b0);
+  const bool act = lane < cnt;
+  const int i = act ? order[b0 + lane] : 0;
+  AtomRec r = rec[i];
+  double Fx = act ? F[3 * i] : 0, Fy = act ? F[3 * i + 1] : 0, Fz = act ? F[3 * i + 2] : 0;
+  const double Ex = act ? ef[3 * i] : 0, Ey = act ? ef[3 * i + 1] : 0, Ez = act ? ef[3 * i + 2] : 0;
+  const double mx0 = r.mx, my0 = r.my, mz0 = r.mz;
+  double dsq = 0.0;
+  for (int k = 0; k < cnt; k++) {
+    const double nx = r.a * (Ex + Fx), ny = r.a * (Ey + Fy), nz = r.a * (Ez + Fz);
+    const double ddx = nx - r.mx, ddy = ny - r.my, ddz = nz - r.mz;
+    const double bx = __shfl(r.x, k, 64), by = __shfl(r.y, k, 64), bz = __shfl(r.z, k, 64);
+    const double bdx = __shfl(ddx, k, 64), bdy = __shfl(ddy, k, 64), bdz = __shfl(ddz, k, 64);
+    if (lane == k) {
+      r.mx = nx; r.my = ny; r.mz = nz;
+    } else if (act && (bdx != 0.0 || bdy != 0.0 || bdz != 0.0)) {
+      double dx, dy, dz;
+      min_image_del(box, r.x, r.y, r.z, bx, by, bz, dx, dy, dz);
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      double s3, s5;
+      tensor_scalars<DAMP>(r2, pd, s3, s5);
+      const double md = bdx * dx + bdy * dy + bdz * dz;
+      const double c = s5 * md;
+      Fx -= s3 * bdx - c * dx; Fy -= s3 * bdy - c * dy; Fz -= s3 * bdz - c * dz;
+    }
+  }
+  if (act) {
+    const double tx = r.mx - mx0, ty = r.my - my0, tz = r.mz - mz0;
+    dsq = tx * tx + ty * ty + tz * tz;
+    rec[i].mx = r.mx; rec[i].my = r.my; rec[i].mz = r.mz;
+    F[3 * i] = Fx; F[3 * i + 1] = Fy; F[3 * i + 2] = Fz;
+    dmu_blk[3 * lane] = tx; dmu_blk[3 * lane + 1] = ty; dmu_blk[3 * lane + 2] = tz;
+  }
+  dsq = wave_sum(dsq);
+  if (lane == 0 && dsq != 0.0) atomicAdd(slots + (size_t)((b0 >> 6) & (POLAR_NSLOT - 1)) * POLAR_SLOT_STRIDE + SL_CHANGE, dsq);
+}
+
+template <int DAMP>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_gs_block_push(int nlocal, int b0, const int *__restrict__ order,
+                                                               const int *__restrict__ pos_in_order,
+                                                               const AtomRec *__restrict__ rec, Box box, double pd,
+                                                               const double *__restrict__ dmu_blk,
+                                                               double *__restrict__ F, const Scal *scal) {
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (j >= nlocal) return;
+  const int pj = pos_in_order[j];
+  if (pj >= b0 && pj < b0 + 64) return;  // rows of the block were updated by k_gs_block_seq
+  const AtomRec rj = rec[j];
+  if (rj.a == 0.0) return;  // mu_j stays 0: its field is never read
+  const int cnt = min(64, nlocal - b0);
+  double fx = 0, fy = 0, fz = 0;
+  if (lane < cnt) {
+    const double bdx = dmu_blk[3 * lane], bdy = dmu_blk[3 * lane + 1], bdz = dmu_blk[3 * lane + 2];
+    if (bdx != 0.0 || bdy != 0.0 || bdz != 0.0) {
+      const AtomRec rk = rec[order[b0 + lane]];
+      double dx, dy, dz;
+      min_image_del(box, rj.x, rj.y, rj.z, rk.x, rk.y, rk.z, dx, dy, dz);
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      double s3, s5;
+      tensor_scalars<DAMP>(r2, pd, s3, s5);
+      const double md = bdx * dx + bdy * dy + bdz * dz;
+      const double c = s5 * md;
+      fx = -(s3 * bdx - c * dx); fy = -(s3 * bdy - c * dy); fz = -(s3 * bdz - c * dz);
+    }
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) { F[3 * j] += fx; F[3 * j + 1] += fy; F[3 * j + 2] += fz; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact mode with the tensor held in HBM, as the reference does (build_dipole_field_matrix,
+// PS.cpp:1243-1316) but packed: T6[i][j] = {Txx,Txy,Txz,Tyy,Tyz,Tzz}, 48 N^2 bytes (the reference's
+// dense matrix is 72 N^2).  Used by the exact-order Gauss-Seidel when it fits: the sequential chain
+// then has no exp / rsqrt / minimum image in it, only 9 FMAs per step.  Atoms are in RANKED order
+// here (s space = sweep order), so a block of 64 consecutive steps reads contiguous tensor rows.
+template <int DAMP>
+__global__ __launch_bounds__(POLAR_BLOCK) void k_build_T6(int n, const AtomRec *__restrict__ rec, Box box, double pd,
+                                                          double *__restrict__ T6) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const AtomRec ri = rec[i];
+  for (int j = lane; j < n; j += 64) {
+    double t[6] = {0, 0, 0, 0, 0, 0};
+    if (j != i) {
+      const AtomRec rj = rec[j];
+      double dx, dy, dz;
+      min_image_del(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);
+      double s3, s5;
+      tensor_scalars<DAMP>(dx * dx + dy * dy + dz * dz, pd, s3, s5);
+      t[0] = s3 - s5 * dx * dx; t[1] = -s5 * dx * dy; t[2] = -s5 * dx * dz;
+      t[3] = s3 - s5 * dy * dy; t[4] = -s5 * dy * dz; t[5] = s3 - s5 * dz * dz;
+    }
+    double *o = T6 + ((size_t)i * n + j) * 6;
+#pragma unroll
+    for (int c = 0; c < 6; c++) o[c] = t[c];
+  }
+}
+
+// F_i = - sum_j T_ij mu_j  (dense mat-vec; initial running field of the Gauss-Seidel)
+__global__ __launch_bounds__(POLAR_BLOCK) void k_dense_field(int n, const double *__restrict__ T6,
+                                                             const AtomRec *__restrict__ rec, double *__restrict__ F) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= n) return;
+  double fx = 0, fy = 0, fz = 0;
+  for (int j = lane; j < n; j += 64) {
+    const double *t = T6 + ((size_t)i * n + j) * 6;
+    const double mx = rec[j].mx, my = rec[j].my, mz = rec[j].mz;
+    fx -= t[0] * mx + t[1] * my + t[2] * mz;
+    fy -= t[1] * mx + t[3] * my + t[4] * mz;
+    fz -= t[2] * mx + t[4] * my + t[5] * mz;
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) { F[3 * i] = fx; F[3 * i + 1] = fy; F[3 * i + 2] = fz; }
+}
+
+__device__ __forceinline__ double readlane_d(double v, int k) {  // k wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+// ONE wave: the sequential recurrence over the 64 atoms b0..b0+63 of the sweep order
+// (PS.cpp:1158-1180).  Lane l owns atom b0+l; step k: mu_k <- alpha_k (E_k + F_k), and every lane
+// folds T_{l,k} dmu_k into its running field.  Tensor rows are prefetched four steps ahead.
+__global__ __launch_bounds__(64) void k_gs_seq_T6(int n, int b0, const double *__restrict__ T6,
+                                                  AtomRec *__restrict__ rec, const double *__restrict__ ef,
+                                                  double *__restrict__ F, double *__restrict__ dmu_blk,
+                                                  const Scal *scal, double *__restrict__ slots) {
+  if (scal->done) return;
+  const int lane = threadIdx.x;
+  const int cnt = min(64, n - b0);
+  const bool act = lane < cnt;
+  const int i = act ? b0 + lane : b0;
+  const AtomRec r = rec[i];
+  const double a = act ? r.a : 0.0;
+  double mx = r.mx, my = r.my, mz = r.mz;
+  const double mx0 = mx, my0 = my, mz0 = mz;
+  double Fx = F[3 * i], Fy = F[3 * i + 1], Fz = F[3 * i + 2];
+  const double Ex = ef[3 * i], Ey = ef[3 * i + 1], Ez = ef[3 * i + 2];
+  // T_{k,l} = T_{l,k}: read row (b0+k), columns b0..b0+63 -> consecutive lanes, contiguous 3 KB
+  const double *tcol = T6 + ((size_t)b0 * n + i) * 6;
+  const size_t rowstride = (size_t)n * 6;
+  double ta[4][6], tb[4][6];
+#define POLAR_LOADT(BUF, K0)                                                     \
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {                                \
+    const int kk = (K0) + u < cnt ? (K0) + u : cnt - 1;                          \
+    const double *t_ = tcol + (size_t)kk * rowstride;                            \
+    _Pragma("unroll") for (int c = 0; c < 6; c++) BUF[u][c] = t_[c];             \
+  }
+#define POLAR_STEPT(BUF, K0)                                                     \
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {                                \
+    const int k = (K0) + u;                                                      \
+    if (k < cnt) {                                                               \
+      const double nx = a * (Ex + Fx), ny = a * (Ey + Fy), nz = a * (Ez + Fz);   \
+      const double bdx = readlane_d(nx - mx, k), bdy = readlane_d(ny - my, k),   \
+                   bdz = readlane_d(nz - mz, k);                                 \
+      if (lane == k) { mx = nx; my = ny; mz = nz; }                              \
+      /* the diagonal block T_kk is stored as zero: lane k leaves its own field alone */ \
+      Fx -= BUF[u][0] * bdx + BUF[u][1] * bdy + BUF[u][2] * bdz;                 \
+      Fy -= BUF[u][1] * bdx + BUF[u][3] * bdy + BUF[u][4] * bdz;                 \
+      Fz -= BUF[u][2] * bdx + BUF[u][4] * bdy + BUF[u][5] * bdz;                 \
+    }                                                                            \
+  }
+  POLAR_LOADT(ta, 0);
+  for (int k0 = 0; k0 < cnt; k0 += 8) {
+    POLAR_LOADT(tb, k0 + 4);
+    POLAR_STEPT(ta, k0);
+    POLAR_LOADT(ta, k0 + 8);
+    POLAR_STEPT(tb, k0 + 4);
+  }
+#undef POLAR_LOADT
+#undef POLAR_STEPT
+  double dsq = 0.0;
+  if (act) {
+    const double tx = mx - mx0, ty = my - my0, tz = mz - mz0;
+    dsq = tx * tx + ty * ty + tz * tz;
+    rec[i].mx = mx; rec[i].my = my; rec[i].mz = mz;
+    F[3 * i] = Fx; F[3 * i + 1] = Fy; F[3 * i + 2] = Fz;
+    dmu_blk[3 * lane] = tx; dmu_blk[3 * lane + 1] = ty; dmu_blk[3 * lane + 2] = tz;
+  }
+  dsq = wave_sum(dsq);
+  if (lane == 0 && dsq != 0.0) atomicAdd(slots + (size_t)((b0 >> 6) & (POLAR_NSLOT - 1)) * POLAR_SLOT_STRIDE + SL_CHANGE, dsq);
+}
+
+// rows outside the block receive the block's dipole changes: F_j -= sum_k T_{j,b0+k} dmu_k
+__global__ __launch_bounds__(POLAR_BLOCK) void k_gs_push_T6(int n, int b0, const double *__restrict__ T6,
+                                                            const AtomRec *__restrict__ rec,
+                                                            const double *__restrict__ dmu_blk, double *__restrict__ F,
+                                                            const Scal *scal) {
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (j >= n || (j >= b0 && j < b0 + 64)) return;
+  if (rec[j].a == 0.0) return;  // mu_j stays 0: its field is never read
+  const int cnt = min(64, n - b0);
+  double fx = 0, fy = 0, fz = 0;
+  if (lane < cnt) {
+    const double *t = T6 + ((size_t)j * n + b0 + lane) * 6;
+    const double bdx = dmu_blk[3 * lane], bdy = dmu_blk[3 * lane + 1], bdz = dmu_blk[3 * lane + 2];
+    fx = -(t[0] * bdx + t[1] * bdy + t[2] * bdz);
+    fy = -(t[1] * bdx + t[3] * bdy + t[4] * bdz);
+    fz = -(t[2] * bdx + t[4] * bdy + t[5] * bdz);
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) { F[3 * j] += fx; F[3 * j + 1] += fy; F[3 * j + 2] += fz; }
+}
+
+// ------------------------------------------------------------------------------------------
+// a7 loop control, one thread: the reference's end-of-sweep logic (PS.cpp:1193-1236) kept on the
+// device so the host never has to look at ||dmu||^2 between sweeps.
+__global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double *__restrict__ slots, int nlocal,
+                                                           int fixed_iteration, int iterations_max, double precision,
+                                                           int jacobi, const double *__restrict__ global_change,
+                                                           int count) {
+  if (scal->done) return;
+  __shared__ double red[POLAR_NSLOT / 64];
+  double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
+  slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE] = 0.0;
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double sum = 0.0;
+  for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+  scal->change = sum;  // this handle's own sum (exported to the all-reduce in multi-GPU runs)
+  // multi-GPU: the all-reduced sum over ranks arrives through global_change (device memory)
+  const double change = (global_change ? *global_change : sum) / ((double)nlocal * 3.0);
+  scal->last_change = change;
+  // `count` > 1: the end-of-sweep logic of several sweeps at once (fixed-iteration Gauss-Seidel takes
+  // no decision between sweeps, so the host launches this only before and after the last one)
+  for (int c = 0; c < count; c++) {
+    scal->sweeps += 1;
+    int keep = 1;
+    if (!fixed_iteration) keep = change > precision * precision;
+    else if (scal->iterations >= iterations_max) { scal->done = 1; return; }  // returns BEFORE the copy
+    if (jacobi) scal->cur ^= 1;  // "mu = mu_new"
+    scal->iterations += 1;
+    if (scal->iterations > iterations_max) { scal->status = 1; scal->done = 1; return; }
+    if (!keep) { scal->done = 1; return; }
+  }
+}
+
+// fold the change slots into scal->change without touching the loop state (multi-GPU export)
+__global__ __launch_bounds__(POLAR_NSLOT) void k_fold_change(Scal *scal, double *__restrict__ slots, double *dst) {
+  __shared__ double red[POLAR_NSLOT / 64];
+  double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
+  slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE] = 0.0;
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double sum = 0.0;
+  for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+  scal->change = sum;
+  *dst = sum;
+}
+
+// fold energies / virial / rmin slots into the Scal block (run before the host reads it)
+__global__ __launch_bounds__(POLAR_NSLOT) void k_fold_scal(Scal *scal, double *__restrict__ slots, int rmin_only) {
+  __shared__ double red[POLAR_NSLOT / 64];
+  const int t = threadIdx.x;
+  {
+    unsigned long long b = ((unsigned long long *)slots)[(size_t)t * POLAR_SLOT_STRIDE + SL_RMIN];
+    double r = __longlong_as_double((long long)b);
+    r = wave_min(r);
+    if ((t & 63) == 0) red[t >> 6] = r;
+    __syncthreads();
+    if (t == 0) {
+      double m = red[0];
+      for (int k = 1; k < POLAR_NSLOT / 64; k++) m = fmin(m, red[k]);
+      scal->rmin_bits = (unsigned long long)__double_as_longlong(m);
+    }
+    __syncthreads();
+  }
+  if (rmin_only) return;
+  for (int f = SL_EVDWL; f <= SL_V5; f++) {
+    double v = slots[(size_t)t * POLAR_SLOT_STRIDE + f];
+    v = wave_sum(v);
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) {
+      double sum = 0.0;
+      for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+      double *dst = f == SL_EVDWL ? &scal->eng_vdwl : f == SL_ECOUL ? &scal->eng_coul : f == SL_USELF ? &scal->u_self
+                  : f == SL_UEF ? &scal->u_ef : f == SL_UDD ? &scal->u_dd : &scal->virial[f - SL_V0];
+      *dst = sum;
+    }
+    __syncthreads();
+  }
+}
+__global__ void k_zero_slots(double *__restrict__ slots) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= POLAR_NSLOT) return;
+  for (int f = 0; f < POLAR_SLOT_STRIDE; f++) slots[(size_t)t * POLAR_SLOT_STRIDE + f] = 0.0;
+  ((unsigned long long *)slots)[(size_t)t * POLAR_SLOT_STRIDE + SL_RMIN] = (unsigned long long)__double_as_longlong(1000.0);
+}
+
+// divergence fallback mu = alpha * E (no gamma), PS.cpp:1227-1235
+__global__ void k_fallback(int n, const Scal *scal, AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
+                           const double *__restrict__ ef) {
+  if (!scal->status) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  AtomRec *r = scal->cur ? recB : recA;
+  const double a = r[i].a;
+  r[i].mx = a * ef[3 * i]; r[i].my = a * ef[3 * i + 1]; r[i].mz = a * ef[3 * i + 2];
+}
+
+// copy the final dipoles and the static field out (records are in s order, outputs in orig order)
+__global__ void k_unpack(int n, const int *__restrict__ perm, const Scal *scal, const AtomRec *__restrict__ recA,
+                         const AtomRec *__restrict__ recB, const double *__restrict__ ef_s, double *__restrict__ mu,
+                         double *__restrict__ ef) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const AtomRec *r = scal->cur ? recB : recA;
+  const int o = perm ? perm[i] : i;
+  mu[3 * o] = r[i].mx; mu[3 * o + 1] = r[i].my; mu[3 * o + 2] = r[i].mz;
+  ef[3 * o] = ef_s[3 * i]; ef[3 * o + 1] = ef_s[3 * i + 1]; ef[3 * o + 2] = ef_s[3 * i + 2];
+}
+
+}  // namespace polar

@@ -264,12 +264,10 @@ def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
     assert np.max(np.abs(vir - ref["virial"])) < max(tol, 1e-9) * np.max(np.abs(ref["virial"]))
 
 
-@pytest.mark.parametrize("knob", ["POLAR_ROWS_PER_WAVE=-1", "POLAR_ROWS_PER_WAVE=3", "POLAR_CACHE_R2=0", "POLAR_CACHE_R2=1",
-                                  "POLAR_CACHE_R2=2"])
+@pytest.mark.parametrize("knob", ["POLAR_SWEEP_KERNEL=1", "POLAR_CACHE_R2=0", "POLAR_CACHE_R2=1", "POLAR_CACHE_R2=2"])
 def test_alternative_sweep_kernels_agree(knob, wl, pkg, oracle, monkeypatch):
-    """The list sweep exists in several forms: the lane-per-pair kernels (one row per wave / several rows
-    streamed by one wave, POLAR_ROWS_PER_WAVE) and the component-per-lane kernel with its three stream
-    modes (POLAR_CACHE_R2: cached (s3,s5), cached r^2, nothing cached -- normally chosen by size).  All
+    """The list sweep exists in several forms: the lane-per-pair kernel (POLAR_SWEEP_KERNEL=1, kept as a
+    cross-check) and the component-per-lane kernel with its three stream modes (POLAR_CACHE_R2: cached (s3,s5), cached r^2, nothing cached -- normally chosen by size).  All
     must reproduce the oracle (Jacobi sweep by sweep, GS at the fixed point; both damping types)."""
     name, val = knob.split("=")
     monkeypatch.setenv(name, val)
