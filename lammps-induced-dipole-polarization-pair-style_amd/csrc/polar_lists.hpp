@@ -46,13 +46,30 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(long long n, const T *_
   const long long a = t * chunk, bnd = (a + chunk < n) ? a + chunk : n;
   long long s = 0;
   for (long long k = a; k < bnd; k++) s += (long long)in[k];
-  part[t] = s;
-  __syncthreads();
-  if (t == 0) {
-    long long run = 0;
-    for (int k = 0; k < 1024; k++) { long long v = part[k]; part[k] = run; run += v; }
-    out[n] = run;
+  // exclusive scan of the 1024 per-thread sums: inclusive scan inside each wave (6 shuffle steps), then
+  // the 16 wave totals by the first wave (a serial loop by one thread over 1024 LDS entries took ~10 us)
+  __shared__ long long wtot[16];
+  const int lane = t & 63, wv = t >> 6;
+  long long inc = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const long long up = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += up;
   }
+  if (lane == 63) wtot[wv] = inc;
+  __syncthreads();
+  if (wv == 0) {
+    long long v = lane < 16 ? wtot[lane] : 0, w = v;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const long long up = __shfl_up(w, off, 64);
+      if (lane >= off) w += up;
+    }
+    if (lane < 16) wtot[lane] = w - v;  // exclusive offset of each wave
+    if (lane == 15) out[n] = w;         // grand total
+  }
+  __syncthreads();
+  part[t] = wtot[wv] + inc - s;
   __syncthreads();
   long long run = part[t];
   for (long long k = a; k < bnd; k++) { out[k] = run; run += (long long)in[k]; }
