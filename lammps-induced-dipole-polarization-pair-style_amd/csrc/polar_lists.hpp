@@ -114,8 +114,22 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   const int i = rows ? rows[row] : row;  // s space: the atoms of cell c are the indices [cell_first[c], cell_first[c+1])
   const double4 ri = pos4[i];            // {x, y, z, (molecule, polarizable)}
   const int imol = __double2hiint(ri.w), ipol = __double2loint(ri.w);
-  const int ci = cell_of(g, box, ri.x, ri.y, ri.z);
-  const int c0 = ci % g.nc[0], c1 = (ci / g.nc[0]) % g.nc[1], c2 = ci / (g.nc[0] * g.nc[1]);
+  // home cell and the position inside it in cell units (same arithmetic as cell_of)
+  int cc[3];
+  double uu[3], edge[3];
+  {
+    const double pp[3] = {ri.x, ri.y, ri.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double fr = (pp[k] - g.lo[k]) / box.prd[k];
+      fr -= floor(fr);
+      const double t = fr * g.nc[k];
+      int ck = (int)t;
+      ck = ck >= g.nc[k] ? g.nc[k] - 1 : ck;
+      cc[k] = ck; uu[k] = t - ck; edge[k] = box.prd[k] / g.nc[k];
+    }
+  }
+  const int c0 = cc[0], c1 = cc[1], c2 = cc[2];
   const long long nl0 = (long long)i * nl_pitch, dd0 = (long long)i * dd_pitch;
   int ncount = 0, dcount = 0;
   // Cells have an edge >= cutoff/2, so the stencil reaches +-2 cells (125 cells hold 42 % fewer
@@ -123,17 +137,33 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   // stencil row are ONE contiguous run of atoms (two runs when the row wraps around the box): the
   // lanes stride runs of ~100 atoms instead of single small cells.  Dimensions with fewer than 5
   // cells visit every cell exactly once.
+  // The stencil is trimmed per atom: a (y,z) row of cells whose nearest point is beyond the cutoff is
+  // skipped, and its x-run is cut to the cells a sphere of the remaining radius can reach.
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int n0 = g.nc[0], n1 = g.nc[1], n2 = g.nc[2];
   const int zlo = n2 >= 5 ? c2 - 2 : 0, zhi = n2 >= 5 ? c2 + 2 : n2 - 1;
   const int ylo = n1 >= 5 ? c1 - 2 : 0, yhi = n1 >= 5 ? c1 + 2 : n1 - 1;
-  const int xlo = n0 >= 5 ? c0 - 2 : 0, xhi = n0 >= 5 ? c0 + 2 : n0 - 1;
+  const double reach = sqrt(cutallsq > ddcutsq ? cutallsq : ddcutsq) + 1e-6;  // margin: atoms sit on cell faces
+  const double reach2 = reach * reach;
   for (int zz = zlo; zz <= zhi; zz++) {
     int b2 = zz;
     if (b2 < 0 || b2 >= n2) { if (!box.periodic[2]) continue; b2 = (b2 + n2) % n2; }
+    double dzmin = 0.0;
+    if (n2 >= 5) { const int d = zz - c2; dzmin = d > 0 ? (d - uu[2]) * edge[2] : (d < 0 ? (uu[2] - (d + 1)) * edge[2] : 0.0); }
     for (int yy = ylo; yy <= yhi; yy++) {
       int b1 = yy;
       if (b1 < 0 || b1 >= n1) { if (!box.periodic[1]) continue; b1 = (b1 + n1) % n1; }
+      double dymin = 0.0;
+      if (n1 >= 5) { const int d = yy - c1; dymin = d > 0 ? (d - uu[1]) * edge[1] : (d < 0 ? (uu[1] - (d + 1)) * edge[1] : 0.0); }
+      const double rem2 = reach2 - dzmin * dzmin - dymin * dymin;
+      if (rem2 < 0.0) continue;  // wave-uniform: the whole row of cells is out of reach
+      int xlo = 0, xhi = n0 - 1;
+      if (n0 >= 5) {
+        const double xr = sqrt(rem2) / edge[0];
+        int lo_off = (int)floor(uu[0] - xr), hi_off = (int)floor(uu[0] + xr);
+        lo_off = lo_off < -2 ? -2 : lo_off; hi_off = hi_off > 2 ? 2 : hi_off;
+        xlo = c0 + lo_off; xhi = c0 + hi_off;
+      }
       const long long rowbase = ((long long)b2 * n1 + b1) * n0;
       // the x-run [xlo, xhi] as at most three pieces: below 0 (wrapped), inside, above n0-1 (wrapped)
       for (int piece = 0; piece < 3; piece++) {
