@@ -217,6 +217,7 @@ void build_cells(polar_handle *h) {
     if (h->box.periodic[k] && h->box.prd[k] < 2.0 * cutall * (1.0 - 1e-12))
       throw InputError("dd_cutoff mode needs box lengths >= 2*max(cut_coul,dd_cutoff); use exact mode (dd_cutoff 0)");
   CellGrid &g = h->grid;
+  g.trim = getenv("POLAR_NL_TRIM") ? atoi(getenv("POLAR_NL_TRIM")) : 1;
   long long ncell = 1;
   for (int k = 0; k < 3; k++) {
     g.nc[k] = std::max(1, (int)std::floor(h->box.prd[k] / (0.5 * cutall)));  // edge >= cutoff/2: +-2 stencil

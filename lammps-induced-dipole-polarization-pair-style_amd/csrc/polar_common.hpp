@@ -80,6 +80,19 @@ __device__ __forceinline__ double dpp_full(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+// a value every lane of the wave holds identically: park it in scalar registers (the VALU can read
+// one SGPR pair per instruction), which keeps wave-uniform row data out of the vector register file
+__device__ __forceinline__ double wave_uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ AtomRec uniform_rec(const AtomRec &r) {
+  AtomRec u;
+  u.x = wave_uniform(r.x); u.mx = wave_uniform(r.mx); u.y = wave_uniform(r.y); u.my = wave_uniform(r.my);
+  u.z = wave_uniform(r.z); u.mz = wave_uniform(r.mz); u.q = wave_uniform(r.q); u.a = wave_uniform(r.a);
+  return u;
+}
 __device__ __forceinline__ double lane63(double v) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);

@@ -10,6 +10,7 @@ namespace polar {
 // ------------------------------------------------------------------------------------------
 // Cutoff-mode lists (extension): cell binning + CSR full lists over LOCAL atoms, minimum image.
 struct CellGrid {
+  int trim;  // 1: per-atom trimming of the stencil in k_nl_build (POLAR_NL_TRIM)
   int nc[3];
   double lo[3], inv[3];  // cell index = floor((x - lo) * inv) wrapped
 };
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
       const double t = fr * g.nc[k];
       int ck = (int)t;
       ck = ck >= g.nc[k] ? g.nc[k] - 1 : ck;
-      cc[k] = ck; uu[k] = t - ck; edge[k] = box.prd[k] / g.nc[k];
+      cc[k] = __builtin_amdgcn_readfirstlane(ck);  // the row atom is the same in every lane
+      uu[k] = wave_uniform(t - ck); edge[k] = wave_uniform(box.prd[k] / g.nc[k]);
     }
   }
   const int c0 = cc[0], c1 = cc[1], c2 = cc[2];
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   const int zlo = n2 >= 5 ? c2 - 2 : 0, zhi = n2 >= 5 ? c2 + 2 : n2 - 1;
   const int ylo = n1 >= 5 ? c1 - 2 : 0, yhi = n1 >= 5 ? c1 + 2 : n1 - 1;
   const double reach = sqrt(cutallsq > ddcutsq ? cutallsq : ddcutsq) + 1e-6;  // margin: atoms sit on cell faces
-  const double reach2 = reach * reach;
+  const double reach2 = wave_uniform(reach * reach);
   for (int zz = zlo; zz <= zhi; zz++) {
     int b2 = zz;
     if (b2 < 0 || b2 >= n2) { if (!box.periodic[2]) continue; b2 = (b2 + n2) % n2; }
@@ -156,13 +158,13 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
       double dymin = 0.0;
       if (n1 >= 5) { const int d = yy - c1; dymin = d > 0 ? (d - uu[1]) * edge[1] : (d < 0 ? (uu[1] - (d + 1)) * edge[1] : 0.0); }
       const double rem2 = reach2 - dzmin * dzmin - dymin * dymin;
-      if (rem2 < 0.0) continue;  // wave-uniform: the whole row of cells is out of reach
-      int xlo = 0, xhi = n0 - 1;
-      if (n0 >= 5) {
+      if (g.trim && rem2 < 0.0) continue;  // wave-uniform: the whole row of cells is out of reach
+      int xlo = n0 >= 5 ? c0 - 2 : 0, xhi = n0 >= 5 ? c0 + 2 : n0 - 1;
+      if (g.trim && n0 >= 5) {
         const double xr = sqrt(rem2) / edge[0];
         int lo_off = (int)floor(uu[0] - xr), hi_off = (int)floor(uu[0] + xr);
         lo_off = lo_off < -2 ? -2 : lo_off; hi_off = hi_off > 2 ? 2 : hi_off;
-        xlo = c0 + lo_off; xhi = c0 + hi_off;
+        xlo = __builtin_amdgcn_readfirstlane(c0 + lo_off); xhi = __builtin_amdgcn_readfirstlane(c0 + hi_off);
       }
       const long long rowbase = ((long long)b2 * n1 + b1) * n0;
       // the x-run [xlo, xhi] as at most three pieces: below 0 (wrapped), inside, above n0-1 (wrapped)

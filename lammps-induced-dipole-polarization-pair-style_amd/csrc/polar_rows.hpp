@@ -184,8 +184,9 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
   if (ii >= inum) return;
   const int i = ilist ? ilist[ii] : ii;
   const double4 pi = xq[i];
-  const double qtmp = pi.w, xtmp = pi.x, ytmp = pi.y, ztmp = pi.z;
-  const int itype = type[i];
+  // row data is the same in every lane: scalar registers (see wave_uniform)
+  const double qtmp = wave_uniform(pi.w), xtmp = wave_uniform(pi.x), ytmp = wave_uniform(pi.y), ztmp = wave_uniform(pi.z);
+  const int itype = __builtin_amdgcn_readfirstlane(type[i]);
   const int *jlist = neigh + first[i];
   const int jnum = numneigh ? numneigh[i] : (int)(first[i + 1] - first[i]);
   if (jnum == 0) return;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restr
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
   const int i = rows ? rows[row] : row;
-  const AtomRec ri = rec[i];
+  const AtomRec ri = uniform_rec(rec[i]);  // row data is the same in every lane: scalar registers
   const int mi = mol[i];
   const double f_shift = -1.0 / cut_coulsq;
   double ex = 0, ey = 0, ez = 0;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
   if (row >= nrows) return;
   const int i = rows ? rows[row] : row;
   const AtomRec *__restrict__ rec = scal_in->cur ? recB : recA;
-  const AtomRec ri = rec[i];
+  const AtomRec ri = uniform_rec(rec[i]);  // row data is the same in every lane: scalar registers
   const int mi = mol[i];
   const double f_shift = -1.0 / cut_coulsq;
   double fx = 0, fy = 0, fz = 0, uef = 0, udd = 0;
