@@ -143,60 +143,71 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   // skipped, and its x-run is cut to the cells a sphere of the remaining radius can reach.
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int n0 = g.nc[0], n1 = g.nc[1], n2 = g.nc[2];
-  const int zlo = n2 >= 5 ? c2 - 2 : 0, zhi = n2 >= 5 ? c2 + 2 : n2 - 1;
-  const int ylo = n1 >= 5 ? c1 - 2 : 0, yhi = n1 >= 5 ? c1 + 2 : n1 - 1;
+  const int zlo = n2 >= 5 ? c2 - 2 : 0, zcnt = n2 >= 5 ? 5 : n2;
+  const int ylo = n1 >= 5 ? c1 - 2 : 0, ycnt = n1 >= 5 ? 5 : n1;
   const double reach = sqrt(cutallsq > ddcutsq ? cutallsq : ddcutsq) + 1e-6;  // margin: atoms sit on cell faces
   const double reach2 = wave_uniform(reach * reach);
-  for (int zz = zlo; zz <= zhi; zz++) {
-    int b2 = zz;
-    if (b2 < 0 || b2 >= n2) { if (!box.periodic[2]) continue; b2 = (b2 + n2) % n2; }
-    double dzmin = 0.0;
+  // Lane L works out stencil row L (<= 25 rows of cells): skipped or not, its x-range, and the atom ranges
+  // of its one or two contiguous runs (two when the row wraps around the box) -- all cell_first loads of a
+  // row atom are issued at once instead of one dependent pair per stencil row.  The wave then walks the
+  // rows uniformly and reads the ranges with v_readlane.
+  const int nsr = zcnt * ycnt;
+  int ra0 = 0, rb0 = 0, ra1 = 0, rb1 = 0;  // run 0: [ra0, rb0), run 1: [ra1, rb1) (s indices)
+  if (lane < nsr) {
+    const int zz = zlo + lane / ycnt, yy = ylo + lane % ycnt;
+    int b2 = zz, b1 = yy;
+    bool ok = true;
+    if (b2 < 0 || b2 >= n2) { if (!box.periodic[2]) ok = false; b2 = (b2 + n2) % n2; }
+    if (b1 < 0 || b1 >= n1) { if (!box.periodic[1]) ok = false; b1 = (b1 + n1) % n1; }
+    double dzmin = 0.0, dymin = 0.0;
     if (n2 >= 5) { const int d = zz - c2; dzmin = d > 0 ? (d - uu[2]) * edge[2] : (d < 0 ? (uu[2] - (d + 1)) * edge[2] : 0.0); }
-    for (int yy = ylo; yy <= yhi; yy++) {
-      int b1 = yy;
-      if (b1 < 0 || b1 >= n1) { if (!box.periodic[1]) continue; b1 = (b1 + n1) % n1; }
-      double dymin = 0.0;
-      if (n1 >= 5) { const int d = yy - c1; dymin = d > 0 ? (d - uu[1]) * edge[1] : (d < 0 ? (uu[1] - (d + 1)) * edge[1] : 0.0); }
-      const double rem2 = reach2 - dzmin * dzmin - dymin * dymin;
-      if (g.trim && rem2 < 0.0) continue;  // wave-uniform: the whole row of cells is out of reach
-      int xlo = n0 >= 5 ? c0 - 2 : 0, xhi = n0 >= 5 ? c0 + 2 : n0 - 1;
-      if (g.trim && n0 >= 5) {
-        const double xr = sqrt(rem2) / edge[0];
-        int lo_off = (int)floor(uu[0] - xr), hi_off = (int)floor(uu[0] + xr);
-        lo_off = lo_off < -2 ? -2 : lo_off; hi_off = hi_off > 2 ? 2 : hi_off;
-        xlo = __builtin_amdgcn_readfirstlane(c0 + lo_off); xhi = __builtin_amdgcn_readfirstlane(c0 + hi_off);
-      }
+    if (n1 >= 5) { const int d = yy - c1; dymin = d > 0 ? (d - uu[1]) * edge[1] : (d < 0 ? (uu[1] - (d + 1)) * edge[1] : 0.0); }
+    const double rem2 = reach2 - dzmin * dzmin - dymin * dymin;
+    if (g.trim && rem2 < 0.0) ok = false;  // the whole row of cells is out of reach
+    int xlo = n0 >= 5 ? c0 - 2 : 0, xhi = n0 >= 5 ? c0 + 2 : n0 - 1;
+    if (ok && g.trim && n0 >= 5) {
+      const double xr = sqrt(rem2) / edge[0];
+      int lo_off = (int)floor(uu[0] - xr), hi_off = (int)floor(uu[0] + xr);
+      lo_off = lo_off < -2 ? -2 : lo_off; hi_off = hi_off > 2 ? 2 : hi_off;
+      xlo = c0 + lo_off; xhi = c0 + hi_off;
+    }
+    if (ok) {
       const long long rowbase = ((long long)b2 * n1 + b1) * n0;
-      // the x-run [xlo, xhi] as at most three pieces: below 0 (wrapped), inside, above n0-1 (wrapped)
-      for (int piece = 0; piece < 3; piece++) {
-        int xa, xb;
-        if (piece == 0) { if (xlo >= 0) continue; if (!box.periodic[0]) continue; xa = xlo + n0; xb = n0 - 1; }
-        else if (piece == 1) { xa = xlo < 0 ? 0 : xlo; xb = xhi >= n0 ? n0 - 1 : xhi; }
-        else { if (xhi < n0) continue; if (!box.periodic[0]) continue; xa = 0; xb = xhi - n0; }
-        const long long a = cell_first[rowbase + xa], b = cell_first[rowbase + xb + 1];
-        for (long long base = a; base < b; base += 64) {
-          const long long p = base + lane;
-          bool in_nl = false, in_dd = false;
-          const int j = (int)p;
-          int same = 0;
-          if (p < b && j != i) {
-            const double4 rj = pos4[j];  // consecutive lanes read consecutive 32-byte entries
-            double ex, ey, ez;
-            min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
-            const double rsq = ex * ex + ey * ey + ez * ez;
-            in_nl = rsq <= cutallsq;
-            in_dd = ipol && __double2loint(rj.w) && (rsq < ddcutsq);
-            same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;
-          }
-          const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
-          const int kn = ncount + __popcll(m_nl & below), kd = dcount + __popcll(m_dd & below);
-          // bit 30 of an nl entry: "same non-zero molecule" -- the static field and the charge-dipole terms
-          // skip such pairs (PS.cpp:342,454), so those kernels need no molecule gather
-          if (in_nl && kn < nl_pitch) nl_j[nl0 + kn] = j | same;
-          if (in_dd && kd < dd_pitch) dd_j[dd0 + kd] = j;
-          ncount += __popcll(m_nl);
-          dcount += __popcll(m_dd);
+      // inside piece, then the wrapped piece (below 0 or above n0-1; never both: the range spans <= 5 <= n0 cells)
+      const int xa = xlo < 0 ? 0 : xlo, xb = xhi >= n0 ? n0 - 1 : xhi;
+      ra0 = (int)cell_first[rowbase + xa]; rb0 = (int)cell_first[rowbase + xb + 1];
+      if (box.periodic[0]) {
+        if (xlo < 0) { ra1 = (int)cell_first[rowbase + xlo + n0]; rb1 = (int)cell_first[rowbase + n0]; }
+        else if (xhi >= n0) { ra1 = (int)cell_first[rowbase]; rb1 = (int)cell_first[rowbase + xhi - n0 + 1]; }
+      }
+    }
+  }
+  for (int sr = 0; sr < nsr; sr++) {
+#pragma unroll
+    for (int piece = 0; piece < 2; piece++) {
+      const int a = __builtin_amdgcn_readlane(piece ? ra1 : ra0, sr), b = __builtin_amdgcn_readlane(piece ? rb1 : rb0, sr);
+      for (int base = a; base < b; base += 64) {
+        const int p = base + lane;
+        bool in_nl = false, in_dd = false;
+        const int j = p;
+        int same = 0;
+        if (p < b && j != i) {
+          const double4 rj = pos4[j];  // consecutive lanes read consecutive 32-byte entries
+          double ex, ey, ez;
+          min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
+          const double rsq = ex * ex + ey * ey + ez * ez;
+          in_nl = rsq <= cutallsq;
+          in_dd = ipol && __double2loint(rj.w) && (rsq < ddcutsq);
+          same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;
         }
+        const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
+        const int kn = ncount + __popcll(m_nl & below), kd = dcount + __popcll(m_dd & below);
+        // bit 30 of an nl entry: "same non-zero molecule" -- the static field and the charge-dipole terms
+        // skip such pairs (PS.cpp:342,454), so those kernels need no molecule gather
+        if (in_nl && kn < nl_pitch) nl_j[nl0 + kn] = j | same;
+        if (in_dd && kd < dd_pitch) dd_j[dd0 + kd] = j;
+        ncount += __popcll(m_nl);
+        dcount += __popcll(m_dd);
       }
     }
   }
