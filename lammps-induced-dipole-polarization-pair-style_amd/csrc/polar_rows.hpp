@@ -192,12 +192,20 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
   if (jnum == 0) return;
   double fx = 0, fy = 0, fz = 0, ev = 0, ec = 0;
   double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  // software prefetch, two trips deep: the index of trip t+2 and the {x,y,z,q} of trip t+1 travel while
+  // trip t is computed (per trip the chain index -> position -> Coulomb bin is three dependent loads)
+  int e_next = jlist[lane < jnum ? lane : 0];
+  double4 p_next = xq[e_next & 0x3FFFFFFF];
+  int e_next2 = jlist[lane + 64 < jnum ? lane + 64 : 0];
   for (int jj = lane; jj < jnum; jj += 64) {
-    int j = jlist[jj];
+    int j = e_next;
+    const double4 pj = p_next;
+    e_next = e_next2;
+    p_next = xq[e_next & 0x3FFFFFFF];
+    e_next2 = jlist[jj + 128 < jnum ? jj + 128 : 0];
     const int sb = (j >> 30) & 3;  // sbmask, src/pair.h:241
     const double factor_lj = P.special_lj[sb], factor_coul = P.special_coul[sb];
     j &= 0x3FFFFFFF;  // NEIGHMASK
-    const double4 pj = xq[j];
     const double delx = xtmp - pj.x, dely = ytmp - pj.y, delz = ztmp - pj.z;
     const double rsq = delx * delx + dely * dely + delz * delz;
     const double *lj = lj_lds + (itype * w + type[j]) * 8;

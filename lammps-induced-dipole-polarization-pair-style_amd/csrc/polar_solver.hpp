@@ -180,6 +180,7 @@ __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__res
   const int k = lane & 3, kk = k < 3 ? k : 2;
   const double *ri = reinterpret_cast<const double *>(src + i);
   const double xi = ri[2 * kk], mi = ri[2 * kk + 1], ai = ri[7];
+  const double efk = ef[3 * i + kk];  // needed only in the epilogue: loaded here so that its latency is hidden
   long long c = ddl.cnt[i];
   if (c > ddl.pitch) c = ddl.pitch;
   if (ai == 0.0) c = 0;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__res
   acc += dpp_full<0x128>(acc);  // row_ror:8
   acc += __shfl_xor(acc, 16, 64);
   acc += __shfl_xor(acc, 32, 64);
-  const double mu_new = ai * (ef[3 * i + kk] + acc);
+  const double mu_new = ai * (efk + acc);
   const double dm = mu_new - mi;
   double chg = (k < 3) ? dm * dm : 0.0;
   chg = chg + dpp_full<0xC9>(chg) + dpp_full<0xD2>(chg);
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restric
   const double xi = rec[i].x, yi = rec[i].y, zi = rec[i].z;
   long long beg, end;
   row_range(ddl, i, beg, end);
-  if (dd_r2 || dd_s)
+  if (dd_r2 || dd_s) {
     for (long long p = beg + lane; p < end; p += 64) {
       const int j = dd_j[p];
       double dx, dy, dz;
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restric
         dd_s[p] = make_double2(s3, s5);
       }
     }
+  }
   // pad the row to whole 64-pair trips with inert entries (the atom itself, zero tensor): the
   // component-per-lane sweep then runs without lane masks.  The pitch is a multiple of 64.
   const long long pad_end = beg + (((end - beg) + 63) & ~63ll);
