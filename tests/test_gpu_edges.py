@@ -204,3 +204,51 @@ def test_device_neighbor_build_special_flag_drop_and_plain(flag, wl, pkg, oracle
     for k in ("eng_vdwl", "eng_coul", "eng_pol"):
         assert rel(out[k], ref[k], 1e-9) < 1e-10
     p.close()
+
+
+_SOLVERS = {
+    "ranked": [],
+    "gs": ["polar_gs_ranked", "no", "polar_gs", "yes"],
+    "jacobi5": ["polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "5"],
+    "zodid": ["polar_gs_ranked", "no", "zodid", "yes"],
+    "undamped": ["damp_type", "none", "max_iterations", "400"],
+}
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+@pytest.mark.parametrize("solver", sorted(_SOLVERS))
+def test_random_systems_against_the_oracle(seed, solver, wl, pkg, oracle):
+    """Random boxes of different size, density, shape and cutoffs, every solver flavour, exact and list
+    mode: GPU vs oracle (forces, dipoles, energies, status).  The box shapes include sides with fewer than
+    five list cells (the stencil then visits every cell once) and a long thin box."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(30, 260))
+    cut = float(rng.uniform(6.0, 9.0))
+    shape = [(2.05, 2.05, 2.05), (2.6, 3.4, 5.2), (2.1, 2.1, 9.0), (4.3, 2.2, 2.9)][seed % 4]
+    Lx, Ly, Lz = (cut * f for f in shape)
+    x = rng.uniform(0.0, 1.0, (n, 3)) * np.array([Lx, Ly, Lz])
+    # keep atoms apart (no polarization catastrophe): reject points closer than 1.9 A
+    keep = []
+    for a in range(n):
+        d = x[keep] - x[a] if keep else np.zeros((0, 3))
+        d -= np.array([Lx, Ly, Lz]) * np.round(d / np.array([Lx, Ly, Lz]))
+        if not len(d) or np.min(np.sum(d * d, axis=1)) > 1.9 ** 2:
+            keep.append(a)
+    x = x[keep]
+    n = len(x)
+    typ = rng.integers(1, 3, n).astype(np.int32)
+    q = rng.normal(0, 0.4, n)
+    q -= q.mean()
+    alpha = np.where(rng.uniform(size=n) < 0.7, rng.uniform(0.3, 1.2, n), 0.0)
+    mol = rng.integers(0, max(2, n // 3), n).astype(np.int32)   # molecule 0 is never excluded
+    rows = [["1", "1", "0.10", "3.0"], ["1", "2", "0.08", "3.2"], ["2", "2", "0.06", "3.4"]]
+    for mode in ("exact", "list"):
+        extra = ["damp_type", "exponential", "precision", "1e-13", "max_iterations", "300"] + _SOLVERS[solver]
+        if mode == "list":
+            extra += ["dd_cutoff", repr(cut)]
+        st = wl.parse_pair_style_args(["7.0", repr(cut)] + extra)
+        s = wl.make_system(x, q, alpha, typ, mol, np.zeros(3), np.array([Lx, Ly, Lz]), 2, rows, st, 0.25,
+                           name=f"rand{seed}")
+        out, ref = _check(pkg, oracle, s)
+        if mode == "exact" and solver in ("ranked", "gs", "jacobi5"):
+            assert out["iterations"] == ref["iterations"]
