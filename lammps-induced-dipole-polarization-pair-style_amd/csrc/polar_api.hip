@@ -490,7 +490,7 @@ void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
   const int qb = h->quad_block;
 #define FQ(M) k_field_quad<EP, M><<<nblk_xcd(nrows, qb / 64), qb, 0, h->stream>>>(                 \
       nrows, rows, h->d_rec0.p, h->d_rec1.p, h->box, RowList{h->d_dd_cnt.p, h->dd_pitch}, h->d_dd_j.p, h->d_dd_s.p, \
-      h->d_dd_r2.p, st.polar_damp, h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
+      h->d_dd_r2.p, st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
   if (h->stream_mode == 0) FQ(0);
   else if (h->stream_mode == 2) { if (expd) FQ(3); else FQ(4); }
@@ -531,7 +531,7 @@ void launch_force(polar_handle *h, int eflag, int vglobal, double *vatom, double
 #define LF(E, V)                                                                                                    \
   k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(own_rows(h), own_n(h), h->sorted ? h->d_perm.p : nullptr, h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
                                                                h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p,  \
-                                                               ccs, dds, st.polar_damp, e2s, fdst, h->d_slots.p, vatom, vglobal)
+                                                               ccs, dds, st.polar_damp, e2s, fdst, h->d_slots.p, vatom, vglobal, make_expcoef())
   if (eflag) { if (vpair) LF(true, true); else LF(true, false); }
   else       { if (vpair) LF(false, true); else LF(false, false); }
 #undef LF

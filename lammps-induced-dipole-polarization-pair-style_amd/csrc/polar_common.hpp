@@ -238,6 +238,34 @@ __device__ __forceinline__ RecQuad fetch_records(const AtomRec *__restrict__ rec
   return r;
 }
 
+// exp(x) for x <= 0 with its constants in SCALAR registers.  The library routine materialises a dozen
+// FP64 constants with v_mov pairs on every call (25 of the 173 vector instructions of a sweep trip);
+// here they arrive as a kernel argument (kernel arguments live in SGPRs, and an FP64 VALU instruction
+// reads one SGPR pair for free).  Cody-Waite reduction x = n ln2 + r, |r| <= ln2/2, Taylor polynomial
+// of degree 13 in Horner form (truncation 4e-18), ldexp.  x is clamped at -745 (the padding pairs of the
+// sweep carry r^2 = 1e60).
+struct ExpCoef {
+  double log2e, ln2hi, ln2lo;
+  double c[14];  // 1/k!
+};
+inline ExpCoef make_expcoef() {
+  ExpCoef K;
+  K.log2e = 1.4426950408889634074; K.ln2hi = 6.93147180369123816490e-01; K.ln2lo = 1.90821492927058770002e-10;
+  const double c[14] = {1.0, 1.0, 0.5, 0.16666666666666666, 0.041666666666666664, 0.008333333333333333, 0.001388888888888889, 0.0001984126984126984, 2.48015873015873e-05, 2.7557319223985893e-06, 2.755731922398589e-07, 2.505210838544172e-08, 2.08767569878681e-09, 1.6059043836821613e-10};
+  for (int k = 0; k < 14; k++) K.c[k] = c[k];
+  return K;
+}
+__device__ __forceinline__ double exp_neg(double x, const ExpCoef &K) {
+  x = fmax(x, -745.0);
+  const double n = rint(x * K.log2e);
+  double r = fma(-n, K.ln2hi, x);
+  r = fma(-n, K.ln2lo, r);
+  double p = K.c[13];
+#pragma unroll
+  for (int k = 12; k >= 0; k--) p = fma(p, r, K.c[k]);
+  return ldexp(p, (int)n);
+}
+
 // Dipole field tensor scalars of build_dipole_field_matrix (PS.cpp:1284-1306):
 //   T_pq = delta_pq * s3 - d_p d_q * s5,  s3 = damp1 / r^3,  s5 = 3 damp2 / r^5
 template <int DAMP>
@@ -250,6 +278,26 @@ __device__ __forceinline__ void tensor_scalars(double r2, double pd, double &s3,
   if (DAMP == 0) {  // exponential (Thole-like) damping
     double ar = pd * r;
     double e = exp(-ar);
+    double p2 = 1.0 + ar + 0.5 * ar * ar;
+    double p3 = p2 + ar * ar * ar * (1.0 / 6.0);
+    s3 = (1.0 - e * p2) * r3;
+    s5 = 3.0 * (1.0 - e * p3) * r5;
+  } else {
+    s3 = r3;
+    s5 = 3.0 * r5;
+  }
+}
+// the same with exp_neg (constants in scalar registers): the sweep kernel's form
+template <int DAMP>
+__device__ __forceinline__ void tensor_scalars_k(double r2, double pd, const ExpCoef &K, double &s3, double &s5) {
+  double rinv = rsqrt(r2);
+  double r = r2 * rinv;
+  double rinv2 = rinv * rinv;
+  double r3 = rinv * rinv2;
+  double r5 = r3 * rinv2;
+  if (DAMP == 0) {  // exponential (Thole-like) damping
+    double ar = pd * r;
+    double e = exp_neg(-ar, K);
     double p2 = 1.0 + ar + 0.5 * ar * ar;
     double p3 = p2 + ar * ar * ar * (1.0 / 6.0);
     s3 = (1.0 - e * p2) * r3;

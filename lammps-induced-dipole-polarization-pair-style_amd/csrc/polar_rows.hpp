@@ -381,7 +381,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
                                                              const int *__restrict__ nl_j, double cut_coulsq,
                                                              double ddcutsq, double pd, double e2s,
                                                              double *__restrict__ f, double *__restrict__ slots,
-                                                             double *__restrict__ vatom, int vglobal) {
+                                                             double *__restrict__ vatom, int vglobal, ExpCoef K) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
       const double pjdotr = rj.mx * dx + rj.my * dy + rj.mz * dz;
       double pre_r, pre2, pre3;
       if (DAMP == 0) {
-        const double t1 = exp(-pd * r);
+        const double t1 = exp_neg(-pd * r, K);
         const double t2 = 1.0 + pd * r + 0.5 * pd * pd * r * r;
         const double t3 = t2 + (1.0 / 6.0) * pd * pd * pd * r * r * r;
         const double g2 = 1.0 - t1 * t2, g3 = 1.0 - t1 * t3;

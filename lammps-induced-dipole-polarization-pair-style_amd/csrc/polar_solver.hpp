@@ -162,7 +162,7 @@ __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__res
                                                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
                                                             Box box, RowList ddl, const int *__restrict__ dd_j,
                                                             const double2 *__restrict__ dd_s,
-                                                            const double *__restrict__ dd_r2, double pd,
+                                                            const double *__restrict__ dd_r2, double pd, ExpCoef K,
                                                             const double *__restrict__ ef, const Scal *scal,
                                                             double *__restrict__ slots, int ablate) {
   if (scal->done) return;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__res
       r2v = k == 0 ? r2s[0] : (k == 1 ? r2s[1] : (k == 2 ? r2s[2] : r2s[3]));
       r2v = r2v > 0.0 ? r2v : 1e60;  // padding entries (the atom itself): an inert pair
     }
-    if (SMODE != 0) tensor_scalars<(SMODE == 1 || SMODE == 3) ? 0 : 1>(r2v, pd, Sv.x, Sv.y);  // lane L: pair L of the trip
+    if (SMODE != 0) tensor_scalars_k<(SMODE == 1 || SMODE == 3) ? 0 : 1>(r2v, pd, K, Sv.x, Sv.y);  // lane L: pair L of the trip
 #define POLAR_QSTEP(R)                                                                          \
   {                                                                                            \
     const double s3_ = dpp_full<(R) * 0x55>(Sv.x), s5_ = dpp_full<(R) * 0x55>(Sv.y);             \
