@@ -220,13 +220,15 @@ __device__ __forceinline__ void pair_del(const Box &b, double xi, double yi, dou
 // lane gets ITS record back.  All 64 lanes call it (idle lanes pass any valid index).
 struct RecQuad { double2 a, b, c, d; };  // {x,mx} {y,my} {z,mz} {q,alpha}
 __device__ __forceinline__ RecQuad fetch_records(const AtomRec *__restrict__ rec, int j, double2 *stage, int lane) {
-  const int q4 = lane >> 2, k = lane & 3;
-  const char *base = reinterpret_cast<const char *>(rec) + k * 16;
+  const int q4 = lane >> 2;
+  // scalar base + 32-bit lane offset (index * 64 + piece * 16; fewer than 2^26 records)
+  const char *base = reinterpret_cast<const char *>(rec);
+  const unsigned piece = (unsigned)(lane & 3) * 16u, k = lane & 3;
   const unsigned j0 = __shfl(j, q4, 64), j1 = __shfl(j, 16 + q4, 64), j2 = __shfl(j, 32 + q4, 64), j3 = __shfl(j, 48 + q4, 64);
-  const double2 p0 = *reinterpret_cast<const double2 *>(base + ((size_t)j0 << 6));
-  const double2 p1 = *reinterpret_cast<const double2 *>(base + ((size_t)j1 << 6));
-  const double2 p2 = *reinterpret_cast<const double2 *>(base + ((size_t)j2 << 6));
-  const double2 p3 = *reinterpret_cast<const double2 *>(base + ((size_t)j3 << 6));
+  const double2 p0 = *reinterpret_cast<const double2 *>(base + ((j0 << 6) + piece));
+  const double2 p1 = *reinterpret_cast<const double2 *>(base + ((j1 << 6) + piece));
+  const double2 p2 = *reinterpret_cast<const double2 *>(base + ((j2 << 6) + piece));
+  const double2 p3 = *reinterpret_cast<const double2 *>(base + ((j3 << 6) + piece));
   stage[q4 * 5 + k] = p0; stage[(16 + q4) * 5 + k] = p1;
   stage[(32 + q4) * 5 + k] = p2; stage[(48 + q4) * 5 + k] = p3;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
   const int i = rows ? rows[row] : row;
-  const AtomRec *__restrict__ rec = scal_in->cur ? recB : recA;
+  const AtomRec *__restrict__ rec = __builtin_amdgcn_readfirstlane(scal_in->cur) ? recB : recA;  // scalar base
   const AtomRec ri = uniform_rec(rec[i]);  // row data is the same in every lane: scalar registers
   const int mi = mol[i];
   const double f_shift = -1.0 / cut_coulsq;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
     const int e = ALLPAIRS ? (int)p : nl_j[p];
     const int j = ALLPAIRS ? e : (e & POLAR_NL_MASK);
     if (j == i) continue;
-    const AtomRec rj = rec[j];
+    const AtomRec rj = *reinterpret_cast<const AtomRec *>(reinterpret_cast<const char *>(rec) + ((unsigned)j << 6));
     const bool molok = ALLPAIRS ? ((mi != mol[j]) || mi == 0) : !(e & POLAR_NL_SAMEMOL);
     double dx, dy, dz;
     pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, dx, dy, dz);

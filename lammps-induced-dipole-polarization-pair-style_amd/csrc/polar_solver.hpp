@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__res
   const int row = lb * rpb + wv;
   if (row >= nrows) return;
   const int i = __builtin_amdgcn_readfirstlane(rows ? rows[row] : row);
-  const int cur = scal->cur;
+  const int cur = __builtin_amdgcn_readfirstlane(scal->cur);  // wave-uniform: the record base stays in SGPRs
   const AtomRec *__restrict__ src = (EP == EP_JACOBI && cur) ? recB : recA;
   AtomRec *__restrict__ dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
   const int k = lane & 3, kk = k < 3 ? k : 2;
@@ -188,7 +188,10 @@ __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__res
   if (ablate & 1) T = 0;             // lab switches (POLAR_ABLATE): timing only, wrong numbers
   if ((ablate & 8) && T > 1) T = 1;
   const double prd = box.periodic[kk] ? box.prd[kk] : 0.0, inv = box.inv[kk];
-  const char *srcb = reinterpret_cast<const char *>(src) + kk * 16;
+  // gather address = scalar base + 32-bit lane offset (j * 64 + piece * 16; j < 2^26): one vector
+  // instruction per gather instead of a 64-bit shift and a 64-bit add
+  const char *srcc = reinterpret_cast<const char *>(src);
+  const unsigned piece = (unsigned)kk * 16u;
   // stream: lane L reads pair L of the trip (ONE coalesced instruction each for j and (s3,s5): the
   // vector-memory address unit spends ~16 cycles per wave instruction however little it fetches, and
   // it is the unit this kernel saturates).  Pair 4q+r of a trip belongs to quad q, step r, so the
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__res
 #define POLAR_QGATHER(R)                                                                        \
   {                                                                                            \
     const unsigned j_ = (unsigned)__builtin_amdgcn_update_dpp(0, jv, (R) * 0x55, 0xF, 0xF, true); \
-    P[R] = *reinterpret_cast<const double2 *>(srcb + ((size_t)j_ << 6));                        \
+    P[R] = *reinterpret_cast<const double2 *>(srcc + ((j_ << 6) + piece));                      \
   }
     POLAR_QGATHER(0) POLAR_QGATHER(1) POLAR_QGATHER(2) POLAR_QGATHER(3)
 #undef POLAR_QGATHER
