@@ -322,7 +322,7 @@ def test_device_neighbor_build_matches_uploaded_list(case, wl, pkg, oracle):
 
 
 @pytest.mark.parametrize("comm", ["device", "host"])
-def test_compact_shards_with_point_to_point_halos_match_single_handle(comm, wl, pkg, oracle):
+def test_compact_shards_with_point_to_point_halos_match_single_handle(comm, wl, pkg, oracle, monkeypatch):
     """The default multi-GPU layout on ONE GPU: three handles that each hold only [own | halo | ghosts]
     (workload.compact_shard), stepped in lock-step with the point-to-point index lists of
     parallel.p2p_buffers (loopback in place of isend/irecv), against the unsharded handle."""
@@ -339,6 +339,8 @@ def test_compact_shards_with_point_to_point_halos_match_single_handle(comm, wl, 
     sfull = wl.replicate_fixture(path, 1, 1, 4, extra_args=extra, rows=np.arange(s.nlocal), full=True)
     reach = float(sfull.extra["cutneigh"]) + 1e-6
     plan = par.P2PHaloPlan(s.x[:s.nlocal], s.prd, offs, reach)
+    if comm == "host":   # start the shards with a row pitch that is too small: POLAR_RETRY_STEP, all repeat
+        monkeypatch.setenv("POLAR_INIT_PITCH", "64")
     bes, bufs, shards = [], [], []
     for r in range(world):
         lo, hi = int(offs[r]), int(offs[r + 1])
@@ -361,20 +363,57 @@ def test_compact_shards_with_point_to_point_halos_match_single_handle(comm, wl, 
         for r, be in enumerate(bes):
             be.scatter_idx(bufs[r]["idx_in"], bufs[r]["recv"])
 
-    for be in bes:
-        be.begin(1, 2)
-    exchange()
-    for sw in range(bes[0].max_it + 1):
+    def exchange_host():
+        """What a LAMMPS rank does around Comm::forward_comm_pair: dipoles of the own rows to a host
+        array, (communication), dipoles of the halo atoms from a host array -- host-pointer entry points."""
+        import ctypes as C
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        own_mu = []
         for be in bes:
-            be.sweep()
-        tot = sum(be.local_change().clone() for be in bes)
+            a = np.zeros((be.hi - be.lo, 3))
+            be.pair._ck(be.pair.L.polar_step_mu_get(be.pair.h, 0, be.hi - be.lo, a.ctypes.data_as(dp)))
+            own_mu.append(a)
+        glob = np.concatenate(own_mu)                      # "the network": every rank's own dipoles by global id
+        for r, be in enumerate(bes):
+            ids = plan.halo_of(r)
+            vals = np.ascontiguousarray(glob[ids])
+            idx = (be.hi - be.lo + np.arange(len(ids))).astype(np.int32)
+            be.pair._ck(be.pair.L.polar_step_mu_put_idx(be.pair.h, len(ids), idx.ctypes.data_as(ip), vals.ctypes.data_as(dp)))
+
+    def end_of_sweep():
+        if comm == "host":     # sum of (dmu)^2 through host doubles (MPI_Allreduce in the LAMMPS shim)
+            import ctypes as C
+            tot = 0.0
+            for be in bes:
+                v = C.c_double()
+                be.pair._ck(be.pair.L.polar_step_change_get(be.pair.h, C.byref(v)))
+                tot += v.value
+            for be in bes:
+                be.pair._ck(be.pair.L.polar_step_sweep_end_host(be.pair.h, tot))
+        else:                  # ... or through device tensors (torch.distributed.all_reduce in parallel.py)
+            tot = sum(be.local_change().clone() for be in bes)
+            for be in bes:
+                be.sweep_end(tot)
+
+    xchg = exchange_host if comm == "host" else exchange
+    retried = False
+    for attempt in range(4):
         for be in bes:
-            be.sweep_end(tot)
-        exchange()
-        if sw % 4 == 3 and all(be.state()[0] for be in bes):
+            be.begin(1, 2)
+        xchg()
+        for sw in range(bes[0].max_it + 1):
+            for be in bes:
+                be.sweep()
+            end_of_sweep()
+            xchg()
+            if sw % 4 == 3 and all(be.state()[0] for be in bes):
+                break
+        outs = [be.finish() for be in bes]
+        if not any(o["status"] == 2 for o in outs):   # POLAR_RETRY_STEP: every shard repeats the step
             break
-    outs = [be.finish() for be in bes]
+        retried = True
     torch.cuda.synchronize()
+    assert retried == (comm == "host")
     f = np.zeros((s.nlocal, 3)); mu = np.zeros((s.nlocal, 3))
     assert all(sc.nlocal < 0.9 * s.nlocal for sc in shards)      # the shards really are compact
     for r, be in enumerate(bes):
@@ -385,7 +424,11 @@ def test_compact_shards_with_point_to_point_halos_match_single_handle(comm, wl, 
         assert np.all(fr[hi - lo:] == 0)                       # halo and ghost atoms receive no force
         mu[lo:hi] = be.pair.download("mu", 3 * nloc).reshape(-1, 3)[:hi - lo]
     assert np.max(np.abs(mu - ref["mu"])) / np.max(np.abs(ref["mu"])) < 1e-8
-    assert force_rel_err(f, fref) < 1e-8
+    # (replicas of the framework are different molecules and overlap at bonded distances: forces span eight
+    #  orders of magnitude here, so the per-atom relative measure gets the parity tolerance and the tight
+    #  bound is taken relative to the largest force)
+    assert np.max(np.linalg.norm(f - fref, axis=1)) < 1e-10 * np.max(np.linalg.norm(fref, axis=1))
+    assert force_rel_err(f, fref) < TOL
     for k in ("eng_vdwl", "eng_coul", "eng_pol"):
         assert rel(sum(o[k] for o in outs), ref[k]) < 1e-9
     vir = sum(o["virial"] for o in outs)
