@@ -110,7 +110,8 @@ struct polar_handle {
   std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
   std::vector<int> h_rows;     // rows sorted by colour (host copy)
   bool colors_valid = false;
-  double color_dist = 2.6;
+  double color_dist = 2.4;  // A (POLAR_COLOR_DIST).  profiles/r01_lab_color_distance.txt: 2.4 -> 4 phases, 2.5-2.6 -> 5, with the same
+                            // number of sweeps to 1e-11 (33); <= 2.2 -> 3 phases but 36-37 sweeps; <= 1.2 does not converge
   int field_block = 256;
   double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // locals + ghosts, recorded by polar_set_atoms
   long long global_count = 0;  // N of the stop rule when the handle holds a part of the system (0: nlocal)
