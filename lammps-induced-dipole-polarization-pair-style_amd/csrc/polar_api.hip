@@ -293,6 +293,7 @@ void build_lists(polar_handle *h) {
   else if (mode == 0) h->d_dd_s.ensure((size_t)n * h->dd_pitch + 64);
   double *r2p = r2c ? h->d_dd_r2.p : nullptr;
   double2 *sp = mode == 0 ? h->d_dd_s.p : nullptr;
+  const bool fuse = mode != 0 && !getenv("POLAR_NO_FUSE_R2");  // r^2 and padding written by k_nl_build (no k_dd_scalars pass)
   const double cutallsq = cutall * cutall, ddsq = st.dd_cutoff * st.dd_cutoff;
   const int nr = own_n(h);
   const int *rows = own_rows(h);
@@ -302,9 +303,11 @@ void build_lists(polar_handle *h) {
   HIPCHECK(hipMemsetAsync(h->d_ddtot.p, 0, 64 * 16 * sizeof(unsigned long long), s));
   k_nl_build<<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
       rows, nr, h->d_pos4.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,
-      h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, h->d_overflow.p, h->d_ddtot.p);
+      h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, fuse ? r2p : nullptr, fuse ? 1 : 0, h->d_overflow.p, h->d_ddtot.p);
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
-  if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
+  if (fuse) {
+    // modes 1 and 2: the list build wrote r^2 (mode 1) and the padding itself
+  } else if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
     k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, sp, r2p);
   else
     k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, sp, r2p);

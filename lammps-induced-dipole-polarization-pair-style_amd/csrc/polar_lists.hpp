@@ -107,6 +107,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
                                                           double ddcutsq, long long nl_pitch, long long dd_pitch,
                                                           int *__restrict__ nl_cnt, int *__restrict__ dd_cnt,
                                                           int *__restrict__ nl_j, int *__restrict__ dd_j,
+                                                          double *__restrict__ dd_r2, int pad_dd,
                                                           int *__restrict__ overflow,
                                                           unsigned long long *__restrict__ dd_total) {
   const int lane = threadIdx.x & 63;
@@ -191,11 +192,12 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
         bool in_nl = false, in_dd = false;
         const int j = p;
         int same = 0;
+        double rsq = 0.0;
         if (p < b && j != i) {
           const double4 rj = pos4[j];  // consecutive lanes read consecutive 32-byte entries
           double ex, ey, ez;
           min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
-          const double rsq = ex * ex + ey * ey + ez * ez;
+          rsq = ex * ex + ey * ey + ez * ez;
           in_nl = rsq <= cutallsq;
           in_dd = ipol && __double2loint(rj.w) && (rsq < ddcutsq);
           same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;
@@ -205,10 +207,21 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
         // bit 30 of an nl entry: "same non-zero molecule" -- the static field and the charge-dipole terms
         // skip such pairs (PS.cpp:342,454), so those kernels need no molecule gather
         if (in_nl && kn < nl_pitch) nl_j[nl0 + kn] = j | same;
-        if (in_dd && kd < dd_pitch) dd_j[dd0 + kd] = j;
+        if (in_dd && kd < dd_pitch) {
+          dd_j[dd0 + kd] = j;
+          if (dd_r2) dd_r2[dd0 + kd] = rsq;  // the sweep's per-pair stream value (same positions, same image rule)
+        }
         ncount += __popcll(m_nl);
         dcount += __popcll(m_dd);
       }
+    }
+  }
+  if (pad_dd) {  // pad the dd row to whole 64-pair trips with inert entries (the component-per-lane sweep has no lane masks)
+    const int have = dcount < dd_pitch ? dcount : (int)dd_pitch;
+    const int padded = (have + 63) & ~63;
+    for (int k = have + lane; k < padded; k += 64) {
+      dd_j[dd0 + k] = i;
+      if (dd_r2) dd_r2[dd0 + k] = 1e60;  // s3 ~ 1e-90, and d = 0 kills the s5 term: contributes nothing
     }
   }
   if (lane == 0) {
