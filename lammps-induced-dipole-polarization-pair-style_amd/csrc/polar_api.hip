@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <initializer_list>
+#include <utility>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -52,6 +54,20 @@ struct DBuf {
 
 // at least one workgroup: every kernel bounds-checks its index, and a zero-sized grid is a launch error
 inline int nblk(long long n, int per) { return n <= 0 ? 1 : (int)((n + per - 1) / per); }
+// one launch zeroing up to six small device buffers (sizes in bytes, multiples of 4)
+inline void zero_many(hipStream_t s, std::initializer_list<std::pair<void *, size_t>> bufs) {
+  ZeroJobs jobs;
+  jobs.n = 0;
+  unsigned long long most = 0;
+  for (const auto &b : bufs) {
+    jobs.p[jobs.n] = (unsigned int *)b.first;
+    jobs.nwords[jobs.n] = b.second / 4;
+    most = std::max<unsigned long long>(most, b.second / 4);
+    jobs.n++;
+  }
+  const int blocks = (int)std::min<unsigned long long>(1024, (most + 255) / 256);
+  k_zero_many<<<std::max(blocks, 1), 256, 0, s>>>(jobs);
+}
 // grid of a kernel that places its workgroups with xcd_block(): 8 * ceil(nblocks / 8)
 inline int nblk_xcd(long long n, int per) { return ((nblk(n, per) + 7) / 8) * 8; }
 
@@ -230,8 +246,7 @@ void build_cells(polar_handle *h) {
   hipStream_t s = h->stream;
   h->d_cell_id.ensure(n); h->d_cell_cnt.ensure(ncell + 1); h->d_cell_fill.ensure(ncell + 1);
   h->d_cell_first.ensure(ncell + 2); h->d_perm.ensure(n + 1); h->d_inv.ensure(n + 1);
-  HIPCHECK(hipMemsetAsync(h->d_cell_cnt.p, 0, (ncell + 1) * sizeof(int), s));
-  HIPCHECK(hipMemsetAsync(h->d_cell_fill.p, 0, (ncell + 1) * sizeof(int), s));
+  zero_many(s, {{h->d_cell_cnt.p, (size_t)(ncell + 1) * sizeof(int)}, {h->d_cell_fill.p, (size_t)(ncell + 1) * sizeof(int)}});
   k_cell_count<<<nblk(n, 256), 256, 0, s>>>(n, h->d_x.p, g, h->box, h->d_cell_id.p, h->d_cell_cnt.p);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>(ncell, h->d_cell_cnt.p, h->d_cell_first.p);
   k_cell_fill<<<nblk(n, 256), 256, 0, s>>>(n, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_fill.p, h->d_perm.p, h->d_inv.p);
@@ -297,10 +312,8 @@ void build_lists(polar_handle *h) {
   const double cutallsq = cutall * cutall, ddsq = st.dd_cutoff * st.dd_cutoff;
   const int nr = own_n(h);
   const int *rows = own_rows(h);
-  HIPCHECK(hipMemsetAsync(h->d_nl_cnt.p, 0, (n + 1) * sizeof(int), s));
-  HIPCHECK(hipMemsetAsync(h->d_dd_cnt.p, 0, (n + 1) * sizeof(int), s));
-  HIPCHECK(hipMemsetAsync(h->d_overflow.p, 0, 16 * sizeof(int), s));
-  HIPCHECK(hipMemsetAsync(h->d_ddtot.p, 0, 64 * 16 * sizeof(unsigned long long), s));
+  zero_many(s, {{h->d_nl_cnt.p, (size_t)(n + 1) * sizeof(int)}, {h->d_dd_cnt.p, (size_t)(n + 1) * sizeof(int)},
+                {h->d_overflow.p, 16 * sizeof(int)}, {h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long)}});
   k_nl_build<<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
       rows, nr, h->d_pos4.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,
       h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, fuse ? r2p : nullptr, fuse ? 1 : 0, h->d_overflow.p, h->d_ddtot.p);
@@ -670,8 +683,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   if (eflag / 2) { h->d_eatom.ensure(nall + 1); eatom = h->d_eatom.p; HIPCHECK(hipMemsetAsync(eatom, 0, (size_t)nall * sizeof(double), s)); }
   if (vflag / 4) { h->d_vatom.ensure(6 * (size_t)nall + 6); vatom = h->d_vatom.p; HIPCHECK(hipMemsetAsync(vatom, 0, 6 * (size_t)nall * sizeof(double), s)); }
   if ((eatom || vatom) && own_n(h) != n) throw InputError("per-atom tallies are not available on a row-sharded handle");
-  k_zero_scal<<<1, 1, 0, s>>>(h->d_scal.p, 0);
-  k_zero_slots<<<nblk(POLAR_NSLOT, 256), 256, 0, s>>>(h->d_slots.p);
+  k_zero_slots<<<nblk(POLAR_NSLOT, 256), 256, 0, s>>>(h->d_slots.p, h->d_scal.p);
   auto launch_lj = [&]() {  // a3 -- on a low-priority side stream when overlap is on: it depends on nothing below, and fills
     // whatever the list build, the static field and the latency-bound solver launches leave idle
     hipStream_t ms = s;

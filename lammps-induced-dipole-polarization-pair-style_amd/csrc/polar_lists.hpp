@@ -407,6 +407,18 @@ __global__ void k_mu_scatter_idx(long long n, const int *__restrict__ idx, const
 }
 
 // small utilities
+// several small buffers zeroed by ONE launch (every launch costs ~4.4 us on this platform whatever it does)
+struct ZeroJobs {
+  unsigned int *p[6];
+  unsigned long long nwords[6];  // 4-byte words
+  int n;
+};
+__global__ void k_zero_many(ZeroJobs jobs) {
+  const unsigned long long gid = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+  const unsigned long long stride = gridDim.x * (unsigned long long)blockDim.x;
+  for (int j = 0; j < jobs.n; j++)
+    for (unsigned long long w = gid; w < jobs.nwords[j]; w += stride) jobs.p[j][w] = 0u;
+}
 __global__ void k_zero_scal(Scal *s, int keep_solver) {
   s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;
   for (int k = 0; k < 6; k++) s->virial[k] = 0.0;

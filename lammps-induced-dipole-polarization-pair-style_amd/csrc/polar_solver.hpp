@@ -620,8 +620,16 @@ __global__ __launch_bounds__(POLAR_NSLOT) void k_fold_scal(Scal *scal, double *_
     __syncthreads();
   }
 }
-__global__ void k_zero_slots(double *__restrict__ slots) {
+// start-of-step reset of the slot accumulators and (thread 0) of the Scal block: one launch
+__global__ void k_zero_slots(double *__restrict__ slots, Scal *s) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 && s) {
+    s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;
+    for (int k = 0; k < 6; k++) s->virial[k] = 0.0;
+    s->change = 0.0; s->last_change = 0.0; s->pad = 0;
+    s->rmin_bits = (unsigned long long)__double_as_longlong(1000.0);
+    s->iterations = 0; s->done = 0; s->status = 0; s->cur = 0; s->sweeps = 0;
+  }
   if (t >= POLAR_NSLOT) return;
   for (int f = 0; f < POLAR_SLOT_STRIDE; f++) slots[(size_t)t * POLAR_SLOT_STRIDE + f] = 0.0;
   ((unsigned long long *)slots)[(size_t)t * POLAR_SLOT_STRIDE + SL_RMIN] = (unsigned long long)__double_as_longlong(1000.0);
