@@ -589,35 +589,28 @@ __global__ __launch_bounds__(POLAR_NSLOT) void k_fold_change(Scal *scal, double 
 
 // fold energies / virial / rmin slots into the Scal block (run before the host reads it)
 __global__ __launch_bounds__(POLAR_NSLOT) void k_fold_scal(Scal *scal, double *__restrict__ slots, int rmin_only) {
-  __shared__ double red[POLAR_NSLOT / 64];
-  const int t = threadIdx.x;
-  {
-    unsigned long long b = ((unsigned long long *)slots)[(size_t)t * POLAR_SLOT_STRIDE + SL_RMIN];
-    double r = __longlong_as_double((long long)b);
-    r = wave_min(r);
-    if ((t & 63) == 0) red[t >> 6] = r;
-    __syncthreads();
-    if (t == 0) {
-      double m = red[0];
-      for (int k = 1; k < POLAR_NSLOT / 64; k++) m = fmin(m, red[k]);
-      scal->rmin_bits = (unsigned long long)__double_as_longlong(m);
+  // one wave per accumulator field (wave 0: rmin; waves 1..11: energies and virial), all at once
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  if (w == 0) {
+    double r = 1.0e300;
+    for (int k = lane; k < POLAR_NSLOT; k += 64) {
+      const unsigned long long b = ((unsigned long long *)slots)[(size_t)k * POLAR_SLOT_STRIDE + SL_RMIN];
+      r = fmin(r, __longlong_as_double((long long)b));
     }
-    __syncthreads();
+    r = wave_min(r);
+    if (lane == 0) scal->rmin_bits = (unsigned long long)__double_as_longlong(r);
+    return;
   }
   if (rmin_only) return;
-  for (int f = SL_EVDWL; f <= SL_V5; f++) {
-    double v = slots[(size_t)t * POLAR_SLOT_STRIDE + f];
-    v = wave_sum(v);
-    if ((t & 63) == 0) red[t >> 6] = v;
-    __syncthreads();
-    if (t == 0) {
-      double sum = 0.0;
-      for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
-      double *dst = f == SL_EVDWL ? &scal->eng_vdwl : f == SL_ECOUL ? &scal->eng_coul : f == SL_USELF ? &scal->u_self
-                  : f == SL_UEF ? &scal->u_ef : f == SL_UDD ? &scal->u_dd : &scal->virial[f - SL_V0];
-      *dst = sum;
-    }
-    __syncthreads();
+  const int f = SL_EVDWL + (w - 1);
+  if (f > SL_V5) return;
+  double v = 0.0;
+  for (int k = lane; k < POLAR_NSLOT; k += 64) v += slots[(size_t)k * POLAR_SLOT_STRIDE + f];
+  v = wave_sum(v);
+  if (lane == 0) {
+    double *dst = f == SL_EVDWL ? &scal->eng_vdwl : f == SL_ECOUL ? &scal->eng_coul : f == SL_USELF ? &scal->u_self
+                : f == SL_UEF ? &scal->u_ef : f == SL_UDD ? &scal->u_dd : &scal->virial[f - SL_V0];
+    *dst = v;
   }
 }
 // start-of-step reset of the slot accumulators and (thread 0) of the Scal block: one launch
