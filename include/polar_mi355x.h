@@ -187,6 +187,10 @@ int polar_step_sweep(polar_handle *h); /* one sweep over the owned rows */
 /* end-of-sweep control (PS.cpp:1193-1236) on the device; dev_global_change = all-reduced sum of
  * (dmu)^2 in device memory, or NULL to use this handle's own sum */
 int polar_step_sweep_end(polar_handle *h, const double *dev_global_change);
+/* the end-of-sweep logic of `count` sweeps at once: fixed-iteration Gauss-Seidel takes no decision between
+ * sweeps, so a driver may call this after the last-but-one sweep (count = sweeps so far) and after the last
+ * (count = 1) instead of once per sweep */
+int polar_step_sweep_end_n(polar_handle *h, const double *dev_global_change, int count);
 int polar_step_state(polar_handle *h, int *done, int *iterations, int *status); /* synchronises */
 int polar_step_finish(polar_handle *h, polar_result *out); /* forces/energies of the owned rows */
 /* dipoles of rows [lo,hi) <-> a packed device buffer [(hi-lo)][3] */

@@ -107,6 +107,7 @@ EXPORTS = {
     "polar_step_mu_put_idx": (C.c_int, [C.c_void_p, C.c_longlong, _ip, _dp]),
     "polar_step_change_get": (C.c_int, [C.c_void_p, _dp]),
     "polar_step_sweep_end_host": (C.c_int, [C.c_void_p, C.c_double]),
+    "polar_step_sweep_end_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "polar_set_list_style": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_step_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "polar_step_sweep": (C.c_int, [C.c_void_p]),

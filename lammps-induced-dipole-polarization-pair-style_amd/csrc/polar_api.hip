@@ -1366,16 +1366,19 @@ int polar_step_sweep(polar_handle *h) {
     return POLAR_OK;
   });
 }
-int polar_step_sweep_end(polar_handle *h, const double *dev_global_change) {
+int polar_step_sweep_end_n(polar_handle *h, const double *dev_global_change, int count) {
   return guarded(h, [&]() {
     if (!h->in_step) throw std::runtime_error("polar_step_sweep_end outside polar_step_begin/finish");
+    if (count < 1) throw InputError("polar_step_sweep_end_n: count must be >= 1");
     const polar_settings &st = h->ph.st;
     const bool gs = st.polar_gs || st.polar_gs_ranked;
+    if (count > 1 && !(gs && st.fixed_iteration)) throw InputError("polar_step_sweep_end_n: count > 1 needs fixed-iteration Gauss-Seidel");
     k_solver_step<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
-                                          gs ? 0 : 1, dev_global_change, 1);
+                                          gs ? 0 : 1, dev_global_change, count);
     return POLAR_OK;
   });
 }
+int polar_step_sweep_end(polar_handle *h, const double *dev_global_change) { return polar_step_sweep_end_n(h, dev_global_change, 1); }
 int polar_step_state(polar_handle *h, int *done, int *iterations, int *status) {
   return guarded(h, [&]() {
     need_device(h);

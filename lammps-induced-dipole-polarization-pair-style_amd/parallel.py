@@ -61,6 +61,7 @@ class HipShardBackend:
         st = pair.get_settings()
         self.fixed, self.max_it = bool(st.fixed_iteration), st.iterations_max
         self.zodid = bool(st.zodid)
+        self.lazy_end = bool(st.fixed_iteration) and bool(st.polar_gs or st.polar_gs_ranked)
 
     def begin(self, eflag, vflag):
         self.pair._ck(self.pair.L.polar_step_begin(self.pair.h, eflag, vflag))
@@ -72,9 +73,9 @@ class HipShardBackend:
         self.pair._ck(self.pair.L.polar_change_export(self.pair.h, C.c_void_p(self.chg.data_ptr())))
         return self.chg
 
-    def sweep_end(self, global_change):
+    def sweep_end(self, global_change, count=1):
         ptr = C.c_void_p(global_change.data_ptr()) if global_change is not None else None
-        self.pair._ck(self.pair.L.polar_step_sweep_end(self.pair.h, ptr))
+        self.pair._ck(self.pair.L.polar_step_sweep_end_n(self.pair.h, ptr, count))
 
     def own_mu(self):
         self.pair._ck(self.pair.L.polar_mu_gather(self.pair.h, self.lo, self.hi, C.c_void_p(self.own.data_ptr())))
@@ -344,6 +345,14 @@ def _run_step_once(backend, dist, rank, world, counts, offs, eflag, vflag, check
                 chg = backend.local_change()
                 dist.all_reduce(chg)
                 backend.sweep_end(chg)
+            elif getattr(backend, "lazy_end", False):
+                # fixed-iteration Gauss-Seidel: no decision between sweeps -> the end-of-sweep logic of all
+                # sweeps but the last in one launch, then the last (its sum |dmu|^2 is the one reported)
+                last = backend.max_it
+                if sw == last - 1:
+                    backend.sweep_end(None, count=last)
+                elif sw == last or last == 0:
+                    backend.sweep_end(None)
             else:
                 backend.sweep_end(None)
             exchange_mu(backend, dist, counts, offs, rank, gather_buf)
