@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reps", type=int, nargs=3, default=[3, 3, 3], help="replication of the 1349-atom cell per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--synth", type=int, default=0, help="use the SURVEY 8(d) synthetic generator with this many atoms instead of the replicated cell")
     ap.add_argument("--extra", nargs="*", default=[], help="extra pair_style keywords (experiments)")
     args = ap.parse_args()
 
@@ -80,7 +81,10 @@ def main():
         return par.bench_distributed(args, rank, world, local_rank)
 
     torch.cuda.set_device(0)
-    s = build_workload(wl, tuple(args.reps), args.extra)
+    if args.synth:
+        s = wl.synth_system(args.synth, seed=1, extra_args=["fixed_iteration", "yes", "max_iterations", "30", "dd_cutoff", repr(CUT_COUL)] + list(args.extra))
+    else:
+        s = build_workload(wl, tuple(args.reps), args.extra)
     p = pkg.pair_from_system(s, device=0)
 
     for _ in range(args.warmup):
@@ -118,13 +122,15 @@ def main():
     # FETCH_SIZE 25,169 KB -> x2 on gfx950 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE 620 KB;
     # profiles/r01_v32_kfield_quad_traffic_pmc.txt, 4 colour launches per sweep) and is reported only for that
     # workload.  It exceeds the streamed bytes by the atom records every launch re-reads into the L2 of each XCD.
-    traffic = 51.0e6 if (tuple(args.reps) == (3, 3, 3) and not args.extra) else None
+    traffic = 51.0e6 if (tuple(args.reps) == (3, 3, 3) and not args.extra and not args.synth) else None
     line = {
         "metric": "atom-steps/sec", "value": value, "unit": "atom-steps/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: MOF5+H2 cell replicated {args.reps[0]}x{args.reps[1]}x{args.reps[2]} = {n} atoms, exponential damping, "
-                               f"fixed_iteration 30 (31 sweeps), ranked GS, dd_cutoff=cut_coul={CUT_COUL}",
+        "config": {"workload": (f"SURVEY 8(d) synthetic generator synth({n}, seed 1), exponential damping, fixed_iteration 30, ranked GS, dd_cutoff=cut_coul={CUT_COUL}"
+                                if args.synth else
+                                f"BASELINE configs[1]: MOF5+H2 cell replicated {args.reps[0]}x{args.reps[1]}x{args.reps[2]} = {n} atoms, exponential damping, "
+                                f"fixed_iteration 30 (31 sweeps), ranked GS, dd_cutoff=cut_coul={CUT_COUL}"),
                    "natoms": n, "sweeps": out["sweeps"], "colors": out["ncolors"], "dd_pairs": out["dd_pairs"],
                    "ms_per_dipole_iteration": (ms_solve / args.steps) / max(out["sweeps"], 1),
                    "ms_solve": ms_solve / args.steps, "ms_ljcoul": out["ms_ljcoul"], "ms_force": out["ms_force"],

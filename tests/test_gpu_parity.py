@@ -434,3 +434,19 @@ def test_compact_shards_with_point_to_point_halos_match_single_handle(comm, wl, 
     vir = sum(o["virial"] for o in outs)
     assert np.max(np.abs(vir - ref["virial"])) < 1e-8 * np.max(np.abs(ref["virial"]))
     assert len({o["iterations"] for o in outs}) == 1
+
+
+def test_synthetic_box_list_mode_matches_oracle(wl, pkg, oracle):
+    """The SURVEY 8(d) synthetic generator (configs 1-4 as specified there) at a size the oracle finishes in
+    seconds: list mode, ranked GS to 1e-12 and fixed-iteration 30, GPU vs oracle."""
+    for extra in (["precision", "1e-12", "max_iterations", "100"], ["fixed_iteration", "yes", "max_iterations", "30"]):
+        s = wl.synth_system(3000, seed=2, extra_args=["dd_cutoff", "12.8345"] + extra)
+        ref = oracle.compute(s, eflag=1, vflag=2)
+        out = pkg.pair_from_system(s).compute()
+        assert out["status"] == ref["status"] == 0
+        f = oracle.fold_ghost_forces(out["f"], s.owner, s.nlocal)
+        fr = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
+        assert force_rel_err(f, fr) < TOL
+        assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+        for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+            assert rel(out[k], ref[k], 1e-9) < TOL

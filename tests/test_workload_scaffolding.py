@@ -60,3 +60,22 @@ def test_special_arrays_round_trip():
     assert nsp[5].tolist() == [0, 0, 0]
     assert list(wl.neighbor_special_flag([1, 0, 0, 0], [1, 0, 0, 0], kspace=True)) == [1, 2, 2, 2]
     assert list(wl.neighbor_special_flag([1, 0, 0.5, 1], [1, 0, 0.5, 1], kspace=False)) == [1, 0, 2, 1]
+
+
+def test_synthetic_generator_matches_its_specification():
+    """SURVEY.md 8(d) generator: density 0.0798 atoms/A^3, 31 % framework on a jittered lattice (molecule 1),
+    69 % rigid 5-site H2 (q = -0.7464, 2 x +0.3732, 0, 0), neutral, reproducible from the seed."""
+    wl = importlib.import_module(PKG + ".workload")
+    a, b = wl.synth(5000, seed=3), wl.synth(5000, seed=3)
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["q"], b["q"])
+    assert not np.array_equal(a["x"], wl.synth(5000, seed=4)["x"])
+    n, L = len(a["x"]), a["L"]
+    assert n == 5000 and abs(n / L ** 3 - 0.0798) < 1e-6
+    assert abs(a["q"].sum()) < 1e-9
+    nfw = int(np.sum(a["molecule"] == 1))
+    assert abs(nfw / n - 0.31) < 0.01 and (n - nfw) % 5 == 0
+    h2 = a["q"][nfw:].reshape(-1, 5)
+    assert np.allclose(h2, [-0.7464, 0.3732, 0.3732, 0.0, 0.0])
+    assert np.all((a["x"] >= 0) & (a["x"] < L))
+    al = a["alpha"][nfw:].reshape(-1, 5)
+    assert np.allclose(al, [0.6938, 0.00044, 0.00044, 0.0, 0.0])
