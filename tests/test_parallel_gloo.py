@@ -62,7 +62,11 @@ class NumpyShardBackend:
     def local_change(self):
         return self.torch.tensor([self.change], dtype=self.torch.float64)
 
-    def sweep_end(self, global_change):
+    def sweep_end(self, global_change, count=1):
+        for _ in range(count):   # count > 1: the batched form for fixed-iteration Gauss-Seidel (lazy_end)
+            self._sweep_end_once(global_change)
+
+    def _sweep_end_once(self, global_change):
         if self.done:
             return
         chg = (float(global_change[0]) if global_change is not None else self.change) / (3.0 * self.n)
@@ -154,6 +158,9 @@ def _worker(rank, world, port, extra, gs, q, use_halo=False):
     be = NumpyShardBackend(T, E, s.alpha[:s.nlocal].copy(), int(offs[rank]), int(offs[rank + 1]), gs,
                            bool(st.fixed_iteration), st.iterations_max, st.polar_precision, st.polar_gamma)
     halo = None
+    if use_halo in ("lazy", "eager"):   # fixed-iteration GS: end-of-sweep logic batched (product default) or per sweep
+        be.lazy_end = use_halo == "lazy"
+        use_halo = False
     if use_halo == "retry":   # rank 1 alone reports an overflow on its first attempt: both ranks must repeat
         be.retry_once = rank == 1
         use_halo = False
@@ -248,6 +255,17 @@ def test_one_rank_asking_for_a_retry_makes_every_rank_repeat_the_step():
     assert np.max(np.abs(mu0[:half] - muref[:half])) < 1e-12 * np.max(np.abs(muref))
     assert np.max(np.abs(mu1[half:] - muref[half:])) < 1e-12 * np.max(np.abs(muref))
     assert abs(e0 - e1) < 1e-12 * abs(e0)
+
+
+def test_batched_end_of_sweep_logic_equals_the_per_sweep_form():
+    """Fixed-iteration Gauss-Seidel takes no decision between sweeps, so run_step applies the end-of-sweep logic
+    of all sweeps but the last in one call (polar_step_sweep_end_n): same dipoles, same counters."""
+    extra = ["fixed_iteration", "yes", "max_iterations", "6"]
+    lazy = _run(extra, gs=True, use_halo="lazy")
+    eager = _run(extra, gs=True, use_halo="eager")
+    for a, b in zip(lazy, eager):
+        assert a[3] == b[3] == 6 and a[4] == b[4] == 7 and a[5] == b[5] == 0     # iterations, sweeps, status
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2]
 
 
 def test_p2p_halo_exchange_three_ranks_matches_the_oracle():
