@@ -198,7 +198,8 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
   if (eflag_atom || vflag_atom)
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization: per-atom tallies are not available on several MPI ranks yet");
   const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
-  if (neighbor->ago == 0 || (int) lib_of_lammps.size() != nall) build_halo_map();
+  const bool relist = neighbor->ago == 0 || (int) lib_of_lammps.size() != nall;
+  if (relist) build_halo_map();
 
   // per-atom inputs in library order
   sh_x.resize(3 * (size_t) nall); sh_q.resize(nall); sh_a.resize(nall); sh_t.resize(nall); sh_m.resize(nall);
@@ -212,7 +213,7 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
   int periodic[3] = {domain->xperiodic,domain->yperiodic,domain->zperiodic};
   check(polar_set_box(h,domain->boxlo,domain->prd,tilt,periodic,domain->triclinic));
   check(polar_set_atoms(h,sh_n,nall - sh_n,sh_x.data(),sh_q.data(),sh_a.data(),sh_t.data(),sh_m.data()));
-  if (neighbor->ago == 0) {
+  if (relist) {
     std::vector<int> il(list->inum);
     for (int ii = 0; ii < list->inum; ii++) il[ii] = list->ilist[ii];
     check(polar_set_neighbors_csr(h,list->inum,il.data(),sh_nn.data(),sh_first.data(),sh_flat.data()));
