@@ -109,9 +109,10 @@ struct polar_handle {
   DBuf<Scal> d_scal;
   DBuf<double> d_slots;
   // cutoff-mode lists
-  DBuf<int> d_cell_id, d_cell_cnt, d_cell_fill, d_nl_cnt, d_dd_cnt, d_nl_j, d_dd_j;
+  DBuf<int> d_cell_id, d_cell_cnt, d_cell_fill, d_nl_cnt, d_dd_cnt, d_nl_j, d_dd_j, d_dd_wrap;
   DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
   DBuf<double2> d_dd_s;
+  DBuf<int2> d_lpdesc;  // row descriptors of k_field_lp
   DBuf<double4> d_xq, d_pos4;
   long long nl_pairs = 0, dd_pairs = 0;
   long long nl_pitch = 0, dd_pitch = 0;   // pitched row lists (see polar_kernels.hpp RowList)
@@ -136,7 +137,8 @@ struct polar_handle {
   int user_full_list = 0;    // polar_set_list_style for uploaded lists
   long long lj_pitch = 0;
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
-  int quad_block = POLAR_BLOCK;  // workgroup size of k_field_quad (POLAR_QUAD_BLOCK)
+  int quad_block = POLAR_BLOCK;  // workgroup size of k_field_quad / k_field_lp (POLAR_QUAD_BLOCK)
+  int lp_tiles = 2;              // LDS tiles per wave of k_field_lp (POLAR_LP_TILES: 1 or 2)
   int cache_r2 = -1;      // sweep stream (POLAR_CACHE_R2): 0 cached (s3,s5), 20 B/pair; 1 cached r^2, 12 B/pair; 2 nothing,
                           // 4 B/pair (r^2 rebuilt from the gathered positions); -1: 1 or 2 by size, see build_lists
   int stream_mode = 1;    // the choice in force for the current lists
@@ -290,6 +292,7 @@ void build_lists(polar_handle *h) {
     double mean = n / vol * 4.18879020478639 * cutall * cutall * cutall;
     h->nl_pitch = h->dd_pitch = (((long long)(1.5 * mean) + 64) / 64 + 1) * 64;
   }
+  if (h->sweep_kernel == 2) h->dd_pitch = ((h->dd_pitch + 255) / 256) * 256;  // whole 4-trip chunks (k_field_lp)
   h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1);
   h->d_nl_j.ensure((size_t)n * h->nl_pitch + 64); h->d_dd_j.ensure((size_t)n * h->dd_pitch + 64);
   // What the sweep streams per pair.  Measured (tools/exp_nocache.sh): while index + r^2 of all pairs
@@ -297,7 +300,8 @@ void build_lists(polar_handle *h) {
   // 160 MB: 99 vs 107 us/sweep); beyond that the stream comes from HBM every sweep and rebuilding r^2 from
   // the gathered positions wins (135k atoms, 595 MB: 320 vs 350 us/sweep).
   int mode = h->cache_r2;
-  if (h->sweep_kernel != 0) mode = 0;
+  if (h->sweep_kernel == 1) mode = 0;
+  if (h->sweep_kernel == 2) mode = 3;  // lane-per-pair sweep: only the index (as a byte offset) is streamed
   if (mode < 0) {
     const double est_pairs = h->dd_pairs > 0 ? (double)h->dd_pairs : 0.35 * (double)own_n(h) * (double)h->dd_pitch;
     mode = (12.0 * est_pairs < 200.0e6) ? 1 : 2;
@@ -314,9 +318,12 @@ void build_lists(polar_handle *h) {
   const int *rows = own_rows(h);
   zero_many(s, {{h->d_nl_cnt.p, (size_t)(n + 1) * sizeof(int)}, {h->d_dd_cnt.p, (size_t)(n + 1) * sizeof(int)},
                 {h->d_overflow.p, 16 * sizeof(int)}, {h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long)}});
+  const bool lp = mode == 3;
+  if (lp) h->d_dd_wrap.ensure(n + 1);
   k_nl_build<<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
       rows, nr, h->d_pos4.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,
-      h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, fuse ? r2p : nullptr, fuse ? 1 : 0, h->d_overflow.p, h->d_ddtot.p);
+      h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, fuse ? r2p : nullptr, fuse ? 1 : 0, lp ? 6 : 0, lp ? n : -1,
+      lp ? h->d_dd_wrap.p : nullptr, h->d_overflow.p, h->d_ddtot.p);
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
   if (fuse) {
     // modes 1 and 2: the list build wrote r^2 (mode 1) and the padding itself
@@ -516,10 +523,44 @@ void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
 #undef FQ
 }
 
+// list-mode sweep, lane-per-pair with LDS-DMA gathers (k_field_lp), one wave per row
+// row descriptors of this step for k_field_lp: the colour phases back to back (GS), or the own rows (Jacobi)
+void prepare_lp(polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  const bool gs = st.polar_gs || st.polar_gs_ranked;
+  const int tot = gs ? (h->color_off.empty() ? 0 : h->color_off.back()) : own_n(h);
+  h->d_lpdesc.ensure((size_t)tot + 1);
+  if (tot > 0)
+    k_lp_desc<<<nblk(tot, 256), 256, 0, h->stream>>>(tot, gs ? h->d_rows.p : own_rows(h), RowList{h->d_dd_cnt.p, h->dd_pitch},
+                                                     h->d_dd_wrap.p, h->d_lpdesc.p);
+}
+template <int EP>
+void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
+  if (nrows <= 0) return;
+  const polar_settings &st = h->ph.st;
+  const int qb = h->quad_block;
+  const int nt = h->lp_tiles;
+  const size_t lds = (size_t)(qb / 64) * nt * POLAR_LP_TILE;
+#define FL(D, NT) k_field_lp<EP, D, NT><<<nblk_xcd(nrows, qb / 64), qb, lds, h->stream>>>(                           \
+      nrows, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                                     \
+      st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
+  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  if (nt == 1) { if (expd) FL(0, 1); else FL(1, 1); }
+  else         { if (expd) FL(0, 2); else FL(1, 2); }
+#undef FL
+}
+
 // one sweep over the rows this handle owns (Jacobi, or the colour phases)
 void sweep_once(polar_handle *h, bool ap) {
   const polar_settings &st = h->ph.st;
   const bool gs = st.polar_gs || st.polar_gs_ranked;
+  if (!ap && h->sweep_kernel == 2) {
+    if (!gs) { launch_field_lp<EP_JACOBI>(h, own_n(h), h->d_lpdesc.p); return; }
+    const int ncol = (int)h->color_off.size() - 1;
+    for (int c = 0; c < ncol; c++)
+      launch_field_lp<EP_INPLACE>(h, h->color_off[c + 1] - h->color_off[c], h->d_lpdesc.p + h->color_off[c]);
+    return;
+  }
   if (!ap && h->sweep_kernel == 0) {
     if (!gs) { launch_field_quad<EP_JACOBI>(h, own_n(h), own_rows(h)); return; }
     const int ncol = (int)h->color_off.size() - 1;
@@ -595,6 +636,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
 
   if (!gs || !ap) {  // Jacobi (reference "polar_gs no") or colour-phase Gauss-Seidel over the dd list
     if (gs) { if (!h->colors_valid) { ensure_colors(h); map_color_rows(h); } out->ncolors = (int)h->color_off.size() - 1; }
+    if (!ap && h->sweep_kernel == 2) prepare_lp(h);
     // fixed-iteration GS takes no decision between sweeps: its end-of-sweep logic is applied in two
     // launches (all sweeps but the last, then the last one, whose sum |dmu|^2 is the one reported)
     const bool lazy = st.fixed_iteration && gs;
@@ -674,7 +716,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   h->step_eflag = eflag; h->step_vflag = vflag;
 
   h->d_f.ensure(3 * (size_t)nall); h->d_ef.ensure(3 * (size_t)n); h->d_F.ensure(3 * (size_t)n);
-  h->d_mu.ensure(3 * (size_t)n); h->d_rank.ensure(n); h->d_rec0.ensure(n); h->d_rec1.ensure(n);
+  h->d_mu.ensure(3 * (size_t)n); h->d_rank.ensure(n); h->d_rec0.ensure(n + 1); h->d_rec1.ensure(n + 1);  // + the dummy record
   h->d_ef_s.ensure(3 * (size_t)n); h->d_mol_s.ensure(n + 1);
   HIPCHECK(hipEventRecord(h->ev[0], s));
   HIPCHECK(hipMemsetAsync(h->d_f.p, 0, 3 * (size_t)nall * sizeof(double), s));
@@ -771,7 +813,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     }
   }
   if (!ap) { build_cells(h); h->d_pos4.ensure(n + 1); }  // cell order: perm / inv
-  k_pack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_x.p, h->d_q.p, h->d_alpha.p, h->d_mol.p, mu0,
+  k_pack<<<nblk(n + 1, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_x.p, h->d_q.p, h->d_alpha.p, h->d_mol.p, mu0,
                                       h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p);
   if (!ap) {
     build_lists(h);
@@ -901,6 +943,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
+  if (const char *e = getenv("POLAR_LP_TILES")) h->lp_tiles = atoi(e) == 1 ? 1 : 2;
   if (const char *e = getenv("POLAR_QUAD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->quad_block = v; }  // 0 quad (default), 1 lane-per-pair kernels
   if (const char *e = getenv("POLAR_FIELD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->field_block = v; }
   int n = polar_device_count();
@@ -951,7 +994,7 @@ int polar_destroy(polar_handle *h) {
     h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release(); h->d_T6.release();
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
-    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_nl_j.release(); h->d_dd_j.release();
+    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
     if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -1355,6 +1398,7 @@ int polar_step_begin(polar_handle *h, int eflag, int vflag) {
     phase_begin(h, eflag, vflag, nullptr);
     const polar_settings &st = h->ph.st;
     if (!st.zodid && (st.polar_gs || st.polar_gs_ranked) && !h->colors_valid) { ensure_colors(h); map_color_rows(h); }
+    if (!st.zodid && st.dd_cutoff > 0.0 && h->sweep_kernel == 2) prepare_lp(h);
     h->in_step = true;
     return POLAR_OK;
   });

@@ -210,6 +210,9 @@ __device__ __forceinline__ void pair_del(const Box &b, double xi, double yi, dou
   else min_image_rint(b, xi, yi, zi, xj, yj, zj, dx, dy, dz);
 }
 
+// chunked order of the lp sweep's index stream (see k_field_lp): entry e of a row -> slot
+__host__ __device__ __forceinline__ long long lp_slot(long long e) { return ((e >> 8) << 8) + ((e & 63) << 2) + ((e >> 6) & 3); }
+
 #define POLAR_NL_SAMEMOL 0x40000000
 #define POLAR_NL_MASK 0x3FFFFFFF
 

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
                                                           int *__restrict__ nl_cnt, int *__restrict__ dd_cnt,
                                                           int *__restrict__ nl_j, int *__restrict__ dd_j,
                                                           double *__restrict__ dd_r2, int pad_dd,
+                                                          int dd_shift, int dd_pad_index, int *__restrict__ dd_wrap,
                                                           int *__restrict__ overflow,
                                                           unsigned long long *__restrict__ dd_total) {
   const int lane = threadIdx.x & 63;
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   const int c0 = cc[0], c1 = cc[1], c2 = cc[2];
   const long long nl0 = (long long)i * nl_pitch, dd0 = (long long)i * dd_pitch;
   int ncount = 0, dcount = 0;
+  unsigned long long anywrap = 0ull;  // a dd pair of this row reaches across a periodic face (lp sweep: rows without skip the wrap)
   // Cells have an edge >= cutoff/2, so the stencil reaches +-2 cells (125 cells hold 42 % fewer
   // candidates than 27 cells of edge >= cutoff).  Cells are stored x-fastest, so the 5 cells of a
   // stencil row are ONE contiguous run of atoms (two runs when the row wraps around the box): the
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
           rsq = ex * ex + ey * ey + ez * ez;
           in_nl = rsq <= cutallsq;
           in_dd = ipol && __double2loint(rj.w) && (rsq < ddcutsq);
+          if (dd_wrap) anywrap |= __ballot(in_dd && (ex != ri.x - rj.x || ey != ri.y - rj.y || ez != ri.z - rj.z));
           same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;
         }
         const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
@@ -208,7 +211,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
         // skip such pairs (PS.cpp:342,454), so those kernels need no molecule gather
         if (in_nl && kn < nl_pitch) nl_j[nl0 + kn] = j | same;
         if (in_dd && kd < dd_pitch) {
-          dd_j[dd0 + kd] = j;
+          // lp sweep (dd_shift 6): byte offset of the 64-byte record, stored in the chunked order (lp_slot)
+          dd_j[dd0 + (dd_shift ? lp_slot(kd) : (long long)kd)] = j << dd_shift;
           if (dd_r2) dd_r2[dd0 + kd] = rsq;  // the sweep's per-pair stream value (same positions, same image rule)
         }
         ncount += __popcll(m_nl);
@@ -220,12 +224,13 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
     const int have = dcount < dd_pitch ? dcount : (int)dd_pitch;
     const int padded = (have + 63) & ~63;
     for (int k = have + lane; k < padded; k += 64) {
-      dd_j[dd0 + k] = i;
+      dd_j[dd0 + (dd_shift ? lp_slot(k) : (long long)k)] = (dd_pad_index >= 0 ? dd_pad_index : i) << dd_shift;
       if (dd_r2) dd_r2[dd0 + k] = 1e60;  // s3 ~ 1e-90, and d = 0 kills the s5 term: contributes nothing
     }
   }
   if (lane == 0) {
     nl_cnt[i] = ncount; dd_cnt[i] = dcount;
+    if (dd_wrap) dd_wrap[i] = anywrap != 0ull;
     if (ncount > nl_pitch || dcount > dd_pitch) atomicMax(overflow, ncount > dcount ? ncount : dcount);
     if (dcount) atomicAdd(dd_total + (blockIdx.x & 63) * 16, (unsigned long long)(dcount < dd_pitch ? dcount : (int)dd_pitch));
   }

@@ -14,6 +14,13 @@ __global__ void k_pack(int n, const int *__restrict__ perm, const double *__rest
                        AtomRec *__restrict__ r0, AtomRec *__restrict__ r1, int *__restrict__ mol_s,
                        double4 *__restrict__ pos4) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == n) {  // the DUMMY record the lp sweep pads its rows with: zero dipole (contributes nothing), zero
+    // polarizability, a finite position (that of atom 0: the sweep floors r^2, so a coincidence is harmless)
+    AtomRec d;
+    d.x = n > 0 ? x[0] : 0.0; d.y = n > 0 ? x[1] : 0.0; d.z = n > 0 ? x[2] : 0.0;
+    d.mx = d.my = d.mz = d.q = d.a = 0.0;
+    r0[n] = d; r1[n] = d;
+  }
   if (i >= n) return;
   const int o = perm ? perm[i] : i;
   AtomRec r;

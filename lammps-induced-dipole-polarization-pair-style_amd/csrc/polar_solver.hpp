@@ -269,6 +269,202 @@ __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__res
   if (lane == 0 && chg != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), chg);
 }
 
+// ------------------------------------------------------------------------------------------
+// List-mode sweep, lane-per-pair form with the gather done by LDS-DMA (`global_load_lds_dwordx4`).
+// A 64-pair trip needs the 64-byte records of 64 neighbours.  Four DMA instructions fetch them
+// quad-cooperatively (lane 4q+k of instruction r loads one 16-byte piece of the record of pair 4q+r:
+// one 64-byte access per quad) straight into a per-wave LDS tile -- no destination registers, no
+// ds_write, no shuffles; the index of pair 4q+r sits in lane 4q+r of the coalesced index load and
+// reaches its quad with one quad_perm DPP move.  Every lane then reads ITS pair's three pieces
+// {x,mu_x} {y,mu_y} {z,mu_z} with three ds_read_b128 and does the whole pair: 64 pairs per vector
+// instruction, no quad hand-round, no idle lane, r^2 from the lane's own displacement (so nothing but
+// the 4-byte index is streamed per pair: SURVEY 8(d)'s algorithmic stream).
+// LDS image of a trip (4 KB): block r (1 KB) = DMA instruction r, written lane-linearly (lane L -> 16-byte
+// slot L).  Lane 4q+k of instruction r fetches piece k^r, so the reader (pair 4q+r) finds piece p in slot
+// 4q + (p^r) of block r: the four lanes of a quad read four different slots of four different blocks and
+// the ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) cover all 16 slots of the 256-byte bank row --
+// conflict-free.  Two tiles per wave: the DMA of trip t+1 lands while trip t is computed.
+// index stream of this kernel: byte offsets (j << 6) into the record table; rows padded to whole trips with the
+// offset of the DUMMY record (index n: zero dipole, so its pairs contribute exactly nothing)
+template <int R>
+__device__ __forceinline__ void lp_gather(const char *srcc, int joff, unsigned piece, char *tile) {
+  // quad_perm broadcast of lane R's offset, folded into the add (v_add_u32_dpp): one vector instruction per gather
+  const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp(0, joff, R * 0x55, 0xF, 0xF, true) + piece;
+  const char *g = srcc + o_;  // scalar base + 32-bit lane offset
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)(tile + R * 1024), 16, 0, 0);
+}
+// 1/sqrt(x), x > 0 finite: v_rsq_f64 (about 2^-23 relative) and one third-order correction
+__device__ __forceinline__ double rsqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+// exp(x), -700 <= x <= 0 after the clamp: round-to-nearest of x*log2(e) through the 1.5*2^52 shift (the integer lands
+// in the low word), Cody-Waite remainder, Taylor polynomial of degree 12 (|r| <= ln2/2: truncation 1.7e-16),
+// and the power of two added straight into the exponent field (the result stays normal: n >= -1010).
+__device__ __forceinline__ double exp_neg_fast(double x, const ExpCoef &K) {
+  x = fmax(x, -700.0);
+  const double shift = 6755399441055744.0;
+  const double ns = fma(x, K.log2e, shift);
+  const double n = ns - shift;
+  double r = fma(-n, K.ln2hi, x);
+  r = fma(-n, K.ln2lo, r);
+  double p = K.c[12];
+#pragma unroll
+  for (int k = 11; k >= 0; k--) p = fma(p, r, K.c[k]);
+  return __hiloint2double(__double2hiint(p) + (__double2loint(ns) << 20), __double2loint(p));
+}
+template <int DAMP>
+__device__ __forceinline__ void tensor_scalars_lp(double r2, double pd, const ExpCoef &K, double &s3, double &s5) {
+  const double rinv = rsqrt_pos(r2);
+  const double rinv2 = rinv * rinv;
+  const double r3 = rinv * rinv2;
+  const double r5 = r3 * rinv2;
+  if (DAMP == 0) {  // exponential (Thole-like) damping, PS.cpp:1287-1297
+    const double ar = pd * (r2 * rinv);
+    const double e = exp_neg_fast(-ar, K);
+    const double ar2 = ar * ar;
+    const double p2 = fma(ar2, 0.5, 1.0 + ar);
+    const double p3 = fma(ar2 * ar, 1.0 / 6.0, p2);
+    s3 = fma(-e, p2, 1.0) * r3;
+    s5 = fma(-e, p3, 1.0) * (3.0 * r5);
+  } else {
+    s3 = r3;
+    s5 = 3.0 * r5;
+  }
+}
+#define POLAR_LP_TILE 4096
+// Index stream layout of this kernel ("chunked"): a row's entries are stored in chunks of 4 trips (256 entries);
+// entry `e` of the row (trip e>>6, lane e&63) lives at  (e>>8)*256 + (e&63)*4 + ((e>>6)&3), so ONE 16-byte load
+// per lane brings a lane's indices of four trips.  The first two chunks are requested when the row starts: a
+// typical row (8 trips) has its whole index stream in flight at once instead of one HBM latency per trip
+// (measured: with a 4-byte load per trip the loop took 110 us per sweep at 135k atoms with neither gathers nor
+// arithmetic in it).  The pitch of the dd rows is a multiple of 256 in this mode.
+// (lp_slot: polar_common.hpp)
+
+// one 64-pair trip: this lane's record out of tile `cur`, the DMA of the next trip (index jnext) into `nxt`, the pair arithmetic
+template <bool WRAP, int DAMP, int NT>
+__device__ __forceinline__ void lp_trip(const char *rd0, const char *rd1, const char *rd2, int cur, int nxt, bool more,
+                                        const char *srcc, int jnext, unsigned g0, unsigned g1, unsigned g2, unsigned g3,
+                                        char *tile0, const AtomRec &ri, double px, double py, double pz, const Box &box,
+                                        double pd, const ExpCoef &K, double &ax, double &ay, double &az, int ablate) {
+  // the compiler waits vmcnt(0) here: the DMA of this trip (issued one trip ago)
+  const double2 A = *reinterpret_cast<const double2 *>(rd0 + cur);
+  const double2 B = *reinterpret_cast<const double2 *>(rd1 + cur);
+  const double2 C = *reinterpret_cast<const double2 *>(rd2 + cur);
+  if (more && !(ablate & 8)) {  // wave-uniform
+    if (NT == 1) __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads above are done before the tile is rewritten
+    char *nt = tile0 + nxt;
+    const int jg = (ablate & 4) ? 0 : jnext;  // lab: every gather hits record 0
+    lp_gather<0>(srcc, jg, g0, nt); lp_gather<1>(srcc, jg, g1, nt);
+    lp_gather<2>(srcc, jg, g2, nt); lp_gather<3>(srcc, jg, g3, nt);
+  }
+  if (ablate & 16) { ax += A.x + B.y + C.x; return; }  // lab: no pair arithmetic
+  double dx = ri.x - A.x, dy = ri.y - B.x, dz = ri.z - C.x;
+  if (WRAP) {
+    dx = fma(-px, rint(dx * box.inv[0]), dx);
+    dy = fma(-py, rint(dy * box.inv[1]), dy);
+    dz = fma(-pz, rint(dz * box.inv[2]), dz);
+  }
+  const double r2 = fmax(fma(dx, dx, fma(dy, dy, dz * dz)), 1e-12);  // the dummy record may coincide with the row atom
+  double s3, s5;
+  tensor_scalars_lp<DAMP>(r2, pd, K, s3, s5);
+  const double dot = fma(A.y, dx, fma(B.y, dy, C.y * dz));
+  const double cc = s5 * dot;
+  ax = fma(cc, dx, fma(-s3, A.y, ax));
+  ay = fma(cc, dy, fma(-s3, B.y, ay));
+  az = fma(cc, dz, fma(-s3, C.y, az));
+}
+template <bool WRAP, int DAMP, int NT>
+__device__ __forceinline__ void lp_row(int T, const int4 *pc, const char *srcc, char *tile0, int lane, const AtomRec &ri,
+                                       const Box &box, double pd, const ExpCoef &K, double &ax, double &ay, double &az,
+                                       int ablate) {
+  const double px = box.periodic[0] ? box.prd[0] : 0.0, py = box.periodic[1] ? box.prd[1] : 0.0,
+               pz = box.periodic[2] ? box.prd[2] : 0.0;
+  const int k = lane & 3, q = lane >> 2;
+  const unsigned g0 = (unsigned)(k * 16), g1 = (unsigned)((k ^ 1) * 16), g2 = (unsigned)((k ^ 2) * 16), g3 = (unsigned)((k ^ 3) * 16);
+  // this lane is pair 4q+k of a trip: its record is in block k, piece p in slot 4q + (p^k)
+  const char *rd0 = tile0 + k * 1024 + (4 * q + k) * 16;
+  const char *rd1 = tile0 + k * 1024 + (4 * q + (k ^ 1)) * 16;
+  const char *rd2 = tile0 + k * 1024 + (4 * q + (k ^ 2)) * 16;
+  if (T <= 0) return;
+  const int C = (T + 3) >> 2;  // chunks of four trips; lane L's int4 of chunk c is pc[64 c]
+  int4 Ja = pc[0], Jb = make_int4(0, 0, 0, 0), Jc = Jb;
+  if (C > 1) Jb = pc[64];
+  lp_gather<0>(srcc, Ja.x, g0, tile0); lp_gather<1>(srcc, Ja.x, g1, tile0);
+  lp_gather<2>(srcc, Ja.x, g2, tile0); lp_gather<3>(srcc, Ja.x, g3, tile0);
+  const int other = NT == 1 ? 0 : POLAR_LP_TILE;
+#define POLAR_LP_TRIP(CUR, NXT, TT, JNEXT)                                                                              \
+  lp_trip<WRAP, DAMP, NT>(rd0, rd1, rd2, CUR, NXT, t0 + (TT) + 1 < T, srcc, JNEXT, g0, g1, g2, g3, tile0, ri, px, py, pz, \
+                          box, pd, K, ax, ay, az, ablate)
+  for (int c = 0; c < C; c++) {
+    const int t0 = 4 * c;
+    if (c + 2 < C) Jc = pc[64 * (c + 2)];  // rows longer than 8 trips: two chunks ahead
+    POLAR_LP_TRIP(0, other, 0, Ja.y);
+    if (t0 + 1 >= T) break;
+    POLAR_LP_TRIP(other, 0, 1, Ja.z);
+    if (t0 + 2 >= T) break;
+    POLAR_LP_TRIP(0, other, 2, Ja.w);
+    if (t0 + 3 >= T) break;
+    POLAR_LP_TRIP(other, 0, 3, Jb.x);
+    Ja = Jb; Jb = Jc;
+  }
+#undef POLAR_LP_TRIP
+}
+// row descriptors of a step: {row atom (s index), trips | wrap flag << 30}; one coalesced 8-byte load tells a wave
+// everything it needs to start its index stream, its record fetch and its field fetch at once
+__global__ void k_lp_desc(int nrows, const int *__restrict__ rows, RowList ddl, const int *__restrict__ dd_wrap,
+                          int2 *__restrict__ desc) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int i = rows ? rows[r] : r;
+  long long c = ddl.cnt[i];
+  if (c > ddl.pitch) c = ddl.pitch;
+  desc[r] = make_int2(i, (int)((c + 63) >> 6) | (dd_wrap[i] ? 0x40000000 : 0));
+}
+template <int EP, int DAMP, int NT>
+__global__ __launch_bounds__(1024) void k_field_lp(int nrows, const int2 *__restrict__ desc, AtomRec *recA,
+                                                   AtomRec *recB, Box box, long long pitch,
+                                                   const int *__restrict__ dd_j, double pd, ExpCoef K,
+                                                   const double *__restrict__ ef, const Scal *scal,
+                                                   double *__restrict__ slots, int ablate) {
+  extern __shared__ __attribute__((aligned(16))) char lp_lds[];
+  if (scal->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rpb = blockDim.x >> 6;
+  const int lb = xcd_block(blockIdx.x, (nrows + rpb - 1) / rpb);
+  if (lb < 0) return;
+  const int row = lb * rpb + wv;
+  if (row >= nrows) return;
+  const int2 de = desc[row];
+  const int i = __builtin_amdgcn_readfirstlane(de.x);
+  int T = __builtin_amdgcn_readfirstlane(de.y & 0xFFFF);
+  const int wrapped = __builtin_amdgcn_readfirstlane(de.y >> 30) | (ablate & 2);
+  const int cur = __builtin_amdgcn_readfirstlane(scal->cur);
+  const AtomRec *src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+  const AtomRec ri = uniform_rec(src[i]);  // the row atom: wave-uniform, parked in scalar registers
+  if (ablate & 1) T = 0;  // lab switches (POLAR_ABLATE): timing only, wrong numbers
+  const double efx = ef[3 * i], efy = ef[3 * i + 1], efz = ef[3 * i + 2];
+  const char *srcc = reinterpret_cast<const char *>(src);
+  char *tile0 = lp_lds + (size_t)wv * (NT * POLAR_LP_TILE);
+  const int4 *pc = reinterpret_cast<const int4 *>(dd_j + (size_t)i * pitch) + lane;
+  double ax = 0.0, ay = 0.0, az = 0.0;
+  // rows whose list holds no pair across a periodic face (flag written by k_nl_build) skip the minimum-image wrap
+  if (wrapped) lp_row<true, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  else lp_row<false, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  ax = wave_sum(ax); ay = wave_sum(ay); az = wave_sum(az);
+  if (lane == 0) {
+    const double mx = ri.a * (efx + ax), my = ri.a * (efy + ay), mz = ri.a * (efz + az);
+    const double ddx = mx - ri.mx, ddy = my - ri.my, ddz = mz - ri.mz;
+    dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz;
+    const double chg = ddx * ddx + ddy * ddy + ddz * ddz;
+    if (chg != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), chg);
+  }
+}
+
 // a6 for the list path: the damped tensor scalars of every listed pair, once per step
 // (the sparse, matrix-free-storage analog of build_dipole_field_matrix, PS.cpp:1273-1306).
 template <int DAMP>
