@@ -121,6 +121,13 @@ int polar_set_neighbors(polar_handle *h, int inum, const int *ilist, const int *
 int polar_set_neighbors_csr(polar_handle *h, int inum, const int *ilist, const int *numneigh,
                             const long long *firstneigh, const int *neigh);
 
+/* force->newton_pair (src/force.h; read by the reference at PS.cpp:293 `if (newton_pair || j < nlocal)` and by
+ * Pair::ev_tally, src/pair.cpp:854-950).  1 (default): half list with newton on -- every pair once, -F deposited on j,
+ * ghost forces returned for reverse_comm.  0: LAMMPS' newton-off half list -- a pair of a local atom with a ghost is
+ * listed by the local atom (both owners list it), ghosts receive no force, and such a pair tallies half its energy and
+ * virial (ev_tally's 0.5 per local atom).  Call before polar_set_neighbors*. */
+int polar_set_newton(polar_handle *h, int newton_pair);
+
 /* Device-side neighbor build for the LJ + Ewald-real loop, INSTEAD of polar_set_neighbors when
  * neighbor->ago == 0.  Replaces what Neighbor builds for this style
  * (src/neighbor.cpp, src/npair_half_bin_newton.cpp) with the rules of NPair::exclusion() and

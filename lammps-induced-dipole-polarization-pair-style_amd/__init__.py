@@ -109,6 +109,7 @@ EXPORTS = {
     "polar_step_sweep_end_host": (C.c_int, [C.c_void_p, C.c_double]),
     "polar_step_sweep_end_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "polar_set_list_style": (C.c_int, [C.c_void_p, C.c_int]),
+    "polar_set_newton": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_step_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "polar_step_sweep": (C.c_int, [C.c_void_p]),
     "polar_step_sweep_end": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -290,6 +291,7 @@ class PolarPair:
         return args
 
     def set_system(self, sysm):
+        self._ck(self.L.polar_set_newton(self.h, int(sysm.extra.get("newton_pair", 1))))
         self.set_box(sysm.boxlo, sysm.prd, tilt=getattr(sysm, "tilt", (0.0, 0.0, 0.0)),
                      triclinic=int(getattr(sysm, "triclinic", 0)))
         self.set_atoms(sysm.nlocal, sysm.nghost, sysm.x, sysm.q, sysm.alpha, sysm.type, sysm.molecule)

@@ -88,6 +88,7 @@ struct polar_handle {
   int nlocal = 0, nghost = 0;
   int row_lo = 0, row_hi = -1;   // rows this handle owns (multi-GPU row sharding); -1 = all
   int full_list = 0;             // LJ/coul list is a LAMMPS full list
+  int newton_pair = 1;           // force->newton_pair of the uploaded half list (polar_set_newton)
   int step_eflag = 0, step_vflag = 0;
   bool in_step = false;
   bool own_stream = true;
@@ -139,6 +140,7 @@ struct polar_handle {
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
   int quad_block = POLAR_BLOCK;  // workgroup size of k_field_quad / k_field_lp (POLAR_QUAD_BLOCK)
   int lp_tiles = 2;              // LDS tiles per wave of k_field_lp (POLAR_LP_TILES: 1 or 2)
+  int lp_depth = 0;              // >= 2: k_field_lpa with the gathers that many trips ahead (POLAR_LP_DEPTH: 0, 2, 3)
   int cache_r2 = -1;      // sweep stream (POLAR_CACHE_R2): 0 cached (s3,s5), 20 B/pair; 1 cached r^2, 12 B/pair; 2 nothing,
                           // 4 B/pair (r^2 rebuilt from the gathered positions); -1: 1 or 2 by size, see build_lists
   int stream_mode = 1;    // the choice in force for the current lists
@@ -545,6 +547,17 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
       nrows, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                                     \
       st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  if (h->lp_depth >= 2) {  // gathers kept lp_depth trips ahead (hand-counted waits), four tiles per wave
+    const int pb = std::min(qb, 256);
+    const size_t plds = (size_t)(pb / 64) * 4 * POLAR_LP_TILE;
+#define FA(D, DEPTH) k_field_lpa<EP, D, DEPTH><<<nblk_xcd(nrows, pb / 64), pb, plds, h->stream>>>(                  \
+      nrows, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                                     \
+      st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
+    if (h->lp_depth == 2) { if (expd) FA(0, 2); else FA(1, 2); }
+    else                  { if (expd) FA(0, 3); else FA(1, 3); }
+#undef FA
+    return;
+  }
   if (nt == 1) { if (expd) FL(0, 1); else FL(1, 1); }
   else         { if (expd) FL(0, 2); else FL(1, 2); }
 #undef FL
@@ -737,7 +750,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     hipStream_t s = h->lj_forked ? h->lj_stream : ms;  // shadows the main stream inside this block
     HIPCHECK(hipEventRecord(h->ev_lj0, s));
     LJCoulParams P = h->P;
-    P.newton_pair = 1; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list; P.ablate = h->ablate;
+    P.newton_pair = h->newton_pair; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list; P.ablate = h->ablate;
     h->d_xq.ensure(nall + 1);
     k_pack_lj<<<nblk(nall, 256), 256, 0, s>>>(nall, h->d_x.p, h->d_q.p, h->d_xq.p);
     const size_t ljlds = (size_t)(h->ntypes + 1) * (h->ntypes + 1) * 8 * sizeof(double);
@@ -761,7 +774,9 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
                                       h->d_sym_fill.p, h->d_sym_j.p);
       h->sym_valid = true;
     }
-    const int nrows_lj = symmetrise ? nall : h->inum;
+    // newton off: ghosts receive no force and tally nothing (PS.cpp:293, ev_tally's 0.5 per LOCAL atom), so only the
+    // local rows of the symmetrised list are walked: a local-ghost pair then counts 0.5, a local-local pair 0.5 + 0.5
+    const int nrows_lj = symmetrise ? (h->newton_pair ? nall : n) : h->inum;
     dim3 grid(nblk(nrows_lj, POLAR_ROWS_PER_BLOCK));
     if (symmetrise) P.full_list = 1;  // rows of the symmetrised list: force on the row atom only, tallies halved
     const int *il = symmetrise ? nullptr : h->d_ilist.p;
@@ -944,6 +959,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
   if (const char *e = getenv("POLAR_LP_TILES")) h->lp_tiles = atoi(e) == 1 ? 1 : 2;
+  if (const char *e = getenv("POLAR_LP_DEPTH")) { int v = atoi(e); h->lp_depth = (v == 2 || v == 3) ? v : 0; }
   if (const char *e = getenv("POLAR_QUAD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->quad_block = v; }  // 0 quad (default), 1 lane-per-pair kernels
   if (const char *e = getenv("POLAR_FIELD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->field_block = v; }
   int n = polar_device_count();
@@ -1097,17 +1113,24 @@ int polar_set_box(polar_handle *h, const double boxlo[3], const double prd[3], c
     // triclinic boxes: supported by the exact (all-pairs) kernels through the triclinic branch of
     // closest_image; the list mode's cell grid is orthogonal only
     const bool tri = triclinic != 0;
-    h->box.triclinic = tri ? 1 : 0;
-    h->box.xy = tri && tilt ? tilt[0] : 0.0;
-    h->box.xz = tri && tilt ? tilt[1] : 0.0;
-    h->box.yz = tri && tilt ? tilt[2] : 0.0;
+    Box nb{};
+    nb.triclinic = tri ? 1 : 0;
+    nb.xy = tri && tilt ? tilt[0] : 0.0;
+    nb.xz = tri && tilt ? tilt[1] : 0.0;
+    nb.yz = tri && tilt ? tilt[2] : 0.0;
+    bool same = h->box_set;
     for (int k = 0; k < 3; k++) {
       if (!(prd[k] > 0.0) || !std::isfinite(prd[k])) throw InputError("box lengths must be positive and finite");
-      h->box.prd[k] = prd[k]; h->box.half[k] = 0.5 * prd[k]; h->box.inv[k] = 1.0 / prd[k]; h->box.periodic[k] = periodic[k] ? 1 : 0;
+      nb.prd[k] = prd[k]; nb.half[k] = 0.5 * prd[k]; nb.inv[k] = 1.0 / prd[k]; nb.periodic[k] = periodic[k] ? 1 : 0;
+      same = same && h->boxlo[k] == boxlo[k] && h->box.prd[k] == nb.prd[k] && h->box.periodic[k] == nb.periodic[k];
       h->boxlo[k] = boxlo[k];
     }
+    same = same && h->box.triclinic == nb.triclinic && h->box.xy == nb.xy && h->box.xz == nb.xz && h->box.yz == nb.yz;
+    h->box = nb;
     h->box_set = true;
-    h->colors_valid = false;
+    // a shim hands the box over every step: the colour phases (host-side colouring, rank metric) are rebuilt only when
+    // the box really changed -- and on reneighbor steps, through polar_set_neighbors* / polar_build_neighbors
+    if (!same) h->colors_valid = false;
     return POLAR_OK;
   });
 }
@@ -1382,6 +1405,11 @@ int polar_set_global_count(polar_handle *h, long long natoms) {
   if (!h) return POLAR_ERR_STATE;
   if (natoms < 0 || natoms > 2147483647LL) return fail(h, POLAR_ERR_INPUT, "bad global atom count");
   h->global_count = natoms;
+  return POLAR_OK;
+}
+int polar_set_newton(polar_handle *h, int newton_pair) {
+  if (!h) return POLAR_ERR_STATE;
+  h->newton_pair = newton_pair ? 1 : 0;
   return POLAR_OK;
 }
 int polar_set_list_style(polar_handle *h, int full) {

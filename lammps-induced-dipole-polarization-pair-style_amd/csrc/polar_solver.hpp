@@ -334,6 +334,35 @@ __device__ __forceinline__ void tensor_scalars_lp(double r2, double pd, const Ex
     s5 = 3.0 * r5;
   }
 }
+// Row epilogue: the three field sums of the 64 lanes, the new dipole, sum (dmu)^2.  The three wave reductions are
+// folded into one butterfly: after the xor-1 step a lane keeps x (even) or y (odd), after the xor-2 step lanes
+// 4m+{0,1,2,3} hold {x, y, z, z}; four more steps finish all three at once (29 instead of 54 vector instructions).
+__device__ __forceinline__ void lp_finish(double ax, double ay, double az, int lane, const AtomRec *self, AtomRec *out,
+                                          const double *efi, double *slots) {
+  const bool odd = lane & 1, hi = lane & 2;
+  const double keep1 = odd ? ay : ax, give1 = odd ? ax : ay;
+  double v = keep1 + dpp_full<0xB1>(give1);  // quad_perm [1,0,3,2]: even lanes x(l)+x(l+1), odd lanes y(l-1)+y(l)
+  double w = az + dpp_full<0xB1>(az);        // z pairs
+  const double keep2 = hi ? w : v, give2 = hi ? v : w;
+  v = keep2 + dpp_full<0x4E>(give2);         // quad_perm [2,3,0,1]: lanes 4m+{0,1}: x, y of the quad; 4m+{2,3}: z of the quad
+  v += dpp_full<0x124>(v);                   // row_ror:4
+  v += dpp_full<0x128>(v);                   // row_ror:8: every lane holds its component's 16-lane row total
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  // lanes 0, 1, 2 hold E_x, E_y, E_z of the row: mu_new = alpha (E_static + E_ind), PS.cpp:1170-1180
+  double d2 = 0.0;
+  if (lane < 3) {
+    const double *r = reinterpret_cast<const double *>(self);
+    const double mu_old = r[2 * lane + 1], alpha = r[7];
+    const double mu_new = alpha * (efi[lane] + v);
+    reinterpret_cast<double *>(out)[2 * lane + 1] = mu_new;
+    const double d = mu_new - mu_old;
+    d2 = d * d;
+  }
+  d2 += dpp_full<0xB1>(d2);
+  d2 += dpp_full<0x4E>(d2);
+  if (lane == 0 && d2 != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), d2);
+}
 #define POLAR_LP_TILE 4096
 // Index stream layout of this kernel ("chunked"): a row's entries are stored in chunks of 4 trips (256 entries);
 // entry `e` of the row (trip e>>6, lane e&63) lives at  (e>>8)*256 + (e&63)*4 + ((e>>6)&3), so ONE 16-byte load
@@ -424,10 +453,157 @@ __global__ void k_lp_desc(int nrows, const int *__restrict__ rows, RowList ddl, 
   desc[r] = make_int2(i, (int)((c + 63) >> 6) | (dd_wrap[i] ? 0x40000000 : 0));
 }
 template <int EP, int DAMP, int NT>
-__global__ __launch_bounds__(1024) void k_field_lp(int nrows, const int2 *__restrict__ desc, AtomRec *recA,
-                                                   AtomRec *recB, Box box, long long pitch,
-                                                   const int *__restrict__ dd_j, double pd, ExpCoef K,
-                                                   const double *__restrict__ ef, const Scal *scal,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void k_field_lp(
+    int nrows, const int2 *__restrict__ desc, AtomRec *recA, AtomRec *recB, Box box, long long pitch,
+    const int *__restrict__ dd_j, double pd, ExpCoef K, const double *__restrict__ ef, const Scal *scal,
+    double *__restrict__ slots, int ablate) {
+  // <= 80 scalar registers: eight 256-thread workgroups per CU (MI355X_MICROARCH.md, residency by .sgpr_count)
+  extern __shared__ __attribute__((aligned(16))) char lp_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rpb = blockDim.x >> 6;
+  const int lb = xcd_block(blockIdx.x, (nrows + rpb - 1) / rpb);
+  if (lb < 0) return;
+  const int row = lb * rpb + wv;
+  if (row >= nrows) return;
+  // a row's start is a chain of dependent round trips (loop state, descriptor, row data + indices, first gathers):
+  // the first two are requested together
+  const int2 de = desc[row];
+  const int done = scal->done, curv = scal->cur;
+  if (done) return;
+  const int i = __builtin_amdgcn_readfirstlane(de.x);
+  int T = __builtin_amdgcn_readfirstlane(de.y & 0xFFFF);
+  const int wrapped = __builtin_amdgcn_readfirstlane(de.y >> 30) | (ablate & 2);
+  const int cur = __builtin_amdgcn_readfirstlane(curv);
+  const AtomRec *src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+  const int4 *pc = reinterpret_cast<const int4 *>(dd_j + (size_t)i * pitch) + lane;
+  AtomRec ri;  // the row atom's position: wave-uniform, parked in scalar registers
+  {
+    const double *r = reinterpret_cast<const double *>(src + i);
+    ri.x = wave_uniform(r[0]); ri.y = wave_uniform(r[2]); ri.z = wave_uniform(r[4]);
+  }
+  if (ablate & 1) T = 0;  // lab switches (POLAR_ABLATE): timing only, wrong numbers
+  const char *srcc = reinterpret_cast<const char *>(src);
+  char *tile0 = lp_lds + (size_t)wv * (NT * POLAR_LP_TILE);
+  double ax = 0.0, ay = 0.0, az = 0.0;
+  // rows whose list holds no pair across a periodic face (flag written by k_nl_build) skip the minimum-image wrap
+  if (wrapped) lp_row<true, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  else lp_row<false, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  lp_finish(ax, ay, az, lane, src + i, dst + i, ef + 3 * (size_t)i, slots);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same sweep with the gathers kept D trips ahead (software pipeline inside the wave).  With compiler-issued
+// LDS-DMA every read of a tile waits vmcnt(0), so a wave alternates "wait for its gathers" and "compute", and the
+// waves of a CU fall into step: the address unit and the vector ALU were each ~55-60 % busy, one after the other
+// (profiles/r02_lp3_*).  Here the DMA instructions are inline assembly (M0 = LDS address of the block, set in the
+// same statement) and the waits are counted by hand: before trip t is read, the 4 (D-1) gather instructions of the
+// trips t+1 .. t+D-1 may still be in flight (trip t+D is requested right after the read).  Four tiles per wave (16 KB): trip t lives in tile t & 3.
+// Compiler-issued loads in the loop (the index chunk of rows longer than 8 trips) only make the hand counts
+// conservative: vmcnt retires in order, and a count that ignores younger operations waits for more, never for less.
+__device__ __forceinline__ void lpa_dma(const char *srcc, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds_addr), "s"(srcc)
+               : "memory");
+}
+template <int R>
+__device__ __forceinline__ void lpa_gather(const char *srcc, int joff, unsigned piece, unsigned tile_addr) {
+  const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp(0, joff, R * 0x55, 0xF, 0xF, true) + piece;
+  lpa_dma(srcc, o_, tile_addr + R * 1024);
+}
+__device__ __forceinline__ void lpa_gather4(const char *srcc, int joff, unsigned g0, unsigned g1, unsigned g2, unsigned g3,
+                                            unsigned tile_addr) {
+  lpa_gather<0>(srcc, joff, g0, tile_addr); lpa_gather<1>(srcc, joff, g1, tile_addr);
+  lpa_gather<2>(srcc, joff, g2, tile_addr); lpa_gather<3>(srcc, joff, g3, tile_addr);
+}
+template <int N>
+__device__ __forceinline__ void lpa_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool WRAP, int DAMP, int D>
+__device__ __forceinline__ void lpa_row(int T, const int4 *pc, const char *srcc, char *tile0, int lane, const AtomRec &ri,
+                                        const Box &box, double pd, const ExpCoef &K, double &ax, double &ay, double &az) {
+  const double px = box.periodic[0] ? box.prd[0] : 0.0, py = box.periodic[1] ? box.prd[1] : 0.0,
+               pz = box.periodic[2] ? box.prd[2] : 0.0;
+  const int k = lane & 3, q = lane >> 2;
+  const unsigned g0 = (unsigned)(k * 16), g1 = (unsigned)((k ^ 1) * 16), g2 = (unsigned)((k ^ 2) * 16), g3 = (unsigned)((k ^ 3) * 16);
+  const char *rd0 = tile0 + k * 1024 + (4 * q + k) * 16;
+  const char *rd1 = tile0 + k * 1024 + (4 * q + (k ^ 1)) * 16;
+  const char *rd2 = tile0 + k * 1024 + (4 * q + (k ^ 2)) * 16;
+  if (T <= 0) return;
+  const unsigned ta = (unsigned)(size_t)(__attribute__((address_space(3))) char *)tile0;  // LDS byte address of tile 0
+  // trip TT of a chunk: tile TT; JAHEAD = index of trip t+D; the wait leaves the gathers of the trips ahead in flight
+#define POLAR_LPA_TRIP(TT, JAHEAD)                                                                       \
+  {                                                                                                      \
+    const int t = t0 + (TT);                                                                             \
+    const int ahead = Tn - 1 - t;  /* trips after this one (wave-uniform) */                             \
+    /* younger than the gathers of trip t: those of the trips t+1 .. t+D-1 (trip t+D is requested below) */ \
+    if (D > 2 && ahead >= 2) lpa_wait<8>();                                                              \
+    else if (ahead >= 1) lpa_wait<4>();                                                                  \
+    else lpa_wait<0>();                                                                                  \
+    const double2 A = *reinterpret_cast<const double2 *>(rd0 + (TT) * POLAR_LP_TILE);                    \
+    const double2 B = *reinterpret_cast<const double2 *>(rd1 + (TT) * POLAR_LP_TILE);                    \
+    const double2 Cc = *reinterpret_cast<const double2 *>(rd2 + (TT) * POLAR_LP_TILE);                   \
+    if (t + D < Tn) lpa_gather4(srcc, JAHEAD, g0, g1, g2, g3, ta + (((TT) + D) & 3) * POLAR_LP_TILE);    \
+    double dx = ri.x - A.x, dy = ri.y - B.x, dz = ri.z - Cc.x;                                           \
+    if (WRAP) {                                                                                          \
+      dx = fma(-px, rint(dx * box.inv[0]), dx);                                                          \
+      dy = fma(-py, rint(dy * box.inv[1]), dy);                                                          \
+      dz = fma(-pz, rint(dz * box.inv[2]), dz);                                                          \
+    }                                                                                                    \
+    const double r2 = fmax(fma(dx, dx, fma(dy, dy, dz * dz)), 1e-12);                                    \
+    double s3, s5;                                                                                       \
+    tensor_scalars_lp<DAMP>(r2, pd, K, s3, s5);                                                          \
+    const double dot = fma(A.y, dx, fma(B.y, dy, Cc.y * dz));                                            \
+    const double cc = s5 * dot;                                                                          \
+    ax = fma(cc, dx, fma(-s3, A.y, ax));                                                                 \
+    ay = fma(cc, dy, fma(-s3, B.y, ay));                                                                 \
+    az = fma(cc, dz, fma(-s3, Cc.y, az));                                                                \
+  }
+  // A row is walked in stretches of up to 12 trips (three index chunks, all requested before the stretch starts, so
+  // the loop below holds no compiler-issued load and nothing but the hand-counted waits); rows longer than 768 pairs
+  // restart the pipeline once per stretch.
+  for (int base = 0; base < T; base += 12) {
+    const int Tn = (T - base) < 12 ? (T - base) : 12;
+    const int4 *p = pc + 64 * (base >> 2);
+    int4 Ja = p[0], Jb = make_int4(0, 0, 0, 0), Jc = Jb;
+    if (Tn > 4) Jb = p[64];
+    if (Tn > 8) Jc = p[128];
+    lpa_gather4(srcc, Ja.x, g0, g1, g2, g3, ta);  // the gathers of trips 0 .. D-1
+    if (Tn > 1) lpa_gather4(srcc, Ja.y, g0, g1, g2, g3, ta + POLAR_LP_TILE);
+    if (D > 2 && Tn > 2) lpa_gather4(srcc, Ja.z, g0, g1, g2, g3, ta + 2 * POLAR_LP_TILE);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int t0 = 4 * c;
+      if (t0 >= Tn) break;
+      if (D == 2) {
+        POLAR_LPA_TRIP(0, Ja.z);
+        if (t0 + 1 >= Tn) break;
+        POLAR_LPA_TRIP(1, Ja.w);
+        if (t0 + 2 >= Tn) break;
+        POLAR_LPA_TRIP(2, Jb.x);
+        if (t0 + 3 >= Tn) break;
+        POLAR_LPA_TRIP(3, Jb.y);
+      } else {
+        POLAR_LPA_TRIP(0, Ja.w);
+        if (t0 + 1 >= Tn) break;
+        POLAR_LPA_TRIP(1, Jb.x);
+        if (t0 + 2 >= Tn) break;
+        POLAR_LPA_TRIP(2, Jb.y);
+        if (t0 + 3 >= Tn) break;
+        POLAR_LPA_TRIP(3, Jb.z);
+      }
+      Ja = Jb; Jb = Jc;
+    }
+  }
+#undef POLAR_LPA_TRIP
+}
+template <int EP, int DAMP, int D>
+__global__ __launch_bounds__(256) void k_field_lpa(int nrows, const int2 *__restrict__ desc, AtomRec *recA, AtomRec *recB,
+                                                   Box box, long long pitch, const int *__restrict__ dd_j, double pd,
+                                                   ExpCoef K, const double *__restrict__ ef, const Scal *scal,
                                                    double *__restrict__ slots, int ablate) {
   extern __shared__ __attribute__((aligned(16))) char lp_lds[];
   if (scal->done) return;
@@ -445,16 +621,15 @@ __global__ __launch_bounds__(1024) void k_field_lp(int nrows, const int2 *__rest
   const int cur = __builtin_amdgcn_readfirstlane(scal->cur);
   const AtomRec *src = (EP == EP_JACOBI && cur) ? recB : recA;
   AtomRec *dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
-  const AtomRec ri = uniform_rec(src[i]);  // the row atom: wave-uniform, parked in scalar registers
-  if (ablate & 1) T = 0;  // lab switches (POLAR_ABLATE): timing only, wrong numbers
+  const AtomRec ri = uniform_rec(src[i]);
+  if (ablate & 1) T = 0;
   const double efx = ef[3 * i], efy = ef[3 * i + 1], efz = ef[3 * i + 2];
   const char *srcc = reinterpret_cast<const char *>(src);
-  char *tile0 = lp_lds + (size_t)wv * (NT * POLAR_LP_TILE);
+  char *tile0 = lp_lds + (size_t)wv * (4 * POLAR_LP_TILE);
   const int4 *pc = reinterpret_cast<const int4 *>(dd_j + (size_t)i * pitch) + lane;
   double ax = 0.0, ay = 0.0, az = 0.0;
-  // rows whose list holds no pair across a periodic face (flag written by k_nl_build) skip the minimum-image wrap
-  if (wrapped) lp_row<true, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
-  else lp_row<false, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  if (wrapped) lpa_row<true, DAMP, D>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az);
+  else lpa_row<false, DAMP, D>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az);
   ax = wave_sum(ax); ay = wave_sum(ay); az = wave_sum(az);
   if (lane == 0) {
     const double mx = ri.a * (efx + ax), my = ri.a * (efy + ay), mz = ri.a * (efz + az);

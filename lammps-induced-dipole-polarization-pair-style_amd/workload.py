@@ -147,13 +147,16 @@ def build_ghosts(x, boxlo, prd, cutghost):
 
 
 def build_half_list(x_all, owner, shift, nlocal, cutneigh, molecule=None, special=None,
-                    exclude_intra=False, rows=None, full=False):
+                    exclude_intra=False, rows=None, full=False, newton=True):
     """Half neighbor list with newton on: every (atom, image) pair within ``cutneigh``
     is stored exactly once, in the list of a LOCAL atom i; j may be a ghost index.
     Special pairs keep their 2-bit code in bits 30-31 (kspace styles keep them in the
     list, reference: src/neighbor.cpp special_flag=2 with a KSpace style).
     ``rows``: optional subset of local atoms that own lists (multi-GPU shards).
-    ``full``: LAMMPS *full* list instead (every pair in the rows of both atoms; newton off)."""
+    ``full``: LAMMPS *full* list instead (every pair in the rows of both atoms; newton off).
+    ``newton=False``: LAMMPS' newton-off HALF list (src/npair_half_bin_newtoff.cpp): a pair is stored by the atom with
+    the lower index, ghosts included -- so a local atom lists every ghost partner, and a pair across a periodic face
+    appears twice (once per local atom, each with the image of the other)."""
     from scipy.spatial import cKDTree
 
     tree = cKDTree(x_all)
@@ -174,6 +177,8 @@ def build_half_list(x_all, owner, shift, nlocal, cutneigh, molecule=None, specia
         lex = (sj[:, 0] > 0) | ((sj[:, 0] == 0) & (sj[:, 1] > 0)) | (
             (sj[:, 0] == 0) & (sj[:, 1] == 0) & (sj[:, 2] > 0))
         keep = np.where(is_local, j > i_rep, (oj > i_rep) | ((oj == i_rep) & lex))
+        if not newton:
+            keep = j > i_rep
         if full:
             keep = j != i_rep
         if exclude_intra and molecule is not None:
@@ -375,7 +380,7 @@ class PolarSystem:
 
 def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings, g_ewald,
                 bonds=None, exclude_intra=False, skin=2.0, ncoultablebits=12, name="",
-                special_lj=(1.0, 0.0, 0.0, 0.0), special_coul=(1.0, 0.0, 0.0, 0.0), rows=None, full=False):
+                special_lj=(1.0, 0.0, 0.0, 0.0), special_coul=(1.0, 0.0, 0.0, 0.0), rows=None, full=False, newton=True):
     """Assemble ghosts, the half list, LJ tables and Coulomb tables for one frame."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     n = len(x)
@@ -386,7 +391,7 @@ def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings,
     special = build_special(n, bonds) if bonds is not None and len(bonds) else None
     ilist, numneigh, first, neigh = build_half_list(
         x_all, owner, shift, n, cutneigh, molecule=np.asarray(mol), special=special,
-        exclude_intra=exclude_intra, rows=rows, full=full)
+        exclude_intra=exclude_intra, rows=rows, full=full, newton=newton)
     coul = init_coul_tables(settings.cut_coul, g_ewald, QQR2E_REAL, ncoultablebits) if ncoultablebits else dict(
         nbits=0, mask=0, shift=0, tabinnersq=0.0, tables=np.zeros((8, 1)))
     g = lambda a, dt: np.ascontiguousarray(np.asarray(a)[owner], dtype=dt)
@@ -398,7 +403,7 @@ def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings,
         special_lj=np.asarray(special_lj, dtype=np.float64), special_coul=np.asarray(special_coul, dtype=np.float64),
         ilist=ilist, numneigh=numneigh, firstneigh=first, neigh=neigh, settings=settings, owner=owner, name=name,
         extra={"coeff_rows": [list(map(str, r)) for r in coeff_rows], "special": special, "cutneigh": cutneigh,
-               "exclude_intra": bool(exclude_intra)})
+               "exclude_intra": bool(exclude_intra), "newton_pair": int(bool(newton))})
 
 
 def compact_shard(s, own, halo):
@@ -597,7 +602,7 @@ def parse_pair_style_args(args, base=None):
     return st
 
 
-def load_fixture(path, extra_args=(), g_ewald=None, ncoultablebits=12):
+def load_fixture(path, extra_args=(), g_ewald=None, ncoultablebits=12, newton=True):
     """tests/golden/<case>.npz -> (PolarSystem, meta dict)."""
     import json
 
@@ -609,7 +614,7 @@ def load_fixture(path, extra_args=(), g_ewald=None, ncoultablebits=12):
     g = meta["known"]["g_ewald"] if g_ewald is None else g_ewald
     sysm = make_system(z["x"], z["q"], z["alpha"], z["type"], z["molecule"], z["boxlo"], z["prd"],
                        meta["ntypes"], rows, st, g, bonds=z["bonds"], exclude_intra=meta["exclude_intra"],
-                       ncoultablebits=ncoultablebits, name=meta["name"])
+                       ncoultablebits=ncoultablebits, name=meta["name"], newton=newton)
     return sysm, meta
 
 

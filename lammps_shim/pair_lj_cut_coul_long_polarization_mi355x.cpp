@@ -88,6 +88,7 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
   check(polar_set_atoms(h,atom->nlocal,atom->nghost,&atom->x[0][0],atom->q,atom->static_polarizability,
                         atom->type,(const int *) atom->molecule));
   if (neighbor->ago == 0) {
+    check(polar_set_newton(h,force->newton_pair));       // PS.cpp:293 and the ev_tally weights read force->newton_pair
     if (device_neigh)
       check(polar_build_neighbors(h,&neighbor->cutneighsq[0][0],(const int *) atom->tag,
                                   atom->molecular ? &atom->nspecial[0][0] : NULL,

@@ -107,7 +107,7 @@ def make_struct(sys, settings=None):
     s.cut_coul, s.g_ewald, s.qqrd2e = st.cut_coul, sys.g_ewald, sys.qqrd2e
     s.special_lj[:] = list(sys.special_lj)
     s.special_coul[:] = list(sys.special_coul)
-    s.newton_pair = 1
+    s.newton_pair = int(getattr(sys, "extra", {}).get("newton_pair", 1))
     s.ncoultablebits = sys.coul["nbits"]
     s.ncoulmask, s.ncoulshiftbits = sys.coul["mask"], sys.coul["shift"]
     s.tabinnersq = sys.coul["tabinnersq"]

@@ -35,10 +35,14 @@ VARIANTS = {
     # per-atom tallies: eflag 3 = global + atom; vflag 6 = fdotr + atom, 5 = pairwise + atom
     "peratom": (["use_previous", "no"], [], 3, 6, 1),
     "peratom_vpair": (["use_previous", "no"], [], 3, 5, 1),
+    # force->newton_pair = 0 with LAMMPS' newton-off half list (variant names starting with "newtoff"):
+    # Integrate::ev_set picks the pairwise virial (vflag 1) when newton is off
+    "newtoff": (["use_previous", "no"], [], 1, 1, 1),
+    "newtoff_peratom": (["use_previous", "no"], [], 3, 5, 1),
 }
 PLAN = {
-    "mof5_h2": list(VARIANTS),
-    "bulk_h2": ["ranked", "gs", "zodid", "notable", "peratom"],
+    "mof5_h2": [v for v in VARIANTS if v != "newtoff_peratom"],
+    "bulk_h2": ["ranked", "gs", "zodid", "notable", "peratom", "newtoff", "newtoff_peratom"],
     "mof5_methane": ["ranked"],
     "sifsix_co2": ["ranked", "nodamp_fallback30"],
 }
@@ -56,14 +60,15 @@ def main():
                 continue
             extra, modify, eflag, vflag, ncalls = VARIANTS[var]
             nbits = 0 if "table" in modify else 12
-            s, _ = wl.load_fixture(os.path.join(GOLD, case + ".npz"), extra_args=extra, ncoultablebits=nbits)
+            newton = not var.startswith("newtoff")
+            s, _ = wl.load_fixture(os.path.join(GOLD, case + ".npz"), extra_args=extra, ncoultablebits=nbits, newton=newton)
             ref = ref_runner.run(s, list(meta["pair_style_args"]) + extra, rows, modify_args=modify,
                                  eflag=eflag, vflag=vflag, ncalls=ncalls)
             assert ref["rc"] == 0, ref["message"]
             f_fold = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
             info = dict(case=case, variant=var, extra_args=extra, modify_args=modify, eflag=eflag, vflag=vflag,
                         ncalls=ncalls, warnings=int(ref["warnings"]), message=ref["message"],
-                        ncoultablebits=nbits)
+                        ncoultablebits=nbits, newton=int(newton))
             peratom = {}
             if ref["eatom"] is not None:  # ghost tallies go to the owner (Comm::reverse_comm_pair role)
                 peratom["eatom"] = oracle.fold_ghost_forces(ref["eatom"], s.owner, s.nlocal)

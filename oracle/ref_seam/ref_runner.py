@@ -21,7 +21,7 @@ class SeamInput(C.Structure):
                 ("inum", C.c_int), ("ilist", ip), ("numneigh", ip), ("firstneigh", llp), ("neigh", ip),
                 ("nstyle", C.c_int), ("style_args", cpp), ("ncoeff", C.c_int), ("coeff_rows", cpp),
                 ("nmodify", C.c_int), ("modify_args", cpp),
-                ("eflag", C.c_int), ("vflag", C.c_int), ("ncalls", C.c_int)]
+                ("eflag", C.c_int), ("vflag", C.c_int), ("ncalls", C.c_int), ("newton_off", C.c_int)]
 
 
 class SeamOutput(C.Structure):
@@ -36,7 +36,8 @@ def available():
 
 
 def build():
-    if not os.path.exists(_SO):
+    src = os.path.join(_HERE, "seam_harness.cpp")
+    if not os.path.exists(_SO) or os.path.getmtime(src) > os.path.getmtime(_SO):
         subprocess.check_call(["make", "-C", os.path.dirname(_HERE), "ref"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -71,6 +72,7 @@ def run(sysm, style_args, coeff_rows, modify_args=(), eflag=1, vflag=2, ncalls=1
     si.ncoeff, si.coeff_rows = len(coeff_rows), S(list(coeff_rows))
     si.nmodify, si.modify_args = len(modify_args), S(list(modify_args))
     si.eflag, si.vflag, si.ncalls = eflag, vflag, ncalls
+    si.newton_off = 0 if int(sysm.extra.get("newton_pair", 1)) else 1
     nall = sysm.nlocal + sysm.nghost
     f = np.zeros((nall, 3)); mu = np.zeros((sysm.nlocal, 3)) if mu0 is None else np.array(mu0, dtype=np.float64)
     ef = np.zeros((sysm.nlocal, 3))

@@ -31,4 +31,4 @@ def golden_refs(case=None):
 
 def load_ref_system(wl, info):
     return wl.load_fixture(os.path.join(GOLD, info["case"] + ".npz"), extra_args=info["extra_args"],
-                           ncoultablebits=info["ncoultablebits"])
+                           ncoultablebits=info["ncoultablebits"], newton=bool(info.get("newton", 1)))
