@@ -114,6 +114,15 @@ struct polar_handle {
   DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
   DBuf<double2> d_dd_s;
   DBuf<int2> d_lpdesc;  // row descriptors of k_field_lp
+  // cluster rows (sweep_kernel 3, k_field_cl): clusters sorted by colour; color_off then counts clusters
+  std::vector<int> h_cl;        // [ncl][4] member atoms (orig ids, -1 padded)
+  DBuf<int> d_cl_orig, d_cl_cnt, d_cl_wrap, d_cl_tw;
+  DBuf<int4> d_cl_s;            // members in this step's s space
+  long long cl_pitch = 0;
+  int ncl = 0;
+  double cluster_dist = 2.0;    // A: largest distance between two members (POLAR_CLUSTER_DIST)
+  int cluster_max = 4;          // members per cluster, 1..4 (POLAR_CLUSTER_MAX)
+  long long cl_slots = 0;       // entries of the union lists (gathered records per sweep)
   DBuf<double4> d_xq, d_pos4;
   long long nl_pairs = 0, dd_pairs = 0;
   long long nl_pitch = 0, dd_pitch = 0;   // pitched row lists (see polar_kernels.hpp RowList)
@@ -144,7 +153,8 @@ struct polar_handle {
   int cache_r2 = -1;      // sweep stream (POLAR_CACHE_R2): 0 cached (s3,s5), 20 B/pair; 1 cached r^2, 12 B/pair; 2 nothing,
                           // 4 B/pair (r^2 rebuilt from the gathered positions); -1: 1 or 2 by size, see build_lists
   int stream_mode = 1;    // the choice in force for the current lists
-  int sweep_kernel = 0;   // 0: k_field_quad (component-per-lane); 1: lane-per-pair kernels (POLAR_SWEEP_KERNEL)
+  int sweep_kernel = 2;   // list-mode sweep (POLAR_SWEEP_KERNEL): 2 k_field_lp (lane-per-pair, LDS-DMA gathers; default), 0 k_field_quad
+                          // (component-per-lane, round 1), 1 k_field (register-staged lane-per-pair), 3 k_field_cl (cluster rows, experimental)
   int ablate = 0;  // lab switches for k_field (POLAR_ABLATE), 0 in production
   Scal *h_scal = nullptr;  // pinned
   hipEvent_t ev[8] = {};
@@ -296,7 +306,9 @@ void build_lists(polar_handle *h) {
   }
   if (h->sweep_kernel == 2) h->dd_pitch = ((h->dd_pitch + 255) / 256) * 256;  // whole 4-trip chunks (k_field_lp)
   h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1);
-  h->d_nl_j.ensure((size_t)n * h->nl_pitch + 64); h->d_dd_j.ensure((size_t)n * h->dd_pitch + 64);
+  h->d_nl_j.ensure((size_t)n * h->nl_pitch + 64);
+  if (h->sweep_kernel != 3) h->d_dd_j.ensure((size_t)n * h->dd_pitch + 64);
+  else h->d_dd_j.ensure(64);
   // What the sweep streams per pair.  Measured (tools/exp_nocache.sh): while index + r^2 of all pairs
   // (12 B/pair) stay resident in the 256 MB Infinity Cache between sweeps the cached r^2 wins (36k atoms,
   // 160 MB: 99 vs 107 us/sweep); beyond that the stream comes from HBM every sweep and rebuilding r^2 from
@@ -304,6 +316,7 @@ void build_lists(polar_handle *h) {
   int mode = h->cache_r2;
   if (h->sweep_kernel == 1) mode = 0;
   if (h->sweep_kernel == 2) mode = 3;  // lane-per-pair sweep: only the index (as a byte offset) is streamed
+  if (h->sweep_kernel == 3) mode = 4;  // cluster sweep: the dd lists are the clusters' union lists (build_cluster_lists)
   if (mode < 0) {
     const double est_pairs = h->dd_pairs > 0 ? (double)h->dd_pairs : 0.35 * (double)own_n(h) * (double)h->dd_pitch;
     mode = (12.0 * est_pairs < 200.0e6) ? 1 : 2;
@@ -314,8 +327,8 @@ void build_lists(polar_handle *h) {
   else if (mode == 0) h->d_dd_s.ensure((size_t)n * h->dd_pitch + 64);
   double *r2p = r2c ? h->d_dd_r2.p : nullptr;
   double2 *sp = mode == 0 ? h->d_dd_s.p : nullptr;
-  const bool fuse = mode != 0 && !getenv("POLAR_NO_FUSE_R2");  // r^2 and padding written by k_nl_build (no k_dd_scalars pass)
-  const double cutallsq = cutall * cutall, ddsq = st.dd_cutoff * st.dd_cutoff;
+  const bool fuse = mode != 0 && mode != 4 && !getenv("POLAR_NO_FUSE_R2");  // r^2 and padding written by k_nl_build (no k_dd_scalars pass)
+  const double cutallsq = cutall * cutall, ddsq = mode == 4 ? -1.0 : st.dd_cutoff * st.dd_cutoff;
   const int nr = own_n(h);
   const int *rows = own_rows(h);
   zero_many(s, {{h->d_nl_cnt.p, (size_t)(n + 1) * sizeof(int)}, {h->d_dd_cnt.p, (size_t)(n + 1) * sizeof(int)},
@@ -327,8 +340,8 @@ void build_lists(polar_handle *h) {
       h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, fuse ? r2p : nullptr, fuse ? 1 : 0, lp ? 6 : 0, lp ? n : -1,
       lp ? h->d_dd_wrap.p : nullptr, h->d_overflow.p, h->d_ddtot.p);
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
-  if (fuse) {
-    // modes 1 and 2: the list build wrote r^2 (mode 1) and the padding itself
+  if (fuse || mode == 4) {
+    // modes 1 and 2: the list build wrote r^2 (mode 1) and the padding itself; mode 4: no per-atom dd rows at all
   } else if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
     k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, sp, r2p);
   else
@@ -336,6 +349,167 @@ void build_lists(polar_handle *h) {
   // overflow flag and dd total come back with the end-of-step read (no sync here)
   HIPCHECK(hipMemcpyAsync(h->h_flags, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+}
+
+// ---- clusters of rows for k_field_cl and their colouring ------------------------------------------
+// Clusters: greedy, in cell order -- a seed atom takes its nearest unassigned polarizable neighbours while every
+// member stays within cluster_dist of every other (adjacency lists hold the atoms within color_dist, so
+// cluster_dist <= color_dist).  Two clusters conflict when any two of their members are closer than color_dist;
+// DSATUR colours the cluster graph, phases are ordered by the mean rank metric, members by descending rank metric
+// (the in-cluster update is sequential: PS.cpp:1130-1143's "most coupled first", restricted to the cluster).
+void build_cluster_colors(polar_handle *h, const std::vector<double> &rank, const std::vector<std::vector<int>> &cells,
+                          const std::vector<std::vector<int>> &adj) {
+  const int n = h->nlocal;
+  const polar_settings &st = h->ph.st;
+  const bool gs = st.polar_gs || st.polar_gs_ranked;
+  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
+  const double dcl = std::min(h->cluster_dist, h->color_dist), dcl2 = dcl * dcl;
+  auto dist2 = [&](int i, int j) {
+    double rsq = 0;
+    for (int k = 0; k < 3; k++) {
+      double d = h->hx[3 * (size_t)i + k] - h->hx[3 * (size_t)j + k];
+      if (h->box.periodic[k]) d -= h->box.prd[k] * std::nearbyint(d / h->box.prd[k]);
+      rsq += d * d;
+    }
+    return rsq;
+  };
+  auto row_atom = [&](int i) { return i >= lo && i < hi && h->halpha[i] != 0.0; };
+  std::vector<int> cl_of((size_t)n, -1);
+  std::vector<int> mem;  // 4 per cluster
+  for (const auto &cell : cells)
+    for (int i : cell) {
+      if (!row_atom(i) || cl_of[i] >= 0) continue;
+      const int c = (int)(mem.size() / 4);
+      int m[4] = {i, -1, -1, -1}, cnt = 1;
+      cl_of[i] = c;
+      if (h->cluster_max > 1) {
+        std::vector<std::pair<double, int>> cand;
+        for (int j : adj[i])
+          if (row_atom(j) && cl_of[j] < 0) { const double d2 = dist2(i, j); if (d2 <= dcl2) cand.push_back({d2, j}); }
+        std::sort(cand.begin(), cand.end());
+        for (const auto &cj : cand) {
+          if (cnt >= h->cluster_max) break;
+          bool ok = true;
+          for (int k = 1; k < cnt; k++) ok = ok && dist2(m[k], cj.second) <= dcl2;
+          if (!ok) continue;
+          m[cnt++] = cj.second;
+          cl_of[cj.second] = c;
+        }
+      }
+      if (!rank.empty()) std::stable_sort(m, m + cnt, [&](int a, int b) { return rank[a] > rank[b]; });
+      mem.insert(mem.end(), m, m + 4);
+    }
+  const int ncl = (int)(mem.size() / 4);
+  // cluster graph
+  std::vector<std::vector<int>> cadj((size_t)ncl);
+  if (gs)
+    for (int c = 0; c < ncl; c++) {
+      for (int k = 0; k < 4; k++) {
+        const int a = mem[4 * (size_t)c + k];
+        if (a < 0) continue;
+        for (int b : adj[a]) { const int o = cl_of[b]; if (o >= 0 && o != c) cadj[c].push_back(o); }
+      }
+      std::sort(cadj[c].begin(), cadj[c].end());
+      cadj[c].erase(std::unique(cadj[c].begin(), cadj[c].end()), cadj[c].end());
+    }
+  std::vector<int> color((size_t)ncl, gs ? -1 : 0), satur((size_t)ncl, 0);
+  int ncolors = gs ? 0 : (ncl > 0 ? 1 : 0);
+  if (gs) {
+    std::vector<unsigned long long> seenmask((size_t)ncl, 0ull);
+    struct Key { int sat, deg, idx; };
+    auto lessk = [](const Key &a, const Key &b) {
+      if (a.sat != b.sat) return a.sat < b.sat;
+      if (a.deg != b.deg) return a.deg < b.deg;
+      return a.idx > b.idx;
+    };
+    std::vector<Key> heap;
+    heap.reserve((size_t)ncl * 2);
+    for (int c = 0; c < ncl; c++) heap.push_back(Key{0, (int)cadj[c].size(), c});
+    std::make_heap(heap.begin(), heap.end(), lessk);
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), lessk);
+      const Key kx = heap.back();
+      heap.pop_back();
+      const int c = kx.idx;
+      if (color[c] >= 0 || kx.sat != satur[c]) continue;
+      int col = 0;
+      while (col < 64 && ((seenmask[c] >> col) & 1ull)) col++;
+      if (col >= 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
+      color[c] = col;
+      ncolors = std::max(ncolors, col + 1);
+      for (int o : cadj[c]) {
+        if (color[o] >= 0) continue;
+        if (!((seenmask[o] >> col) & 1ull)) {
+          seenmask[o] |= 1ull << col;
+          satur[o]++;
+          heap.push_back(Key{satur[o], (int)cadj[o].size(), o});
+          std::push_heap(heap.begin(), heap.end(), lessk);
+        }
+      }
+    }
+    // balance the phases: DSATUR leaves classes as uneven as 3k / 9k / 6k / 25k clusters, and a phase with few
+    // clusters cannot fill the GPU.  A cluster of the heaviest class moves to the lightest class none of its
+    // neighbours uses, while that narrows the spread (weights = rows per cluster).
+    if (getenv("POLAR_COLOR_BALANCE")) {  // measured: no gain (135k atoms: 246 vs 232 us per sweep), off by default
+      std::vector<long long> wsum((size_t)ncolors, 0);
+      std::vector<int> wcl((size_t)ncl, 0);
+      for (int c = 0; c < ncl; c++) {
+        for (int k = 0; k < 4; k++) wcl[c] += mem[4 * (size_t)c + k] >= 0;
+        wsum[color[c]] += wcl[c];
+      }
+      for (int pass = 0; pass < 8; pass++) {
+        long long moved = 0;
+        for (int c = 0; c < ncl; c++) {
+          const int from = color[c];
+          unsigned long long used = 0ull;
+          for (int o : cadj[c]) used |= 1ull << color[o];
+          int best = -1;
+          for (int k = 0; k < ncolors; k++)
+            if (k != from && !((used >> k) & 1ull) && wsum[k] + wcl[c] < wsum[from] && (best < 0 || wsum[k] < wsum[best])) best = k;
+          if (best >= 0) { wsum[from] -= wcl[c]; wsum[best] += wcl[c]; color[c] = best; moved++; }
+        }
+        if (!moved) break;
+      }
+    }
+    // phase order: colours by descending mean rank metric (ranked flavour) or by descending size
+    std::vector<double> key((size_t)ncolors, 0.0);
+    std::vector<int> cnt((size_t)ncolors, 0), ord((size_t)ncolors), relabel((size_t)ncolors);
+    for (int c = 0; c < ncl; c++)
+      for (int k = 0; k < 4; k++) {
+        const int a = mem[4 * (size_t)c + k];
+        if (a < 0) continue;
+        cnt[color[c]]++;
+        key[color[c]] += rank.empty() ? 1.0 : rank[a];
+      }
+    if (!rank.empty())
+      for (int c = 0; c < ncolors; c++) key[c] /= std::max(cnt[c], 1);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] > key[b]; });
+    for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
+    for (int c = 0; c < ncl; c++) color[c] = relabel[color[c]];
+  }
+  // clusters sorted by colour (cell order inside a colour, i.e. the order they were formed in)
+  h->color_off.assign((size_t)ncolors + 1, 0);
+  for (int c = 0; c < ncl; c++) h->color_off[color[c] + 1]++;
+  for (int c = 0; c < ncolors; c++) h->color_off[c + 1] += h->color_off[c];
+  std::vector<int> fill(h->color_off.begin(), h->color_off.end() - 1);
+  h->h_cl.assign((size_t)ncl * 4, -1);
+  long long natoms = 0;
+  for (int c = 0; c < ncl; c++) {
+    const int slot = fill[color[c]]++;
+    for (int k = 0; k < 4; k++) { h->h_cl[4 * (size_t)slot + k] = mem[4 * (size_t)c + k]; natoms += mem[4 * (size_t)c + k] >= 0; }
+  }
+  h->ncl = ncl;
+  h->d_cl_orig.ensure((size_t)ncl * 4 + 4);
+  h->d_cl_s.ensure((size_t)ncl + 1);
+  if (ncl > 0) HIPCHECK(hipMemcpy(h->d_cl_orig.p, h->h_cl.data(), (size_t)ncl * 4 * sizeof(int), hipMemcpyHostToDevice));
+  if (getenv("POLAR_DEBUG")) {
+    fprintf(stderr, "[polar] %d clusters of %lld rows (%.2f per cluster, dist %.2f), %d colour phases:", ncl, natoms,
+            ncl ? (double)natoms / ncl : 0.0, dcl, ncolors);
+    for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
+    fprintf(stderr, "\n");
+  }
+  h->colors_valid = true;
 }
 
 // ---- host-side greedy distance colouring for the colour-phase Gauss-Seidel (cutoff mode) ----
@@ -396,6 +570,7 @@ void build_colors(polar_handle *h, const std::vector<double> &rank) {
           }
         }
   }
+  if (h->sweep_kernel == 3) { build_cluster_colors(h, rank, cells, adj); return; }
   // 2. DSATUR (Brelaz): always colour the vertex that sees the most distinct colours; ties by degree,
   //    then by index (deterministic: every rank of a multi-GPU run derives the same colouring).
   //    One colour fewer, and better balanced, than first-fit on the MOF test systems -> one launch
@@ -563,10 +738,35 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
 #undef FL
 }
 
+// cluster sweep (k_field_cl): one wave per cluster, clusters [first, first + ncl) of the colour-sorted table
+template <int EP>
+void launch_field_cl(polar_handle *h, int ncl, int first) {
+  if (ncl <= 0) return;
+  const polar_settings &st = h->ph.st;
+  const int qb = std::min(h->quad_block, 256);
+  const int nt = h->lp_tiles;
+  const size_t lds = (size_t)(qb / 64) * nt * POLAR_LP_TILE;
+#define FC(D, NT) k_field_cl<EP, D, NT><<<nblk_xcd(ncl, qb / 64), qb, lds, h->stream>>>(                              \
+      ncl, first, h->d_cl_s.p, h->d_cl_tw.p, h->d_rec0.p, h->d_rec1.p, h->box, h->cl_pitch, h->d_dd_j.p,              \
+      st.dd_cutoff * st.dd_cutoff, st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
+  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  if (nt == 1) { if (expd) FC(0, 1); else FC(1, 1); }
+  else         { if (expd) FC(0, 2); else FC(1, 2); }
+#undef FC
+}
+
 // one sweep over the rows this handle owns (Jacobi, or the colour phases)
 void sweep_once(polar_handle *h, bool ap) {
   const polar_settings &st = h->ph.st;
   const bool gs = st.polar_gs || st.polar_gs_ranked;
+  if (!ap && h->sweep_kernel == 3) {
+    const int ncol = (int)h->color_off.size() - 1;
+    for (int c = 0; c < ncol; c++) {
+      if (gs) launch_field_cl<EP_INPLACE>(h, h->color_off[c + 1] - h->color_off[c], h->color_off[c]);
+      else launch_field_cl<EP_JACOBI>(h, h->color_off[c + 1] - h->color_off[c], h->color_off[c]);
+    }
+    return;
+  }
   if (!ap && h->sweep_kernel == 2) {
     if (!gs) { launch_field_lp<EP_JACOBI>(h, own_n(h), h->d_lpdesc.p); return; }
     const int ncol = (int)h->color_off.size() - 1;
@@ -637,6 +837,25 @@ void map_color_rows(polar_handle *h) {
   if (tot > 0) k_map_rows<<<nblk(tot, 256), 256, 0, h->stream>>>(tot, h->d_inv.p, h->d_rows_orig.p, h->d_rows.p);
 }
 
+// cluster mode, per step: members -> s space, union lists, descriptors (needs the colours AND this step's cell order)
+void build_cluster_lists(polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  hipStream_t s = h->stream;
+  const int ncl = h->ncl;
+  if (h->cl_pitch == 0) h->cl_pitch = ((h->dd_pitch * 5 / 4 + 255) / 256) * 256;
+  h->d_cl_cnt.ensure(ncl + 1); h->d_cl_wrap.ensure(ncl + 1); h->d_cl_tw.ensure(ncl + 1);
+  h->d_dd_j.ensure((size_t)std::max(ncl, 1) * h->cl_pitch + 256);
+  if (ncl <= 0) return;
+  k_map_rows_pad<<<nblk(4 * (long long)ncl, 256), 256, 0, s>>>(4 * ncl, h->d_inv.p, h->d_cl_orig.p, reinterpret_cast<int *>(h->d_cl_s.p));
+  zero_many(s, {{h->d_overflow.p + 4, 4 * sizeof(int)}, {h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long)}});
+  k_cl_build<<<nblk(ncl, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
+      ClusterRows{h->d_cl_s.p, ncl}, h->d_pos4.p, h->box, h->grid, h->d_cell_first.p, st.dd_cutoff * st.dd_cutoff, h->cl_pitch,
+      h->d_cl_cnt.p, h->d_dd_j.p, h->nlocal, h->d_cl_wrap.p, h->d_overflow.p + 4, h->d_ddtot.p);
+  k_cl_desc<<<nblk(ncl, 256), 256, 0, s>>>(ncl, h->d_cl_cnt.p, h->cl_pitch, h->d_cl_wrap.p, h->d_cl_tw.p);
+  HIPCHECK(hipMemcpyAsync(h->h_flags + 4, h->d_overflow.p + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+}
+
 void solve(polar_handle *h, bool ap, polar_result *out) {
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
@@ -648,7 +867,9 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
   out->ncolors = 0;
 
   if (!gs || !ap) {  // Jacobi (reference "polar_gs no") or colour-phase Gauss-Seidel over the dd list
-    if (gs) { if (!h->colors_valid) { ensure_colors(h); map_color_rows(h); } out->ncolors = (int)h->color_off.size() - 1; }
+    const bool clm = !ap && h->sweep_kernel == 3;
+    if ((gs || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
+    if (gs) out->ncolors = (int)h->color_off.size() - 1;
     if (!ap && h->sweep_kernel == 2) prepare_lp(h);
     // fixed-iteration GS takes no decision between sweeps: its end-of-sweep logic is applied in two
     // launches (all sweeps but the last, then the last one, whose sum |dmu|^2 is the one reported)
@@ -832,7 +1053,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
                                       h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p);
   if (!ap) {
     build_lists(h);
-    if (h->colors_valid) map_color_rows(h);
+    if (h->colors_valid) { if (h->sweep_kernel == 3) build_cluster_lists(h); else map_color_rows(h); }
   }
   HIPCHECK(hipEventRecord(h->ev[1], s));
 
@@ -922,19 +1143,22 @@ int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, pol
   const bool ap = !(h->ph.st.dd_cutoff > 0.0);
   int rc = 0;
   for (int attempt = 0; attempt < 4; attempt++) {
-    h->h_flags[0] = 0;
+    h->h_flags[0] = 0; h->h_flags[4] = 0;
     phase_begin(h, eflag, vflag, mu_host);
     if (!h->ph.st.zodid) solve(h, ap, out);  // a6 + a7 (PS.cpp:389)
     const int nc = out->ncolors;
     rc = phase_finish(h, out);
     out->ncolors = nc;
-    if (ap || h->h_flags[0] == 0) break;
+    if (ap || (h->h_flags[0] == 0 && h->h_flags[4] == 0)) break;
     // a row did not fit its pitch: grow it to the reported need (+25 %) and redo the step
-    const long long need = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
-    h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
+    if (h->h_flags[0] != 0) {
+      const long long need = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
+      h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
+    }
+    if (h->h_flags[4] != 0) h->cl_pitch = (((long long)(1.25 * h->h_flags[4]) + 255) / 256) * 256;
     memset(out, 0, sizeof(*out));
   }
-  if (!ap && h->h_flags[0] != 0) throw std::runtime_error("neighbor list pitch overflow persists");
+  if (!ap && (h->h_flags[0] != 0 || h->h_flags[4] != 0)) throw std::runtime_error("neighbor list pitch overflow persists");
   return rc;
 }
 
@@ -959,6 +1183,8 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
   if (const char *e = getenv("POLAR_LP_TILES")) h->lp_tiles = atoi(e) == 1 ? 1 : 2;
+  if (const char *e = getenv("POLAR_CLUSTER_DIST")) h->cluster_dist = atof(e);
+  if (const char *e = getenv("POLAR_CLUSTER_MAX")) h->cluster_max = std::max(1, std::min(4, atoi(e)));
   if (const char *e = getenv("POLAR_LP_DEPTH")) { int v = atoi(e); h->lp_depth = (v == 2 || v == 3) ? v : 0; }
   if (const char *e = getenv("POLAR_QUAD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->quad_block = v; }  // 0 quad (default), 1 lane-per-pair kernels
   if (const char *e = getenv("POLAR_FIELD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->field_block = v; }
@@ -1010,7 +1236,7 @@ int polar_destroy(polar_handle *h) {
     h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release(); h->d_T6.release();
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
-    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_nl_j.release(); h->d_dd_j.release();
+    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
     if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -1027,7 +1253,7 @@ const char *polar_last_error(const polar_handle *h) { return h ? h->err.c_str() 
 const char *polar_last_warning(const polar_handle *h) { return h ? h->warn.c_str() : ""; }
 
 int polar_pair_settings(polar_handle *h, int narg, const char *const *arg) {
-  return guarded(h, [&]() { h->ph.settings(narg, arg); h->colors_valid = false; h->nl_pitch = h->dd_pitch = 0; return POLAR_OK; });
+  return guarded(h, [&]() { h->ph.settings(narg, arg); h->colors_valid = false; h->nl_pitch = h->dd_pitch = 0; h->cl_pitch = 0; return POLAR_OK; });
 }
 int polar_pair_coeff(polar_handle *h, int ntypes, int narg, const char *const *arg) {
   return guarded(h, [&]() { h->ph.coeff(ntypes, narg, arg); return POLAR_OK; });
@@ -1422,10 +1648,11 @@ int polar_step_begin(polar_handle *h, int eflag, int vflag) {
   return guarded(h, [&]() {
     HIPCHECK(hipSetDevice(h->device));
     if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not available in the stepwise (sharded) interface");
-    h->h_flags[0] = 0;
+    h->h_flags[0] = 0; h->h_flags[4] = 0;
     phase_begin(h, eflag, vflag, nullptr);
     const polar_settings &st = h->ph.st;
-    if (!st.zodid && (st.polar_gs || st.polar_gs_ranked) && !h->colors_valid) { ensure_colors(h); map_color_rows(h); }
+    const bool clm = st.dd_cutoff > 0.0 && h->sweep_kernel == 3;
+    if (!st.zodid && (st.polar_gs || st.polar_gs_ranked || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
     if (!st.zodid && st.dd_cutoff > 0.0 && h->sweep_kernel == 2) prepare_lp(h);
     h->in_step = true;
     return POLAR_OK;
@@ -1468,9 +1695,10 @@ int polar_step_finish(polar_handle *h, polar_result *out) {
     int rc = phase_finish(h, out);
     out->ncolors = (h->ph.st.polar_gs || h->ph.st.polar_gs_ranked) ? (int)h->color_off.size() - 1 : 0;
     h->in_step = false;
-    if (h->h_flags[0] != 0) {  // the driver must redo the step (all ranks see their own flag)
+    if (h->h_flags[0] != 0 || h->h_flags[4] != 0) {  // the driver must redo the step (all ranks see their own flag)
+      if (h->h_flags[4] != 0) h->cl_pitch = (((long long)(1.25 * h->h_flags[4]) + 255) / 256) * 256;
       const long long need = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
-      h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
+      if (h->h_flags[0] != 0) h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
       out->status = POLAR_RETRY_STEP;
       h->warn = "neighbor list pitch overflow: pitch enlarged, repeat the step";
       return POLAR_RETRY_STEP;

@@ -453,11 +453,10 @@ __global__ void k_lp_desc(int nrows, const int *__restrict__ rows, RowList ddl, 
   desc[r] = make_int2(i, (int)((c + 63) >> 6) | (dd_wrap[i] ? 0x40000000 : 0));
 }
 template <int EP, int DAMP, int NT>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void k_field_lp(
+__global__ __launch_bounds__(1024) void k_field_lp(
     int nrows, const int2 *__restrict__ desc, AtomRec *recA, AtomRec *recB, Box box, long long pitch,
     const int *__restrict__ dd_j, double pd, ExpCoef K, const double *__restrict__ ef, const Scal *scal,
     double *__restrict__ slots, int ablate) {
-  // <= 80 scalar registers: eight 256-thread workgroups per CU (MI355X_MICROARCH.md, residency by .sgpr_count)
   extern __shared__ __attribute__((aligned(16))) char lp_lds[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -491,6 +490,225 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void k_f
   if (wrapped) lp_row<true, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
   else lp_row<false, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
   lp_finish(ax, ay, az, lane, src + i, dst + i, ef + 3 * (size_t)i, slots);
+}
+
+// ------------------------------------------------------------------------------------------
+// Cluster sweep: one wave = one CLUSTER of up to four rows (polar_lists.hpp, k_cl_build) against the union of
+// their neighbours.  Per 64-neighbour trip the gather, the index stream and the LDS reads are paid once and the
+// pair arithmetic M times (a pair outside the dd cutoff of a member is switched off through its r^2), so the bytes
+// that go through the gather path per computed pair drop by M x (list efficiency).
+// The members of a cluster are closer than the colour distance, so they must not be updated Jacobi-style against
+// each other (colour-phase GS diverges for couplings closer than ~1.2 A): the list holds no member, the wave adds the
+// in-cluster fields itself and updates the members ONE AFTER THE OTHER with the newest dipoles -- exactly the
+// reference's sequential rule (PS.cpp:1158-1180) restricted to the cluster.  Across clusters of one colour the
+// phase is Jacobi-like as before (clusters of a colour are farther apart than the colour distance).
+template <int DAMP>
+__device__ __forceinline__ void cl_pair(double xm, double ym, double zm, const double2 &A, const double2 &B, const double2 &C,
+                                        bool wrap, double px, double py, double pz, const Box &box, double ddcutsq, double pd,
+                                        const ExpCoef &K, double &ax, double &ay, double &az) {
+  double dx = xm - A.x, dy = ym - B.x, dz = zm - C.x;
+  if (wrap) {
+    dx = fma(-px, rint(dx * box.inv[0]), dx);
+    dy = fma(-py, rint(dy * box.inv[1]), dy);
+    dz = fma(-pz, rint(dz * box.inv[2]), dz);
+  }
+  double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+  r2 = r2 < ddcutsq ? r2 : 1e30;  // outside this member's cutoff: s3 ~ 1e-45, s5 ~ 1e-75 -- below every ulp of the sums
+  r2 = fmax(r2, 1e-12);           // the dummy record may coincide with a member
+  double s3, s5;
+  tensor_scalars_lp<DAMP>(r2, pd, K, s3, s5);
+  const double dot = fma(A.y, dx, fma(B.y, dy, C.y * dz));
+  const double cc = s5 * dot;
+  ax = fma(cc, dx, fma(-s3, A.y, ax));
+  ay = fma(cc, dy, fma(-s3, B.y, ay));
+  az = fma(cc, dz, fma(-s3, C.y, az));
+}
+// the three wave sums of one member: lanes 0, 1, 2 (and every lane = its lane&3 class; class 3 = z) get x, y, z
+__device__ __forceinline__ double cl_reduce3(double ax, double ay, double az, int lane) {
+  const bool odd = lane & 1, hi = lane & 2;
+  const double keep1 = odd ? ay : ax, give1 = odd ? ax : ay;
+  double v = keep1 + dpp_full<0xB1>(give1);
+  double w = az + dpp_full<0xB1>(az);
+  const double keep2 = hi ? w : v, give2 = hi ? v : w;
+  v = keep2 + dpp_full<0x4E>(give2);
+  v += dpp_full<0x124>(v);
+  v += dpp_full<0x128>(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ double lane_value(double v, int k) {  // k compile-time
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+template <bool WRAP, int DAMP, int NT>
+__device__ __forceinline__ void cl_rows(int T, int M, const int4 *pc, const char *srcc, char *tile0, int lane,
+                                        const double (&xm)[4], const double (&ym)[4], const double (&zm)[4], const Box &box,
+                                        double ddcutsq, double pd, const ExpCoef &K, double (&ax)[4], double (&ay)[4],
+                                        double (&az)[4]) {
+  const double px = box.periodic[0] ? box.prd[0] : 0.0, py = box.periodic[1] ? box.prd[1] : 0.0,
+               pz = box.periodic[2] ? box.prd[2] : 0.0;
+  const int k = lane & 3, q = lane >> 2;
+  const unsigned g0 = (unsigned)(k * 16), g1 = (unsigned)((k ^ 1) * 16), g2 = (unsigned)((k ^ 2) * 16), g3 = (unsigned)((k ^ 3) * 16);
+  const char *rd0 = tile0 + k * 1024 + (4 * q + k) * 16;
+  const char *rd1 = tile0 + k * 1024 + (4 * q + (k ^ 1)) * 16;
+  const char *rd2 = tile0 + k * 1024 + (4 * q + (k ^ 2)) * 16;
+  if (T <= 0) return;
+  const int C = (T + 3) >> 2;
+  int4 Ja = pc[0], Jb = make_int4(0, 0, 0, 0), Jc = Jb;
+  if (C > 1) Jb = pc[64];
+  lp_gather<0>(srcc, Ja.x, g0, tile0); lp_gather<1>(srcc, Ja.x, g1, tile0);
+  lp_gather<2>(srcc, Ja.x, g2, tile0); lp_gather<3>(srcc, Ja.x, g3, tile0);
+  const int other = NT == 1 ? 0 : POLAR_LP_TILE;
+#define POLAR_CL_TRIP(CUR, NXT, TT, JNEXT)                                                                 \
+  {                                                                                                        \
+    const double2 A = *reinterpret_cast<const double2 *>(rd0 + (CUR));                                     \
+    const double2 B = *reinterpret_cast<const double2 *>(rd1 + (CUR));                                     \
+    const double2 Cc = *reinterpret_cast<const double2 *>(rd2 + (CUR));                                    \
+    if (t0 + (TT) + 1 < T) {                                                                               \
+      if (NT == 1) __builtin_amdgcn_s_waitcnt(0xc07f);                                                     \
+      char *nt_ = tile0 + (NXT);                                                                           \
+      lp_gather<0>(srcc, JNEXT, g0, nt_); lp_gather<1>(srcc, JNEXT, g1, nt_);                              \
+      lp_gather<2>(srcc, JNEXT, g2, nt_); lp_gather<3>(srcc, JNEXT, g3, nt_);                              \
+    }                                                                                                      \
+    cl_pair<DAMP>(xm[0], ym[0], zm[0], A, B, Cc, WRAP, px, py, pz, box, ddcutsq, pd, K, ax[0], ay[0], az[0]); \
+    if (M > 1) cl_pair<DAMP>(xm[1], ym[1], zm[1], A, B, Cc, WRAP, px, py, pz, box, ddcutsq, pd, K, ax[1], ay[1], az[1]); \
+    if (M > 2) cl_pair<DAMP>(xm[2], ym[2], zm[2], A, B, Cc, WRAP, px, py, pz, box, ddcutsq, pd, K, ax[2], ay[2], az[2]); \
+    if (M > 3) cl_pair<DAMP>(xm[3], ym[3], zm[3], A, B, Cc, WRAP, px, py, pz, box, ddcutsq, pd, K, ax[3], ay[3], az[3]); \
+  }
+  for (int c = 0; c < C; c++) {
+    const int t0 = 4 * c;
+    if (c + 2 < C) Jc = pc[64 * (c + 2)];
+    POLAR_CL_TRIP(0, other, 0, Ja.y);
+    if (t0 + 1 >= T) break;
+    POLAR_CL_TRIP(other, 0, 1, Ja.z);
+    if (t0 + 2 >= T) break;
+    POLAR_CL_TRIP(0, other, 2, Ja.w);
+    if (t0 + 3 >= T) break;
+    POLAR_CL_TRIP(other, 0, 3, Jb.x);
+    Ja = Jb; Jb = Jc;
+  }
+#undef POLAR_CL_TRIP
+}
+// descriptors of a step: members (s-space) come from the cluster table; {trips | wrap << 30}
+__global__ void k_cl_desc(int ncl, const int *__restrict__ cnt, long long pitch, const int *__restrict__ wrapf,
+                          int *__restrict__ tw) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncl) return;
+  long long n = cnt[c];
+  if (n > pitch) n = pitch;
+  tw[c] = (int)((n + 63) >> 6) | (wrapf[c] ? 0x40000000 : 0);
+}
+template <int EP, int DAMP, int NT>
+__global__ __launch_bounds__(256) void k_field_cl(int ncl, int first, const int4 *__restrict__ members,
+                                                  const int *__restrict__ tw, AtomRec *recA, AtomRec *recB, Box box,
+                                                  long long pitch, const int *__restrict__ dd_j, double ddcutsq,
+                                                  double pd, ExpCoef K, const double *__restrict__ ef, const Scal *scal,
+                                                  double *__restrict__ slots, int ablate) {
+  extern __shared__ __attribute__((aligned(16))) char lp_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rpb = blockDim.x >> 6;
+  const int lb = xcd_block(blockIdx.x, (ncl + rpb - 1) / rpb);
+  if (lb < 0) return;
+  const int r_ = lb * rpb + wv;
+  if (r_ >= ncl) return;
+  const int c = first + r_;  // cluster index: the list row and the member table entry
+  const int4 mem = members[c];
+  const int twv = tw[c];
+  const int done = scal->done, curv = scal->cur;
+  if (done) return;
+  const int mi[4] = {__builtin_amdgcn_readfirstlane(mem.x), __builtin_amdgcn_readfirstlane(mem.y),
+                     __builtin_amdgcn_readfirstlane(mem.z), __builtin_amdgcn_readfirstlane(mem.w)};
+  const int M = (mi[1] >= 0) + (mi[2] >= 0) + (mi[3] >= 0) + 1;  // members are packed to the front
+  int T = __builtin_amdgcn_readfirstlane(twv & 0xFFFF);
+  const int wrapped = __builtin_amdgcn_readfirstlane(twv >> 30) | (ablate & 2);
+  const int cur = __builtin_amdgcn_readfirstlane(curv);
+  const AtomRec *src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+  double xm[4], ym[4], zm[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const double *r = reinterpret_cast<const double *>(src + (mi[m] >= 0 ? mi[m] : mi[0]));
+    xm[m] = wave_uniform(r[0]); ym[m] = wave_uniform(r[2]); zm[m] = wave_uniform(r[4]);
+  }
+  if (ablate & 1) T = 0;
+  const char *srcc = reinterpret_cast<const char *>(src);
+  char *tile0 = lp_lds + (size_t)wv * (NT * POLAR_LP_TILE);
+  const int4 *pc = reinterpret_cast<const int4 *>(dd_j + (size_t)c * pitch) + lane;
+  double ax[4] = {0, 0, 0, 0}, ay[4] = {0, 0, 0, 0}, az[4] = {0, 0, 0, 0};
+  if (wrapped) cl_rows<true, DAMP, NT>(T, M, pc, srcc, tile0, lane, xm, ym, zm, box, ddcutsq, pd, K, ax, ay, az);
+  else cl_rows<false, DAMP, NT>(T, M, pc, srcc, tile0, lane, xm, ym, zm, box, ddcutsq, pd, K, ax, ay, az);
+  // ---- in-cluster part: external fields -> uniform values, then the members one after the other ----
+  const double px = box.periodic[0] ? box.prd[0] : 0.0, py = box.periodic[1] ? box.prd[1] : 0.0,
+               pz = box.periodic[2] ? box.prd[2] : 0.0;
+  double Ex[4], Ey[4], Ez[4], mux[4], muy[4], muz[4], al[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    Ex[m] = Ey[m] = Ez[m] = mux[m] = muy[m] = muz[m] = al[m] = 0.0;
+    if (m < M) {
+      const double v = cl_reduce3(ax[m], ay[m], az[m], lane);
+      const double *r = reinterpret_cast<const double *>(src + mi[m]);
+      const double *e = ef + 3 * (size_t)mi[m];
+      Ex[m] = e[0] + lane_value(v, 0); Ey[m] = e[1] + lane_value(v, 1); Ez[m] = e[2] + lane_value(v, 2);
+      mux[m] = r[1]; muy[m] = r[3]; muz[m] = r[5]; al[m] = r[7];
+    }
+  }
+  // pair tensors of the cluster (symmetric): p = (a,b), a < b
+  double s3p[6], s5p[6], dxp[6], dyp[6], dzp[6];
+  {
+    const int pa[6] = {0, 0, 1, 0, 1, 2}, pb[6] = {1, 2, 2, 3, 3, 3};
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+      s3p[p] = s5p[p] = dxp[p] = dyp[p] = dzp[p] = 0.0;
+      if (pb[p] < M) {
+        double dx = xm[pa[p]] - xm[pb[p]], dy = ym[pa[p]] - ym[pb[p]], dz = zm[pa[p]] - zm[pb[p]];
+        dx = fma(-px, rint(dx * box.inv[0]), dx);
+        dy = fma(-py, rint(dy * box.inv[1]), dy);
+        dz = fma(-pz, rint(dz * box.inv[2]), dz);
+        const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+        // the dipole-dipole cutoff applies inside a cluster too (members are ~2 A apart: always inside);
+        // coincident atoms follow the reference's r = 0 rule (PS.cpp:1285-1286: no coupling through DBL_MAX r3/r5 is
+        // NOT reproduced: such pairs are dropped here)
+        if (r2 < ddcutsq && r2 > 0.0) tensor_scalars_lp<DAMP>(r2, pd, K, s3p[p], s5p[p]);
+        dxp[p] = dx; dyp[p] = dy; dzp[p] = dz;
+      }
+    }
+  }
+  double nx[4], ny[4], nz[4];
+  double chg = 0.0;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    nx[m] = mux[m]; ny[m] = muy[m]; nz[m] = muz[m];
+  }
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    if (m < M) {
+      double ex = Ex[m], ey = Ey[m], ez = Ez[m];
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        if (o != m && o < M) {
+          const int a = o < m ? o : m, b = o < m ? m : o;
+          const int p = a == 0 ? (b == 1 ? 0 : (b == 2 ? 1 : 3)) : (a == 1 ? (b == 2 ? 2 : 4) : 5);
+          // Gauss-Seidel: members earlier in the cluster order already carry their new dipoles; Jacobi: all old
+          const double ox = (EP == EP_JACOBI || o > m) ? mux[o] : nx[o];
+          const double oy = (EP == EP_JACOBI || o > m) ? muy[o] : ny[o];
+          const double oz = (EP == EP_JACOBI || o > m) ? muz[o] : nz[o];
+          const double dot = ox * dxp[p] + oy * dyp[p] + oz * dzp[p];
+          const double cc = s5p[p] * dot;
+          ex = fma(cc, dxp[p], fma(-s3p[p], ox, ex));
+          ey = fma(cc, dyp[p], fma(-s3p[p], oy, ey));
+          ez = fma(cc, dzp[p], fma(-s3p[p], oz, ez));
+        }
+      }
+      nx[m] = al[m] * ex; ny[m] = al[m] * ey; nz[m] = al[m] * ez;
+      const double ddx = nx[m] - mux[m], ddy = ny[m] - muy[m], ddz = nz[m] - muz[m];
+      chg += ddx * ddx + ddy * ddy + ddz * ddz;
+      if (lane == 0) { dst[mi[m]].mx = nx[m]; dst[mi[m]].my = ny[m]; dst[mi[m]].mz = nz[m]; }
+    }
+  }
+  if (lane == 0 && chg != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), chg);
 }
 
 // ------------------------------------------------------------------------------------------
