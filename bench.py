@@ -2,17 +2,23 @@
 """bench.py -- headline benchmark of the MI355X-native polarization pair style.
 
 metric   : atom-steps/s (BASELINE.json), one "step" = one full Pair::compute pass
-           (list build, rank metric, LJ+coul, static field, dipole solve, forces, virial)
-workload : BASELINE.json configs[1]: "32k-atom replicated polarizable box" = the MOF5+H2 example
-           cell replicated 3x3x3 (36,423 atoms, LAMMPS `replicate` semantics), exponential damping,
-           fixed_iteration yes max_iterations 30 (31 sweeps), ranked GS, cutoff mode
-           r_dd = cut_coul = 12.8345 A.  Inputs resident in HBM before timing.
-N > 1    : weak scaling, 36,423 atoms per GPU (3x3x3N replica), one rank per GPU, dipoles
-           all-gathered over RCCL once per sweep (see parallel.py).
+           (cell sort, list build, LJ + Ewald-real, static field, dipole solve, forces, virial).
+N = 1    : headline = BASELINE.json configs[2]: the MOF5+H2 example cell replicated 5x5x4 = 134,900 atoms
+           ("131k-atom box"), polar_gs_ranked, precision 1e-11, exponential damping, cutoff mode
+           r_dd = cut_coul = 12.8345 A.  Inputs resident in HBM before timing.  The same JSON line carries
+             config.config1_36k          configs[1] (3x3x3 = 36,423 atoms, fixed_iteration 30)
+             config.config4_529k_one_gpu configs[4]'s box (7x7x8 = 528,808 atoms) on ONE GPU: the denominator of
+                                         the ">= 6x at 8 GPUs vs 1" target
+             config.md_leg               the headline box driven the way LAMMPS drives it: positions re-uploaded
+                                         through polar_set_atoms every step, f / mu downloaded, list re-upload +
+                                         colour rebuild + rank metric every 10th step.
+N > 1    : strong scaling on a fixed box (BASELINE configs[3], configs[4]): 6x6x6 = 291,384 atoms for N = 2, 4;
+           7x7x8 = 528,808 atoms for N = 8 (other N: the 6x6x6 box); one rank per GPU, spatial slabs, point-to-point
+           halo exchange of the dipoles over RCCL once per sweep (parallel.py).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : dipole-field sweep kernel, algorithmic bytes / launch over measured launch time
-  cpu_baseline : the CPU oracle ("port") timed on this host on a bounded sample.
+  roofline     : dipole-field sweep kernel, algorithmic bytes / launch over the measured launch time
+  cpu_baseline : the CPU oracle ("port") timed on this host on a bounded sample (N = 1 only).
 """
 import argparse
 import importlib
@@ -29,30 +35,149 @@ PKG = "lammps-induced-dipole-polarization-pair-style_amd"
 
 CUT_COUL = 12.8345
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FIXED30 = ["fixed_iteration", "yes", "max_iterations", "30"]
+PREC11 = ["fixed_iteration", "no", "precision", "1e-11", "max_iterations", "100"]
+CONFIGS = {  # BASELINE.json configs[k] -> replication of the 1,349-atom MOF5+H2 cell, solver keywords
+    1: dict(reps=(3, 3, 3), solver=FIXED30, label="configs[1] 32k-atom replicated box, fixed_iteration 30"),
+    2: dict(reps=(5, 5, 4), solver=PREC11, label="configs[2] 131k-atom box, polar_gs_ranked, precision 1e-11"),
+    3: dict(reps=(6, 6, 6), solver=PREC11, label="configs[3] 262k-atom box, precision 1e-11"),
+    4: dict(reps=(7, 7, 8), solver=PREC11, label="configs[4] 512k-atom box, precision 1e-11"),
+}
 
 
-def build_workload(wl, reps, extra=()):
-    """BASELINE configs[1]: the MOF5+H2 example cell (1349 atoms) replicated reps=(nx,ny,nz):
-    3x3x3 = 36,423 atoms ("32k-atom replicated polarizable box")."""
-    args = ["use_previous", "no", "fixed_iteration", "yes", "max_iterations", "30", "polar_gs_ranked", "yes",
-            "dd_cutoff", repr(CUT_COUL)] + list(extra)
-    return wl.replicate_fixture(os.path.join(ROOT, "tests", "golden", "mof5_h2.npz"), *reps, extra_args=args)
+def build_workload(wl, reps, extra=(), build_list=True, solver=FIXED30):
+    """The MOF5+H2 example cell (1349 atoms) replicated reps = (nx, ny, nz) with LAMMPS `replicate` semantics,
+    exponential damping, ranked GS, cutoff mode r_dd = cut_coul."""
+    args = ["use_previous", "no", "polar_gs_ranked", "yes", "dd_cutoff", repr(CUT_COUL)] + list(solver) + list(extra)
+    return wl.replicate_fixture(os.path.join(ROOT, "tests", "golden", "mof5_h2.npz"), *reps, extra_args=args,
+                                build_list=build_list)
 
 
-def cpu_baseline(wl, reps=(3, 2, 2)):
-    """Oracle (CPU restatement, 1 core) on a bounded sample of the same workload: the same cell,
-    cutoffs and solver settings at a smaller replication (cost per atom is N-independent in
-    cutoff mode)."""
+def describe(cfg, n):
+    r = cfg["reps"]
+    return (f"BASELINE {cfg['label']}: MOF5+H2 cell replicated {r[0]}x{r[1]}x{r[2]} = {n} atoms, exponential damping, "
+            f"ranked GS, dd_cutoff=cut_coul={CUT_COUL}")
+
+
+def cpu_baseline(wl, solver, reps=(3, 2, 2)):
+    """Oracle (CPU restatement, 1 core) on a bounded sample of the same workload: the same cell, cutoffs and solver
+    settings at a smaller replication (cost per atom is N-independent in cutoff mode)."""
     from oracle import oracle
 
-    s = build_workload(wl, reps)
-    natoms_sample = s.nlocal
+    s = build_workload(wl, reps, solver=solver)
     t = time.time()
     out = oracle.compute(s, eflag=1, vflag=2)
     dt = time.time() - t
-    return dict(value=natoms_sample / dt, unit="atom-steps/s", cores=1, kind="port",
-                sample=f"1 full step of the {reps[0]}x{reps[1]}x{reps[2]} replica ({natoms_sample} atoms, same cell/settings as the GPU workload), "
-                       f"{dt:.1f} s, {out['sweeps']} sweeps; host has {os.cpu_count()} cores"), out
+    return dict(value=s.nlocal / dt, unit="atom-steps/s", cores=1, kind="port",
+                sample=f"1 full step of the {reps[0]}x{reps[1]}x{reps[2]} replica ({s.nlocal} atoms, same cell/settings as "
+                       f"the GPU workload), {dt:.1f} s, {out['sweeps']} sweeps; host has {os.cpu_count()} cores")
+
+
+def timed_steps(torch, p, steps, warmup):
+    for _ in range(warmup):
+        out = p.compute_resident(eflag=1, vflag=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_solve, launches = 0.0, 0
+    for _ in range(steps):
+        out = p.compute_resident(eflag=1, vflag=2)
+        ms_solve += out["ms_solve"]
+        launches += out["sweeps"] * max(out["ncolors"], 1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return out, dt, ms_solve, launches
+
+
+def roofline(s, out, ms_solve, launches, steps, pkg):
+    """Dominant kernel: the dipole-field sweep (k_field_lp), one launch per colour phase.
+    ALGORITHMIC bytes of one sweep, SURVEY.md 8(d): N*(4*K + 8) + N*104 -- int32 neighbor index per pair, int64 row
+    offset, and the per-row streams (x 24, mu 24, E 24, alpha 8, mu_new 24); gathers of x_j / mu_j are not counted.
+    K*N = dd_pairs (the directed polarizable pairs a sweep walks).  The kernel streams exactly that index
+    (4 B per pair) and nothing else per pair.  Launch time = HIP events recorded on the library's stream around
+    the solve / number of sweep launches (it therefore includes launch gaps and the end-of-sweep control launches)."""
+    rows = int(np.count_nonzero(s.alpha[:s.nlocal]))
+    ncol = max(out["ncolors"], 1)
+    bytes_launch = (4.0 * out["dd_pairs"] + rows * 112.0) / ncol
+    ms_launch = ms_solve / max(launches, 1)
+    achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
+    # HBM traffic per launch from PMC counters: read from the committed profile of THIS kernel generation on THIS
+    # workload (tools/pmc_traffic.sh writes it); null when the file does not match the built library
+    traffic, src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as fh:
+            t = json.load(fh)
+        if t.get("kernel_version") == pkg.kernel_version() and t.get("natoms") == s.nlocal:
+            traffic, src = float(t["bytes_per_launch"]), t.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; {pkg.kernel_version()})",
+            "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch, "launches_per_step": launches / max(steps, 1)}
+
+
+def sub_config(torch, pkg, wl, k, steps, warmup, device_neigh=False):
+    cfg = CONFIGS[k]
+    s = build_workload(wl, cfg["reps"], solver=cfg["solver"], build_list=not device_neigh)
+    p = pkg.pair_from_system(s, device_neigh=device_neigh)
+    out, dt, ms_solve, launches = timed_steps(torch, p, steps, warmup)
+    rf = roofline(s, out, ms_solve, launches, steps, pkg)
+    p.close()
+    return {"workload": describe(cfg, s.nlocal) + (", LJ/Coulomb list built on the device" if device_neigh else ""),
+            "natoms": s.nlocal, "steps": steps, "ms_per_step": 1e3 * dt / steps, "atom_steps_per_s": s.nlocal * steps / dt,
+            "sweeps": out["sweeps"], "colors": out["ncolors"], "dd_pairs": out["dd_pairs"],
+            "ms_per_dipole_iteration": ms_solve / steps / max(out["sweeps"], 1), "ms_solve": ms_solve / steps,
+            "rms_dmu_last_sweep": out["rms_dmu"], "roofline_frac": rf["frac"], "ms_per_sweep_launch": rf["ms_per_launch"]}
+
+
+def md_leg(pkg, s, steps=20, every=10, seed=7):
+    """The headline box driven the way a LAMMPS run drives the shim (lammps_shim/...:compute): every step the positions
+    (moved by a thermal-size random displacement, well inside the skin) go up through polar_set_box + polar_set_atoms
+    and f, mu, E_static come back through polar_compute (host pointers); every `every`-th step the neighbor list is
+    handed over again (polar_set_neighbors_csr), which re-uploads it, re-symmetrises it and rebuilds the colour phases
+    (rank metric + host-side colouring)."""
+    rng = np.random.default_rng(seed)
+    p = pkg.pair_from_system(s)
+    x0 = s.x.copy()
+    n, nall = s.nlocal, s.nlocal + s.nghost
+    disp = np.zeros_like(x0)
+    p.compute(eflag=1, vflag=2)  # first step of a run: lists, colours, allocations
+    t_plain, t_relist, ms_color, ms_dev, t_up, t_cmp, t_nb = [], [], [], [], [], [], []
+    f = np.zeros((nall, 3)); mu = np.zeros((n, 3)); ef = np.zeros((n, 3))
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+    res = pkg.Result()
+    for k in range(steps):
+        d = rng.normal(scale=0.01, size=(n, 3))
+        disp[:n] += d
+        disp[n:] = disp[s.owner[n:]]  # ghosts are images of their owners
+        x = np.ascontiguousarray(x0 + disp)
+        f[:] = 0.0
+        relist = (k % every) == every - 1
+        t0 = time.perf_counter()          # --- what the shim does per step, through the C-ABI ---
+        p.set_box(s.boxlo, s.prd)
+        p.set_atoms(s.nlocal, s.nghost, x, s.q, s.alpha, s.type, s.molecule)
+        t1 = time.perf_counter()
+        if relist:
+            p.set_neighbors_csr(s.ilist, s.numneigh, s.firstneigh, s.neigh)
+        t2 = time.perf_counter()
+        p._ck(p.L.polar_compute(p.h, 1, 2, f.ctypes.data_as(dp), mu.ctypes.data_as(dp), ef.ctypes.data_as(dp), C.byref(res)))
+        t3 = time.perf_counter()
+        (t_relist if relist else t_plain).append(1e3 * (t3 - t0))
+        t_up.append(1e3 * (t1 - t0)); t_cmp.append(1e3 * (t3 - t2))
+        ms_dev.append(res.ms_total)
+        if relist:
+            ms_color.append(res.ms_color_host); t_nb.append(1e3 * (t2 - t1))
+    p.close()
+    ms_plain = float(np.mean(t_plain))
+    ms_rel = float(np.mean(t_relist)) if t_relist else ms_plain
+    ms_md = (ms_plain * (every - 1) + ms_rel) / every
+    return {"what": f"polar_set_box + polar_set_atoms + polar_compute(host f, mu, E) per step, neighbor list handed over every {every}th step; "
+                    f"wall clock of the C-ABI calls ({nall} atoms incl. ghosts)",
+            "steps": steps, "ms_per_step_md": ms_md, "atom_steps_per_s_md": n / (ms_md * 1e-3), "ms_plain_step": ms_plain,
+            "ms_reneighbor_step": ms_rel, "ms_color_host": float(np.mean(ms_color)) if ms_color else 0.0,
+            "ms_device_per_step": float(np.mean(ms_dev)), "ms_set_atoms": float(np.mean(t_up)),
+            "ms_compute_call": float(np.median(t_cmp)), "ms_set_neighbors": float(np.mean(t_nb)) if t_nb else 0.0,
+            "color_share_of_amortised_step": (float(np.mean(ms_color)) / every / ms_md) if ms_color else 0.0}
 
 
 def main():
@@ -60,8 +185,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reps", type=int, nargs=3, default=[3, 3, 3], help="replication of the 1349-atom cell per GPU")
+    ap.add_argument("--config", type=int, default=0, help="BASELINE configs[k] as the headline (default: 2 at N=1; 3 at N=2,4; 4 at N=8)")
+    ap.add_argument("--reps", type=int, nargs=3, default=None, help="replication of the 1349-atom cell (experiments; overrides --config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip the configs[1] / 529k / MD-shaped legs")
     ap.add_argument("--synth", type=int, default=0, help="use the SURVEY 8(d) synthetic generator with this many atoms instead of the replicated cell")
     ap.add_argument("--extra", nargs="*", default=[], help="extra pair_style keywords (experiments)")
     args = ap.parse_args()
@@ -81,69 +208,39 @@ def main():
         return par.bench_distributed(args, rank, world, local_rank)
 
     torch.cuda.set_device(0)
+    k = args.config or 2
+    cfg = dict(CONFIGS[k])
+    if args.reps:
+        cfg["reps"] = tuple(args.reps)
+        cfg["label"] = f"(experiment) {cfg['label']}"
     if args.synth:
-        s = wl.synth_system(args.synth, seed=1, extra_args=["fixed_iteration", "yes", "max_iterations", "30", "dd_cutoff", repr(CUT_COUL)] + list(args.extra))
+        s = wl.synth_system(args.synth, seed=1, extra_args=cfg["solver"] + ["dd_cutoff", repr(CUT_COUL)] + list(args.extra))
+        workload = f"SURVEY 8(d) synthetic generator synth({s.nlocal}, seed 1), exponential damping, ranked GS, dd_cutoff=cut_coul={CUT_COUL}"
     else:
-        s = build_workload(wl, tuple(args.reps), args.extra)
+        s = build_workload(wl, cfg["reps"], args.extra, solver=cfg["solver"])
+        workload = describe(cfg, s.nlocal)
     p = pkg.pair_from_system(s, device=0)
-
-    for _ in range(args.warmup):
-        out = p.compute_resident(eflag=1, vflag=2)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ms_solve = 0.0
-    for _ in range(args.steps):
-        out = p.compute_resident(eflag=1, vflag=2)
-        ms_solve += out["ms_solve"]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    out, dt, ms_solve, launches = timed_steps(torch, p, args.steps, args.warmup)
+    p.close()
 
     n = s.nlocal
-    ms_step = 1e3 * dt / args.steps
-    value = n * args.steps / dt
-    # dominant kernel: k_field_quad (dipole-field sweep).  One sweep = ncolors launches.
-    launches = out["sweeps"] * max(out["ncolors"], 1)
-    rows = int(np.count_nonzero(s.alpha[:n]))
-    # ALGORITHMIC bytes of one sweep, SURVEY.md 8(d): N*(4*K + 8) + N*104 -- int32 neighbor index per
-    # pair, int64 row offset, and the per-row streams (x 24, mu 24, E 24, alpha 8, mu_new 24).  Gathers
-    # of x_j / mu_j are not counted.  K*N = dd_pairs (the directed polarizable pairs the launch walks).
-    bytes_sweep = 4.0 * out["dd_pairs"] + rows * 112.0
-    bytes_launch = bytes_sweep / max(out["ncolors"], 1)
-    ms_launch = (ms_solve / args.steps) / launches      # HIP events on the library's stream around the solve
-    achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
-    # What the kernel actually streams by design: + the cached r^2 of every pair (8 B), a deliberate
-    # bytes-for-flops trade: 12 B/pair.
-    # (the library drops the r^2 stream -- 4 B/pair, r^2 rebuilt in the kernel -- once 12 B/pair no longer fit
-    # the 256 MB Infinity Cache: same rule as build_lists in polar_api.hip)
-    stream_b = 12.0 if 12.0 * out["dd_pairs"] < 200.0e6 else 4.0
-    stream_launch = (stream_b * out["dd_pairs"] + rows * 112.0) / max(out["ncolors"], 1)
-    # HBM bytes per launch from PMC counters cannot be read inside this process; the value below was
-    # collected with tools/pmc_traffic.sh on this exact workload (separate --pmc passes, per launch:
-    # FETCH_SIZE 25,169 KB -> x2 on gfx950 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE 620 KB;
-    # profiles/r01_v32_kfield_quad_traffic_pmc.txt, 4 colour launches per sweep) and is reported only for that
-    # workload.  It exceeds the streamed bytes by the atom records every launch re-reads into the L2 of each XCD.
-    traffic = 51.0e6 if (tuple(args.reps) == (3, 3, 3) and not args.extra and not args.synth) else None
+    config = {"workload": workload, "natoms": n, "sweeps": out["sweeps"], "iterations": out["iterations"], "colors": out["ncolors"],
+              "dd_pairs": out["dd_pairs"], "ms_per_dipole_iteration": (ms_solve / args.steps) / max(out["sweeps"], 1),
+              "ms_solve": ms_solve / args.steps, "ms_ljcoul": out["ms_ljcoul"], "ms_force": out["ms_force"],
+              "ms_static": out["ms_static"], "ms_list": out["ms_list"], "ms_rank": out["ms_rank"],
+              "rms_dmu_last_sweep": out["rms_dmu"], "eng_pol": out["eng_pol"], "kernel_version": pkg.kernel_version()}
     line = {
-        "metric": "atom-steps/sec", "value": value, "unit": "atom-steps/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": (f"SURVEY 8(d) synthetic generator synth({n}, seed 1), exponential damping, fixed_iteration 30, ranked GS, dd_cutoff=cut_coul={CUT_COUL}"
-                                if args.synth else
-                                f"BASELINE configs[1]: MOF5+H2 cell replicated {args.reps[0]}x{args.reps[1]}x{args.reps[2]} = {n} atoms, exponential damping, "
-                                f"fixed_iteration 30 (31 sweeps), ranked GS, dd_cutoff=cut_coul={CUT_COUL}"),
-                   "natoms": n, "sweeps": out["sweeps"], "colors": out["ncolors"], "dd_pairs": out["dd_pairs"],
-                   "ms_per_dipole_iteration": (ms_solve / args.steps) / max(out["sweeps"], 1),
-                   "ms_solve": ms_solve / args.steps, "ms_ljcoul": out["ms_ljcoul"], "ms_force": out["ms_force"],
-                   "ms_static": out["ms_static"], "ms_list": out["ms_list"], "ms_rank": out["ms_rank"],
-                   "rms_dmu_last_sweep": out["rms_dmu"], "eng_pol": out["eng_pol"]},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_field_quad (dipole-field sweep, one launch per colour phase)",
-                     "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch,
-                     "streamed_bytes_per_launch": stream_launch,
-                     "streamed_frac": stream_launch / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "metric": "atom-steps/sec", "value": n * args.steps / dt, "unit": "atom-steps/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": config,
+        "roofline": roofline(s, out, ms_solve, launches, args.steps, pkg),
     }
+    if not args.no_extras and not args.synth and not args.reps:
+        config["md_leg"] = md_leg(pkg, s)
+        config["config1_36k"] = sub_config(torch, pkg, wl, 1, steps=max(args.steps, 10), warmup=args.warmup)
+        config["config4_529k_one_gpu"] = sub_config(torch, pkg, wl, 4, steps=min(args.steps, 5), warmup=1, device_neigh=True)
     if not args.no_cpu_baseline:
-        line["cpu_baseline"], _ = cpu_baseline(wl)
+        line["cpu_baseline"] = cpu_baseline(wl, cfg["solver"])
     print(json.dumps(line))
 
 

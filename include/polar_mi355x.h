@@ -65,6 +65,8 @@ typedef struct {
   /* device time of the last compute, milliseconds (HIP events on the compute stream) */
   double ms_total, ms_rank, ms_ljcoul, ms_static, ms_solve, ms_force, ms_list;
   long long dd_pairs;                 /* entries of the dipole-dipole list swept per sweep */
+  double ms_color_host;               /* host wall time of the colour-phase rebuild (conflict graph + DSATUR) when this
+                                         step rebuilt it (reneighbor steps in list mode), else 0 */
 } polar_result;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -73,6 +75,8 @@ int polar_destroy(polar_handle *h);
 const char *polar_last_error(const polar_handle *h);
 const char *polar_last_warning(const polar_handle *h);
 int polar_device_count(void); /* 0 when no GPU is usable; never throws */
+/* identifies the kernel generation of the built library (bench.py matches PMC traffic files in profiles/ against it) */
+const char *polar_kernel_version(void);
 
 /* ---- host mirror of the Pair text interface (same grammar, defaults and error strings) --- */
 /* PairLJCutCoulLongPolarization::settings, PS.cpp:678-766. argv = pair_style args after the name. */

@@ -65,7 +65,7 @@ class Result(C.Structure):
                 ("rms_dmu", C.c_double), ("iterations", C.c_int), ("sweeps", C.c_int), ("status", C.c_int),
                 ("ncolors", C.c_int), ("ms_total", C.c_double), ("ms_rank", C.c_double), ("ms_ljcoul", C.c_double),
                 ("ms_static", C.c_double), ("ms_solve", C.c_double), ("ms_force", C.c_double), ("ms_list", C.c_double),
-                ("dd_pairs", C.c_longlong)]
+                ("dd_pairs", C.c_longlong), ("ms_color_host", C.c_double)]
 
 
 _dp, _ip, _llp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong)
@@ -76,6 +76,7 @@ EXPORTS = {
     "polar_last_error": (C.c_char_p, [C.c_void_p]),
     "polar_last_warning": (C.c_char_p, [C.c_void_p]),
     "polar_device_count": (C.c_int, []),
+    "polar_kernel_version": (C.c_char_p, []),
     "polar_pair_settings": (C.c_int, [C.c_void_p, C.c_int, _cpp]),
     "polar_pair_coeff": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _cpp]),
     "polar_pair_modify": (C.c_int, [C.c_void_p, C.c_int, _cpp]),
@@ -148,6 +149,10 @@ def lib():
 
 def device_count():
     return lib().polar_device_count()
+
+
+def kernel_version():
+    return lib().polar_kernel_version().decode()
 
 
 def _dptr(a):
@@ -366,9 +371,11 @@ def _result_dict(res):
     return out
 
 
-def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0):
+def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0, device_neigh=False):
     """Build a PolarPair from a workload.PolarSystem the way an input script would:
-    pair_style -> pair_modify -> pair_coeff -> init -> per-step data."""
+    pair_style -> pair_modify -> pair_coeff -> init -> per-step data.
+    ``device_neigh``: the LJ/Coulomb list is built on the device (keyword ``device_neigh yes`` of the shim)
+    instead of being uploaded; systems made with ``build_list=False`` need it."""
     p = PolarPair(device)
     p.load_system(sysm, modify_args)
     rows = coeff_rows if coeff_rows is not None else sysm.extra.get("coeff_rows")
@@ -377,5 +384,11 @@ def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0):
     for r in rows:
         p.coeff(sysm.ntypes, list(r))
     p.init(sysm.g_ewald, sysm.qqrd2e, sysm.special_lj, sysm.special_coul)
-    p.set_system(sysm)
+    if device_neigh:
+        p._ck(p.L.polar_set_newton(p.h, int(sysm.extra.get("newton_pair", 1))))
+        p.set_box(sysm.boxlo, sysm.prd, tilt=getattr(sysm, "tilt", (0.0, 0.0, 0.0)), triclinic=int(getattr(sysm, "triclinic", 0)))
+        p.set_atoms(sysm.nlocal, sysm.nghost, sysm.x, sysm.q, sysm.alpha, sysm.type, sysm.molecule)
+        p.build_neighbors_from_system(sysm)
+    else:
+        p.set_system(sysm)
     return p

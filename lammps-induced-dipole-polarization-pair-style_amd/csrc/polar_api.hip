@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <initializer_list>
 #include <utility>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +19,9 @@
 #include "polar_kernels.hpp"
 
 using namespace polar;
+
+// bump when a kernel on the hot path changes: PMC files under profiles/ are keyed by it (bench.py, roofline.traffic)
+#define POLAR_KERNEL_VERSION "r02-lp2-v1"
 
 namespace {
 
@@ -137,6 +141,13 @@ struct polar_handle {
   std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
   std::vector<int> h_rows;     // rows sorted by colour (host copy)
   bool colors_valid = false;
+  double color_keep = 2.0;      // A (POLAR_COLOR_KEEP): a colouring built at color_dist stays in use on later lists while
+                                // every same-colour pair is still farther apart than this (hysteresis: atoms move)
+  bool colors_recheck = false;  // a new neighbor list arrived: keep the colouring if it still separates every same-colour pair
+  std::vector<int> h_color;     // colour of every atom (orig ids), -1: none
+  DBuf<int> d_color_orig, d_color_s;
+  int colors_reused = 0, colors_rebuilt = 0;
+  double ms_color_host = 0.0;  // host time of the last colour rebuild; reported once, then cleared
   double color_dist = 2.4;  // A (POLAR_COLOR_DIST).  profiles/r01_lab_color_distance.txt: 2.4 -> 4 phases, 2.5-2.6 -> 5, with the same
                             // number of sweeps to 1e-11 (33); <= 2.2 -> 3 phases but 36-37 sweeps; <= 1.2 does not converge
   int field_block = 256;
@@ -165,6 +176,8 @@ struct polar_handle {
   bool overlap_lj = true;  // POLAR_NO_OVERLAP=1 keeps a3 on the main stream
   bool lj_forked = false;
   std::vector<double> h_tmp;
+  double *h_stage = nullptr;  // pinned staging area for downloads
+  size_t h_stage_cap = 0;
 };
 
 namespace {
@@ -188,6 +201,18 @@ int guarded(polar_handle *h, F &&fn) {
   } catch (const std::exception &e) {
     return fail(h, POLAR_ERR_STATE, e.what());
   }
+}
+
+// pinned host staging area of at least `count` doubles (grown geometrically, freed with the handle)
+double *staging(polar_handle *h, size_t count) {
+  if (count > h->h_stage_cap) {
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    h->h_stage = nullptr; h->h_stage_cap = 0;
+    const size_t want = count + count / 4 + 1024;
+    HIPCHECK(hipHostMalloc((void **)&h->h_stage, want * sizeof(double)));
+    h->h_stage_cap = want;
+  }
+  return h->h_stage;
 }
 
 void need_device(polar_handle *h) {
@@ -335,10 +360,17 @@ void build_lists(polar_handle *h) {
                 {h->d_overflow.p, 16 * sizeof(int)}, {h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long)}});
   const bool lp = mode == 3;
   if (lp) h->d_dd_wrap.ensure(n + 1);
+  const bool recheck = h->colors_valid && h->colors_recheck && h->sweep_kernel != 3 && (int)h->h_color.size() == n;
+  if (h->colors_recheck && !recheck) { h->colors_valid = false; h->colors_recheck = false; }
+  if (recheck) {
+    h->d_color_s.ensure(n + 1);
+    k_color_map<<<nblk(n, 256), 256, 0, s>>>(n, h->d_perm.p, h->d_color_orig.p, h->d_color_s.p);
+  }
   k_nl_build<<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
       rows, nr, h->d_pos4.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,
       h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, fuse ? r2p : nullptr, fuse ? 1 : 0, lp ? 6 : 0, lp ? n : -1,
-      lp ? h->d_dd_wrap.p : nullptr, h->d_overflow.p, h->d_ddtot.p);
+      lp ? h->d_dd_wrap.p : nullptr, recheck ? h->d_color_s.p : nullptr, h->color_keep * h->color_keep, h->d_overflow.p + 8,
+      h->d_overflow.p, h->d_ddtot.p);
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
   if (fuse || mode == 4) {
     // modes 1 and 2: the list build wrote r^2 (mode 1) and the padding itself; mode 4: no per-atom dd rows at all
@@ -642,6 +674,10 @@ void build_colors(polar_handle *h, const std::vector<double> &rank) {
     for (int i : cell)
       if (mine(i)) rows[fill[color[i]]++] = i;
   h->h_rows = rows;
+  h->h_color.assign(color.begin(), color.end());
+  h->d_color_orig.ensure((size_t)n + 1);
+  if (n > 0) HIPCHECK(hipMemcpy(h->d_color_orig.p, h->h_color.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  h->colors_rebuilt++;
   h->d_rows_orig.ensure(rows.size() + 1);
   h->d_rows.ensure(rows.size() + 1);
   if (!rows.empty()) HIPCHECK(hipMemcpy(h->d_rows_orig.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -829,12 +865,27 @@ void ensure_colors(polar_handle *h) {
     HIPCHECK(hipStreamSynchronize(h->stream));
     for (int k = 0; k < n; k++) rk[perm[k]] = rs[k];  // rank metric was computed in s space
   }
+  const auto t0 = std::chrono::steady_clock::now();
   build_colors(h, rk);
+  h->ms_color_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 // per step: the colour rows (orig ids) -> s space of this step's cell order
 void map_color_rows(polar_handle *h) {
   const int tot = h->color_off.empty() ? 0 : h->color_off.back();
   if (tot > 0) k_map_rows<<<nblk(tot, 256), 256, 0, h->stream>>>(tot, h->d_inv.p, h->d_rows_orig.p, h->d_rows.p);
+}
+
+// reneighbor steps: k_nl_build has checked the colouring in use against the new positions; rebuild only on a clash
+void resolve_colors(polar_handle *h) {
+  if (!h->colors_recheck) return;
+  h->colors_recheck = false;
+  if (!h->colors_valid) return;
+  int clash = 0;
+  HIPCHECK(hipMemcpyAsync(&clash, h->d_overflow.p + 8, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  if (!clash) { h->colors_reused++; return; }
+  h->colors_valid = false;
+  if (h->ph.st.polar_gs_ranked) { launch_rank<false>(h, 1); launch_rank<false>(h, 2); }  // a2 for the phase order
 }
 
 // cluster mode, per step: members -> s space, union lists, descriptors (needs the colours AND this step's cell order)
@@ -868,6 +919,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
 
   if (!gs || !ap) {  // Jacobi (reference "polar_gs no") or colour-phase Gauss-Seidel over the dd list
     const bool clm = !ap && h->sweep_kernel == 3;
+    if (!ap) resolve_colors(h);
     if ((gs || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
     if (gs) out->ncolors = (int)h->color_off.size() - 1;
     if (!ap && h->sweep_kernel == 2) prepare_lp(h);
@@ -1128,6 +1180,8 @@ int phase_finish(polar_handle *h, polar_result *out) {
     h->dd_pairs = (long long)tot;
   }
   out->dd_pairs = ap ? (long long)n * (n - 1) : h->dd_pairs;
+  out->ms_color_host = h->ms_color_host;
+  h->ms_color_host = 0.0;
   float ms;
   auto el = [&](int a, int b) { HIPCHECK(hipEventElapsedTime(&ms, h->ev[a], h->ev[b])); return (double)ms; };
   out->ms_list = el(0, 1); out->ms_rank = el(1, 2); out->ms_static = el(3, 4);
@@ -1167,6 +1221,8 @@ int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, pol
 // =============================================================================================
 extern "C" {
 
+const char *polar_kernel_version(void) { return POLAR_KERNEL_VERSION; }
+
 int polar_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1179,6 +1235,8 @@ int polar_create(int device, polar_handle **out) {
   *out = h;
   h->device = device;
   if (const char *e = getenv("POLAR_COLOR_DIST")) h->color_dist = atof(e);
+  h->color_keep = std::max(h->color_dist - 0.4, 0.75 * h->color_dist);
+  if (const char *e = getenv("POLAR_COLOR_KEEP")) h->color_keep = atof(e);
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
@@ -1236,12 +1294,13 @@ int polar_destroy(polar_handle *h) {
     h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release(); h->d_T6.release();
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
-    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
+    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     if (h->h_ddtot) (void)hipHostFree(h->h_ddtot);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   }
@@ -1373,6 +1432,10 @@ int polar_set_atoms(polar_handle *h, int nlocal, int nghost, const double *x, co
     for (size_t k = 0; k < nall; k++)
       if (alpha[k] < 0.0) throw InputError("Invalid value in set command");  // src/set.cpp:174-184 rejects negatives
     if (nlocal != h->nlocal) { h->colors_valid = false; h->mu_resident = false; }
+    else if (h->colors_valid) {  // the rows of the colour phases are the polarizable atoms: same atoms, same rows
+      for (int k = 0; k < nlocal; k++)
+        if ((alpha[k] != 0.0) != (h->halpha[k] != 0.0)) { h->colors_valid = false; break; }
+    }
     h->nlocal = nlocal; h->nghost = nghost;
     h->d_x.ensure(3 * nall + 3); h->d_q.ensure(nall + 1); h->d_alpha.ensure(nall + 1); h->d_type.ensure(nall + 1); h->d_mol.ensure(nall + 1);
     hipStream_t s = h->stream;
@@ -1423,7 +1486,7 @@ int polar_set_neighbors_csr(polar_handle *h, int inum, const int *ilist, const i
     HIPCHECK(hipStreamSynchronize(s));
     h->neigh_set = true;
     h->sym_valid = false;
-    h->colors_valid = false;  // reneighbor step: refresh the colour phases too
+    if (h->colors_valid) h->colors_recheck = true;  // reneighbor step: the colour phases are re-validated (k_nl_build)
     h->device_list = false;
     h->full_list = h->user_full_list;
     return POLAR_OK;
@@ -1503,7 +1566,8 @@ int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *
     h->h_flags[0] = 0;
     k_lj_rows<<<nblk(n, 256), 256, 0, s>>>(n, h->lj_pitch, h->d_ilist.p, h->d_first.p);
     h->inum = n; h->nneigh = (long long)tot;
-    h->neigh_set = true; h->sym_valid = false; h->colors_valid = false;
+    h->neigh_set = true; h->sym_valid = false;
+    if (h->colors_valid) h->colors_recheck = true;
     h->device_list = true; h->full_list = 1;
     return POLAR_OK;
   });
@@ -1539,11 +1603,16 @@ int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, 
     int rc = do_compute(h, eflag, vflag, mu, out);
     if (rc < 0) return rc;
     const size_t n = h->nlocal, nall = (size_t)h->nlocal + h->nghost;
-    h->h_tmp.resize(3 * nall);
-    HIPCHECK(hipMemcpy(h->h_tmp.data(), h->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < 3 * nall; k++) f[k] += h->h_tmp[k];
-    HIPCHECK(hipMemcpy(mu, h->d_mu.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
-    if (ef_static) HIPCHECK(hipMemcpy(ef_static, h->d_ef.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    // results come back through one pinned staging area (pageable destinations cost ~3x the PCIe time):
+    // [f nall*3 | mu n*3 | ef n*3], three asynchronous copies, one synchronisation
+    double *st = staging(h, 3 * nall + 6 * n);
+    HIPCHECK(hipMemcpyAsync(st, h->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(st + 3 * nall, h->d_mu.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (ef_static) HIPCHECK(hipMemcpyAsync(st + 3 * nall + 3 * n, h->d_ef.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    for (size_t k = 0; k < 3 * nall; k++) f[k] += st[k];
+    memcpy(mu, st + 3 * nall, 3 * n * sizeof(double));
+    if (ef_static) memcpy(ef_static, st + 3 * nall + 3 * n, 3 * n * sizeof(double));
     return rc;
   });
 }
@@ -1652,6 +1721,7 @@ int polar_step_begin(polar_handle *h, int eflag, int vflag) {
     phase_begin(h, eflag, vflag, nullptr);
     const polar_settings &st = h->ph.st;
     const bool clm = st.dd_cutoff > 0.0 && h->sweep_kernel == 3;
+    if (st.dd_cutoff > 0.0) resolve_colors(h);
     if (!st.zodid && (st.polar_gs || st.polar_gs_ranked || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
     if (!st.zodid && st.dd_cutoff > 0.0 && h->sweep_kernel == 2) prepare_lp(h);
     h->in_step = true;

@@ -95,6 +95,11 @@ __global__ void k_map_rows_pad(int n, const int *__restrict__ inv, const int *__
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] >= 0 ? inv[in[i]] : -1;  // -1: padding of a cluster's member table
 }
+// colours of the atoms in this step's s order (colour re-validation): -1 = no colour
+__global__ void k_color_map(int n, const int *__restrict__ perm, const int *__restrict__ color_orig, int *__restrict__ color_s) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) color_s[i] = color_orig[perm[i]];
+}
 __global__ void k_map_range(int lo, int n, const int *__restrict__ inv, int *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = inv[lo + i];
@@ -113,6 +118,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
                                                           int *__restrict__ nl_j, int *__restrict__ dd_j,
                                                           double *__restrict__ dd_r2, int pad_dd,
                                                           int dd_shift, int dd_pad_index, int *__restrict__ dd_wrap,
+                                                          const int *__restrict__ color_s, double colordistsq,
+                                                          int *__restrict__ color_conflict,
                                                           int *__restrict__ overflow,
                                                           unsigned long long *__restrict__ dd_total) {
   const int lane = threadIdx.x & 63;
@@ -121,6 +128,10 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   const int i = rows ? rows[row] : row;  // s space: the atoms of cell c are the indices [cell_first[c], cell_first[c+1])
   const double4 ri = pos4[i];            // {x, y, z, (molecule, polarizable)}
   const int imol = __double2hiint(ri.w), ipol = __double2loint(ri.w);
+  // colour re-validation on reneighbor steps (color_s != NULL): the colouring of the previous list stays in use unless
+  // two polarizable atoms of one colour have come closer than the colour distance
+  const int icol = (color_s && ipol) ? color_s[i] : -2;
+  bool clash = color_s && ipol && icol < 0;  // a polarizable atom without a colour
   // home cell and the position inside it in cell units (same arithmetic as cell_of)
   int cc[3];
   double uu[3], edge[3];
@@ -206,6 +217,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
           rsq = ex * ex + ey * ey + ez * ez;
           in_nl = rsq <= cutallsq;
           in_dd = ipol && __double2loint(rj.w) && (rsq < ddcutsq);
+          if (icol >= 0 && rsq < colordistsq && __double2loint(rj.w) && color_s[j] == icol) clash = true;
           if (dd_wrap) anywrap |= __ballot(in_dd && (ex != ri.x - rj.x || ey != ri.y - rj.y || ez != ri.z - rj.z));
           same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;
         }
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
       if (dd_r2) dd_r2[dd0 + k] = 1e60;  // s3 ~ 1e-90, and d = 0 kills the s5 term: contributes nothing
     }
   }
+  if (color_s && __ballot(clash) != 0ull && lane == 0) atomicOr(color_conflict, 1);
   if (lane == 0) {
     nl_cnt[i] = ncount; dd_cnt[i] = dcount;
     if (dd_wrap) dd_wrap[i] = anywrap != 0ull;

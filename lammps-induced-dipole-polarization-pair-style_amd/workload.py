@@ -380,8 +380,11 @@ class PolarSystem:
 
 def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings, g_ewald,
                 bonds=None, exclude_intra=False, skin=2.0, ncoultablebits=12, name="",
-                special_lj=(1.0, 0.0, 0.0, 0.0), special_coul=(1.0, 0.0, 0.0, 0.0), rows=None, full=False, newton=True):
-    """Assemble ghosts, the half list, LJ tables and Coulomb tables for one frame."""
+                special_lj=(1.0, 0.0, 0.0, 0.0), special_coul=(1.0, 0.0, 0.0, 0.0), rows=None, full=False, newton=True,
+                build_list=True):
+    """Assemble ghosts, the half list, LJ tables and Coulomb tables for one frame.
+    ``build_list=False`` leaves the neighbor list empty: the caller lets the library build it on the device
+    (PolarPair.build_neighbors_from_system), which is how the 0.5 M-atom boxes are set up."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     n = len(x)
     tables = init_one_all(ntypes, coeff_rows, settings.cut_lj_global, settings.cut_coul)
@@ -389,9 +392,13 @@ def make_system(x, q, alpha, typ, mol, boxlo, prd, ntypes, coeff_rows, settings,
     cutneigh = cutmax + skin
     x_all, owner, shift = build_ghosts(x, np.asarray(boxlo), np.asarray(prd), cutneigh)
     special = build_special(n, bonds) if bonds is not None and len(bonds) else None
-    ilist, numneigh, first, neigh = build_half_list(
-        x_all, owner, shift, n, cutneigh, molecule=np.asarray(mol), special=special,
-        exclude_intra=exclude_intra, rows=rows, full=full, newton=newton)
+    if build_list:
+        ilist, numneigh, first, neigh = build_half_list(
+            x_all, owner, shift, n, cutneigh, molecule=np.asarray(mol), special=special,
+            exclude_intra=exclude_intra, rows=rows, full=full, newton=newton)
+    else:
+        ilist, numneigh = np.zeros(0, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        first, neigh = np.zeros(n, dtype=np.int64), np.zeros(0, dtype=np.int32)
     coul = init_coul_tables(settings.cut_coul, g_ewald, QQR2E_REAL, ncoultablebits) if ncoultablebits else dict(
         nbits=0, mask=0, shift=0, tabinnersq=0.0, tables=np.zeros((8, 1)))
     g = lambda a, dt: np.ascontiguousarray(np.asarray(a)[owner], dtype=dt)
@@ -630,7 +637,7 @@ def synth_system(N, seed=1, extra_args=(), cut_lj=2.5, cut_coul=12.8345, skin=2.
                        synth_coeff_rows(), st, g, bonds=None, exclude_intra=True, skin=skin, name=f"synth{N}_s{seed}")
 
 
-def replicate_fixture(path, nx, ny, nz, extra_args=(), g_ewald=None, skin=2.0, rows=None, full=False):
+def replicate_fixture(path, nx, ny, nz, extra_args=(), g_ewald=None, skin=2.0, rows=None, full=False, build_list=True):
     """``replicate nx ny nz`` of a golden fixture (BASELINE configs[1..4] are replicated boxes).
     Follows LAMMPS' replicate semantics: molecule ids are offset per replica (so framework
     replicas no longer exclude each other, SURVEY.md 8(d) caveat); bonds are not replicated
@@ -660,4 +667,4 @@ def replicate_fixture(path, nx, ny, nz, extra_args=(), g_ewald=None, skin=2.0, r
     g = ewald_g(1.0e-4, q, st.cut_coul, prd) if g_ewald is None else g_ewald
     return make_system(x, q, np.tile(z["alpha"], nrep), np.tile(z["type"], nrep), np.concatenate(mols),
                        z["boxlo"], prd, meta["ntypes"], coeff_rows, st, g, bonds=None, exclude_intra=True, skin=skin,
-                       name=f"{meta['name']}_rep{nx}x{ny}x{nz}", rows=rows, full=full)
+                       name=f"{meta['name']}_rep{nx}x{ny}x{nz}", rows=rows, full=full, build_list=build_list)
