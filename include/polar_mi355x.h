@@ -167,6 +167,11 @@ int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, 
 int polar_compute_peratom(polar_handle *h, int eflag, int vflag, double *f, double *mu, double *ef_static,
                           double *eatom, double *vatom, polar_result *out);
 
+/* `debug yes` (PS.cpp:1182-1191): u_polar = -1/2 sum E_static . mu after every sweep of the last solve, in the
+ * units the library works in (the reference prints it times 22.432653052265^2).  Writes at most `max` values and
+ * returns how many sweeps were recorded (0 unless the debug keyword is on), < 0 on error. */
+int polar_get_debug_trace(polar_handle *h, double *u_polar, int max);
+
 /* ---- device-resident variant (bench, multi-GPU driver): no host<->device traffic ---------- */
 /* Runs compute() on the atoms/lists already resident from polar_set_*; results stay on the
  * device (polar_dev_ptr) and only the scalars in polar_result come back. */

@@ -111,6 +111,7 @@ EXPORTS = {
     "polar_step_sweep_end_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "polar_set_list_style": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_set_newton": (C.c_int, [C.c_void_p, C.c_int]),
+    "polar_get_debug_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "polar_step_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "polar_step_sweep": (C.c_int, [C.c_void_p]),
     "polar_step_sweep_end": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -356,6 +357,12 @@ class PolarPair:
         out = _result_dict(res)
         out.update(status=rc, warning=self.L.polar_last_warning(self.h).decode())
         return out
+
+    def debug_trace(self, nmax=1024):
+        """u_polar after every sweep of the last solve (`debug yes`, reference PS.cpp:1182-1191)."""
+        a = np.zeros(nmax)
+        n = self._ck(self.L.polar_get_debug_trace(self.h, _dptr(a), nmax))
+        return a[:n].copy()
 
     def download(self, name, n):
         a = np.zeros(n)

@@ -177,6 +177,8 @@ struct polar_handle {
   bool lj_forked = false;
   std::vector<double> h_tmp;
   double *h_stage = nullptr;  // pinned staging area for downloads
+  DBuf<double> d_trace;       // `debug yes`: u_polar after every sweep of the last solve
+  int ntrace = 0;
   size_t h_stage_cap = 0;
 };
 
@@ -907,6 +909,15 @@ void build_cluster_lists(polar_handle *h) {
   HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 }
 
+// `debug yes` (PS.cpp:1182-1191): u_polar after sweep `sw`, kept on the device until polar_get_debug_trace
+void debug_trace(polar_handle *h, int sw, bool /*jacobi*/) {
+  if (!h->ph.st.debug) return;
+  h->d_trace.ensure((size_t)h->ph.st.iterations_max + 8);
+  if (sw > h->ph.st.iterations_max + 1) return;
+  k_debug_upolar<<<1, 1024, 0, h->stream>>>(h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p, h->d_trace.p, sw, 0);  // Jacobi: like the reference, the value is formed BEFORE "mu = mu_new" (jacobi unused)
+  h->ntrace = sw + 1;
+}
+
 void solve(polar_handle *h, bool ap, polar_result *out) {
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
@@ -928,6 +939,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     const bool lazy = st.fixed_iteration && gs;
     for (int sw = 0; sw < max_sweeps; sw++) {
       sweep_once(h, ap);
+      debug_trace(h, sw, !gs);
       if (lazy && sw < max_sweeps - 2) continue;
       const int count = (lazy && sw == max_sweeps - 2) ? max_sweeps - 1 : 1;
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count);
@@ -946,6 +958,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
         k_gs_seq_T6<<<1, 64, 0, s>>>(n, b0, h->d_T6.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
         k_gs_push_T6<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_T6.p, h->d_rec0.p, h->d_dmu.p, h->d_F.p, h->d_scal.p);
       }
+      debug_trace(h, sw, false);
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
@@ -977,6 +990,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
           k_gs_block_push<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_order.p, h->d_pos.p, h->d_rec0.p, h->box, st.polar_damp, h->d_dmu.p, h->d_F.p, h->d_scal.p);
         }
       }
+      debug_trace(h, sw, false);
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
@@ -999,6 +1013,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   const int vmode = vflag % 4;
   hipStream_t s = h->stream;
   h->warn.clear();
+  h->ntrace = 0;
   h->step_eflag = eflag; h->step_vflag = vflag;
 
   h->d_f.ensure(3 * (size_t)nall); h->d_ef.ensure(3 * (size_t)n); h->d_F.ensure(3 * (size_t)n);
@@ -1173,6 +1188,7 @@ int phase_finish(polar_handle *h, polar_result *out) {
   long long rb = (long long)sc.rmin_bits;
   memcpy(&out->rmin, &rb, sizeof(double));
   out->rms_dmu = std::sqrt(std::max(0.0, sc.last_change));
+  h->ntrace = std::min(h->ntrace, sc.sweeps);
   out->iterations = sc.iterations; out->sweeps = sc.sweeps; out->status = sc.status ? POLAR_WARN_NOT_CONVERGED : POLAR_OK;
   if (!ap) {
     unsigned long long tot = 0;
@@ -1294,7 +1310,7 @@ int polar_destroy(polar_handle *h) {
     h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release(); h->d_T6.release();
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
-    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
+    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_trace.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
     if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -1701,6 +1717,17 @@ int polar_set_global_count(polar_handle *h, long long natoms) {
   if (natoms < 0 || natoms > 2147483647LL) return fail(h, POLAR_ERR_INPUT, "bad global atom count");
   h->global_count = natoms;
   return POLAR_OK;
+}
+int polar_get_debug_trace(polar_handle *h, double *u_polar, int max) {
+  if (!h) return POLAR_ERR_STATE;
+  int n = 0;
+  int rc = guarded(h, [&]() {
+    need_device(h);
+    n = std::min(h->ntrace, max);
+    if (n > 0) HIPCHECK(hipMemcpy(u_polar, h->d_trace.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return (int)POLAR_OK;
+  });
+  return rc < 0 ? rc : n;
 }
 int polar_set_newton(polar_handle *h, int newton_pair) {
   if (!h) return POLAR_ERR_STATE;

@@ -1217,6 +1217,26 @@ __global__ void k_zero_slots(double *__restrict__ slots, Scal *s) {
   ((unsigned long long *)slots)[(size_t)t * POLAR_SLOT_STRIDE + SL_RMIN] = (unsigned long long)__double_as_longlong(1000.0);
 }
 
+// `debug yes`: u_polar = -1/2 sum_i E_static,i . mu_i after a sweep (PS.cpp:1182-1191 prints it per iteration)
+__global__ __launch_bounds__(1024) void k_debug_upolar(int n, const Scal *scal, const AtomRec *__restrict__ recA,
+                                                       const AtomRec *__restrict__ recB, const double *__restrict__ ef,
+                                                       double *__restrict__ trace, int slot, int jacobi_next) {
+  if (scal->done) return;  // a launch past the end of a finished solve (the host looks at the state every 4 sweeps)
+  __shared__ double red[16];
+  // Jacobi: the sweep that just ran wrote the OTHER buffer (the copy "mu = mu_new" happens in k_solver_step)
+  const AtomRec *r = (scal->cur ^ jacobi_next) ? recB : recA;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += ef[3 * i] * r[i].mx + ef[3 * i + 1] * r[i].my + ef[3 * i + 2] * r[i].mz;
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sum = 0.0;
+    for (int k = 0; k < 16; k++) sum += red[k];
+    trace[slot] = -0.5 * sum;
+  }
+}
+
 // divergence fallback mu = alpha * E (no gamma), PS.cpp:1227-1235
 __global__ void k_fallback(int n, const Scal *scal, AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
                            const double *__restrict__ ef) {

@@ -42,6 +42,7 @@ PairLJCutCoulLongPolarizationMI355X::PairLJCutCoulLongPolarizationMI355X(LAMMPS 
   epsilon = sigma = cut_lj = NULL;
   pair_inited = 0;
   device_neigh = 0;
+  debug_flag = 0;
   cut_lj_global = cut_coul = 0.0;
   h = NULL;
   // one MPI rank per GPU: the dipoles of ghost atoms travel through
@@ -70,8 +71,34 @@ PairLJCutCoulLongPolarizationMI355X::~PairLJCutCoulLongPolarizationMI355X()
 
 void PairLJCutCoulLongPolarizationMI355X::check(int rc)
 {
-  if (rc < 0) error->all(FLERR,polar_last_error(h));
+  // several ranks: a library error is local to one rank (its GPU, its atoms), and error->all from inside the
+  // per-sweep loop would leave the others waiting in MPI_Allreduce / forward_comm -> error->one (MPI_Abort)
+  if (rc < 0) { if (comm->nprocs > 1) error->one(FLERR,polar_last_error(h)); else error->all(FLERR,polar_last_error(h)); }
   else if (rc == POLAR_WARN_NOT_CONVERGED) error->warning(FLERR,polar_last_warning(h));  // PS.cpp:1233
+}
+
+/* ----------------------------------------------------------------------
+   `debug yes`: the reference's prints (PS.cpp:391-404, 633-640, 1182-1191), same formats.  The two
+   "polar force on atom 0" lines of the reference print loop temporaries of its last pair and are
+   not reproduced.
+------------------------------------------------------------------------- */
+
+void PairLJCutCoulLongPolarizationMI355X::debug_prints(const polar_result &res)
+{
+  std::vector<double> trace((size_t) res.sweeps + 8);
+  const int nt = polar_get_debug_trace(h,trace.data(),(int) trace.size());
+  for (int k = 0; k < nt; k++)
+    printf("u_polar (K) %d: %.18f\n",k,trace[k]*22.432653052265*22.432653052265);     // PS.cpp:1190
+  if (screen) fprintf(screen,"iterations: %d\n",res.iterations);                       // PS.cpp:391
+  double u_polar = 0.0;
+  for (int i = 0; i < atom->nlocal; i++)
+    u_polar += atom->ef_static[i][0]*atom->mu_induced[i][0] + atom->ef_static[i][1]*atom->mu_induced[i][1] +
+               atom->ef_static[i][2]*atom->mu_induced[i][2];
+  u_polar *= -0.5;
+  printf("u_polar: %.18f\n",u_polar);                                                  // PS.cpp:403
+  printf("self: %.18f\nef: %.18f\ndd: %.18f\n",res.u_self,res.u_ef,res.u_dd);        // PS.cpp:635
+  printf("u_polar calc: %.18f\n",res.eng_pol);
+  if (atom->nlocal > 0) printf("pos of atom 0: %.5f,%.5f,%.5f\n",atom->x[0][0],atom->x[0][1],atom->x[0][2]);
 }
 
 /* ---------------------------------------------------------------------- */
@@ -122,6 +149,7 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
   force->pair->eng_pol = res.eng_pol;   // PS.cpp:641 (zero on steps without eflag)
   if (vflag_global) for (int k = 0; k < 6; k++) virial[k] += res.virial[k];
   if (vflag_fdotr) virial_fdotr_compute();
+  if (debug_flag) debug_prints(res);
 }
 
 /* ----------------------------------------------------------------------
@@ -198,6 +226,12 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization: device_neigh is not available on several MPI ranks yet");
   if (eflag_atom || vflag_atom)
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization: per-atom tallies are not available on several MPI ranks yet");
+  if (!force->newton_pair)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization on several MPI ranks needs newton_pair on");
+  // halo atoms are LAMMPS ghosts: the ghost shell must reach as far as the polarization loops do
+  const double reach = MAX(pst.cut_coul,pst.dd_cutoff);
+  if (comm->cutghost[0] < reach || comm->cutghost[1] < reach || comm->cutghost[2] < reach)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization: ghost cutoff is shorter than max(cut_coul,dd_cutoff): use comm_modify cutoff");
   const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
   const bool relist = neighbor->ago == 0 || (int) lib_of_lammps.size() != nall;
   if (relist) build_halo_map();
@@ -221,6 +255,19 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
   }
   check(polar_set_row_range(h,0,nlocal));
   check(polar_set_global_count(h,(long long) atom->natoms));
+  check(polar_set_newton(h,1));
+  if (pst.use_previous) {
+    // the initial guess is atom->mu_induced (PS.cpp:376-386): it migrates with the atoms (AtomVecFullPolar packs it
+    // into exchange records) and reaches the ghosts through forward_comm; the library's resident copy is in LAST
+    // step's library order and must not be trusted across a relist, a sort or a migration
+    comm->forward_comm_pair(this);
+    sh_mu.resize(3 * (size_t) sh_n + 3);
+    for (int k = 0; k < sh_n; k++) {
+      const double *m = atom->mu_induced[lammps_of_lib[k]];
+      sh_mu[3*k] = m[0]; sh_mu[3*k+1] = m[1]; sh_mu[3*k+2] = m[2];
+    }
+    check(polar_upload_mu(h,sh_mu.data(),3 * (long long) sh_n));
+  }
 
   const int ef = eflag_either ? 1 : 0, vf = vflag_global ? 1 : 0;
   polar_result res;
@@ -267,6 +314,7 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
     eng_vdwl += res.eng_vdwl;
     eng_coul += res.eng_coul;
   }
+  if (debug_flag && comm->me == 0) debug_prints(res);
   force->pair->eng_pol = res.eng_pol;   // this rank's share; compute pe / thermo sum over ranks
   if (vflag_global) for (int k = 0; k < 6; k++) virial[k] += res.virial[k];
   if (vflag_fdotr) virial_fdotr_compute();
@@ -364,6 +412,7 @@ void PairLJCutCoulLongPolarizationMI355X::init_style()
   polar_settings pst;
   check(polar_get_settings(h,&pst));
   device_neigh = pst.device_neigh;
+  debug_flag = pst.debug;
   if (device_neigh) {
     // extension keyword `device_neigh yes`: the library bins locals + ghosts and builds the (full) list
     // itself (polar_build_neighbors), so Neighbor never builds this request -- it still decides WHEN to

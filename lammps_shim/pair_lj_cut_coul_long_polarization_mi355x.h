@@ -21,8 +21,8 @@ PairStyle(lj/cut/coul/long/polarization,PairLJCutCoulLongPolarizationMI355X)
 
 #include "pair.h"
 #include <vector>
+#include "polar_mi355x.h"
 
-struct polar_handle;
 
 namespace LAMMPS_NS {
 
@@ -52,6 +52,7 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   double **epsilon, **sigma, **cut_lj;   // row-pointer views into the library's tables (extract())
   int pair_inited;
   int device_neigh;                      // extension keyword: list built by polar_build_neighbors
+  int debug_flag;                        // keyword `debug yes`: the reference's prints (debug_prints)
   // one MPI rank per GPU: library order = [own | halo (one ghost per foreign tag) | other ghosts]
   int nhalo, sh_n;
   std::vector<int> lib_of_lammps, lammps_of_lib, halo_ghost, sh_nn, sh_flat, sh_idx, sh_t, sh_m;
@@ -62,6 +63,7 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   void exchange_dipoles();
   virtual void allocate();
   void check(int rc);                    // C-ABI status -> error->all / error->warning
+  void debug_prints(const polar_result &res);
   void sync_views();
 };
 

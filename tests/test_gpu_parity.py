@@ -255,6 +255,13 @@ def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
     tol = 1e-11 if mode == "jacobi" else 1e-8
     assert np.max(np.abs(mu - ref["mu"])) / np.max(np.abs(ref["mu"])) < tol
     assert force_rel_err(f, fref) < max(tol, 1e-9)
+    # the CPU oracle on the same system (LAMMPS half list, same truncated model) is the reference proper
+    sh, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
+    orc = oracle.compute(sh, eflag=1, vflag=2)
+    assert np.max(np.abs(mu - orc["mu"])) / np.max(np.abs(orc["mu"])) < TOL
+    assert force_rel_err(f, oracle.fold_ghost_forces(orc["f"], sh.owner, sh.nlocal)) < TOL
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert rel(tot[k], orc[k], 1e-9) < TOL
     for k in ("eng_vdwl", "eng_coul", "eng_pol"):
         assert rel(tot[k], ref[k]) < max(tol, 1e-10)
     assert len({o["iterations"] for o in outs}) == 1
@@ -264,13 +271,20 @@ def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
     assert np.max(np.abs(vir - ref["virial"])) < max(tol, 1e-9) * np.max(np.abs(ref["virial"]))
 
 
-@pytest.mark.parametrize("knob", ["POLAR_SWEEP_KERNEL=1", "POLAR_CACHE_R2=0", "POLAR_CACHE_R2=1", "POLAR_CACHE_R2=2"])
+@pytest.mark.parametrize("knob", ["POLAR_SWEEP_KERNEL=1", "POLAR_SWEEP_KERNEL=0", "POLAR_SWEEP_KERNEL=0;POLAR_CACHE_R2=0",
+                                  "POLAR_SWEEP_KERNEL=0;POLAR_CACHE_R2=1", "POLAR_SWEEP_KERNEL=0;POLAR_CACHE_R2=2",
+                                  "POLAR_SWEEP_KERNEL=2;POLAR_LP_TILES=1", "POLAR_SWEEP_KERNEL=2;POLAR_LP_DEPTH=2",
+                                  "POLAR_SWEEP_KERNEL=2;POLAR_LP_DEPTH=3", "POLAR_SWEEP_KERNEL=3",
+                                  "POLAR_SWEEP_KERNEL=3;POLAR_CLUSTER_MAX=2"])
 def test_alternative_sweep_kernels_agree(knob, wl, pkg, oracle, monkeypatch):
-    """The list sweep exists in several forms: the lane-per-pair kernel (POLAR_SWEEP_KERNEL=1, kept as a
-    cross-check) and the component-per-lane kernel with its three stream modes (POLAR_CACHE_R2: cached (s3,s5), cached r^2, nothing cached -- normally chosen by size).  All
-    must reproduce the oracle (Jacobi sweep by sweep, GS at the fixed point; both damping types)."""
-    name, val = knob.split("=")
-    monkeypatch.setenv(name, val)
+    """The list sweep exists in several forms besides the default (k_field_lp, two LDS tiles): the register-staged
+    lane-per-pair kernel (POLAR_SWEEP_KERNEL=1), the component-per-lane kernel of round 1 (0) with its three stream modes
+    (POLAR_CACHE_R2: cached (s3,s5), cached r^2, nothing cached), k_field_lp with one tile or with hand-counted
+    gathers two / three trips ahead, and the cluster-row sweep (3).  All must reproduce the oracle (Jacobi sweep by
+    sweep, GS at the fixed point; both damping types)."""
+    for kv in knob.split(";"):
+        name, val = kv.split("=")
+        monkeypatch.setenv(name, val)
     extra = ["use_previous", "no", "polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "4",
              "dd_cutoff", "9.0"]
     s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
@@ -295,29 +309,54 @@ def test_alternative_sweep_kernels_agree(knob, wl, pkg, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["bulk_h2", "mof5_h2", "sifsix_co2"])
-def test_device_neighbor_build_matches_uploaded_list(case, wl, pkg, oracle):
-    """polar_build_neighbors (device cell grid over locals + ghosts, molecule/intra exclusion,
-    special-bond bits) against the host-built LAMMPS-style half list: same forces on the local atoms
-    (ghost forces of the half list folded back), same energies, same virial (pairwise tally on the
-    full list == fdotr over locals + ghosts on the half list)."""
+def test_device_neighbor_build_matches_reference_golden(case, wl, pkg, oracle):
+    """polar_build_neighbors (device cell grid over locals + ghosts, molecule/intra exclusion, special-bond bits)
+    against the REFERENCE's own numbers for the same system (tests/golden/ref_<case>__ranked.npz, produced by the
+    reference's compiled pair style on LAMMPS' half list): same forces on the local atoms (the golden has the ghost
+    forces of the half list folded back), same energies, same virial (pairwise tally on the full list == fdotr over
+    locals + ghosts on the half list), same dipoles."""
+    z = np.load(os.path.join(GOLD, f"ref_{case}__ranked.npz"))
     s, _ = wl.load_fixture(os.path.join(GOLD, case + ".npz"), extra_args=["use_previous", "no"])
-    p = pkg.pair_from_system(s)
-    ref = p.compute(eflag=1, vflag=2)
-    fref = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
-    p.build_neighbors_from_system(s)
+    p = pkg.pair_from_system(s, device_neigh=True)
     out = p.compute(eflag=1, vflag=2)
     assert np.all(out["f"][s.nlocal:] == 0.0)          # a full list leaves no force on ghosts
-    assert force_rel_err(out["f"][:s.nlocal], fref) < 1e-10
-    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
-        assert rel(out[k], ref[k], 1e-9) < 1e-10
-    assert np.max(np.abs(out["virial"] - ref["virial"])) < 1e-9 * np.max(np.abs(ref["virial"]))
+    assert force_rel_err(out["f"][:s.nlocal], z["f"]) < TOL
+    e = z["energies"]
+    for k, name in enumerate(("eng_vdwl", "eng_coul", "eng_pol")):
+        assert rel(out[name], e[k], 1e-6) < TOL
+    assert np.max(np.abs(out["virial"] - z["virial"])) < TOL * max(1.0, np.max(np.abs(z["virial"])))
+    assert np.max(np.abs(out["mu"] - z["mu"])) / np.max(np.abs(z["mu"])) < TOL
+    # the oracle on the uploaded half list says the same (forces folded)
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    fref = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
+    assert force_rel_err(out["f"][:s.nlocal], fref) < TOL
     # per-atom tallies work on the device list too (rows are complete by construction)
     pa = p.compute(eflag=3, vflag=5)
-    assert rel(pa["eatom"].sum(), ref["eng_vdwl"] + ref["eng_coul"], 1e-9) < 1e-9
-    # going back to an uploaded half list restores the newton-on behaviour
+    assert rel(pa["eatom"].sum(), e[0] + e[1], 1e-9) < TOL
+    # going back to an uploaded half list restores the newton-on behaviour: ghost forces as the oracle has them
     p.set_neighbors_csr(s.ilist, s.numneigh, s.firstneigh, s.neigh)
     again = p.compute(eflag=1, vflag=2)
     assert np.max(np.abs(again["f"] - ref["f"])) < 1e-9 * np.max(np.abs(ref["f"]))
+    p.close()
+
+
+def test_debug_trace_matches_the_oracle(wl, pkg, oracle):
+    """`debug yes`: u_polar = -1/2 sum E_static . mu after every sweep (PS.cpp:1182-1191), exact mode, ranked GS
+    and Jacobi (where the reference forms it before "mu = mu_new")."""
+    for extra in ([], ["polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "6"]):
+        s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=["use_previous", "no", "debug", "yes"] + extra)
+        ref = oracle.compute(s, eflag=1, vflag=2, trace=True)
+        p = pkg.pair_from_system(s)
+        out = p.compute()
+        tr = p.debug_trace()
+        p.close()
+        assert len(tr) == out["sweeps"] == ref["sweeps"]
+        assert np.max(np.abs(tr - ref["utrace"][:len(tr)])) < 1e-9 * np.max(np.abs(ref["utrace"][:len(tr)]))
+    # without the keyword nothing is recorded
+    s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=["use_previous", "no"])
+    p = pkg.pair_from_system(s)
+    p.compute()
+    assert len(p.debug_trace()) == 0
     p.close()
 
 
@@ -334,6 +373,8 @@ def test_compact_shards_with_point_to_point_halos_match_single_handle(comm, wl, 
     s = wl.replicate_fixture(path, 1, 1, 4, extra_args=extra)            # 5,396 atoms, z slabs of one cell each
     ref = pkg.pair_from_system(s).compute()
     fref = oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)
+    orc = oracle.compute(s, eflag=1, vflag=2)                            # the CPU oracle in the same truncated model
+    forc = oracle.fold_ghost_forces(orc["f"], s.owner, s.nlocal)
     world = 4
     counts, offs = par.split_rows(s.nlocal, world)
     sfull = wl.replicate_fixture(path, 1, 1, 4, extra_args=extra, rows=np.arange(s.nlocal), full=True)
@@ -424,6 +465,12 @@ def test_compact_shards_with_point_to_point_halos_match_single_handle(comm, wl, 
         assert np.all(fr[hi - lo:] == 0)                       # halo and ghost atoms receive no force
         mu[lo:hi] = be.pair.download("mu", 3 * nloc).reshape(-1, 3)[:hi - lo]
     assert np.max(np.abs(mu - ref["mu"])) / np.max(np.abs(ref["mu"])) < 1e-8
+    # ... and against the oracle (sequential GS on the CPU; the shards iterate colour-phase GS inside a rank and
+    # block-Jacobi across ranks: same fixed point)
+    assert np.max(np.abs(mu - orc["mu"])) / np.max(np.abs(orc["mu"])) < TOL
+    assert force_rel_err(f, forc) < TOL
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert rel(sum(o[k] for o in outs), orc[k]) < TOL
     # (replicas of the framework are different molecules and overlap at bonded distances: forces span eight
     #  orders of magnitude here, so the per-atom relative measure gets the parity tolerance and the tight
     #  bound is taken relative to the largest force)
