@@ -85,14 +85,17 @@ int polar_pair_settings(polar_handle *h, int narg, const char *const *arg);
 int polar_pair_coeff(polar_handle *h, int ntypes, int narg, const char *const *arg);
 /* Pair::modify_params subset used with this style (src/pair.cpp:125-185): mix, shift, table, tabinner. */
 int polar_pair_modify(polar_handle *h, int narg, const char *const *arg);
-/* Pair::init + ::init_style + ::init_one for all pairs (src/pair.cpp:189-263, PS.cpp:806-921) and
- * Pair::init_tables (src/pair.cpp:313-520).  g_ewald = force->kspace->g_ewald (PS.cpp:847),
- * qqrd2e/special_* = Force members.  Uploads the tables to the device. */
+/* Pair::init + ::init_style + ::init_one for all pairs (src/pair.cpp:189-263, PS.cpp:806-921): mixing, lj1..lj4,
+ * offset, cutsq, uploaded to the device.  g_ewald = force->kspace->g_ewald (PS.cpp:847), qqrd2e/special_* = Force
+ * members.  The Coulomb lookup tables of Pair::init_tables (src/pair.cpp:313-520, called at PS.cpp:851) stay LAMMPS
+ * host code: unless `pair_modify table 0` is in force, hand them over with polar_set_coul afterwards --
+ * compute entry points and polar_pair_single refuse to run without them. */
 int polar_pair_init(polar_handle *h, double g_ewald, double qqrd2e, const double special_lj[4],
                     const double special_coul[4]);
 /* ::init_one return value (cutoff) for a type pair, after polar_pair_init. */
 double polar_pair_cut(const polar_handle *h, int itype, int jtype);
-/* ::single, PS.cpp:1035-1097 (LJ + real-space Coulomb only).  Host arithmetic. */
+/* ::single, PS.cpp:1035-1097 (LJ + real-space Coulomb only).  Host arithmetic.  Returns NaN (message in
+ * polar_last_error) when the Coulomb tables it needs were not handed over. */
 double polar_pair_single(const polar_handle *h, double qi, double qj, int itype, int jtype, double rsq,
                          double factor_coul, double factor_lj, double *fforce);
 /* ::extract, PS.cpp:1101-1109: "cut_coul" (dim 0), "epsilon"/"sigma" (dim 2, [(n+1)*(n+1)] row-major). */
@@ -104,7 +107,9 @@ int polar_set_settings(polar_handle *h, const polar_settings *s);
 /* tables are [(ntypes+1)*(ntypes+1)] row-major as lj1[i][j] (PS.h:62) */
 int polar_set_types(polar_handle *h, int ntypes, const double *lj1, const double *lj2, const double *lj3,
                     const double *lj4, const double *offset, const double *cut_ljsq, const double *cutsq);
-/* Pair::{rtable,drtable,ftable,dftable,ctable,dctable,etable,detable}; ncoultablebits==0: none */
+/* Pair::{rtable,drtable,ftable,dftable,ctable,dctable,etable,detable} with Pair::ncoultablebits, ncoulmask,
+ * ncoulshiftbits, tabinnersq as Pair::init_tables left them (src/pair.h:205-216); ncoultablebits == 0: no table.
+ * A host copy serves polar_pair_single. */
 int polar_set_coul(polar_handle *h, double g_ewald, double qqrd2e, const double special_lj[4],
                    const double special_coul[4], int ncoultablebits, int ncoulmask, int ncoulshiftbits,
                    double tabinnersq, const double *rtable, const double *drtable, const double *ftable,

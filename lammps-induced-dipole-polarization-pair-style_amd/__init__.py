@@ -214,6 +214,17 @@ class PolarPair:
         sc = np.asarray(special_coul, dtype=np.float64)
         self._ck(self.L.polar_pair_init(self.h, g_ewald, qqrd2e, _dptr(slj), _dptr(sc)))
 
+    def set_coul(self, g_ewald, qqrd2e, coul, special_lj=(1.0, 0.0, 0.0, 0.0), special_coul=(1.0, 0.0, 0.0, 0.0)):
+        """Hand over the Coulomb lookup tables (what a LAMMPS shim takes from Pair::init_tables; tests take them from
+        workload.init_coul_tables): ``coul`` = dict(nbits, mask, shift, tabinnersq, tables[8][2**nbits])."""
+        slj = np.asarray(special_lj, dtype=np.float64)
+        sc = np.asarray(special_coul, dtype=np.float64)
+        tb = np.ascontiguousarray(coul["tables"], dtype=np.float64)
+        rows = [np.ascontiguousarray(tb[k]) for k in range(8)]
+        self._keep = rows
+        self._ck(self.L.polar_set_coul(self.h, g_ewald, qqrd2e, _dptr(slj), _dptr(sc), int(coul["nbits"]), int(coul["mask"]),
+                                       int(coul["shift"]), float(coul["tabinnersq"]), *[_dptr(r) for r in rows]))
+
     def get_settings(self):
         s = Settings()
         self._ck(self.L.polar_get_settings(self.h, C.byref(s)))
@@ -225,6 +236,8 @@ class PolarPair:
     def single(self, qi, qj, itype, jtype, rsq, factor_coul=1.0, factor_lj=1.0):
         ff = C.c_double()
         e = self.L.polar_pair_single(self.h, qi, qj, itype, jtype, rsq, factor_coul, factor_lj, C.byref(ff))
+        if e != e:  # NaN: the library could not evaluate the pair (message in polar_last_error)
+            raise PolarError(-1, self.L.polar_last_error(self.h).decode())
         return e, ff.value
 
     def extract(self, name):
@@ -391,6 +404,8 @@ def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0, device_nei
     for r in rows:
         p.coeff(sysm.ntypes, list(r))
     p.init(sysm.g_ewald, sysm.qqrd2e, sysm.special_lj, sysm.special_coul)
+    if sysm.coul["nbits"]:  # the role of Pair::init_tables (PS.cpp:851) is played by workload.init_coul_tables
+        p.set_coul(sysm.g_ewald, sysm.qqrd2e, sysm.coul, sysm.special_lj, sysm.special_coul)
     if device_neigh:
         p._ck(p.L.polar_set_newton(p.h, int(sysm.extra.get("newton_pair", 1))))
         p.set_box(sysm.boxlo, sysm.prd, tilt=getattr(sysm, "tilt", (0.0, 0.0, 0.0)), triclinic=int(getattr(sysm, "triclinic", 0)))

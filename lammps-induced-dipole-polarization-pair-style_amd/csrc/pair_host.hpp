@@ -5,7 +5,7 @@
 //   coeff      <- ::coeff                                   PS.cpp:772-800
 //   modify     <- Pair::modify_params (subset)              src/pair.cpp:125-185
 //   init       <- Pair::init / ::init_style / ::init_one    src/pair.cpp:189-263, PS.cpp:806-921
-//   tables     <- Pair::init_bitmap / Pair::init_tables     src/pair.cpp:1676-1723, 313-520
+//   tables     <- handed over (polar_set_coul); Pair::init_tables stays LAMMPS host code
 //   single     <- ::single                                  PS.cpp:1035-1097
 // Pure host C++ (no HIP); the device library consumes the tables it produces.
 #pragma once
@@ -248,8 +248,7 @@ class PairHost {
       if (setflag[i * w() + i] == 0) throw InputError("All pair coeffs are not set");
     g_ewald = g; qqrd2e = qq;
     for (int k = 0; k < 4; k++) { special_lj[k] = slj[k]; special_coul[k] = scoul[k]; }
-    if (ncoultablebits) init_tables();  // PS.cpp:851
-    else tab = CoulTables();
+    tab = CoulTables();  // PS.cpp:851 builds the tables here; this library receives them through polar_set_coul
     for (int i = 1; i <= ntypes; i++)
       for (int j = i; j <= ntypes; j++) {
         double cut = init_one(i, j);
@@ -258,96 +257,19 @@ class PairHost {
     inited = true;
   }
 
-  static void init_bitmap(double inner, double outer, int ntablebits, int &masklo, int &maskhi, int &nmask,
-                          int &nshiftbits) {  // src/pair.cpp:1676-1723
-    int nlowermin = 1;
-    while (!((std::pow(2.0, (double)nlowermin) <= inner * inner) && (std::pow(2.0, (double)nlowermin + 1.0) > inner * inner))) {
-      if (std::pow(2.0, (double)nlowermin) <= inner * inner) nlowermin++;
-      else nlowermin--;
+  // The Coulomb lookup tables (Pair::init_tables, src/pair.cpp:313-520) are NOT generated here: SURVEY 8(b) keeps them
+  // LAMMPS host code.  The shim hands over the arrays Pair::init_tables built (polar_set_coul); tests and the bench
+  // hand over workload.init_coul_tables' (test infrastructure).  This class only keeps a copy for single().
+  void set_tables(int nbits, int mask, int shift, double tabinnersq, const double *const t[8]) {
+    tab = CoulTables();
+    if (nbits <= 0) return;
+    if (nbits > 24) throw InputError("Too many bits for lookup table");
+    const size_t ntable = (size_t)1 << nbits;
+    for (int k = 0; k < 8; k++) {
+      if (!t[k]) throw InputError("polar_set_coul: null Coulomb table");
+      tab.t[k].assign(t[k], t[k] + ntable);
     }
-    int nexpbits = 0;
-    double required_range = outer * outer / std::pow(2.0, (double)nlowermin);
-    double available_range = 2.0;
-    while (available_range < required_range) {
-      nexpbits++;
-      available_range = std::pow(2.0, std::pow(2.0, (double)nexpbits));
-    }
-    int nmantbits = ntablebits - nexpbits;
-    if (nexpbits > (int)(sizeof(float) * CHAR_BIT) - FLT_MANT_DIG) throw InputError("Too many exponent bits for lookup table");
-    if (nmantbits + 1 > FLT_MANT_DIG) throw InputError("Too many mantissa bits for lookup table");
-    if (nmantbits < 3) throw InputError("Too few bits for lookup table");
-    nshiftbits = FLT_MANT_DIG - (nmantbits + 1);
-    nmask = 1;
-    for (int j = 0; j < ntablebits + nshiftbits; j++) nmask *= 2;
-    nmask -= 1;
-    int_float_t u;
-    u.f = (float)(outer * outer);
-    maskhi = u.i & ~nmask;
-    u.f = (float)(inner * inner);
-    masklo = u.i & ~nmask;
-  }
-
-  void init_tables() {  // src/pair.cpp:313-520, cut_respa == NULL, msmflag == 0
-    const double MY_ISPI4 = 1.12837916709551257390;
-    const double cut_coul = st.cut_coul, cut_coulsq = cut_coul * cut_coul;
-    int masklo, maskhi;
-    double tabinnersq = tabinner * tabinner;
-    init_bitmap(tabinner, cut_coul, ncoultablebits, masklo, maskhi, tab.mask, tab.shift);
-    tab.nbits = ncoultablebits;
-    int ntable = 1;
-    for (int i = 0; i < ncoultablebits; i++) ntable *= 2;
-    for (auto &v : tab.t) v.assign((size_t)ntable, 0.0);
-    auto &rt = tab.t[0], &drt = tab.t[1], &ft = tab.t[2], &dft = tab.t[3], &ct = tab.t[4], &dct = tab.t[5],
-         &et = tab.t[6], &det = tab.t[7];
-    int_float_t rsq_lookup, minrsq_lookup;
-    minrsq_lookup.i = 0 << tab.shift;
-    minrsq_lookup.i |= maskhi;
-    for (int i = 0; i < ntable; i++) {
-      rsq_lookup.i = i << tab.shift;
-      rsq_lookup.i |= masklo;
-      if (rsq_lookup.f < tabinnersq) {
-        rsq_lookup.i = i << tab.shift;
-        rsq_lookup.i |= maskhi;
-      }
-      double r = sqrtf(rsq_lookup.f);
-      double grij = g_ewald * r;
-      double expm2 = std::exp(-grij * grij);
-      double derfc = std::erfc(grij);
-      rt[i] = rsq_lookup.f;
-      ct[i] = qqrd2e / r;
-      ft[i] = qqrd2e / r * (derfc + MY_ISPI4 * grij * expm2);
-      et[i] = qqrd2e / r * derfc;
-      if (rsq_lookup.f < minrsq_lookup.f) minrsq_lookup.f = rsq_lookup.f;
-    }
-    tab.tabinnersq = minrsq_lookup.f;
-    int ntablem1 = ntable - 1;
-    for (int i = 0; i < ntablem1; i++) {
-      drt[i] = 1.0 / (rt[i + 1] - rt[i]);
-      dft[i] = ft[i + 1] - ft[i];
-      dct[i] = ct[i + 1] - ct[i];
-      det[i] = et[i + 1] - et[i];
-    }
-    drt[ntablem1] = 1.0 / (rt[0] - rt[ntablem1]);
-    dft[ntablem1] = ft[0] - ft[ntablem1];
-    dct[ntablem1] = ct[0] - ct[ntablem1];
-    det[ntablem1] = et[0] - et[ntablem1];
-    int itablemin = minrsq_lookup.i & tab.mask;
-    itablemin >>= tab.shift;
-    int itablemax = itablemin - 1;
-    if (itablemin == 0) itablemax = ntablem1;
-    rsq_lookup.i = itablemax << tab.shift;
-    rsq_lookup.i |= maskhi;
-    if (rsq_lookup.f < cut_coulsq) {
-      rsq_lookup.f = (float)cut_coulsq;
-      double r = sqrtf(rsq_lookup.f);
-      double grij = g_ewald * r;
-      double expm2 = std::exp(-grij * grij);
-      double derfc = std::erfc(grij);
-      drt[itablemax] = 1.0 / (rsq_lookup.f - rt[itablemax]);
-      dft[itablemax] = qqrd2e / r * (derfc + MY_ISPI4 * grij * expm2) - ft[itablemax];
-      dct[itablemax] = qqrd2e / r - ct[itablemax];
-      det[itablemax] = qqrd2e / r * derfc - et[itablemax];
-    }
+    tab.nbits = nbits; tab.mask = mask; tab.shift = shift; tab.tabinnersq = tabinnersq;
   }
 
   // PS.cpp:1035-1097
@@ -360,6 +282,7 @@ class PairHost {
     const double cut_coulsq = st.cut_coul * st.cut_coul;
     const int ij = itype * w() + jtype;
     if (rsq < cut_coulsq) {
+      if (ncoultablebits && !tab.nbits) throw InputError("Coulomb tables were not handed over (polar_set_coul after polar_pair_init)");
       if (!tab.nbits || rsq <= tab.tabinnersq) {
         double r = std::sqrt(rsq), grij = g_ewald * r, expm2 = std::exp(-grij * grij);
         double t = 1.0 / (1.0 + EWALD_P * grij);

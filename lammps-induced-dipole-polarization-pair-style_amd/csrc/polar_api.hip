@@ -1003,7 +1003,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
 // PS.cpp:125-386: everything before the solve
 void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   need_device(h);
-  if (!h->types_set || !h->coul_set) throw std::runtime_error("polar_compute before pair tables were set (polar_pair_init or polar_set_types/polar_set_coul)");
+  if (!h->types_set || !h->coul_set) throw std::runtime_error("polar_compute before the pair tables were set: polar_pair_init (or polar_set_types), then polar_set_coul with the Coulomb tables of Pair::init_tables unless pair_modify table 0");
   if (!h->box_set || !h->atoms_set || !h->neigh_set) throw std::runtime_error("polar_compute before polar_set_box/polar_set_atoms/polar_set_neighbors");
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal, nall = h->nlocal + h->nghost;
@@ -1341,14 +1341,18 @@ int polar_pair_init(polar_handle *h, double g_ewald, double qqrd2e, const double
   return guarded(h, [&]() {
     PairHost &p = h->ph;
     p.init(g_ewald, qqrd2e, special_lj, special_coul);
+    h->coul_set = false;
     if (h->have_device) {
       HIPCHECK(hipSetDevice(h->device));
       const double *t[7] = {p.lj1.data(), p.lj2.data(), p.lj3.data(), p.lj4.data(), p.offset.data(), p.cut_ljsq.data(), p.cutsq.data()};
       upload_types(h, p.ntypes, t);
-      const double *c[8];
-      double dummy = 0.0;
-      for (int k = 0; k < 8; k++) c[k] = p.tab.nbits ? p.tab.t[k].data() : &dummy;
-      upload_coul(h, g_ewald, qqrd2e, special_lj, special_coul, p.tab.nbits, p.tab.mask, p.tab.shift, p.tab.tabinnersq, c);
+      if (p.ncoultablebits == 0) {  // pair_modify table 0: the erfc polynomial everywhere, no table to wait for
+        const double *c[8];
+        double dummy = 0.0;
+        for (int k = 0; k < 8; k++) c[k] = &dummy;
+        upload_coul(h, g_ewald, qqrd2e, special_lj, special_coul, 0, 0, 0, 0.0, c);
+      }
+      // otherwise the Coulomb tables of Pair::init_tables (PS.cpp:851) arrive through polar_set_coul
     }
     return POLAR_OK;
   });
@@ -1359,7 +1363,13 @@ double polar_pair_cut(const polar_handle *h, int i, int j) {
 }
 double polar_pair_single(const polar_handle *h, double qi, double qj, int itype, int jtype, double rsq,
                          double factor_coul, double factor_lj, double *fforce) {
-  double ff = 0.0, e = h->ph.single(qi, qj, itype, jtype, rsq, factor_coul, factor_lj, ff);
+  double ff = 0.0, e;
+  try {
+    e = h->ph.single(qi, qj, itype, jtype, rsq, factor_coul, factor_lj, ff);
+  } catch (const std::exception &ex) {  // no status channel in this signature: NaN + polar_last_error
+    const_cast<polar_handle *>(h)->err = ex.what();
+    e = ff = std::nan("");
+  }
   if (fforce) *fforce = ff;
   return e;
 }
@@ -1401,9 +1411,16 @@ int polar_set_coul(polar_handle *h, double g_ewald, double qqrd2e, const double 
                    const double *rtable, const double *drtable, const double *ftable, const double *dftable,
                    const double *ctable, const double *dctable, const double *etable, const double *detable) {
   return guarded(h, [&]() {
-    HIPCHECK(hipSetDevice(h->device));
     const double *c[8] = {rtable, drtable, ftable, dftable, ctable, dctable, etable, detable};
-    upload_coul(h, g_ewald, qqrd2e, special_lj, special_coul, nbits, mask, shift, tabinnersq, c);
+    h->ph.set_tables(nbits, mask, shift, tabinnersq, c);  // host copy: polar_pair_single reads the same table
+    h->ph.g_ewald = g_ewald; h->ph.qqrd2e = qqrd2e;
+    for (int k = 0; k < 4; k++) { h->ph.special_lj[k] = special_lj[k]; h->ph.special_coul[k] = special_coul[k]; }
+    if (h->have_device) {
+      HIPCHECK(hipSetDevice(h->device));
+      double dummy = 0.0;
+      if (nbits <= 0) for (int k = 0; k < 8; k++) c[k] = &dummy;
+      upload_coul(h, g_ewald, qqrd2e, special_lj, special_coul, nbits > 0 ? nbits : 0, mask, shift, tabinnersq, c);
+    }
     return POLAR_OK;
   });
 }

@@ -438,6 +438,13 @@ void PairLJCutCoulLongPolarizationMI355X::init_style()
                          "tail",tail_flag ? "yes" : "no"};
   check(polar_pair_modify(h,10,mod));
   check(polar_pair_init(h,force->kspace->g_ewald,force->qqrd2e,force->special_lj,force->special_coul));
+  // the Coulomb lookup tables stay LAMMPS host code: Pair::init_tables (src/pair.cpp:313-520), as PS.cpp:851 calls it
+  if (ncoultablebits) {
+    init_tables(cut_coul,NULL);
+    check(polar_set_coul(h,force->kspace->g_ewald,force->qqrd2e,force->special_lj,force->special_coul,
+                         ncoultablebits,ncoulmask,ncoulshiftbits,tabinnersq,rtable,drtable,ftable,dftable,
+                         ctable,dctable,etable,detable));
+  }
   sync_views();
   pair_inited = 1;
 }

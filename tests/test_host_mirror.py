@@ -89,6 +89,7 @@ def test_coeff_mixing_and_init_one(pkg, wl):
     p.coeff(3, ["2*3", "2*3", "0.20", "3.5"])      # wildcard bounds, global LJ cutoff 2.5
     p.coeff(3, ["1", "3", "0.05", "3.3", "13.0"])  # explicit cross term with cut_lj > cut_coul
     p.init(0.21, wl.QQR2E_REAL)
+    p.set_coul(0.21, wl.QQR2E_REAL, wl.init_coul_tables(12.0, 0.21, wl.QQR2E_REAL))  # the tables Pair::init_tables would hand over
     # geometric mixing for the unset 1-2 pair (src/pair.cpp:660-690), cutoff = max(cut_lj, cut_coul)
     assert p.cut(1, 2) == 12.0 and p.cut(1, 3) == 13.0 and p.cut(2, 3) == 12.0
     eps12, sig12, cut12 = math.sqrt(0.1 * 0.2), math.sqrt(3.0 * 3.5), math.sqrt(9.0 * 2.5)
@@ -117,6 +118,10 @@ def test_coulomb_tables_match_reference_scheme(pkg, wl):
     p.coeff(1, ["1", "1", "0.0", "1.0"])
     p.init(g, wl.QQR2E_REAL)
     tab = wl.init_coul_tables(cut, g, wl.QQR2E_REAL)
+    # the library does not generate the tables (Pair::init_tables stays LAMMPS host code) and says so
+    with pytest.raises(pkg.PolarError, match="Coulomb tables were not handed over"):
+        p.single(0.4, -0.7, 1, 1, 9.0)
+    p.set_coul(g, wl.QQR2E_REAL, tab)
     for r in (1.2, 1.5, 2.0, 3.7, 7.9, 12.8):
         rsq = r * r
         e, ff = p.single(0.4, -0.7, 1, 1, rsq)
