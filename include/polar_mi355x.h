@@ -50,6 +50,10 @@ typedef struct {
   /* device_neigh yes|no (extension keyword): the LAMMPS shim lets the library build the LJ/Coulomb
    * neighbor list on the device (polar_build_neighbors) instead of uploading Neighbor's list. */
   int device_neigh;
+  /* restart_polar yes|no (extension keyword): write_restart_settings appends the polarization keywords behind the
+   * stock record (polar_restart_pack); off by default, so restart files keep the reference's layout (PS.cpp:976-985),
+   * which stores none of them.  The dipoles persist through the atom style (AtomVecFullPolar::pack_restart). */
+  int restart_polar;
 } polar_settings;
 
 typedef struct {
@@ -101,6 +105,17 @@ double polar_pair_single(const polar_handle *h, double qi, double qj, int itype,
 /* ::extract, PS.cpp:1101-1109: "cut_coul" (dim 0), "epsilon"/"sigma" (dim 2, [(n+1)*(n+1)] row-major). */
 const void *polar_pair_extract(const polar_handle *h, const char *name, int *dim);
 int polar_get_settings(const polar_handle *h, polar_settings *out);
+
+/* Restart persistence of the polarization keywords (the reference persists only the stock
+ * lj/cut/coul/long fields, PS.cpp:976-1009, so after read_restart its defaults apply).  polar_restart_pack writes a
+ * self-describing record -- int32 magic 'POLR', int32 version, int32 payload bytes, payload = precision, damp, gamma,
+ * dd_cutoff (doubles), max_iterations, damp_type, zodid, fixed_iteration, polar_gs, polar_gs_ranked, use_previous, debug,
+ * device_neigh, restart_polar (int32) -- into buf and returns its length (with buf == NULL: the length needed).
+ * polar_restart_unpack applies such a record (cut_lj / cut_coul stay as the stock record set them) and returns
+ * POLAR_ERR_INPUT, changing nothing, when buf does not start with one: a reader can probe the stream and seek back. */
+int polar_restart_pack(const polar_handle *h, void *buf, int max_bytes);
+int polar_restart_unpack(polar_handle *h, const void *buf, int nbytes);
+#define POLAR_RESTART_HEADER_BYTES 12 /* magic, version, payload length */
 
 /* ---- raw setters for a LAMMPS shim that keeps LAMMPS' own tables ------------------------- */
 int polar_set_settings(polar_handle *h, const polar_settings *s);

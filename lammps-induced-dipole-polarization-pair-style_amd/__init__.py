@@ -56,7 +56,7 @@ class Settings(C.Structure):
                 ("polar_damp", C.c_double), ("polar_gamma", C.c_double), ("iterations_max", C.c_int),
                 ("damping_type", C.c_int), ("zodid", C.c_int), ("fixed_iteration", C.c_int), ("polar_gs", C.c_int),
                 ("polar_gs_ranked", C.c_int), ("use_previous", C.c_int), ("debug", C.c_int), ("dd_cutoff", C.c_double),
-                ("device_neigh", C.c_int)]
+                ("device_neigh", C.c_int), ("restart_polar", C.c_int)]
 
 
 class Result(C.Structure):
@@ -112,6 +112,8 @@ EXPORTS = {
     "polar_set_list_style": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_set_newton": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_get_debug_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "polar_restart_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "polar_restart_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "polar_step_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "polar_step_sweep": (C.c_int, [C.c_void_p]),
     "polar_step_sweep_end": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -224,6 +226,16 @@ class PolarPair:
         self._keep = rows
         self._ck(self.L.polar_set_coul(self.h, g_ewald, qqrd2e, _dptr(slj), _dptr(sc), int(coul["nbits"]), int(coul["mask"]),
                                        int(coul["shift"]), float(coul["tabinnersq"]), *[_dptr(r) for r in rows]))
+
+    def restart_pack(self):
+        """The polarization keywords as the record write_restart_settings appends with ``restart_polar yes``."""
+        n = self.L.polar_restart_pack(self.h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._ck(self.L.polar_restart_pack(self.h, buf, n))
+        return buf.raw
+
+    def restart_unpack(self, data):
+        self._ck(self.L.polar_restart_unpack(self.h, C.c_char_p(bytes(data)), len(data)))
 
     def get_settings(self):
         s = Settings()

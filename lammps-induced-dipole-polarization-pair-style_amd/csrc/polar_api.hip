@@ -75,6 +75,29 @@ inline void zero_many(hipStream_t s, std::initializer_list<std::pair<void *, siz
 // grid of a kernel that places its workgroups with xcd_block(): 8 * ceil(nblocks / 8)
 inline int nblk_xcd(long long n, int per) { return ((nblk(n, per) + 7) / 8) * 8; }
 
+// widths of the simulation cell between opposite faces: the box lengths, or V / |face area| when the box is tilted
+inline void box_widths(const Box &b, double w[3]) {
+  w[0] = b.prd[0]; w[1] = b.prd[1]; w[2] = b.prd[2];
+  if (!b.triclinic) return;
+  const double vol = b.prd[0] * b.prd[1] * b.prd[2];
+  const double bxc[3] = {b.prd[1] * b.prd[2], -b.xy * b.prd[2], b.xy * b.yz - b.prd[1] * b.xz};  // b x c
+  w[0] = vol / std::sqrt(bxc[0] * bxc[0] + bxc[1] * bxc[1] + bxc[2] * bxc[2]);
+  w[1] = vol / (b.prd[0] * std::sqrt(b.prd[2] * b.prd[2] + b.yz * b.yz));                      // |a x c|
+}
+// squared minimum-image distance on the host (colouring, clustering): the rule of min_image_rint
+inline double min_image_dist2(const Box &b, const double *xi, const double *xj) {
+  double d[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
+  if (b.triclinic) {
+    if (b.periodic[2]) { const double n = std::nearbyint(d[2] / b.prd[2]); d[2] -= n * b.prd[2]; d[1] -= n * b.yz; d[0] -= n * b.xz; }
+    if (b.periodic[1]) { const double n = std::nearbyint(d[1] / b.prd[1]); d[1] -= n * b.prd[1]; d[0] -= n * b.xy; }
+    if (b.periodic[0]) d[0] -= b.prd[0] * std::nearbyint(d[0] / b.prd[0]);
+  } else {
+    for (int k = 0; k < 3; k++)
+      if (b.periodic[k]) d[k] -= b.prd[k] * std::nearbyint(d[k] / b.prd[k]);
+  }
+  return d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+}
+
 }  // namespace
 
 struct polar_handle {
@@ -271,14 +294,17 @@ void build_cells(polar_handle *h) {
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
   const double cutall = std::max(st.cut_coul, st.dd_cutoff);
+  double width[3];
+  box_widths(h->box, width);
   for (int k = 0; k < 3; k++)
-    if (h->box.periodic[k] && h->box.prd[k] < 2.0 * cutall * (1.0 - 1e-12))
+    if (h->box.periodic[k] && width[k] < 2.0 * cutall * (1.0 - 1e-12))
       throw InputError("dd_cutoff mode needs box lengths >= 2*max(cut_coul,dd_cutoff); use exact mode (dd_cutoff 0)");
   CellGrid &g = h->grid;
   g.trim = getenv("POLAR_NL_TRIM") ? atoi(getenv("POLAR_NL_TRIM")) : 1;
+  if (h->box.triclinic) g.trim = 0;  // the per-atom stencil trimming measures orthogonal distances
   long long ncell = 1;
   for (int k = 0; k < 3; k++) {
-    g.nc[k] = std::max(1, (int)std::floor(h->box.prd[k] / (0.5 * cutall)));  // edge >= cutoff/2: +-2 stencil
+    g.nc[k] = std::max(1, (int)std::floor(width[k] / (0.5 * cutall)));  // cell height >= cutoff/2: +-2 stencil
     g.lo[k] = h->boxlo[k];
     g.inv[k] = g.nc[k] / h->box.prd[k];
     ncell *= g.nc[k];
@@ -398,15 +424,7 @@ void build_cluster_colors(polar_handle *h, const std::vector<double> &rank, cons
   const bool gs = st.polar_gs || st.polar_gs_ranked;
   const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
   const double dcl = std::min(h->cluster_dist, h->color_dist), dcl2 = dcl * dcl;
-  auto dist2 = [&](int i, int j) {
-    double rsq = 0;
-    for (int k = 0; k < 3; k++) {
-      double d = h->hx[3 * (size_t)i + k] - h->hx[3 * (size_t)j + k];
-      if (h->box.periodic[k]) d -= h->box.prd[k] * std::nearbyint(d / h->box.prd[k]);
-      rsq += d * d;
-    }
-    return rsq;
-  };
+  auto dist2 = [&](int i, int j) { return min_image_dist2(h->box, &h->hx[3 * (size_t)i], &h->hx[3 * (size_t)j]); };
   auto row_atom = [&](int i) { return i >= lo && i < hi && h->halpha[i] != 0.0; };
   std::vector<int> cl_of((size_t)n, -1);
   std::vector<int> mem;  // 4 per cluster
@@ -555,10 +573,14 @@ void build_colors(polar_handle *h, const std::vector<double> &rank) {
   const double dc = h->color_dist, dcsq = dc * dc;
   int nc[3];
   long long ncell = 1;
-  for (int k = 0; k < 3; k++) { nc[k] = std::max(1, (int)std::floor(h->box.prd[k] / dc)); nc[k] = std::min(nc[k], 512); ncell *= nc[k]; }
+  double width[3];
+  box_widths(h->box, width);
+  for (int k = 0; k < 3; k++) { nc[k] = std::max(1, (int)std::floor(width[k] / dc)); nc[k] = std::min(nc[k], 512); ncell *= nc[k]; }
   auto cellof = [&](int i, int c[3]) {
+    double fr3[3];
+    frac_coords(h->box, h->boxlo, h->hx[3 * (size_t)i], h->hx[3 * (size_t)i + 1], h->hx[3 * (size_t)i + 2], fr3);
     for (int k = 0; k < 3; k++) {
-      double fr = (h->hx[3 * (size_t)i + k] - h->boxlo[k]) / h->box.prd[k];
+      double fr = fr3[k];
       fr -= std::floor(fr);
       c[k] = std::min(nc[k] - 1, (int)(fr * nc[k]));
     }
@@ -594,12 +616,7 @@ void build_colors(polar_handle *h, const std::vector<double> &rank) {
           seen[nseen++] = cj;
           for (int j : cells[cj]) {
             if (j == i) continue;
-            double rsq = 0;
-            for (int k = 0; k < 3; k++) {
-              double d = h->hx[3 * (size_t)i + k] - h->hx[3 * (size_t)j + k];
-              if (h->box.periodic[k]) d -= h->box.prd[k] * std::nearbyint(d / h->box.prd[k]);
-              rsq += d * d;
-            }
+            const double rsq = min_image_dist2(h->box, &h->hx[3 * (size_t)i], &h->hx[3 * (size_t)j]);
             if (rsq < dcsq) adj[i].push_back(j);
           }
         }
@@ -1009,7 +1026,8 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   const int n = h->nlocal, nall = h->nlocal + h->nghost;
   const bool ap = !(st.dd_cutoff > 0.0);
   if (ap && own_n(h) != n) throw InputError("row sharding needs dd_cutoff > 0 (exact all-pairs mode runs as replicas only)");
-  if (!ap && h->box.triclinic) throw InputError("dd_cutoff (list) mode needs an orthogonal box; triclinic boxes run in exact mode");
+  if (!ap && h->box.triclinic && (h->sweep_kernel != 2 || h->lp_depth != 0))
+    throw InputError("dd_cutoff (list) mode in a triclinic box needs the default sweep kernel (k_field_lp)");
   const int vmode = vflag % 4;
   hipStream_t s = h->stream;
   h->warn.clear();
@@ -1387,6 +1405,50 @@ int polar_get_settings(const polar_handle *h, polar_settings *out) {
   if (!h || !out) return POLAR_ERR_STATE;
   *out = h->ph.st;
   return POLAR_OK;
+}
+namespace {
+const int kRestartMagic = 0x524C4F50;  // 'POLR' (little endian)
+const int kRestartVersion = 1;
+const int kRestartPayload = 4 * (int)sizeof(double) + 10 * (int)sizeof(int);
+}
+int polar_restart_pack(const polar_handle *h, void *buf, int max_bytes) {
+  if (!h) return POLAR_ERR_STATE;
+  const int total = POLAR_RESTART_HEADER_BYTES + kRestartPayload;
+  if (!buf) return total;
+  if (max_bytes < total) return POLAR_ERR_INPUT;
+  const polar_settings &st = h->ph.st;
+  char *p = (char *)buf;
+  const int head[3] = {kRestartMagic, kRestartVersion, kRestartPayload};
+  memcpy(p, head, sizeof(head)); p += sizeof(head);
+  const double d[4] = {st.polar_precision, st.polar_damp, st.polar_gamma, st.dd_cutoff};
+  memcpy(p, d, sizeof(d)); p += sizeof(d);
+  const int iv[10] = {st.iterations_max, st.damping_type, st.zodid, st.fixed_iteration, st.polar_gs, st.polar_gs_ranked,
+                      st.use_previous, st.debug, st.device_neigh, st.restart_polar};
+  memcpy(p, iv, sizeof(iv));
+  return total;
+}
+int polar_restart_unpack(polar_handle *h, const void *buf, int nbytes) {
+  return guarded(h, [&]() {
+    if (!buf || nbytes < POLAR_RESTART_HEADER_BYTES) throw InputError("not a polarization restart record");
+    const char *p = (const char *)buf;
+    int head[3];
+    memcpy(head, p, sizeof(head)); p += sizeof(head);
+    if (head[0] != kRestartMagic) throw InputError("not a polarization restart record");
+    if (head[1] != kRestartVersion || head[2] != kRestartPayload || nbytes < POLAR_RESTART_HEADER_BYTES + head[2])
+      throw InputError("polarization restart record of an unknown version or length");
+    double d[4]; int iv[10];
+    memcpy(d, p, sizeof(d)); p += sizeof(d);
+    memcpy(iv, p, sizeof(iv));
+    polar_settings s = h->ph.st;  // the cutoffs stay as the stock record set them
+    s.polar_precision = d[0]; s.polar_damp = d[1]; s.polar_gamma = d[2]; s.dd_cutoff = d[3];
+    s.iterations_max = iv[0]; s.damping_type = iv[1]; s.zodid = iv[2]; s.fixed_iteration = iv[3]; s.polar_gs = iv[4];
+    s.polar_gs_ranked = iv[5]; s.use_previous = iv[6]; s.debug = iv[7]; s.device_neigh = iv[8]; s.restart_polar = iv[9];
+    if (s.zodid && (s.polar_gs || s.polar_gs_ranked)) throw InputError("Zodid doesn't work with polar_gs or polar_gs_ranked");
+    if (s.polar_gs && s.polar_gs_ranked) throw InputError("polar_gs and polar_gs_ranked are mutually exclusive");
+    h->ph.st = s;
+    h->colors_valid = false; h->nl_pitch = h->dd_pitch = 0; h->cl_pitch = 0;
+    return POLAR_OK;
+  });
 }
 int polar_set_settings(polar_handle *h, const polar_settings *s) {
   return guarded(h, [&]() {

@@ -199,9 +199,30 @@ __device__ __forceinline__ void row_range(const RowList &L, int i, long long &be
 __device__ __forceinline__ void min_image_rint(const Box &b, double xi, double yi, double zi, double xj, double yj,
                                                double zj, double &dx, double &dy, double &dz) {
   dx = xi - xj; dy = yi - yj; dz = zi - zj;
+  if (b.triclinic) {
+    // tilted box (list mode): whole lattice vectors c = (xz, yz, zprd), b = (xy, yprd, 0), a = (xprd, 0, 0) are taken
+    // off in that order -- the order of Domain::closest_image's triclinic branch (domain.cpp:1258-1305); equal to it
+    // for every pair inside a cutoff <= half the perpendicular box widths (what the list mode requires)
+    if (b.periodic[2]) { const double n = rint(dz * b.inv[2]); dz = fma(-b.prd[2], n, dz); dy = fma(-b.yz, n, dy); dx = fma(-b.xz, n, dx); }
+    if (b.periodic[1]) { const double n = rint(dy * b.inv[1]); dy = fma(-b.prd[1], n, dy); dx = fma(-b.xy, n, dx); }
+    if (b.periodic[0]) dx = fma(-b.prd[0], rint(dx * b.inv[0]), dx);
+    return;
+  }
   if (b.periodic[0]) dx = fma(-b.prd[0], rint(dx * b.inv[0]), dx);
   if (b.periodic[1]) dy = fma(-b.prd[1], rint(dy * b.inv[1]), dy);
   if (b.periodic[2]) dz = fma(-b.prd[2], rint(dz * b.inv[2]), dz);
+}
+// fractional ("lamda") coordinates of a point, src/domain.cpp x2lamda: orthogonal boxes divide by the box lengths,
+// tilted boxes back-substitute through the triangular cell matrix
+__host__ __device__ __forceinline__ void frac_coords(const Box &b, const double lo[3], double x, double y, double z, double fr[3]) {
+  fr[2] = (z - lo[2]) * b.inv[2];
+  if (b.triclinic) {
+    fr[1] = ((y - lo[1]) - b.yz * fr[2] * 1.0) * b.inv[1];
+    fr[0] = ((x - lo[0]) - b.xy * fr[1] - b.xz * fr[2]) * b.inv[0];
+  } else {
+    fr[1] = (y - lo[1]) * b.inv[1];
+    fr[0] = (x - lo[0]) * b.inv[0];
+  }
 }
 template <bool EXACT>
 __device__ __forceinline__ void pair_del(const Box &b, double xi, double yi, double zi, double xj, double yj,

@@ -17,10 +17,11 @@ struct CellGrid {
 
 __device__ __forceinline__ int cell_of(const CellGrid &g, const Box &b, double x, double y, double z) {
   int c[3];
-  const double p[3] = {x, y, z};
+  double fr3[3];
+  frac_coords(b, g.lo, x, y, z, fr3);
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    double fr = (p[k] - g.lo[k]) / b.prd[k];
+    double fr = fr3[k];
     fr -= floor(fr);
     int ck = (int)(fr * g.nc[k]);
     c[k] = ck >= g.nc[k] ? g.nc[k] - 1 : ck;
@@ -136,22 +137,23 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   int cc[3];
   double uu[3], edge[3];
   {
-    const double pp[3] = {ri.x, ri.y, ri.z};
+    double fr3[3];
+    frac_coords(box, g.lo, ri.x, ri.y, ri.z, fr3);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      double fr = (pp[k] - g.lo[k]) / box.prd[k];
+      double fr = fr3[k];
       fr -= floor(fr);
       const double t = fr * g.nc[k];
       int ck = (int)t;
       ck = ck >= g.nc[k] ? g.nc[k] - 1 : ck;
       cc[k] = __builtin_amdgcn_readfirstlane(ck);  // the row atom is the same in every lane
-      uu[k] = wave_uniform(t - ck); edge[k] = wave_uniform(box.prd[k] / g.nc[k]);
+      uu[k] = wave_uniform(t - ck); edge[k] = wave_uniform(box.prd[k] / g.nc[k]);  // (trimming: orthogonal boxes only)
     }
   }
   const int c0 = cc[0], c1 = cc[1], c2 = cc[2];
   const long long nl0 = (long long)i * nl_pitch, dd0 = (long long)i * dd_pitch;
   int ncount = 0, dcount = 0;
-  unsigned long long anywrap = 0ull;  // a dd pair of this row reaches across a periodic face (lp sweep: rows without skip the wrap)
+  bool wrap_lane = false;  // this lane saw a dd pair of the row that reaches across a periodic face (lp sweep: rows without skip the wrap)
   // Cells have an edge >= cutoff/2, so the stencil reaches +-2 cells (125 cells hold 42 % fewer
   // candidates than 27 cells of edge >= cutoff).  Cells are stored x-fastest, so the 5 cells of a
   // stencil row are ONE contiguous run of atoms (two runs when the row wraps around the box): the
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
           in_nl = rsq <= cutallsq;
           in_dd = ipol && __double2loint(rj.w) && (rsq < ddcutsq);
           if (icol >= 0 && rsq < colordistsq && __double2loint(rj.w) && color_s[j] == icol) clash = true;
-          if (dd_wrap) anywrap |= __ballot(in_dd && (ex != ri.x - rj.x || ey != ri.y - rj.y || ez != ri.z - rj.z));
+          wrap_lane |= in_dd && (ex != ri.x - rj.x || ey != ri.y - rj.y || ez != ri.z - rj.z);
           same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;
         }
         const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
     }
   }
   if (color_s && __ballot(clash) != 0ull && lane == 0) atomicOr(color_conflict, 1);
+  const unsigned long long anywrap = __ballot(wrap_lane);  // all lanes are back together here
   if (lane == 0) {
     nl_cnt[i] = ncount; dd_cnt[i] = dcount;
     if (dd_wrap) dd_wrap[i] = anywrap != 0ull;
@@ -300,10 +303,11 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_cl_build(ClusterRows cl, const 
   int cc[3], W[3];
   double uu[3], edge[3];
   {
-    const double pp[3] = {mx[0], my[0], mz[0]};
+    double fr3[3];
+    frac_coords(box, g.lo, mx[0], my[0], mz[0], fr3);  // the arithmetic of cell_of (orthogonal boxes only in cluster mode)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      double fr = (pp[k] - g.lo[k]) / box.prd[k];
+      double fr = fr3[k];
       fr -= floor(fr);
       const double t = fr * g.nc[k];
       int ck = (int)t;

@@ -373,7 +373,9 @@ __device__ __forceinline__ void lp_finish(double ax, double ay, double az, int l
 // (lp_slot: polar_common.hpp)
 
 // one 64-pair trip: this lane's record out of tile `cur`, the DMA of the next trip (index jnext) into `nxt`, the pair arithmetic
-template <bool WRAP, int DAMP, int NT>
+// WRAP: 0 the row has no pair across a periodic face, 1 orthogonal minimum image, 2 tilted box (list mode in a
+// triclinic cell: whole lattice vectors c, b, a taken off in that order, as min_image_rint)
+template <int WRAP, int DAMP, int NT>
 __device__ __forceinline__ void lp_trip(const char *rd0, const char *rd1, const char *rd2, int cur, int nxt, bool more,
                                         const char *srcc, int jnext, unsigned g0, unsigned g1, unsigned g2, unsigned g3,
                                         char *tile0, const AtomRec &ri, double px, double py, double pz, const Box &box,
@@ -391,10 +393,16 @@ __device__ __forceinline__ void lp_trip(const char *rd0, const char *rd1, const 
   }
   if (ablate & 16) { ax += A.x + B.y + C.x; return; }  // lab: no pair arithmetic
   double dx = ri.x - A.x, dy = ri.y - B.x, dz = ri.z - C.x;
-  if (WRAP) {
+  if (WRAP == 1) {
     dx = fma(-px, rint(dx * box.inv[0]), dx);
     dy = fma(-py, rint(dy * box.inv[1]), dy);
     dz = fma(-pz, rint(dz * box.inv[2]), dz);
+  } else if (WRAP == 2) {
+    const double nz = pz != 0.0 ? rint(dz * box.inv[2]) : 0.0;
+    dz = fma(-pz, nz, dz); dy = fma(-box.yz, nz, dy); dx = fma(-box.xz, nz, dx);
+    const double ny = py != 0.0 ? rint(dy * box.inv[1]) : 0.0;
+    dy = fma(-py, ny, dy); dx = fma(-box.xy, ny, dx);
+    dx = fma(-px, rint(dx * box.inv[0]), dx);
   }
   const double r2 = fmax(fma(dx, dx, fma(dy, dy, dz * dz)), 1e-12);  // the dummy record may coincide with the row atom
   double s3, s5;
@@ -405,7 +413,7 @@ __device__ __forceinline__ void lp_trip(const char *rd0, const char *rd1, const 
   ay = fma(cc, dy, fma(-s3, B.y, ay));
   az = fma(cc, dz, fma(-s3, C.y, az));
 }
-template <bool WRAP, int DAMP, int NT>
+template <int WRAP, int DAMP, int NT>
 __device__ __forceinline__ void lp_row(int T, const int4 *pc, const char *srcc, char *tile0, int lane, const AtomRec &ri,
                                        const Box &box, double pd, const ExpCoef &K, double &ax, double &ay, double &az,
                                        int ablate) {
@@ -487,8 +495,9 @@ __global__ __launch_bounds__(1024) void k_field_lp(
   char *tile0 = lp_lds + (size_t)wv * (NT * POLAR_LP_TILE);
   double ax = 0.0, ay = 0.0, az = 0.0;
   // rows whose list holds no pair across a periodic face (flag written by k_nl_build) skip the minimum-image wrap
-  if (wrapped) lp_row<true, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
-  else lp_row<false, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  if (!wrapped) lp_row<0, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  else if (!box.triclinic) lp_row<1, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  else lp_row<2, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
   lp_finish(ax, ay, az, lane, src + i, dst + i, ef + 3 * (size_t)i, slots);
 }
 

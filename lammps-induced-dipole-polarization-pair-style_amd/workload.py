@@ -345,6 +345,7 @@ class PolarSettings:
     debug: int = 0
     dd_cutoff: float = 0.0  # extension: <=0 exact all-pairs (reference), >0 truncated
     device_neigh: int = 0   # extension: the LAMMPS shim builds the LJ/coul list on the device
+    restart_polar: int = 0  # extension: restart files carry the polarization keywords
 
 
 @dataclass

@@ -530,6 +530,16 @@ void PairLJCutCoulLongPolarizationMI355X::write_restart_settings(FILE *fp)
   fwrite(&tail_flag,sizeof(int),1,fp);
   fwrite(&ncoultablebits,sizeof(int),1,fp);
   fwrite(&tabinner,sizeof(double),1,fp);
+  // extension (keyword restart_polar yes): the polarization keywords behind the stock record, tagged and
+  // length-prefixed; without the keyword the file has the reference's layout (PS.cpp:976-985)
+  polar_settings pst;
+  check(polar_get_settings(h,&pst));
+  if (pst.restart_polar) {
+    char rec[256];
+    int n = polar_restart_pack(h,rec,(int) sizeof(rec));
+    if (n < 0) error->one(FLERR,"Pair style lj/cut/coul/long/polarization: cannot pack its restart record");
+    fwrite(rec,1,n,fp);
+  }
 }
 
 void PairLJCutCoulLongPolarizationMI355X::read_restart_settings(FILE *fp)
@@ -550,11 +560,30 @@ void PairLJCutCoulLongPolarizationMI355X::read_restart_settings(FILE *fp)
   MPI_Bcast(&tail_flag,1,MPI_INT,0,world);
   MPI_Bcast(&ncoultablebits,1,MPI_INT,0,world);
   MPI_Bcast(&tabinner,1,MPI_DOUBLE,0,world);
-  // polarization keywords are not in the restart file (reference behaviour): defaults apply
+  // a reference-format file holds no polarization keywords: defaults apply (reference behaviour) ...
   char a[2][32];
   sprintf(a[0],"%.17g",cut_lj_global); sprintf(a[1],"%.17g",cut_coul);
   const char *argv[2] = {a[0],a[1]};
   check(polar_pair_settings(h,2,argv));
+  // ... unless the writer ran with restart_polar yes: probe for the tagged record, seek back when it is not there
+  char rec[256];
+  int nrec = 0;
+  if (comm->me == 0) {
+    const long pos = ftell(fp);
+    size_t got = fread(rec,1,POLAR_RESTART_HEADER_BYTES,fp);
+    int head[3] = {0,0,0};
+    if (got == POLAR_RESTART_HEADER_BYTES) memcpy(head,rec,sizeof(head));
+    if (got == POLAR_RESTART_HEADER_BYTES && head[0] == 0x524C4F50 && head[2] > 0 &&
+        head[2] <= (int) sizeof(rec) - POLAR_RESTART_HEADER_BYTES &&
+        fread(rec + POLAR_RESTART_HEADER_BYTES,1,head[2],fp) == (size_t) head[2])
+      nrec = POLAR_RESTART_HEADER_BYTES + head[2];
+    else fseek(fp,pos,SEEK_SET);
+  }
+  MPI_Bcast(&nrec,1,MPI_INT,0,world);
+  if (nrec) {
+    MPI_Bcast(rec,nrec,MPI_CHAR,0,world);
+    check(polar_restart_unpack(h,rec,nrec));
+  }
 }
 
 void PairLJCutCoulLongPolarizationMI355X::write_data(FILE *fp)

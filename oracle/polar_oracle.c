@@ -248,9 +248,12 @@ static void nbr_free(nbr_list *L) {
   memset(L, 0, sizeof(*L));
 }
 
+static void nbr_build_allpairs(const orc_system *s, double cut, nbr_list *L);
+
 static void nbr_build(const orc_system *s, double cut, nbr_list *L) {
   const int n = s->nlocal;
   const double *x = s->x;
+  if (s->triclinic) { nbr_build_allpairs(s, cut, L); return; } /* the grid below is orthogonal */
   int nc[3];
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int i = 0; i < n; i++)
@@ -621,6 +624,43 @@ static int cmp_rank(const void *a, const void *b) {
 /* ------------------------------------------------------------------ a7 --
  * PS.cpp:1113-1238.  `matrix` dense (reference semantics) or NULL with dd_cutoff>0, in which
  * case the sparse tensor list built by orc_compute is passed through `res`-side statics.      */
+/* tilted boxes (list-mode extension in a triclinic cell; test systems are small): every pair through
+ * Domain::closest_image's triclinic branch (orc_closest_image), no grid */
+static void nbr_build_allpairs(const orc_system *s, double cut, nbr_list *L) {
+  const int n = s->nlocal;
+  const double *x = s->x;
+  const double cutsq = cut * cut;
+  L->first = (long long *)malloc(sizeof(long long) * ((size_t)n + 1));
+  for (int pass = 0; pass < 2; pass++) {
+    long long tot = 0;
+    for (int i = 0; i < n; i++) {
+      if (pass == 1) tot = L->first[i];
+      for (int j = 0; j < n; j++) {
+        if (j == i) continue;
+        double xim[3];
+        orc_closest_image(s, &x[3 * i], &x[3 * j], xim);
+        double ddx = x[3 * i] - xim[0], ddy = x[3 * i + 1] - xim[1], ddz = x[3 * i + 2] - xim[2];
+        double rsq = ddx * ddx + ddy * ddy + ddz * ddz;
+        if (rsq <= cutsq) {
+          if (pass == 1) {
+            L->j[tot] = j; L->rsq[tot] = rsq;
+            L->d[3 * tot] = ddx; L->d[3 * tot + 1] = ddy; L->d[3 * tot + 2] = ddz;
+          }
+          tot++;
+        }
+      }
+      if (pass == 0) L->first[i + 1] = tot;
+    }
+    if (pass == 0) {
+      L->first[0] = 0;
+      L->npairs = L->first[n];
+      L->j = (int *)malloc(sizeof(int) * (size_t)(L->npairs + 1));
+      L->d = (double *)malloc(sizeof(double) * 3 * (size_t)(L->npairs + 1));
+      L->rsq = (double *)malloc(sizeof(double) * (size_t)(L->npairs + 1));
+    }
+  }
+}
+
 typedef struct { const nbr_list *L; const double *T6; } sparse_T; /* T6: xx,xy,xz,yy,yz,zz per pair */
 static const sparse_T *g_sparse = NULL;
 

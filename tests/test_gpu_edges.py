@@ -152,10 +152,20 @@ def test_triclinic_box_exact_mode(wl, pkg, oracle):
                                                 "max_iterations", "200"] + extra)
         out, ref = _check(pkg, oracle, s2)
         assert out["iterations"] == ref["iterations"]
-    # list mode refuses a tilted box instead of silently using an orthogonal grid
-    s2.settings = wl.parse_pair_style_args(["8.0", "7.5", "dd_cutoff", "7.5"])
-    with pytest.raises(pkg.PolarError):
-        pkg.pair_from_system(s2).compute()
+    # list mode in the tilted cell (cell grid in fractional coordinates, whole lattice vectors taken off c, b, a):
+    # against the oracle's list mode, whose pair list comes from closest_image's triclinic branch.  "Restated,
+    # unpinned": no reference log or golden exercises a tilted box.
+    for extra in (["precision", "1e-13", "max_iterations", "200"],
+                  ["polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "5"]):
+        s2.settings = wl.parse_pair_style_args(["8.0", "7.5", "damp_type", "exponential", "dd_cutoff", "7.5"] + extra)
+        out, ref = _check(pkg, oracle, s2)
+        assert out["dd_pairs"] > 0
+    # a box too thin for the cutoff between two opposite faces is refused (widths, not edge lengths, count)
+    s3 = copy.copy(s2)
+    s3.tilt = (7.9, 0.0, 0.0)
+    s3.settings = wl.parse_pair_style_args(["8.0", "7.5", "dd_cutoff", "7.5"])
+    with pytest.raises(pkg.PolarError, match="box lengths"):
+        pkg.pair_from_system(s3).compute()
 
 
 def _filter_csr(s, wl, keep_fn):

@@ -150,3 +150,35 @@ def test_compute_fails_loudly_without_gpu_or_setup(pkg):
 def test_triclinic_box_is_accepted_for_exact_mode(pkg):
     p = pkg.PolarPair(0)
     p.set_box([0, 0, 0], [10, 10, 10], tilt=(1.0, 0.5, -0.5), triclinic=1)   # exact-mode kernels handle it
+
+
+def test_restart_record_of_the_polarization_keywords(pkg):
+    """with `restart_polar yes` the keywords travel in a tagged record behind the stock restart
+    fields; a reader finds the record by its magic and leaves a reference-format stream alone."""
+    import struct
+
+    p = pkg.PolarPair(0)
+    p.settings(["2.5", "12.8345", "precision", "1e-9", "max_iterations", "77", "damp_type", "exponential", "damp", "1.9",
+                "polar_gamma", "1.01", "use_previous", "yes", "dd_cutoff", "11.5", "restart_polar", "yes",
+                "polar_gs_ranked", "no", "polar_gs", "yes"])
+    rec = p.restart_pack()
+    magic, ver, nb = struct.unpack("<iii", rec[:12])
+    assert magic == 0x524C4F50 and ver == 1 and nb == len(rec) - 12
+    q = pkg.PolarPair(0)
+    q.settings(["2.5", "12.8345"])          # what read_restart_settings does first: cutoffs from the stock record
+    assert q.get_settings().polar_gs_ranked == 1 and q.get_settings().restart_polar == 0
+    q.restart_unpack(rec)
+    a, b = p.get_settings(), q.get_settings()
+    for k, _ in pkg.Settings._fields_:
+        assert getattr(a, k) == getattr(b, k), k
+    # a stream that continues with something else (reference-format file): refused, nothing changes
+    r = pkg.PolarPair(0)
+    r.settings(["2.5", "12.8345"])
+    with pytest.raises(pkg.PolarError, match="not a polarization restart record"):
+        r.restart_unpack(struct.pack("<iii", 7, 1, 72) + bytes(72))
+    with pytest.raises(pkg.PolarError, match="unknown version or length"):
+        r.restart_unpack(rec[:12] + rec[12:40])
+    assert r.get_settings().iterations_max == 50
+    # the keyword itself follows the grammar of the other yes/no keywords
+    with pytest.raises(pkg.PolarError, match="Illegal pair_style command"):
+        r.settings(["2.5", "12.8345", "restart_polar", "maybe"])
