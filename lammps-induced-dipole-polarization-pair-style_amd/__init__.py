@@ -403,11 +403,13 @@ def _result_dict(res):
     return out
 
 
-def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0, device_neigh=False):
+def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0, device_neigh=False, row_range=None):
     """Build a PolarPair from a workload.PolarSystem the way an input script would:
     pair_style -> pair_modify -> pair_coeff -> init -> per-step data.
     ``device_neigh``: the LJ/Coulomb list is built on the device (keyword ``device_neigh yes`` of the shim)
-    instead of being uploaded; systems made with ``build_list=False`` need it."""
+    instead of being uploaded; systems made with ``build_list=False`` need it.
+    ``row_range`` = (lo, hi): a sharded handle (polar_set_row_range) -- set before the device list is built, which
+    then covers the own rows only."""
     p = PolarPair(device)
     p.load_system(sysm, modify_args)
     rows = coeff_rows if coeff_rows is not None else sysm.extra.get("coeff_rows")
@@ -418,6 +420,8 @@ def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0, device_nei
     p.init(sysm.g_ewald, sysm.qqrd2e, sysm.special_lj, sysm.special_coul)
     if sysm.coul["nbits"]:  # the role of Pair::init_tables (PS.cpp:851) is played by workload.init_coul_tables
         p.set_coul(sysm.g_ewald, sysm.qqrd2e, sysm.coul, sysm.special_lj, sysm.special_coul)
+    if row_range is not None:
+        p._ck(p.L.polar_set_row_range(p.h, int(row_range[0]), int(row_range[1])))
     if device_neigh:
         p._ck(p.L.polar_set_newton(p.h, int(sysm.extra.get("newton_pair", 1))))
         p.set_box(sysm.boxlo, sysm.prd, tilt=getattr(sysm, "tilt", (0.0, 0.0, 0.0)), triclinic=int(getattr(sysm, "triclinic", 0)))

@@ -1598,6 +1598,9 @@ int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *
     if (!cutneighsq || !special_flag) throw InputError("polar_build_neighbors: null cutneighsq/special_flag");
     if ((nspecial == nullptr) != (special == nullptr) || (special && maxspecial <= 0)) throw InputError("polar_build_neighbors: nspecial/special/maxspecial are inconsistent");
     const int n = h->nlocal, nall = h->nlocal + h->nghost, w = h->ntypes + 1;
+    // a sharded handle (polar_set_row_range) holds [own | halo | ghosts]: only the own atoms get list rows -- the halo
+    // atoms are somebody else's rows and would otherwise be counted into this rank's energies and virial
+    const int nown = own_n(h);
     hipStream_t s = h->stream;
     double cutmax2 = 0.0;
     for (int a = 1; a < w; a++) for (int b = 1; b < w; b++) cutmax2 = std::max(cutmax2, cutneighsq[a * w + b]);
@@ -1644,8 +1647,8 @@ int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *
       h->d_neigh.ensure((size_t)std::max(n, 1) * h->lj_pitch + 64);
       HIPCHECK(hipMemsetAsync(h->d_overflow.p, 0, 16 * sizeof(int), s));
       HIPCHECK(hipMemsetAsync(h->d_ddtot.p, 0, 64 * 16 * sizeof(unsigned long long), s));
-      k_lj_nl_build<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, lds, s>>>(
-          n, h->ntypes, h->d_x.p, h->d_type.p, h->d_mol.p, h->d_ljpos.p, h->d_ljaux.p, g, h->d_ljcell_first.p,
+      k_lj_nl_build<<<nblk(nown, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, lds, s>>>(
+          own_lo(h), nown, h->ntypes, h->d_x.p, h->d_type.p, h->d_mol.p, h->d_ljpos.p, h->d_ljaux.p, g, h->d_ljcell_first.p,
           h->d_cutneighsq.p, h->box, exclude_molecule_intra, d_nsp, d_sp, maxspecial, special_flag[1], special_flag[2],
           special_flag[3], h->lj_pitch, h->d_numneigh.p, h->d_neigh.p, h->d_overflow.p, h->d_ddtot.p);
       HIPCHECK(hipMemcpyAsync(h->h_flags, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1659,8 +1662,8 @@ int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *
     unsigned long long tot = 0;
     for (int k = 0; k < 64; k++) tot += h->h_ddtot[16 * k];
     h->h_flags[0] = 0;
-    k_lj_rows<<<nblk(n, 256), 256, 0, s>>>(n, h->lj_pitch, h->d_ilist.p, h->d_first.p);
-    h->inum = n; h->nneigh = (long long)tot;
+    k_lj_rows<<<nblk(nown, 256), 256, 0, s>>>(own_lo(h), nown, h->lj_pitch, h->d_ilist.p, h->d_first.p);
+    h->inum = nown; h->nneigh = (long long)tot;
     h->neigh_set = true; h->sym_valid = false;
     if (h->colors_valid) h->colors_recheck = true;
     h->device_list = true; h->full_list = 1;

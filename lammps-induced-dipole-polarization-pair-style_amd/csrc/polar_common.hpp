@@ -198,19 +198,19 @@ __device__ __forceinline__ void row_range(const RowList &L, int i, long long &be
 // (the list path requires L >= 2*cutoff).  The all-pairs (reference-exact) kernels keep wrap_ci.
 __device__ __forceinline__ void min_image_rint(const Box &b, double xi, double yi, double zi, double xj, double yj,
                                                double zj, double &dx, double &dy, double &dz) {
-  dx = xi - xj; dy = yi - yj; dz = zi - zj;
-  if (b.triclinic) {
-    // tilted box (list mode): whole lattice vectors c = (xz, yz, zprd), b = (xy, yprd, 0), a = (xprd, 0, 0) are taken
-    // off in that order -- the order of Domain::closest_image's triclinic branch (domain.cpp:1258-1305); equal to it
-    // for every pair inside a cutoff <= half the perpendicular box widths (what the list mode requires)
-    if (b.periodic[2]) { const double n = rint(dz * b.inv[2]); dz = fma(-b.prd[2], n, dz); dy = fma(-b.yz, n, dy); dx = fma(-b.xz, n, dx); }
-    if (b.periodic[1]) { const double n = rint(dy * b.inv[1]); dy = fma(-b.prd[1], n, dy); dx = fma(-b.xy, n, dx); }
-    if (b.periodic[0]) dx = fma(-b.prd[0], rint(dx * b.inv[0]), dx);
-    return;
-  }
-  if (b.periodic[0]) dx = fma(-b.prd[0], rint(dx * b.inv[0]), dx);
-  if (b.periodic[1]) dy = fma(-b.prd[1], rint(dy * b.inv[1]), dy);
-  if (b.periodic[2]) dz = fma(-b.prd[2], rint(dz * b.inv[2]), dz);
+  // One straight-line form for orthogonal and tilted boxes: whole lattice vectors c = (xz, yz, zprd), b = (xy, yprd, 0),
+  // a = (xprd, 0, 0) are taken off in that order -- the order of Domain::closest_image's triclinic branch
+  // (domain.cpp:1258-1305), equal to it for every pair inside a cutoff <= half the perpendicular box widths (what the
+  // list mode requires).  With zero tilt factors the extra FMAs add exact zeros: bit-identical to the per-component
+  // d - L*rint(d/L).  (A branch on b.triclinic with an early return cost 24 bytes of scratch per lane in four kernels.)
+  double ex = xi - xj, ey = yi - yj, ez = zi - zj;
+  const double nz = b.periodic[2] ? rint(ez * b.inv[2]) : 0.0;
+  ez = fma(-b.prd[2], nz, ez); ey = fma(-b.yz, nz, ey); ex = fma(-b.xz, nz, ex);
+  const double ny = b.periodic[1] ? rint(ey * b.inv[1]) : 0.0;
+  ey = fma(-b.prd[1], ny, ey); ex = fma(-b.xy, ny, ex);
+  const double nx = b.periodic[0] ? rint(ex * b.inv[0]) : 0.0;
+  ex = fma(-b.prd[0], nx, ex);
+  dx = ex; dy = ey; dz = ez;
 }
 // fractional ("lamda") coordinates of a point, src/domain.cpp x2lamda: orthogonal boxes divide by the box lengths,
 // tilted boxes back-substitute through the triangular cell matrix

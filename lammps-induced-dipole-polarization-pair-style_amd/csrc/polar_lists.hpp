@@ -451,7 +451,7 @@ __global__ void k_lj_cell_fill(int nall, const int *__restrict__ cell_id, const 
 //            (0: drop the pair, 1: keep plain, 2: keep with `which` in bits 30-31), except that a
 //            pair farther apart than half a periodic box length is an image and kept plain
 //            (Domain::minimum_image_check).
-__global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int nlocal, int ntypes, const double *__restrict__ x,
+__global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int row_lo, int nrows, int ntypes, const double *__restrict__ x,
                                                              const int *__restrict__ type, const int *__restrict__ mol,
                                                              const double4 *__restrict__ pos, const int2 *__restrict__ aux,
                                                              LJGrid g, const long long *__restrict__ cell_first,
@@ -466,8 +466,9 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int nlocal, int nty
   for (int t = threadIdx.x; t < w * w; t += blockDim.x) cn_lds[t] = cutneighsq[t];
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (i >= nlocal) return;
+  const int r_ = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (r_ >= nrows) return;
+  const int i = row_lo + r_;  // rows [row_lo, row_lo + nrows): the atoms this handle owns (all locals unless sharded)
   const double xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
   const int itype = type[i], imol = mol[i];
   const double *cn = cn_lds + itype * w;
@@ -527,11 +528,11 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int nlocal, int nty
     atomicAdd(total + (blockIdx.x & 63) * 16, (unsigned long long)count);
   }
 }
-__global__ void k_lj_rows(int nlocal, long long pitch, int *__restrict__ ilist, long long *__restrict__ first) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nlocal) return;
-  ilist[i] = i;
-  first[i] = (long long)i * pitch;
+__global__ void k_lj_rows(int row_lo, int nrows, long long pitch, int *__restrict__ ilist, long long *__restrict__ first) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  ilist[r] = row_lo + r;
+  first[row_lo + r] = (long long)(row_lo + r) * pitch;
 }
 
 // multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers

@@ -315,6 +315,29 @@ def run_step(backend, dist, rank, world, counts, offs, eflag=1, vflag=2, check_e
     raise RuntimeError("neighbor list pitch overflow persists")
 
 
+class SweepGraph:
+    """The per-sweep sequence of a step -- sweep launches, the all-reduced stop rule, pack / point-to-point exchange /
+    unpack of the halo dipoles -- recorded ONCE as a HIP graph of `block` sweeps and replayed, so that a sweep costs
+    the host one graph launch per `block` sweeps instead of ~10 Python calls (each sweep is only ~0.1-0.3 ms of GPU
+    work at 65k atoms per GPU).  Everything in the body is stream-ordered work on buffers that exist before the
+    capture: library kernels on torch's current stream (polar_set_stream), in-place collectives of torch.distributed
+    (RCCL records its kernels into the graph).  Opt-in (POLAR_DIST_GRAPH=1): exercised here with one rank only."""
+
+    def __init__(self, torch, backend, body, block):
+        self.torch, self.block = torch, block
+        self.graph = torch.cuda.CUDAGraph()
+        stream = torch.cuda.current_stream(backend.dev)
+        # one eager pass first: lazy initialisations (RCCL channels, kernel modules) must not happen under capture
+        body()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph, stream=stream):
+            for _ in range(block):
+                body()
+
+    def replay(self):
+        self.graph.replay()
+
+
 def _run_step_once(backend, dist, rank, world, counts, offs, eflag, vflag, check_every, gather_buf, halo, timer):
     """``halo`` = (HaloPlan | P2PHaloPlan, buffers) switches the dipole exchange from "all owned rows" to halo rows."""
     maxc = max(counts)
@@ -334,7 +357,33 @@ def _run_step_once(backend, dist, rank, world, counts, offs, eflag, vflag, check
     backend.begin(eflag, vflag)
     exchange_mu(backend, dist, counts, offs, rank, gather_buf)   # initial guess of the other ranks
     sweeps = 0
-    if not backend.zodid:
+    use_graph = (os.environ.get("POLAR_DIST_GRAPH") == "1" and hasattr(backend, "torch") and not backend.zodid
+                 and not getattr(backend, "lazy_end", False) and timer is None)
+    if use_graph:
+        def body():  # one sweep of the precision-mode loop below, with nothing the host has to look at
+            backend.sweep()
+            if world > 1:
+                chg = backend.local_change()
+                dist.all_reduce(chg)
+                backend.sweep_end(chg)
+            else:
+                backend.sweep_end(None)
+            exchange_mu(backend, dist, counts, offs, rank, gather_buf)
+
+        sg = getattr(backend, "_sweep_graph", None)
+        if sg is None:
+            # the recording pass runs real sweeps: do it on a scratch step, then start this step again
+            sg = backend._sweep_graph = SweepGraph(backend.torch, backend, body, check_every)
+            backend.finish()
+            backend.begin(eflag, vflag)
+            exchange_mu(backend, dist, counts, offs, rank, gather_buf)
+        while sweeps < backend.max_it + 1:
+            sg.replay()
+            sweeps += check_every
+            done, _, _ = backend.state()   # sweeps past the end of a finished solve are no-ops on the device
+            if done:
+                break
+    elif not backend.zodid:
         for sw in range(backend.max_it + 1):
             if timer is not None:
                 timer.start()
@@ -378,32 +427,40 @@ def _run_step_once(backend, dist, rank, world, counts, offs, eflag, vflag, check
 
 # --------------------------------------------------------------------------------------------
 def bench_distributed(args, rank, world, local_rank):
-    """bench.py --gpus N (N > 1): weak scaling, one 3x3x3 replica block (36,423 atoms) per GPU,
-    box = 3 x 3 x 3N cells, slabs along z."""
+    """bench.py --gpus N (N > 1): STRONG scaling on a fixed box -- BASELINE configs[3] (6x6x6 = 291,384 atoms) for
+    N = 2, 4 and configs[4] (7x7x8 = 528,808 atoms) for N = 8, ranked GS to precision 1e-11 -- one rank per GPU,
+    contiguous row ranges (z slabs: the replicas are stored z-outermost), every rank holding only
+    [own | halo | ghosts], LJ/Coulomb lists of the own rows built on the device, halo dipoles exchanged
+    point-to-point with the slab neighbours once per sweep, one all-reduced double per sweep for the stop rule."""
     import torch
     import torch.distributed as dist
 
     pkg = importlib.import_module(__package__)
     wl = importlib.import_module(__package__ + ".workload")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import bench as B  # repo root is on sys.path (bench.py put it there)
+
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    reps = (args.reps[0], args.reps[1], args.reps[2] * world)
-    cut = 12.8345
-    extra = ["use_previous", "no", "fixed_iteration", "yes", "max_iterations", "30", "polar_gs_ranked", "yes",
-             "dd_cutoff", repr(cut)]
-    n_total = 1349 * reps[0] * reps[1] * reps[2]
+    if os.environ.get("POLAR_DIST_GRAPH") == "1":
+        # graph capture needs a non-default stream: everything of this run (library kernels, RCCL) goes onto one side stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
+    k = args.config or (4 if world >= 8 else (3 if world > 1 else 2))
+    cfg = dict(B.CONFIGS[k])
+    if args.reps:
+        cfg["reps"] = tuple(args.reps)
+    reps = cfg["reps"]
+    cut = B.CUT_COUL
+    sg = B.build_workload(wl, reps, args.extra, build_list=False, solver=cfg["solver"])   # atoms + ghosts, no host list
+    n_total = sg.nlocal
     counts, offs = split_rows(n_total, world)
     lo, hi = int(offs[rank]), int(offs[rank + 1])
-    sg = wl.replicate_fixture(os.path.join(root, "tests", "golden", "mof5_h2.npz"), *reps, extra_args=extra,
-                              rows=np.arange(lo, hi), full=True)
     # reach = the neighbor-list cutoff of the LJ/Coulomb rows (max cut + skin) -- it covers the dd cutoff
     reach = float(sg.extra["cutneigh"]) + 1e-6
     mode = os.environ.get("POLAR_HALO_MODE", "p2p")
     if mode == "allgather":
         # every rank holds ALL atoms and owns the rows [lo, hi); one all-gather of the halos per sweep
         s = sg
-        p = pkg.pair_from_system(s, device=local_rank)
+        p = pkg.pair_from_system(s, device=local_rank, device_neigh=True, row_range=(lo, hi))
         be = HipShardBackend(p, lo, hi, local_rank)
         plan = HaloPlan(s.x[:s.nlocal], s.prd, offs, reach)
         halo = (plan, halo_buffers(be, plan, rank)) if world > 1 else None
@@ -412,11 +469,12 @@ def bench_distributed(args, rank, world, local_rank):
         # default: every rank holds only [own | halo | ghosts] (per-step cost independent of the number of
         # ranks) and exchanges face layers point-to-point with its slab neighbours
         plan = P2PHaloPlan(sg.x[:sg.nlocal], sg.prd, offs, reach)
-        s = wl.compact_shard(sg, np.arange(lo, hi), plan.halo_of(rank))
-        p = pkg.pair_from_system(s, device=local_rank)
+        s = wl.compact_shard_geometric(sg, np.arange(lo, hi), plan.halo_of(rank), reach)
+        p = pkg.pair_from_system(s, device=local_rank, device_neigh=True, row_range=(0, hi - lo))
         be = HipShardBackend(p, 0, hi - lo, local_rank, global_count=n_total)
         halo = (plan, p2p_buffers(be, plan, rank, compact_lo=lo))
         rows_own = int(np.count_nonzero(s.alpha[:hi - lo]))
+    n_held = s.nlocal + s.nghost
     del sg
     if world > 1:
         # establish the RCCL connections (peer-to-peer channels are created lazily at first use) outside
@@ -425,12 +483,12 @@ def bench_distributed(args, rank, world, local_rank):
         if isinstance(plan, P2PHaloPlan):
             hb = halo[1]
             ops = []
-            for k, r in enumerate(hb["peers"]):
-                a, b = 3 * hb["seg_in"][k], 3 * hb["seg_in"][k + 1]
+            for kk, r in enumerate(hb["peers"]):
+                a, b = 3 * hb["seg_in"][kk], 3 * hb["seg_in"][kk + 1]
                 if b > a:
                     ops.append(dist.P2POp(dist.irecv, hb["recv"][a:b], r))
-            for k, r in enumerate(hb["peers"]):
-                a, b = 3 * hb["seg_out"][k], 3 * hb["seg_out"][k + 1]
+            for kk, r in enumerate(hb["peers"]):
+                a, b = 3 * hb["seg_out"][kk], 3 * hb["seg_out"][kk + 1]
                 if b > a:
                     ops.append(dist.P2POp(dist.isend, hb["send"][a:b], r))
             for req in dist.batch_isend_irecv(ops):
@@ -439,7 +497,7 @@ def bench_distributed(args, rank, world, local_rank):
         dist.all_reduce(t)
         torch.cuda.synchronize()
     gbuf = None
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         out = run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo)
     dist.barrier()
     torch.cuda.synchronize()
@@ -456,27 +514,26 @@ def bench_distributed(args, rank, world, local_rank):
     # roofline of the dominant kernel on this rank (same accounting as the single-GPU line, bench.py)
     launches = max(len(timer.pairs), 1) * max(out["ncolors"], 1)
     ms_launch = timer.total_ms() / launches
-    pairs_rank = out["dd_pairs"] / world          # dd_pairs was all-reduced; weak scaling: equal shares
+    pairs_rank = out["dd_pairs"] / world          # dd_pairs was all-reduced; equal shares of a uniform box
     bytes_launch = (4.0 * pairs_rank + 112.0 * rows_own) / max(out["ncolors"], 1)
-    stream_launch = (12.0 * pairs_rank + 112.0 * rows_own) / max(out["ncolors"], 1)
     achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
     if rank == 0:
         line = {
             "metric": "atom-steps/sec", "value": n_total * args.steps / dt, "unit": "atom-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"MOF5+H2 cell replicated {reps[0]}x{reps[1]}x{reps[2]} = {n_total} atoms "
-                                   f"({n_total // world} per GPU, z slabs), exponential damping, fixed_iteration 30 "
-                                   f"(31 sweeps), colour-phase GS per rank + {'all-gather' if isinstance(plan, HaloPlan) else 'point-to-point exchange'} of the halo dipoles per sweep (RCCL), "
-                                   f"dd_cutoff=cut_coul={cut}",
-                       "natoms": n_total, "sweeps": out["sweeps"], "colors": out["ncolors"],
-                       "dd_pairs": out["dd_pairs"], "eng_pol": out["eng_pol"],
-                       "halo_rows_per_rank": plan.counts, "rows_per_rank": counts},
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": B.describe(cfg, n_total) + f"; {world} rank(s), {n_total // world} own atoms per GPU (z slabs), "
+                                   f"colour-phase GS per rank + {'all-gather' if isinstance(plan, HaloPlan) else 'point-to-point exchange'} "
+                                   "of the halo dipoles per sweep (RCCL), LJ/Coulomb lists built on the device",
+                       "natoms": n_total, "sweeps": out["sweeps"], "iterations": out["iterations"], "colors": out["ncolors"],
+                       "dd_pairs": out["dd_pairs"], "eng_pol": out["eng_pol"], "rms_dmu_last_sweep": out["rms_dmu"],
+                       "ms_per_dipole_iteration": 1e3 * dt / args.steps / max(out["sweeps"], 1),
+                       "ms_device_rank0": {k2: out[k2] for k2 in ("ms_total", "ms_list", "ms_ljcoul", "ms_static", "ms_solve", "ms_force")},
+                       "atoms_held_rank0": n_held, "halo_rows_per_rank": plan.counts, "rows_per_rank": counts,
+                       "kernel_version": pkg.kernel_version()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "k_field_quad (dipole-field sweep, one launch per colour phase; rank 0)",
-                         "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch,
-                         "streamed_bytes_per_launch": stream_launch,
-                         "streamed_frac": stream_launch / (ms_launch * 1e-3) / 1e9 / 8000.0},
+                         "traffic": None, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; rank 0; {pkg.kernel_version()})",
+                         "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch},
         }
         print(json.dumps(line))
     dist.destroy_process_group()

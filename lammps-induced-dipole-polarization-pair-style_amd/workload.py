@@ -451,6 +451,30 @@ def compact_shard(s, own, halo):
         neigh=neigh, settings=s.settings, owner=None, name=s.name + "_shard", extra=dict(s.extra, n_own=len(own)))
 
 
+def compact_shard_geometric(s, own, halo, reach):
+    """compact_shard for systems made WITHOUT a host neighbor list (``build_list=False``; the library builds the list
+    of the own rows on the device): [own | halo | ghosts], ghosts = the periodic images within ``reach`` of the
+    bounding box of the own atoms (a superset of what the own rows can reference).  ``owner`` keeps the global atom
+    ids (they serve as tags in polar_build_neighbors)."""
+    own = np.asarray(own, dtype=np.int64)
+    halo = np.asarray(halo, dtype=np.int64)
+    n, nall = s.nlocal, s.nlocal + s.nghost
+    lo = s.x[own].min(axis=0) - reach
+    hi = s.x[own].max(axis=0) + reach
+    g = np.arange(n, nall)
+    xg = s.x[g]
+    ghosts = g[np.all((xg >= lo) & (xg <= hi), axis=1)]
+    keep = np.concatenate([own, halo, ghosts])
+    nloc = len(own) + len(halo)
+    return PolarSystem(
+        nlocal=nloc, nghost=len(ghosts), x=np.ascontiguousarray(s.x[keep]), q=s.q[keep].copy(), alpha=s.alpha[keep].copy(),
+        type=s.type[keep].copy(), molecule=s.molecule[keep].copy(), boxlo=s.boxlo, prd=s.prd, ntypes=s.ntypes,
+        tables=s.tables, coul=s.coul, g_ewald=s.g_ewald, qqrd2e=s.qqrd2e, special_lj=s.special_lj,
+        special_coul=s.special_coul, ilist=np.zeros(0, dtype=np.int32), numneigh=np.zeros(nloc, dtype=np.int32),
+        firstneigh=np.zeros(nloc, dtype=np.int64), neigh=np.zeros(0, dtype=np.int32), settings=s.settings,
+        owner=np.asarray(s.owner)[keep], name=s.name + "_shard", extra=dict(s.extra, n_own=len(own)))
+
+
 def lammps_special_arrays(n, special):
     """{(i,j): which} -> atom->nspecial [n][3] (cumulative 1-2, 1-3, 1-4 counts) and atom->special
     [n][maxspecial] (partner TAGS = index + 1, ordered 1-2 | 1-3 | 1-4), the layout

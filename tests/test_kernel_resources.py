@@ -1,0 +1,62 @@
+"""Register / scratch budget of the hot kernels, read from hipcc's resource remarks (cross-compiles for gfx950 without a
+GPU).  A kernel that starts spilling to scratch or drops below its wave occupancy loses tens of percent silently --
+e.g. an early return inside the minimum-image helper once cost 24 bytes of scratch per lane in four kernels and 20 %
+of the step time."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "lammps-induced-dipole-polarization-pair-style_amd", "csrc", "polar_api.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def usage(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("res") / "lib.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out, SRC,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res, cur = {}, None
+    for ln in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+        m = re.search(r"(VGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|VGPRs Spill): (\d+)", ln)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    assert res, "no resource remarks parsed"
+    return res
+
+
+def _pick(usage, *frags):
+    return {k: v for k, v in usage.items() if all(f in k for f in frags)}
+
+
+def test_no_kernel_uses_scratch_or_spills_vector_registers(usage):
+    bad = {k: v for k, v in usage.items() if v.get("ScratchSize [bytes/lane]", 0) or v.get("VGPRs Spill", 0)}
+    assert not bad, bad
+
+
+def test_sweep_kernel_keeps_its_occupancy(usage):
+    lp = _pick(usage, "k_field_lpI")          # the default list-mode sweep: <= 64 VGPRs -> eight waves per SIMD by registers
+    assert lp
+    for k, v in lp.items():
+        assert v["VGPRs"] <= 64, (k, v)
+
+
+def test_list_and_row_kernels_stay_within_their_budgets(usage):
+    for frag, cap in (("k_nl_build", 64), ("k_static_fieldILb0", 64), ("k_lj_nl_build", 64)):
+        ks = _pick(usage, frag)
+        assert ks, frag
+        for k, v in ks.items():
+            assert v["VGPRs"] <= cap, (k, v)
+    for k, v in _pick(usage, "k_polar_forceILb0").items():   # FP64-heavy: four waves per SIMD at least
+        assert v["VGPRs"] <= 128, (k, v)
+    for k, v in _pick(usage, "k_ljcoul").items():
+        assert v["VGPRs"] <= 128, (k, v)
