@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>_pmc*/ (tools/pmc_traffic.sh) -> profiles/traffic_pmc.json + profiles/r02_<version>_traffic_pmc.txt"""
+import collections, csv, glob, importlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else "k_field_lp"
+acc = collections.defaultdict(list)
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc*", "*", "*counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+mean = {k: sum(v) / len(v) for k, v in acc.items()}
+line = None
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc*.log"))):
+    for ln in open(f):
+        if ln.startswith('{"metric"'):
+            line = json.loads(ln)
+pkg = importlib.import_module("lammps-induced-dipole-polarization-pair-style_amd")
+ver = line["config"]["kernel_version"] if line else "unknown"
+fetch_kb, write_kb = mean.get("FETCH_SIZE", 0.0), mean.get("WRITE_SIZE", 0.0)
+# gfx950: FETCH_SIZE counts 64 B per 128-B memory-side request of a wide coalesced stream (MI355X_MICROARCH.md, HBM):
+# doubled, as the guide prescribes for such streams; the 64-byte quad gathers of this kernel are served by L2 hits for the
+# most part (TCC hit rate below), so the memory-side traffic is dominated by the 16-byte-per-lane index stream
+traffic = (2.0 * fetch_kb + write_kb) * 1024.0
+out = {"kernel_version": ver, "natoms": line["config"]["natoms"] if line else None, "kernel": pat,
+       "bytes_per_launch": traffic, "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
+       "launches_sampled": len(acc.get("FETCH_SIZE", [])), "counters_mean": mean,
+       "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"] if line else None,
+       "source": f"profiles/r02_{ver}_traffic_pmc.txt (tools/pmc_traffic.sh: separate --pmc passes of bench.py --no-extras)"}
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_pmc.json"), "w"), indent=1)
+with open(os.path.join(ROOT, "profiles", f"r02_{ver}_traffic_pmc.txt"), "w") as fh:
+    fh.write(f"# {pat}, bench headline (BASELINE configs[2], {out['natoms']} atoms), kernel version {ver}; means per launch\n")
+    for k, v in sorted(mean.items()):
+        fh.write(f"{k:28s} n={len(acc[k]):5d} mean={v:16.1f}\n")
+    fh.write(f"# traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB = {traffic / 1e6:.1f} MB per launch; algorithmic {out['algorithmic_bytes_per_launch'] / 1e6 if out['algorithmic_bytes_per_launch'] else 0:.1f} MB per launch\n")
+print(json.dumps(out, indent=1))
