@@ -21,7 +21,7 @@
 using namespace polar;
 
 // bump when a kernel on the hot path changes: PMC files under profiles/ are keyed by it (bench.py, roofline.traffic)
-#define POLAR_KERNEL_VERSION "r02-lp2-v1"
+#define POLAR_KERNEL_VERSION "r02-lp2-v2"
 
 namespace {
 
@@ -141,6 +141,7 @@ struct polar_handle {
   DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
   DBuf<double2> d_dd_s;
   DBuf<int2> d_lpdesc;  // row descriptors of k_field_lp
+  DBuf<int> d_slot;     // lp sweep: launch row of every atom's dd row (s space), -1: none
   // cluster rows (sweep_kernel 3, k_field_cl): clusters sorted by colour; color_off then counts clusters
   std::vector<int> h_cl;        // [ncl][4] member atoms (orig ids, -1 padded)
   DBuf<int> d_cl_orig, d_cl_cnt, d_cl_wrap, d_cl_tw;
@@ -166,6 +167,7 @@ struct polar_handle {
   bool colors_valid = false;
   double color_keep = 2.0;      // A (POLAR_COLOR_KEEP): a colouring built at color_dist stays in use on later lists while
                                 // every same-colour pair is still farther apart than this (hysteresis: atoms move)
+  bool slots_by_color = false;  // the dd rows of the current lists are laid out in colour-phase order (compute_slots)
   bool colors_recheck = false;  // a new neighbor list arrived: keep the colouring if it still separates every same-colour pair
   std::vector<int> h_color;     // colour of every atom (orig ids), -1: none
   DBuf<int> d_color_orig, d_color_s;
@@ -324,6 +326,26 @@ void build_cells(polar_handle *h) {
   }
 }
 
+// lp sweep: where k_nl_build stores every atom's dd row = its row in launch order (colour phases back to back for GS,
+// own rows for Jacobi).  While no colouring exists yet (first step, or after a clash) the rows are laid out in atom
+// order and the lists are built once more after the colouring (solve / polar_step_begin).
+void compute_slots(polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  const bool gs = st.polar_gs || st.polar_gs_ranked;
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  h->d_slot.ensure(n + 1);
+  HIPCHECK(hipMemsetAsync(h->d_slot.p, 0xFF, (size_t)(n + 1) * sizeof(int), s));
+  if (gs && h->colors_valid) {
+    const int tot = h->color_off.empty() ? 0 : h->color_off.back();
+    if (tot > 0) k_slot_from_rows<<<nblk(tot, 256), 256, 0, s>>>(tot, h->d_rows.p, h->d_slot.p);
+    h->slots_by_color = true;
+  } else {
+    k_slot_from_rows<<<nblk(own_n(h), 256), 256, 0, s>>>(own_n(h), own_rows(h), h->d_slot.p);
+    h->slots_by_color = false;
+  }
+}
+
 void build_lists(polar_handle *h) {
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
@@ -360,7 +382,7 @@ void build_lists(polar_handle *h) {
   if (h->sweep_kernel == 2) h->dd_pitch = ((h->dd_pitch + 255) / 256) * 256;  // whole 4-trip chunks (k_field_lp)
   h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1);
   h->d_nl_j.ensure((size_t)n * h->nl_pitch + 64);
-  if (h->sweep_kernel != 3) h->d_dd_j.ensure((size_t)n * h->dd_pitch + 64);
+  if (h->sweep_kernel != 3) h->d_dd_j.ensure((size_t)n * h->dd_pitch + 1024);  // slack: k_field_lp requests two index chunks per row up front
   else h->d_dd_j.ensure(64);
   // What the sweep streams per pair.  Measured (tools/exp_nocache.sh): while index + r^2 of all pairs
   // (12 B/pair) stay resident in the 256 MB Infinity Cache between sweeps the cached r^2 wins (36k atoms,
@@ -398,7 +420,7 @@ void build_lists(polar_handle *h) {
       rows, nr, h->d_pos4.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,
       h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, fuse ? r2p : nullptr, fuse ? 1 : 0, lp ? 6 : 0, lp ? n : -1,
       lp ? h->d_dd_wrap.p : nullptr, recheck ? h->d_color_s.p : nullptr, h->color_keep * h->color_keep, h->d_overflow.p + 8,
-      h->d_overflow.p, h->d_ddtot.p);
+      lp ? h->d_slot.p : nullptr, h->d_overflow.p, h->d_ddtot.p);
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
   if (fuse || mode == 4) {
     // modes 1 and 2: the list build wrote r^2 (mode 1) and the padding itself; mode 4: no per-atom dd rows at all
@@ -768,20 +790,21 @@ void prepare_lp(polar_handle *h) {
 }
 template <int EP>
 void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
+  const long long row0 = desc - h->d_lpdesc.p;  // launch row of the first descriptor = its dd row
   if (nrows <= 0) return;
   const polar_settings &st = h->ph.st;
   const int qb = h->quad_block;
   const int nt = h->lp_tiles;
   const size_t lds = (size_t)(qb / 64) * nt * POLAR_LP_TILE;
 #define FL(D, NT) k_field_lp<EP, D, NT><<<nblk_xcd(nrows, qb / 64), qb, lds, h->stream>>>(                           \
-      nrows, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                                     \
+      nrows, row0, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                               \
       st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
   if (h->lp_depth >= 2) {  // gathers kept lp_depth trips ahead (hand-counted waits), four tiles per wave
     const int pb = std::min(qb, 256);
     const size_t plds = (size_t)(pb / 64) * 4 * POLAR_LP_TILE;
 #define FA(D, DEPTH) k_field_lpa<EP, D, DEPTH><<<nblk_xcd(nrows, pb / 64), pb, plds, h->stream>>>(                  \
-      nrows, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                                     \
+      nrows, row0, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                                     \
       st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
     if (h->lp_depth == 2) { if (expd) FA(0, 2); else FA(1, 2); }
     else                  { if (expd) FA(0, 3); else FA(1, 3); }
@@ -949,6 +972,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     const bool clm = !ap && h->sweep_kernel == 3;
     if (!ap) resolve_colors(h);
     if ((gs || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
+    if (!ap && gs && h->sweep_kernel == 2 && !h->slots_by_color) { compute_slots(h); build_lists(h); }  // rows into launch order
     if (gs) out->ncolors = (int)h->color_off.size() - 1;
     if (!ap && h->sweep_kernel == 2) prepare_lp(h);
     // fixed-iteration GS takes no decision between sweeps: its end-of-sweep logic is applied in two
@@ -1137,8 +1161,10 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   k_pack<<<nblk(n + 1, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_x.p, h->d_q.p, h->d_alpha.p, h->d_mol.p, mu0,
                                       h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p);
   if (!ap) {
+    if (h->colors_valid && h->sweep_kernel != 3) map_color_rows(h);  // the colour rows in this step's cell order
+    if (h->sweep_kernel == 2) compute_slots(h);
     build_lists(h);
-    if (h->colors_valid) { if (h->sweep_kernel == 3) build_cluster_lists(h); else map_color_rows(h); }
+    if (h->colors_valid && h->sweep_kernel == 3) build_cluster_lists(h);
   }
   HIPCHECK(hipEventRecord(h->ev[1], s));
 
@@ -1328,7 +1354,7 @@ int polar_destroy(polar_handle *h) {
     h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release(); h->d_T6.release();
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
-    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_trace.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
+    h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_slot.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_trace.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
     if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -1832,6 +1858,7 @@ int polar_step_begin(polar_handle *h, int eflag, int vflag) {
     const bool clm = st.dd_cutoff > 0.0 && h->sweep_kernel == 3;
     if (st.dd_cutoff > 0.0) resolve_colors(h);
     if (!st.zodid && (st.polar_gs || st.polar_gs_ranked || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
+    if (!st.zodid && st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && h->sweep_kernel == 2 && !h->slots_by_color) { compute_slots(h); build_lists(h); }
     if (!st.zodid && st.dd_cutoff > 0.0 && h->sweep_kernel == 2) prepare_lp(h);
     h->in_step = true;
     return POLAR_OK;

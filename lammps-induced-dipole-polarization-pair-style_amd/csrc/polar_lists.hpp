@@ -96,6 +96,11 @@ __global__ void k_map_rows_pad(int n, const int *__restrict__ inv, const int *__
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] >= 0 ? inv[in[i]] : -1;  // -1: padding of a cluster's member table
 }
+// dd_slot[rows[r]] = r: where k_nl_build stores the dd row of an atom (launch order of the lp sweep)
+__global__ void k_slot_from_rows(int n, const int *__restrict__ rows, int *__restrict__ slot) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) slot[rows ? rows[r] : r] = r;
+}
 // colours of the atoms in this step's s order (colour re-validation): -1 = no colour
 __global__ void k_color_map(int n, const int *__restrict__ perm, const int *__restrict__ color_orig, int *__restrict__ color_s) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
                                                           int dd_shift, int dd_pad_index, int *__restrict__ dd_wrap,
                                                           const int *__restrict__ color_s, double colordistsq,
                                                           int *__restrict__ color_conflict,
+                                                          const int *__restrict__ dd_slot,
                                                           int *__restrict__ overflow,
                                                           unsigned long long *__restrict__ dd_total) {
   const int lane = threadIdx.x & 63;
@@ -151,7 +157,10 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
     }
   }
   const int c0 = cc[0], c1 = cc[1], c2 = cc[2];
-  const long long nl0 = (long long)i * nl_pitch, dd0 = (long long)i * dd_pitch;
+  // lp sweep: the dd row of atom i is stored where the sweep will walk it (dd_slot[i] = its row in launch order), so that a
+  // sweep wave can request its index stream before it knows which atom it works on; rows without a slot hold no dd pair
+  const int slot_i = dd_slot ? dd_slot[i] : i;
+  const long long nl0 = (long long)i * nl_pitch, dd0 = (long long)(slot_i >= 0 ? slot_i : 0) * dd_pitch;
   int ncount = 0, dcount = 0;
   bool wrap_lane = false;  // this lane saw a dd pair of the row that reaches across a periodic face (lp sweep: rows without skip the wrap)
   // Cells have an edge >= cutoff/2, so the stencil reaches +-2 cells (125 cells hold 42 % fewer
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
           min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
           rsq = ex * ex + ey * ey + ez * ez;
           in_nl = rsq <= cutallsq;
-          in_dd = ipol && __double2loint(rj.w) && (rsq < ddcutsq);
+          in_dd = ipol && slot_i >= 0 && __double2loint(rj.w) && (rsq < ddcutsq);
           if (icol >= 0 && rsq < colordistsq && __double2loint(rj.w) && color_s[j] == icol) clash = true;
           wrap_lane |= in_dd && (ex != ri.x - rj.x || ey != ri.y - rj.y || ez != ri.z - rj.z);
           same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;

@@ -337,8 +337,19 @@ __device__ __forceinline__ void tensor_scalars_lp(double r2, double pd, const Ex
 // Row epilogue: the three field sums of the 64 lanes, the new dipole, sum (dmu)^2.  The three wave reductions are
 // folded into one butterfly: after the xor-1 step a lane keeps x (even) or y (odd), after the xor-2 step lanes
 // 4m+{0,1,2,3} hold {x, y, z, z}; four more steps finish all three at once (29 instead of 54 vector instructions).
-__device__ __forceinline__ void lp_finish(double ax, double ay, double az, int lane, const AtomRec *self, AtomRec *out,
-                                          const double *efi, double *slots) {
+struct LpSelf { double mu_old, alpha, ef; };  // lanes 0..2: component `lane` of the row atom's dipole, its alpha, its E_static
+// requested when the row STARTS: the epilogue below then finds them in registers instead of paying a memory round trip
+// per row after the last trip (rows are only ~8 trips long)
+__device__ __forceinline__ LpSelf lp_self(int lane, const AtomRec *self, const double *efi) {
+  LpSelf s{0.0, 0.0, 0.0};
+  if (lane < 3) {
+    const double *r = reinterpret_cast<const double *>(self);
+    s.mu_old = r[2 * lane + 1]; s.alpha = r[7]; s.ef = efi[lane];
+  }
+  return s;
+}
+__device__ __forceinline__ void lp_finish(double ax, double ay, double az, int lane, const LpSelf &self, AtomRec *out,
+                                          double *slots) {
   const bool odd = lane & 1, hi = lane & 2;
   const double keep1 = odd ? ay : ax, give1 = odd ? ax : ay;
   double v = keep1 + dpp_full<0xB1>(give1);  // quad_perm [1,0,3,2]: even lanes x(l)+x(l+1), odd lanes y(l-1)+y(l)
@@ -352,11 +363,9 @@ __device__ __forceinline__ void lp_finish(double ax, double ay, double az, int l
   // lanes 0, 1, 2 hold E_x, E_y, E_z of the row: mu_new = alpha (E_static + E_ind), PS.cpp:1170-1180
   double d2 = 0.0;
   if (lane < 3) {
-    const double *r = reinterpret_cast<const double *>(self);
-    const double mu_old = r[2 * lane + 1], alpha = r[7];
-    const double mu_new = alpha * (efi[lane] + v);
+    const double mu_new = self.alpha * (self.ef + v);
     reinterpret_cast<double *>(out)[2 * lane + 1] = mu_new;
-    const double d = mu_new - mu_old;
+    const double d = mu_new - self.mu_old;
     d2 = d * d;
   }
   d2 += dpp_full<0xB1>(d2);
@@ -414,7 +423,7 @@ __device__ __forceinline__ void lp_trip(const char *rd0, const char *rd1, const 
   az = fma(cc, dz, fma(-s3, C.y, az));
 }
 template <int WRAP, int DAMP, int NT>
-__device__ __forceinline__ void lp_row(int T, const int4 *pc, const char *srcc, char *tile0, int lane, const AtomRec &ri,
+__device__ __forceinline__ void lp_row(int T, const int4 *pc, const int4 &Ja0, const int4 &Jb0, const char *srcc, char *tile0, int lane, const AtomRec &ri,
                                        const Box &box, double pd, const ExpCoef &K, double &ax, double &ay, double &az,
                                        int ablate) {
   const double px = box.periodic[0] ? box.prd[0] : 0.0, py = box.periodic[1] ? box.prd[1] : 0.0,
@@ -427,8 +436,7 @@ __device__ __forceinline__ void lp_row(int T, const int4 *pc, const char *srcc, 
   const char *rd2 = tile0 + k * 1024 + (4 * q + (k ^ 2)) * 16;
   if (T <= 0) return;
   const int C = (T + 3) >> 2;  // chunks of four trips; lane L's int4 of chunk c is pc[64 c]
-  int4 Ja = pc[0], Jb = make_int4(0, 0, 0, 0), Jc = Jb;
-  if (C > 1) Jb = pc[64];
+  int4 Ja = Ja0, Jb = Jb0, Jc = Jb0;  // the first two chunks were requested before the row descriptor arrived
   lp_gather<0>(srcc, Ja.x, g0, tile0); lp_gather<1>(srcc, Ja.x, g1, tile0);
   lp_gather<2>(srcc, Ja.x, g2, tile0); lp_gather<3>(srcc, Ja.x, g3, tile0);
   const int other = NT == 1 ? 0 : POLAR_LP_TILE;
@@ -461,10 +469,11 @@ __global__ void k_lp_desc(int nrows, const int *__restrict__ rows, RowList ddl, 
   desc[r] = make_int2(i, (int)((c + 63) >> 6) | (dd_wrap[i] ? 0x40000000 : 0));
 }
 template <int EP, int DAMP, int NT>
-__global__ __launch_bounds__(1024) void k_field_lp(
-    int nrows, const int2 *__restrict__ desc, AtomRec *recA, AtomRec *recB, Box box, long long pitch,
-    const int *__restrict__ dd_j, double pd, ExpCoef K, const double *__restrict__ ef, const Scal *scal,
-    double *__restrict__ slots, int ablate) {
+__global__ __launch_bounds__(1024) void k_field_lp(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA,
+                                                   AtomRec *recB, Box box, long long pitch,
+                                                   const int *__restrict__ dd_j, double pd, ExpCoef K,
+                                                   const double *__restrict__ ef, const Scal *scal,
+                                                   double *__restrict__ slots, int ablate) {
   extern __shared__ __attribute__((aligned(16))) char lp_lds[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -473,9 +482,12 @@ __global__ __launch_bounds__(1024) void k_field_lp(
   if (lb < 0) return;
   const int row = lb * rpb + wv;
   if (row >= nrows) return;
-  // a row's start is a chain of dependent round trips (loop state, descriptor, row data + indices, first gathers):
-  // the first two are requested together
+  // A row starts with a chain of dependent round trips (descriptor -> row atom's record -> first gathers).  Everything
+  // that needs only the launch row is requested at once: the loop state, the descriptor, and the first two chunks of
+  // the index stream -- dd rows are stored in launch order (k_nl_build, dd_slot), row row0 + row of this launch.
+  const int4 *pc = reinterpret_cast<const int4 *>(dd_j + (size_t)(row0 + row) * pitch) + lane;
   const int2 de = desc[row];
+  const int4 Ja0 = pc[0], Jb0 = pc[64];
   const int done = scal->done, curv = scal->cur;
   if (done) return;
   const int i = __builtin_amdgcn_readfirstlane(de.x);
@@ -484,21 +496,21 @@ __global__ __launch_bounds__(1024) void k_field_lp(
   const int cur = __builtin_amdgcn_readfirstlane(curv);
   const AtomRec *src = (EP == EP_JACOBI && cur) ? recB : recA;
   AtomRec *dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
-  const int4 *pc = reinterpret_cast<const int4 *>(dd_j + (size_t)i * pitch) + lane;
   AtomRec ri;  // the row atom's position: wave-uniform, parked in scalar registers
   {
     const double *r = reinterpret_cast<const double *>(src + i);
     ri.x = wave_uniform(r[0]); ri.y = wave_uniform(r[2]); ri.z = wave_uniform(r[4]);
   }
+  const LpSelf self = lp_self(lane, src + i, ef + 3 * (size_t)i);
   if (ablate & 1) T = 0;  // lab switches (POLAR_ABLATE): timing only, wrong numbers
   const char *srcc = reinterpret_cast<const char *>(src);
   char *tile0 = lp_lds + (size_t)wv * (NT * POLAR_LP_TILE);
   double ax = 0.0, ay = 0.0, az = 0.0;
   // rows whose list holds no pair across a periodic face (flag written by k_nl_build) skip the minimum-image wrap
-  if (!wrapped) lp_row<0, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
-  else if (!box.triclinic) lp_row<1, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
-  else lp_row<2, DAMP, NT>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
-  lp_finish(ax, ay, az, lane, src + i, dst + i, ef + 3 * (size_t)i, slots);
+  if (!wrapped) lp_row<0, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  else if (!box.triclinic) lp_row<1, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  else lp_row<2, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
+  lp_finish(ax, ay, az, lane, self, dst + i, slots);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -828,7 +840,7 @@ __device__ __forceinline__ void lpa_row(int T, const int4 *pc, const char *srcc,
 #undef POLAR_LPA_TRIP
 }
 template <int EP, int DAMP, int D>
-__global__ __launch_bounds__(256) void k_field_lpa(int nrows, const int2 *__restrict__ desc, AtomRec *recA, AtomRec *recB,
+__global__ __launch_bounds__(256) void k_field_lpa(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA, AtomRec *recB,
                                                    Box box, long long pitch, const int *__restrict__ dd_j, double pd,
                                                    ExpCoef K, const double *__restrict__ ef, const Scal *scal,
                                                    double *__restrict__ slots, int ablate) {
@@ -853,7 +865,7 @@ __global__ __launch_bounds__(256) void k_field_lpa(int nrows, const int2 *__rest
   const double efx = ef[3 * i], efy = ef[3 * i + 1], efz = ef[3 * i + 2];
   const char *srcc = reinterpret_cast<const char *>(src);
   char *tile0 = lp_lds + (size_t)wv * (4 * POLAR_LP_TILE);
-  const int4 *pc = reinterpret_cast<const int4 *>(dd_j + (size_t)i * pitch) + lane;
+  const int4 *pc = reinterpret_cast<const int4 *>(dd_j + (size_t)(row0 + row) * pitch) + lane;  // dd rows are in launch order
   double ax = 0.0, ay = 0.0, az = 0.0;
   if (wrapped) lpa_row<true, DAMP, D>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az);
   else lpa_row<false, DAMP, D>(T, pc, srcc, tile0, lane, ri, box, pd, K, ax, ay, az);

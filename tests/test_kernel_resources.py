@@ -44,10 +44,10 @@ def test_no_kernel_uses_scratch_or_spills_vector_registers(usage):
 
 
 def test_sweep_kernel_keeps_its_occupancy(usage):
-    lp = _pick(usage, "k_field_lpI")          # the default list-mode sweep: <= 64 VGPRs -> eight waves per SIMD by registers
-    assert lp
+    lp = _pick(usage, "k_field_lpI")          # the default list-mode sweep: two 4 KB LDS tiles per wave allow five
+    assert lp                                 # 256-thread workgroups per CU = five waves per SIMD -> <= 96 VGPRs
     for k, v in lp.items():
-        assert v["VGPRs"] <= 64, (k, v)
+        assert v["VGPRs"] <= 96, (k, v)
 
 
 def test_list_and_row_kernels_stay_within_their_budgets(usage):
