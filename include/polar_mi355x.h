@@ -27,7 +27,7 @@ extern "C" {
 #define POLAR_ERR_INPUT -1         /* reference error->all() conditions; message = reference text */
 #define POLAR_ERR_NO_DEVICE -2
 #define POLAR_ERR_HIP -3
-#define POLAR_ERR_UNSUPPORTED -4   /* not offered in this mode (e.g. per-atom tallies through the stepwise/sharded entry points) */
+#define POLAR_ERR_UNSUPPORTED -4   /* not offered in this mode (e.g. exact mode on a row-sharded handle) */
 #define POLAR_ERR_STATE -5         /* call order (e.g. compute before set_atoms) */
 
 enum { POLAR_DAMP_EXPONENTIAL = 0, POLAR_DAMP_NONE = 1 }; /* PS.cpp:51 */
@@ -217,7 +217,10 @@ int polar_set_row_range(polar_handle *h, int lo, int hi); /* hi < 0: all rows */
 int polar_set_global_count(polar_handle *h, long long natoms);
 /* 1: the LJ/coul list is a LAMMPS *full* list (each pair in both rows): force on i only, tallies halved */
 int polar_set_list_style(polar_handle *h, int full);
-/* compute() split at the exchange points: begin = list build, LJ+coul, static field, initial guess */
+/* compute() split at the exchange points: begin = list build, LJ+coul, static field, initial guess.
+ * eflag & 2 / vflag & 4 ask for the per-atom tallies as polar_compute_peratom does; they stay on the device
+ * ("eatom" [nall], "vatom" [nall][6] of polar_dev_ptr / polar_download, valid after polar_step_finish) and hold what THIS
+ * handle's rows tallied: the shards' arrays add up to the unsharded ones. */
 int polar_step_begin(polar_handle *h, int eflag, int vflag);
 int polar_step_sweep(polar_handle *h); /* one sweep over the owned rows */
 /* end-of-sweep control (PS.cpp:1193-1236) on the device; dev_global_change = all-reduced sum of

@@ -1067,7 +1067,9 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   double *eatom = nullptr, *vatom = nullptr;
   if (eflag / 2) { h->d_eatom.ensure(nall + 1); eatom = h->d_eatom.p; HIPCHECK(hipMemsetAsync(eatom, 0, (size_t)nall * sizeof(double), s)); }
   if (vflag / 4) { h->d_vatom.ensure(6 * (size_t)nall + 6); vatom = h->d_vatom.p; HIPCHECK(hipMemsetAsync(vatom, 0, 6 * (size_t)nall * sizeof(double), s)); }
-  if ((eatom || vatom) && own_n(h) != n) throw InputError("per-atom tallies are not available on a row-sharded handle");
+  // (on a row-sharded handle every kernel tallies into the rows it walks -- half of each pair per row atom -- so the
+  //  shards' arrays add up to the unsharded ones: LJ/Coulomb over the rows of the list the shard was given, polarization
+  //  over the own rows)
   k_zero_slots<<<nblk(POLAR_NSLOT, 256), 256, 0, s>>>(h->d_slots.p, h->d_scal.p);
   auto launch_lj = [&]() {  // a3 -- on a low-priority side stream when overlap is on: it depends on nothing below, and fills
     // whatever the list build, the static field and the latency-bound solver launches leave idle
@@ -1851,7 +1853,6 @@ int polar_set_list_style(polar_handle *h, int full) {
 int polar_step_begin(polar_handle *h, int eflag, int vflag) {
   return guarded(h, [&]() {
     HIPCHECK(hipSetDevice(h->device));
-    if (eflag / 2 || vflag / 4) return fail(h, POLAR_ERR_UNSUPPORTED, "per-atom energy/virial tallies are not available in the stepwise (sharded) interface");
     h->h_flags[0] = 0; h->h_flags[4] = 0;
     phase_begin(h, eflag, vflag, nullptr);
     const polar_settings &st = h->ph.st;

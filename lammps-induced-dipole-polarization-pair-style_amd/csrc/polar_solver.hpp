@@ -422,6 +422,11 @@ __device__ __forceinline__ void lp_trip(const char *rd0, const char *rd1, const 
   ay = fma(cc, dy, fma(-s3, B.y, ay));
   az = fma(cc, dz, fma(-s3, C.y, az));
 }
+__device__ __forceinline__ void lp_first_gather(const char *srcc, int joff, int lane, char *tile0) {
+  const int k = lane & 3;
+  lp_gather<0>(srcc, joff, (unsigned)(k * 16), tile0); lp_gather<1>(srcc, joff, (unsigned)((k ^ 1) * 16), tile0);
+  lp_gather<2>(srcc, joff, (unsigned)((k ^ 2) * 16), tile0); lp_gather<3>(srcc, joff, (unsigned)((k ^ 3) * 16), tile0);
+}
 template <int WRAP, int DAMP, int NT>
 __device__ __forceinline__ void lp_row(int T, const int4 *pc, const int4 &Ja0, const int4 &Jb0, const char *srcc, char *tile0, int lane, const AtomRec &ri,
                                        const Box &box, double pd, const ExpCoef &K, double &ax, double &ay, double &az,
@@ -436,9 +441,8 @@ __device__ __forceinline__ void lp_row(int T, const int4 *pc, const int4 &Ja0, c
   const char *rd2 = tile0 + k * 1024 + (4 * q + (k ^ 2)) * 16;
   if (T <= 0) return;
   const int C = (T + 3) >> 2;  // chunks of four trips; lane L's int4 of chunk c is pc[64 c]
-  int4 Ja = Ja0, Jb = Jb0, Jc = Jb0;  // the first two chunks were requested before the row descriptor arrived
-  lp_gather<0>(srcc, Ja.x, g0, tile0); lp_gather<1>(srcc, Ja.x, g1, tile0);
-  lp_gather<2>(srcc, Ja.x, g2, tile0); lp_gather<3>(srcc, Ja.x, g3, tile0);
+  int4 Ja = Ja0, Jb = Jb0, Jc = Jb0;  // the first two chunks were requested before the row descriptor arrived;
+  // the gathers of trip 0 are already in flight (lp_first_gather, issued before the row atom's own data was requested)
   const int other = NT == 1 ? 0 : POLAR_LP_TILE;
 #define POLAR_LP_TRIP(CUR, NXT, TT, JNEXT)                                                                              \
   lp_trip<WRAP, DAMP, NT>(rd0, rd1, rd2, CUR, NXT, t0 + (TT) + 1 < T, srcc, JNEXT, g0, g1, g2, g3, tile0, ri, px, py, pz, \
@@ -496,15 +500,16 @@ __global__ __launch_bounds__(1024) void k_field_lp(int nrows, long long row0, co
   const int cur = __builtin_amdgcn_readfirstlane(curv);
   const AtomRec *src = (EP == EP_JACOBI && cur) ? recB : recA;
   AtomRec *dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
-  AtomRec ri;  // the row atom's position: wave-uniform, parked in scalar registers
+  if (ablate & 1) T = 0;  // lab switches (POLAR_ABLATE): timing only, wrong numbers
+  const char *srcc = reinterpret_cast<const char *>(src);
+  char *tile0 = lp_lds + (size_t)wv * (NT * POLAR_LP_TILE);
+  if (T > 0) lp_first_gather(srcc, Ja0.x, lane, tile0);  // second round trip: the first gathers ...
+  AtomRec ri;  // ... together with the row atom's position (wave-uniform, parked in scalar registers) and epilogue data
   {
     const double *r = reinterpret_cast<const double *>(src + i);
     ri.x = wave_uniform(r[0]); ri.y = wave_uniform(r[2]); ri.z = wave_uniform(r[4]);
   }
   const LpSelf self = lp_self(lane, src + i, ef + 3 * (size_t)i);
-  if (ablate & 1) T = 0;  // lab switches (POLAR_ABLATE): timing only, wrong numbers
-  const char *srcc = reinterpret_cast<const char *>(src);
-  char *tile0 = lp_lds + (size_t)wv * (NT * POLAR_LP_TILE);
   double ax = 0.0, ay = 0.0, az = 0.0;
   // rows whose list holds no pair across a periodic face (flag written by k_nl_build) skip the minimum-image wrap
   if (!wrapped) lp_row<0, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);

@@ -652,7 +652,12 @@ def load_fixture(path, extra_args=(), g_ewald=None, ncoultablebits=12, newton=Tr
 
 def synth_system(N, seed=1, extra_args=(), cut_lj=2.5, cut_coul=12.8345, skin=2.0):
     """PolarSystem of the synthetic generator (SURVEY.md 8(d) "primary" configs 1-4): synth(N, seed)
-    with the MOF5+H2 deck's pair_style line (exponential damping a = 2.1304, ranked GS) plus ``extra_args``."""
+    with the MOF5+H2 deck's pair_style line (exponential damping a = 2.1304, ranked GS) plus ``extra_args``.
+
+    A LOAD GENERATOR, not a physical system: sorbate centres are placed without regard to the framework sites, so
+    sites overlap (E_pol ~ -2 kcal/mol per atom, 350x the MOF replica) and the solver's convergence history means
+    nothing.  It has the right density, list lengths and memory pattern; bench.py uses it only behind ``--synth`` and the
+    headline and every parity property run on the replicated MOF5+H2 cell."""
     d = synth(N, seed)
     args = [repr(cut_lj), repr(cut_coul), "damp_type", "exponential", "damp", "2.1304", "polar_gs_ranked", "yes",
             "use_previous", "no"] + list(extra_args)

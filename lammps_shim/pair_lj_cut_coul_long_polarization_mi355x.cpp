@@ -184,6 +184,9 @@ void PairLJCutCoulLongPolarizationMI355X::build_halo_map()
   lammps_of_lib.assign(nall,0);
   for (int a = 0; a < nall; a++) lammps_of_lib[lib_of_lammps[a]] = a;
 
+  sh_n = nlocal + nhalo;
+  if (device_neigh) return;        // the library builds the rows of the own atoms itself (polar_build_neighbors)
+
   // the half list with its indices in library order (special bits kept), rows = own atoms
   const int inum = list->inum;
   std::vector<int> nn(nlocal + nhalo,0);
@@ -197,7 +200,6 @@ void PairLJCutCoulLongPolarizationMI355X::build_halo_map()
     for (int k = 0; k < nn[i]; k++)
       flat[first[i] + k] = lib_of_lammps[jl[k] & NEIGHMASK] | (jl[k] & ~NEIGHMASK);
   }
-  sh_n = nlocal + nhalo;
   sh_nn.swap(nn); sh_first.swap(first); sh_flat.swap(flat);
 }
 
@@ -222,10 +224,6 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
   check(polar_get_settings(h,&pst));
   if (!(pst.dd_cutoff > 0.0))
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization on several MPI ranks needs the dd_cutoff keyword (list mode)");
-  if (device_neigh)
-    error->all(FLERR,"Pair style lj/cut/coul/long/polarization: device_neigh is not available on several MPI ranks yet");
-  if (eflag_atom || vflag_atom)
-    error->all(FLERR,"Pair style lj/cut/coul/long/polarization: per-atom tallies are not available on several MPI ranks yet");
   if (!force->newton_pair)
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization on several MPI ranks needs newton_pair on");
   // halo atoms are LAMMPS ghosts: the ghost shell must reach as far as the polarization loops do
@@ -248,14 +246,23 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
   int periodic[3] = {domain->xperiodic,domain->yperiodic,domain->zperiodic};
   check(polar_set_box(h,domain->boxlo,domain->prd,tilt,periodic,domain->triclinic));
   check(polar_set_atoms(h,sh_n,nall - sh_n,sh_x.data(),sh_q.data(),sh_a.data(),sh_t.data(),sh_m.data()));
-  if (relist) {
+  check(polar_set_row_range(h,0,nlocal));
+  check(polar_set_global_count(h,(long long) atom->natoms));
+  check(polar_set_newton(h,1));
+  if (relist && device_neigh) {
+    // full list for the own rows, built on the device among [own | halo | other ghosts]: tags in library order; the
+    // special lists are read for the own atoms only, which keep their LAMMPS indices
+    sh_t2.resize(nall);
+    for (int k = 0; k < nall; k++) sh_t2[k] = (int) atom->tag[lammps_of_lib[k]];
+    check(polar_build_neighbors(h,&neighbor->cutneighsq[0][0],sh_t2.data(),
+                                atom->molecular ? &atom->nspecial[0][0] : NULL,
+                                atom->molecular ? (const int *) &atom->special[0][0] : NULL,atom->maxspecial,
+                                neighbor->special_flag,neighbor->nex_mol > 0));
+  } else if (relist) {
     std::vector<int> il(list->inum);
     for (int ii = 0; ii < list->inum; ii++) il[ii] = list->ilist[ii];
     check(polar_set_neighbors_csr(h,list->inum,il.data(),sh_nn.data(),sh_first.data(),sh_flat.data()));
   }
-  check(polar_set_row_range(h,0,nlocal));
-  check(polar_set_global_count(h,(long long) atom->natoms));
-  check(polar_set_newton(h,1));
   if (pst.use_previous) {
     // the initial guess is atom->mu_induced (PS.cpp:376-386): it migrates with the atoms (AtomVecFullPolar packs it
     // into exchange records) and reaches the ghosts through forward_comm; the library's resident copy is in LAST
@@ -269,7 +276,8 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
     check(polar_upload_mu(h,sh_mu.data(),3 * (long long) sh_n));
   }
 
-  const int ef = eflag_either ? 1 : 0, vf = vflag_global ? 1 : 0;
+  // eflag & 2 / vflag & 4: per-atom tallies (src/pair.cpp:760-764), fetched after the step
+  const int ef = (eflag_either ? 1 : 0) | (eflag_atom ? 2 : 0), vf = (vflag_global ? 1 : 0) | (vflag_atom ? 4 : 0);
   polar_result res;
   for (int attempt = 0;; attempt++) {
     check(polar_step_begin(h,ef,vf));
@@ -309,6 +317,22 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
   memcpy(&atom->mu_induced[0][0],sh_x.data(),3 * (size_t) nlocal * sizeof(double));
   check(polar_download(h,"ef_static",sh_x.data(),3 * (long long) sh_n));
   memcpy(&atom->ef_static[0][0],sh_x.data(),3 * (size_t) nlocal * sizeof(double));
+
+  // per-atom tallies of this rank's rows, locals and ghosts (the ghosts' halves travel home with the reverse
+  // communication compute pe/atom and compute stress/atom do), accumulated like ev_tally does
+  if (eflag_atom) {
+    sh_f.resize((size_t) nall);
+    check(polar_download(h,"eatom",sh_f.data(),(long long) nall));
+    for (int k = 0; k < nall; k++) eatom[lammps_of_lib[k]] += sh_f[k];
+  }
+  if (vflag_atom) {
+    sh_f.resize(6 * (size_t) nall);
+    check(polar_download(h,"vatom",sh_f.data(),6 * (long long) nall));
+    for (int k = 0; k < nall; k++) {
+      double *va = vatom[lammps_of_lib[k]];
+      for (int c = 0; c < 6; c++) va[c] += sh_f[6*k+c];
+    }
+  }
 
   if (eflag_global) {
     eng_vdwl += res.eng_vdwl;

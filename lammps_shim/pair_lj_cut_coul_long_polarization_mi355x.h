@@ -55,7 +55,7 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   int debug_flag;                        // keyword `debug yes`: the reference's prints (debug_prints)
   // one MPI rank per GPU: library order = [own | halo (one ghost per foreign tag) | other ghosts]
   int nhalo, sh_n;
-  std::vector<int> lib_of_lammps, lammps_of_lib, halo_ghost, sh_nn, sh_flat, sh_idx, sh_t, sh_m;
+  std::vector<int> lib_of_lammps, lammps_of_lib, halo_ghost, sh_nn, sh_flat, sh_idx, sh_t, sh_t2, sh_m;
   std::vector<long long> sh_first;
   std::vector<double> sh_x, sh_q, sh_a, sh_f, sh_mu;
   void compute_sharded(int, int);

@@ -64,7 +64,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(os.environ.get("POLAR_ORACLE_SO") or build())   # the override: a sanitizer build (tests/test_sanitizers.py)
         _LIB.orc_compute.restype = C.c_int
         _LIB.orc_compute.argtypes = [C.POINTER(OrcSystem), C.c_int, C.c_int, dp, dp, dp, C.POINTER(OrcResult), dp]
         _LIB.orc_compute_peratom.restype = C.c_int

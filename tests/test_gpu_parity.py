@@ -221,6 +221,11 @@ def _run_sharded_lockstep(pkg, par, s, world, eflag=1, vflag=2):
         assert np.all(fr[:lo] == 0) and np.all(fr[hi:n] == 0)      # a shard touches only its rows
         mu[lo:hi] = be.pair.download("mu", 3 * n).reshape(-1, 3)[lo:hi]
     tot = {k: sum(o[k] for o in outs) for k in ("eng_vdwl", "eng_coul", "eng_pol")}
+    nall = s.nlocal + s.nghost
+    if eflag & 2:   # per-atom tallies: every shard holds what its rows tallied; the arrays add up
+        tot["eatom"] = sum(be.pair.download("eatom", nall) for be in bes)
+    if vflag & 4:
+        tot["vatom"] = sum(be.pair.download("vatom", 6 * nall).reshape(-1, 6) for be in bes)
     return f, mu, tot, outs
 
 
@@ -269,6 +274,29 @@ def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
     # and only the polarization forces go through f.x -- the sum must equal the half-list fdotr virial
     vir = sum(o["virial"] for o in outs)
     assert np.max(np.abs(vir - ref["virial"])) < max(tol, 1e-9) * np.max(np.abs(ref["virial"]))
+
+
+def test_row_sharded_handles_tally_per_atom(wl, pkg, oracle):
+    """eflag & 2 / vflag & 4 through the stepwise interface: the shards' eatom / vatom add up to the per-atom
+    tallies of the reference's ev_tally (oracle, LAMMPS half list; ghosts folded onto their owners)."""
+    import importlib
+    par = importlib.import_module(pkg.__name__ + ".parallel")
+    extra = ["use_previous", "no", "dd_cutoff", "9.0", "precision", "1e-13", "max_iterations", "200"]
+    s = _full_list_system(wl, "bulk_h2", extra)
+    f, mu, tot, outs = _run_sharded_lockstep(pkg, par, s, world=3, eflag=3, vflag=6)
+    sh, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
+    orc = oracle.compute(sh, eflag=3, vflag=6)
+    ea = oracle.fold_ghost_forces(tot["eatom"], s.owner, s.nlocal)
+    va = oracle.fold_ghost_forces(tot["vatom"], s.owner, s.nlocal)
+    ea_ref = oracle.fold_ghost_forces(orc["eatom"], sh.owner, sh.nlocal)
+    va_ref = oracle.fold_ghost_forces(orc["vatom"], sh.owner, sh.nlocal)
+    assert np.max(np.abs(ea - ea_ref)) < TOL * np.max(np.abs(ea_ref))
+    assert np.max(np.abs(va - va_ref)) < TOL * np.max(np.abs(va_ref))
+    assert rel(ea.sum(), orc["eng_vdwl"] + orc["eng_coul"], 1e-9) < TOL
+    # and the unsharded handle's own per-atom arrays
+    ref = pkg.pair_from_system(sh).compute(eflag=3, vflag=6)
+    assert np.max(np.abs(ea - oracle.fold_ghost_forces(ref["eatom"], sh.owner, sh.nlocal))) < 1e-9 * np.max(np.abs(ea_ref))
+    assert np.max(np.abs(va - oracle.fold_ghost_forces(ref["vatom"], sh.owner, sh.nlocal))) < 1e-8 * np.max(np.abs(va_ref))
 
 
 @pytest.mark.parametrize("knob", ["POLAR_SWEEP_KERNEL=1", "POLAR_SWEEP_KERNEL=0", "POLAR_SWEEP_KERNEL=0;POLAR_CACHE_R2=0",
