@@ -425,6 +425,60 @@ def _run_step_once(backend, dist, rank, world, counts, offs, eflag, vflag, check
     return out
 
 
+class HostStagedDist:
+    """torch.distributed with every device tensor staged through the host (REHEARSAL ONLY, POLAR_DIST_BACKEND=gloo):
+    lets several ranks share the one GPU of a test box -- RCCL refuses two ranks on one device -- so that the whole
+    of bench_distributed (shard construction, halo plans, device-built lists of the own rows, the sweep protocol,
+    the retry path, the JSON line) runs with world > 1.  Only the RCCL calls themselves stay unrehearsed."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+        self.isend, self.irecv = "isend", "irecv"
+
+    class _Op:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Req:
+        def __init__(self, req, host, dev):
+            self.req, self.host, self.dev = req, host, dev
+
+        def wait(self):
+            self.req.wait()
+            if self.dev is not None:
+                self.dev.copy_(self.host)
+
+    def P2POp(self, op, tensor, peer):
+        return HostStagedDist._Op(op, tensor, peer)
+
+    def batch_isend_irecv(self, ops):
+        reqs = []
+        for o in ops:
+            host = o.tensor.detach().cpu().contiguous()
+            if o.op == "isend":
+                reqs.append(HostStagedDist._Req(self._d.isend(host, o.peer), host, None))
+            else:
+                reqs.append(HostStagedDist._Req(self._d.irecv(host, o.peer), host, o.tensor))
+        return reqs
+
+    def all_reduce(self, t, op=None):
+        host = t.detach().cpu()
+        self._d.all_reduce(host, op=op if op is not None else self._d.ReduceOp.SUM)
+        t.copy_(host)
+
+    def all_gather_into_tensor(self, out, inp):
+        ho, hi = out.detach().cpu(), inp.detach().cpu()
+        self._d.all_gather(list(ho.chunk(self._d.get_world_size())), hi)
+        out.copy_(ho)
+
+    def barrier(self):
+        self._d.barrier()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+
 # --------------------------------------------------------------------------------------------
 def bench_distributed(args, rank, world, local_rank):
     """bench.py --gpus N (N > 1): STRONG scaling on a fixed box -- BASELINE configs[3] (6x6x6 = 291,384 atoms) for
@@ -439,8 +493,16 @@ def bench_distributed(args, rank, world, local_rank):
     wl = importlib.import_module(__package__ + ".workload")
     import bench as B  # repo root is on sys.path (bench.py put it there)
 
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    backend_name = os.environ.get("POLAR_DIST_BACKEND", "nccl")
+    if backend_name == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        # rehearsal on a box with fewer GPUs than ranks: ranks share devices, exchanges go through the host
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend_name)
+        dist = HostStagedDist(dist)
     if os.environ.get("POLAR_DIST_GRAPH") == "1":
         # graph capture needs a non-default stream: everything of this run (library kernels, RCCL) goes onto one side stream
         torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
@@ -524,7 +586,8 @@ def bench_distributed(args, rank, world, local_rank):
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": B.describe(cfg, n_total) + f"; {world} rank(s), {n_total // world} own atoms per GPU (z slabs), "
                                    f"colour-phase GS per rank + {'all-gather' if isinstance(plan, HaloPlan) else 'point-to-point exchange'} "
-                                   "of the halo dipoles per sweep (RCCL), LJ/Coulomb lists built on the device",
+                                   f"of the halo dipoles per sweep ({'RCCL' if backend_name == 'nccl' else 'REHEARSAL: ' + backend_name + ', host-staged, ranks sharing a GPU'}), "
+                                   "LJ/Coulomb lists built on the device",
                        "natoms": n_total, "sweeps": out["sweeps"], "iterations": out["iterations"], "colors": out["ncolors"],
                        "dd_pairs": out["dd_pairs"], "eng_pol": out["eng_pol"], "rms_dmu_last_sweep": out["rms_dmu"],
                        "ms_per_dipole_iteration": 1e3 * dt / args.steps / max(out["sweeps"], 1),

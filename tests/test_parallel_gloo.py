@@ -164,6 +164,9 @@ def _worker(rank, world, port, extra, gs, q, use_halo=False):
     if use_halo == "retry":   # rank 1 alone reports an overflow on its first attempt: both ranks must repeat
         be.retry_once = rank == 1
         use_halo = False
+    staged = use_halo == "p2p_staged"   # the one-GPU rehearsal wrapper (every tensor through the host) must be a no-op here
+    if staged:
+        use_halo = "p2p"
     if use_halo == "p2p":  # point-to-point form: every other rank is a peer and gets all owned rows
         plan = par.P2PHaloPlan(s.x[:s.nlocal], s.prd, offs, reach=1.0e9)
         assert plan.counts == [c * (world - 1) for c in counts] and plan.peers(rank) == [r for r in range(world) if r != rank]
@@ -172,7 +175,7 @@ def _worker(rank, world, port, extra, gs, q, use_halo=False):
         plan = par.HaloPlan(s.x[:s.nlocal], s.prd, offs, reach=1.0e9)
         assert plan.counts == counts
         halo = (plan, par.halo_buffers(be, plan, rank))
-    out = par.run_step(be, dist, rank, world, counts, offs, halo=halo)
+    out = par.run_step(be, par.HostStagedDist(dist) if staged else dist, rank, world, counts, offs, halo=halo)
     q.put((rank, be.mu.copy(), out["eng_pol"], out["iterations"], out["sweeps"], out["status"],
            ref["mu"].reshape(-1), ref["iterations"], ref["sweeps"]))
     dist.barrier()
@@ -282,6 +285,18 @@ def test_p2p_halo_exchange_three_ranks_matches_the_oracle():
         sl = slice(3 * int(offs[rank]), 3 * int(offs[rank + 1]))
         assert np.max(np.abs(mu[sl] - muref[sl])) < 1e-12 * np.max(np.abs(muref))
     assert max(abs(r[2] - res[0][2]) for r in res) < 1e-12 * abs(res[0][2])
+
+
+def test_host_staged_rehearsal_wrapper_runs_the_same_protocol():
+    """parallel.HostStagedDist (used to rehearse bench.py --gpus N with ranks sharing one GPU) in front of gloo:
+    precision-mode Gauss-Seidel on two ranks (all-reduced stop rule + point-to-point exchange every sweep) gives the
+    result of the plain run."""
+    extra = ["polar_gs_ranked", "no", "polar_gs", "yes", "precision", "1e-12", "max_iterations", "200"]
+    a = _run(extra, gs=True, world=2, use_halo="p2p")
+    b = _run(extra, gs=True, world=2, use_halo="p2p_staged")
+    for ra, rb in zip(a, b):
+        assert ra[3] == rb[3] and ra[4] == rb[4] and ra[5] == rb[5] == 0
+        assert np.array_equal(ra[1], rb[1]) and ra[2] == rb[2]
 
 
 def test_p2p_plan_of_slabs_has_two_peers_and_covers_all_visible_atoms():
