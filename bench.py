@@ -129,14 +129,15 @@ def sub_config(torch, pkg, wl, k, steps, warmup, device_neigh=False):
             "rms_dmu_last_sweep": out["rms_dmu"], "roofline_frac": rf["frac"], "ms_per_sweep_launch": rf["ms_per_launch"]}
 
 
-def md_leg(pkg, s, steps=20, every=10, seed=7):
+def md_leg(pkg, s, steps=20, every=10, seed=7, device_neigh=False):
     """The headline box driven the way a LAMMPS run drives the shim (lammps_shim/...:compute): every step the positions
     (moved by a thermal-size random displacement, well inside the skin) go up through polar_set_box + polar_set_atoms
     and f, mu, E_static come back through polar_compute (host pointers); every `every`-th step the neighbor list is
     handed over again (polar_set_neighbors_csr), which re-uploads it, re-symmetrises it and rebuilds the colour phases
-    (rank metric + host-side colouring)."""
+    (rank metric + host-side colouring).  ``device_neigh``: the extension keyword `device_neigh yes` -- on those steps the
+    library builds the list itself (polar_build_neighbors) instead of taking Neighbor's."""
     rng = np.random.default_rng(seed)
-    p = pkg.pair_from_system(s)
+    p = pkg.pair_from_system(s, device_neigh=device_neigh)
     x0 = s.x.copy()
     n, nall = s.nlocal, s.nlocal + s.nghost
     disp = np.zeros_like(x0)
@@ -157,7 +158,9 @@ def md_leg(pkg, s, steps=20, every=10, seed=7):
         p.set_box(s.boxlo, s.prd)
         p.set_atoms(s.nlocal, s.nghost, x, s.q, s.alpha, s.type, s.molecule)
         t1 = time.perf_counter()
-        if relist:
+        if relist and device_neigh:
+            p.build_neighbors_from_system(s)
+        elif relist:
             p.set_neighbors_csr(s.ilist, s.numneigh, s.firstneigh, s.neigh)
         t2 = time.perf_counter()
         p._ck(p.L.polar_compute(p.h, 1, 2, f.ctypes.data_as(dp), mu.ctypes.data_as(dp), ef.ctypes.data_as(dp), C.byref(res)))
@@ -171,7 +174,8 @@ def md_leg(pkg, s, steps=20, every=10, seed=7):
     ms_plain = float(np.mean(t_plain))
     ms_rel = float(np.mean(t_relist)) if t_relist else ms_plain
     ms_md = (ms_plain * (every - 1) + ms_rel) / every
-    return {"what": f"polar_set_box + polar_set_atoms + polar_compute(host f, mu, E) per step, neighbor list handed over every {every}th step; "
+    how = "built on the device (device_neigh yes)" if device_neigh else "handed over"
+    return {"what": f"polar_set_box + polar_set_atoms + polar_compute(host f, mu, E) per step, neighbor list {how} every {every}th step; "
                     f"wall clock of the C-ABI calls ({nall} atoms incl. ghosts)",
             "steps": steps, "ms_per_step_md": ms_md, "atom_steps_per_s_md": n / (ms_md * 1e-3), "ms_plain_step": ms_plain,
             "ms_reneighbor_step": ms_rel, "ms_color_host": float(np.mean(ms_color)) if ms_color else 0.0,
@@ -237,6 +241,7 @@ def main():
     }
     if not args.no_extras and not args.synth and not args.reps:
         config["md_leg"] = md_leg(pkg, s)
+        config["md_leg_device_neigh"] = md_leg(pkg, s, device_neigh=True)
         config["config1_36k"] = sub_config(torch, pkg, wl, 1, steps=max(args.steps, 10), warmup=args.warmup)
         config["config4_529k_one_gpu"] = sub_config(torch, pkg, wl, 4, steps=min(args.steps, 5), warmup=1, device_neigh=True)
     if not args.no_cpu_baseline:

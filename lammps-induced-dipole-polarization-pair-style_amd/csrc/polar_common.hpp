@@ -231,8 +231,16 @@ __device__ __forceinline__ void pair_del(const Box &b, double xi, double yi, dou
   else min_image_rint(b, xi, yi, zi, xj, yj, zj, dx, dy, dz);
 }
 
-// chunked order of the lp sweep's index stream (see k_field_lp): entry e of a row -> slot
-__host__ __device__ __forceinline__ long long lp_slot(long long e) { return ((e >> 8) << 8) + ((e & 63) << 2) + ((e >> 6) & 3); }
+// chunked order of the lp sweep's index stream (see k_field_lp): entry e of a row -> slot.  Chunks of 256 entries = 4 trips;
+// inside a chunk the slot is 4 * lane + trip.  `qm` (quad-major, the default): entry p of a trip goes to lane 4 * (p % 16) +
+// p / 16, so that gather instruction r of the sweep (quad q fetches the record of lane 4q + r) works on the 16 CONSECUTIVE
+// list entries 16r .. 16r + 15 -- consecutive entries are mostly consecutive records of one cell, i.e. the two halves of
+// one 128-byte line and neighbouring lines, requested by neighbouring quads of ONE instruction.
+__host__ __device__ __forceinline__ long long lp_slot(long long e, int qm = 1) {
+  const long long p = e & 63;
+  const long long lane = qm ? (((p & 15) << 2) | (p >> 4)) : p;
+  return ((e >> 8) << 8) + (lane << 2) + ((e >> 6) & 3);
+}
 
 #define POLAR_NL_SAMEMOL 0x40000000
 #define POLAR_NL_MASK 0x3FFFFFFF

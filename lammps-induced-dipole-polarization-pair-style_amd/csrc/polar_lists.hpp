@@ -123,12 +123,13 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
                                                           int *__restrict__ nl_cnt, int *__restrict__ dd_cnt,
                                                           int *__restrict__ nl_j, int *__restrict__ dd_j,
                                                           double *__restrict__ dd_r2, int pad_dd,
-                                                          int dd_shift, int dd_pad_index, int *__restrict__ dd_wrap,
+                                                          int dd_shift_qm, int dd_pad_index, int *__restrict__ dd_wrap,
                                                           const int *__restrict__ color_s, double colordistsq,
                                                           int *__restrict__ color_conflict,
                                                           const int *__restrict__ dd_slot,
                                                           int *__restrict__ overflow,
                                                           unsigned long long *__restrict__ dd_total) {
+  const int dd_shift = dd_shift_qm & 255, dd_qm = dd_shift_qm >> 8;  // record shift of the lp stream | quad-major slot order
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
         if (in_nl && kn < nl_pitch) nl_j[nl0 + kn] = j | same;
         if (in_dd && kd < dd_pitch) {
           // lp sweep (dd_shift 6): byte offset of the 64-byte record, stored in the chunked order (lp_slot)
-          dd_j[dd0 + (dd_shift ? lp_slot(kd) : (long long)kd)] = j << dd_shift;
+          dd_j[dd0 + (dd_shift ? lp_slot(kd, dd_qm) : (long long)kd)] = j << dd_shift;
           if (dd_r2) dd_r2[dd0 + kd] = rsq;  // the sweep's per-pair stream value (same positions, same image rule)
         }
         ncount += __popcll(m_nl);
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
     const int have = dcount < dd_pitch ? dcount : (int)dd_pitch;
     const int padded = (have + 63) & ~63;
     for (int k = have + lane; k < padded; k += 64) {
-      dd_j[dd0 + (dd_shift ? lp_slot(k) : (long long)k)] = (dd_pad_index >= 0 ? dd_pad_index : i) << dd_shift;
+      dd_j[dd0 + (dd_shift ? lp_slot(k, dd_qm) : (long long)k)] = (dd_pad_index >= 0 ? dd_pad_index : i) << dd_shift;
       if (dd_r2) dd_r2[dd0 + k] = 1e60;  // s3 ~ 1e-90, and d = 0 kills the s5 term: contributes nothing
     }
   }

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Lab: sweep counts of the multi-GPU iteration (colour-phase GS inside a rank, block-Jacobi across ranks) emulated in ONE
+process on one GPU: `world` compact handles [own | halo | ghosts] stepped in lock-step with a loopback exchange, exactly
+the protocol of parallel.bench_distributed.  Used to try exchange variants before they go into parallel.py.
+
+  LAB_REPS  "2x2x8"     replication of the MOF5+H2 cell (z slabs: one rank per z range)
+  LAB_WORLD "8"
+  LAB_W     "0,0.3,0.5,adaptive"   extrapolation weights for the received halo dipoles
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+pkg = importlib.import_module(bench.PKG)
+wl = importlib.import_module(bench.PKG + ".workload")
+par = importlib.import_module(bench.PKG + ".parallel")
+
+reps = tuple(int(v) for v in os.environ.get("LAB_REPS", "2x2x8").split("x"))
+world = int(os.environ.get("LAB_WORLD", "8"))
+ws = os.environ.get("LAB_W", "0,0.3,0.5,adaptive").split(",")
+PREC = ["fixed_iteration", "no", "precision", "1e-11", "max_iterations", "200"]
+
+sg = bench.build_workload(wl, reps, [], build_list=False, solver=PREC)
+n_total = sg.nlocal
+p = pkg.pair_from_system(sg, device_neigh=True)
+ref = p.compute_resident()
+mu_ref = p.download("mu", 3 * n_total).reshape(-1, 3)
+p.close()
+print(f"single handle: {n_total} atoms, sweeps {ref['sweeps']}, E_pol {ref['eng_pol']:.9f}", flush=True)
+
+counts, offs = par.split_rows(n_total, world)
+reach = float(sg.extra["cutneigh"]) + 1e-6
+plan = par.P2PHaloPlan(sg.x[:sg.nlocal], sg.prd, offs, reach)
+bes, bufs = [], []
+for r in range(world):
+    lo, hi = int(offs[r]), int(offs[r + 1])
+    sc = wl.compact_shard_geometric(sg, np.arange(lo, hi), plan.halo_of(r), reach)
+    pr = pkg.pair_from_system(sc, device_neigh=True, row_range=(0, hi - lo))
+    be = par.HipShardBackend(pr, 0, hi - lo, 0, global_count=n_total)
+    bes.append(be)
+    bufs.append(par.p2p_buffers(be, plan, r, compact_lo=lo))
+print(f"{world} shards: own {counts[0]}, halo {plan.counts[0]}", flush=True)
+prev = [torch.zeros_like(b["recv"]) for b in bufs]
+raw = [torch.zeros_like(b["recv"]) for b in bufs]
+
+
+def exchange(w):
+    for r, be in enumerate(bes):
+        be.gather_idx(bufs[r]["idx_out"], bufs[r]["send"])
+    for r in range(world):
+        for k, q in enumerate(bufs[r]["peers"]):
+            kq = bufs[q]["peers"].index(r)
+            a, b = 3 * bufs[r]["seg_in"][k], 3 * bufs[r]["seg_in"][k + 1]
+            c, d = 3 * bufs[q]["seg_out"][kq], 3 * bufs[q]["seg_out"][kq + 1]
+            raw[r][a:b] = bufs[q]["send"][c:d]
+    for r, be in enumerate(bes):
+        if w:
+            bufs[r]["recv"].copy_(raw[r] + w * (raw[r] - prev[r]))   # predicted value of the sweep now starting
+        else:
+            bufs[r]["recv"].copy_(raw[r])
+        prev[r].copy_(raw[r])
+        be.scatter_idx(bufs[r]["idx_in"], bufs[r]["recv"])
+
+
+for wspec in ws:
+    for be in bes:
+        be.begin(1, 2)
+    exchange(0.0)
+    changes = []
+    sweeps = 0
+    for sw in range(bes[0].max_it + 1):
+        for be in bes:
+            be.sweep()
+        tot = sum(be.local_change().clone() for be in bes)
+        for be in bes:
+            be.sweep_end(tot)
+        changes.append(float(tot.item()))
+        sweeps += 1
+        if wspec == "adaptive":
+            w = min(0.9, (changes[-1] / changes[-2]) ** 0.5) if len(changes) >= 3 else 0.0
+        else:
+            w = float(wspec) if sw >= 1 else 0.0
+        exchange(w)
+        if all(be.state()[0] for be in bes):
+            break
+    outs = [be.finish() for be in bes]
+    torch.cuda.synchronize()
+    mu = np.zeros((n_total, 3))
+    for r, be in enumerate(bes):
+        lo, hi = int(offs[r]), int(offs[r + 1])
+        mu[lo:hi] = be.pair.download("mu", 3 * (hi - lo)).reshape(-1, 3)
+    err = np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref))
+    rate = (changes[-1] / changes[-6]) ** 0.1 if len(changes) > 6 else float("nan")
+    print(f"w={wspec:9s} sweeps {sweeps:3d}  status {[o['status'] for o in outs][:2]}  E_pol {sum(o['eng_pol'] for o in outs):.9f}  "
+          f"mu vs single {err:.2e}  contraction/sweep {rate:.3f}", flush=True)

@@ -3,7 +3,7 @@
 # gloo with every exchange staged through the host (parallel.HostStagedDist).  Checks the glue of bench_distributed --
 # shard construction, point-to-point halo plans, device-built lists of the own rows, the all-reduced stop rule, the JSON
 # line -- against the single-process run of the same box (E_pol, sweeps).  Timings of these runs mean nothing.
-# usage: bash tools/rehearse_dist.sh <tag> [N ...]      (N <= 6: the pool allows 6 processes on a card)
+# usage: bash tools/rehearse_dist.sh <tag> [N ...]      (N <= 5: the pool allows 6 processes on a card and the launcher is one of them)
 set -u
 tag=${1:-reh}; shift
 ns=${@:-2 4}
@@ -12,7 +12,7 @@ mkdir -p $out
 export POLAR_DIST_BACKEND=gloo
 port=29517
 for n in $ns; do
-  cfg=3; [ "$n" -ge 6 ] && cfg=4
+  cfg=3; [ "$n" -ge 5 ] && cfg=4
   timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
       bench.py --gpus $n --steps 2 --warmup 1 --config $cfg > $out/${tag}_n$n.log 2>&1
   echo "N=$n config $cfg rc=$?"
