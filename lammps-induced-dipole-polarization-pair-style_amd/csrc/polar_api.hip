@@ -21,7 +21,7 @@
 using namespace polar;
 
 // bump when a kernel on the hot path changes: PMC files under profiles/ are keyed by it (bench.py, roofline.traffic)
-#define POLAR_KERNEL_VERSION "r02-lp2-v2"
+#define POLAR_KERNEL_VERSION "r02-lp2-v3"
 
 namespace {
 
@@ -183,6 +183,7 @@ struct polar_handle {
   int user_full_list = 0;    // polar_set_list_style for uploaded lists
   long long lj_pitch = 0;
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
+  int lp_wg_per_cu = 0;          // lab (POLAR_LP_WG_PER_CU): workgroups of k_field_lp resident per CU, capped through the LDS size
   int lp_quad_major = 1;         // slot order of the lp index stream (lp_slot), POLAR_LP_QM=0: lane = entry
   int quad_block = POLAR_BLOCK;  // workgroup size of k_field_quad / k_field_lp (POLAR_QUAD_BLOCK)
   int lp_tiles = 2;              // LDS tiles per wave of k_field_lp (POLAR_LP_TILES: 1 or 2)
@@ -796,7 +797,8 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
   const polar_settings &st = h->ph.st;
   const int qb = h->quad_block;
   const int nt = h->lp_tiles;
-  const size_t lds = (size_t)(qb / 64) * nt * POLAR_LP_TILE;
+  size_t lds = (size_t)(qb / 64) * nt * POLAR_LP_TILE;
+  if (h->lp_wg_per_cu > 0) lds = std::max(lds, std::min((size_t)64 * 1024, (size_t)160 * 1024 / h->lp_wg_per_cu));  // lab: cap the residency
 #define FL(D, NT) k_field_lp<EP, D, NT><<<nblk_xcd(nrows, qb / 64), qb, lds, h->stream>>>(                           \
       nrows, row0, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                               \
       st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
@@ -1303,6 +1305,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
+  if (const char *e = getenv("POLAR_LP_WG_PER_CU")) h->lp_wg_per_cu = atoi(e);
   if (const char *e = getenv("POLAR_LP_QM")) h->lp_quad_major = atoi(e) != 0;
   if (const char *e = getenv("POLAR_LP_TILES")) h->lp_tiles = atoi(e) == 1 ? 1 : 2;
   if (const char *e = getenv("POLAR_CLUSTER_DIST")) h->cluster_dist = atof(e);
