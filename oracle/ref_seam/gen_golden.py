@@ -45,12 +45,16 @@ PLAN = {
     "bulk_h2": ["ranked", "gs", "zodid", "notable", "peratom", "newtoff", "newtoff_peratom"],
     "mof5_methane": ["ranked"],
     "sifsix_co2": ["ranked", "nodamp_fallback30"],
+    "mof5_co2": ["ranked", "gs"],   # the deck's precision 1e-15 stays in force (extra args come after the deck's)
 }
 
 
 def main():
-    only = set(sys.argv[1:])  # optional: regenerate just these variants
+    only = set(a for a in sys.argv[1:] if a not in PLAN)       # optional: regenerate just these variants ...
+    only_cases = set(a for a in sys.argv[1:] if a in PLAN)     # ... of just these cases
     for case, variants in PLAN.items():
+        if only_cases and case not in only_cases:
+            continue
         z = np.load(os.path.join(GOLD, case + ".npz"))
         meta = json.loads(str(z["meta"]))
         rows = [" ".join([str(int(r[0])), str(int(r[1])), repr(float(r[2])), repr(float(r[3])), repr(float(r[4]))])

@@ -39,11 +39,18 @@ CASES = {
                      source="SURVEY.md section 8(c) (reference binary, run 0)")),
     "sifsix_co2": ("SIFSIX-2-Cu-i+CO2", "BIPA+CO2.pdb.data", "BIPA+CO2.pdb.input", False,
                    dict(g_ewald=0.0, source="no log; non-cubic box edge case")),
+    # the deck asks for precision 1e-15, which the rms of double-precision dipole changes does not reach on this system
+    # every run: the case that walks the solver to max_iterations with a CONVERGED iterate (the log ends in fix rigid's error)
+    "mof5_co2": ("MOF5+CO2", "co2_mof5.restart.pdb.data", "co2_mof5.restart.pdb.input", False,
+                 dict(g_ewald=0.0, source="no thermo output in the log; precision 1e-15 edge case")),
 }
 
 
 def main():
+    only = set(sys.argv[1:])  # optional: (re)write just these cases
     for name, (d, data, deck, excl, known) in CASES.items():
+        if only and name not in only:
+            continue
         dat = wl.parse_lammps_data(os.path.join(EX, d, data))
         dk = wl.parse_deck(os.path.join(EX, d, deck))
         alpha = np.array([dk["alpha_by_type"].get(int(t), 0.0) for t in dat["type"]])
