@@ -199,7 +199,7 @@ struct polar_handle {
   // a3 runs on its own stream beside the list build / static field / dipole solve (it only shares the
   // force and tally accumulators with them): fork after the accumulators are zeroed, join before they are read
   hipStream_t lj_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_lj0 = nullptr, ev_lj1 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_lj0 = nullptr, ev_lj1 = nullptr, ev_dl0 = nullptr, ev_dl1 = nullptr;
   bool overlap_lj = true;  // POLAR_NO_OVERLAP=1 keeps a3 on the main stream
   bool lj_forked = false;
   std::vector<double> h_tmp;
@@ -1330,6 +1330,7 @@ int polar_create(int device, polar_handle **out) {
     }
     HIPCHECK(hipEventCreate(&h->ev_fork)); HIPCHECK(hipEventCreate(&h->ev_join));
     HIPCHECK(hipEventCreate(&h->ev_lj0)); HIPCHECK(hipEventCreate(&h->ev_lj1));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_dl0, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&h->ev_dl1, hipEventDisableTiming));
     if (getenv("POLAR_NO_OVERLAP")) h->overlap_lj = false;
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
     HIPCHECK(hipHostMalloc((void **)&h->h_flags, 16 * sizeof(int)));
@@ -1348,7 +1349,7 @@ int polar_destroy(polar_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->lj_stream) { (void)hipStreamSynchronize(h->lj_stream); (void)hipStreamDestroy(h->lj_stream); }
-    for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1, h->ev_dl0, h->ev_dl1}) if (e) (void)hipEventDestroy(e);
     h->d_ljpos.release(); h->d_ljaux.release(); h->d_tag.release(); h->d_nspecial.release(); h->d_special.release();
     h->d_ljcell_id.release(); h->d_ljcell_cnt.release(); h->d_ljcell_fill.release(); h->d_ljcell_first.release(); h->d_cutneighsq.release();
     h->d_xchg.release(); h->d_xidx.release();
@@ -1735,13 +1736,16 @@ int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, 
     if (rc < 0) return rc;
     const size_t n = h->nlocal, nall = (size_t)h->nlocal + h->nghost;
     // results come back through one pinned staging area (pageable destinations cost ~3x the PCIe time):
-    // [f nall*3 | mu n*3 | ef n*3], three asynchronous copies, one synchronisation
+    // [f nall*3 | mu n*3 | ef n*3], three asynchronous copies; the host adds the forces in while mu and ef still travel
     double *st = staging(h, 3 * nall + 6 * n);
     HIPCHECK(hipMemcpyAsync(st, h->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipEventRecord(h->ev_dl0, h->stream));
     HIPCHECK(hipMemcpyAsync(st + 3 * nall, h->d_mu.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (ef_static) HIPCHECK(hipMemcpyAsync(st + 3 * nall + 3 * n, h->d_ef.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipEventRecord(h->ev_dl1, h->stream));
+    HIPCHECK(hipEventSynchronize(h->ev_dl0));
     for (size_t k = 0; k < 3 * nall; k++) f[k] += st[k];
+    HIPCHECK(hipEventSynchronize(h->ev_dl1));
     memcpy(mu, st + 3 * nall, 3 * n * sizeof(double));
     if (ef_static) memcpy(ef_static, st + 3 * nall + 3 * n, 3 * n * sizeof(double));
     return rc;
