@@ -129,21 +129,28 @@ def sub_config(torch, pkg, wl, k, steps, warmup, device_neigh=False):
             "rms_dmu_last_sweep": out["rms_dmu"], "roofline_frac": rf["frac"], "ms_per_sweep_launch": rf["ms_per_launch"]}
 
 
-def md_leg(pkg, s, steps=20, every=10, seed=7, device_neigh=False):
+def md_leg(pkg, s, steps=20, every=10, seed=7, device_neigh=False, use_previous=False):
     """The headline box driven the way a LAMMPS run drives the shim (lammps_shim/...:compute): every step the positions
     (moved by a thermal-size random displacement, well inside the skin) go up through polar_set_box + polar_set_atoms
     and f, mu, E_static come back through polar_compute (host pointers); every `every`-th step the neighbor list is
     handed over again (polar_set_neighbors_csr), which re-uploads it, re-symmetrises it and rebuilds the colour phases
     (rank metric + host-side colouring).  ``device_neigh``: the extension keyword `device_neigh yes` -- on those steps the
-    library builds the list itself (polar_build_neighbors) instead of taking Neighbor's."""
+    library builds the list itself (polar_build_neighbors) instead of taking Neighbor's.  ``use_previous``: the keyword every
+    example deck of the reference sets (`use_previous yes`, PS.cpp:376-386): the solve starts from the dipoles of the step
+    before -- the rate an MD run of the reference's own decks would see."""
+    if use_previous:
+        import copy
+        import dataclasses
+        s = copy.copy(s)
+        s.settings = dataclasses.replace(s.settings, use_previous=1)
     rng = np.random.default_rng(seed)
     p = pkg.pair_from_system(s, device_neigh=device_neigh)
     x0 = s.x.copy()
     n, nall = s.nlocal, s.nlocal + s.nghost
     disp = np.zeros_like(x0)
-    p.compute(eflag=1, vflag=2)  # first step of a run: lists, colours, allocations
-    t_plain, t_relist, ms_color, ms_dev, t_up, t_cmp, t_nb = [], [], [], [], [], [], []
-    f = np.zeros((nall, 3)); mu = np.zeros((n, 3)); ef = np.zeros((n, 3))
+    first = p.compute(eflag=1, vflag=2)  # first step of a run: lists, colours, allocations
+    t_plain, t_relist, ms_color, ms_dev, t_up, t_cmp, t_nb, nsw = [], [], [], [], [], [], [], []
+    f = np.zeros((nall, 3)); mu = np.ascontiguousarray(first["mu"]); ef = np.zeros((n, 3))   # mu: atom->mu_induced
     import ctypes as C
     dp = C.POINTER(C.c_double)
     res = pkg.Result()
@@ -168,6 +175,7 @@ def md_leg(pkg, s, steps=20, every=10, seed=7, device_neigh=False):
         (t_relist if relist else t_plain).append(1e3 * (t3 - t0))
         t_up.append(1e3 * (t1 - t0)); t_cmp.append(1e3 * (t3 - t2))
         ms_dev.append(res.ms_total)
+        nsw.append(res.sweeps)
         if relist:
             ms_color.append(res.ms_color_host); t_nb.append(1e3 * (t2 - t1))
     p.close()
@@ -175,9 +183,11 @@ def md_leg(pkg, s, steps=20, every=10, seed=7, device_neigh=False):
     ms_rel = float(np.mean(t_relist)) if t_relist else ms_plain
     ms_md = (ms_plain * (every - 1) + ms_rel) / every
     how = "built on the device (device_neigh yes)" if device_neigh else "handed over"
+    if use_previous:
+        how += ", use_previous yes"
     return {"what": f"polar_set_box + polar_set_atoms + polar_compute(host f, mu, E) per step, neighbor list {how} every {every}th step; "
                     f"wall clock of the C-ABI calls ({nall} atoms incl. ghosts)",
-            "steps": steps, "ms_per_step_md": ms_md, "atom_steps_per_s_md": n / (ms_md * 1e-3), "ms_plain_step": ms_plain,
+            "steps": steps, "sweeps_per_step": float(np.mean(nsw)), "ms_per_step_md": ms_md, "atom_steps_per_s_md": n / (ms_md * 1e-3), "ms_plain_step": ms_plain,
             "ms_reneighbor_step": ms_rel, "ms_color_host": float(np.mean(ms_color)) if ms_color else 0.0,
             "ms_device_per_step": float(np.mean(ms_dev)), "ms_set_atoms": float(np.mean(t_up)),
             "ms_compute_call": float(np.median(t_cmp)), "ms_set_neighbors": float(np.mean(t_nb)) if t_nb else 0.0,
@@ -242,6 +252,7 @@ def main():
     if not args.no_extras and not args.synth and not args.reps:
         config["md_leg"] = md_leg(pkg, s)
         config["md_leg_device_neigh"] = md_leg(pkg, s, device_neigh=True)
+        config["md_leg_use_previous"] = md_leg(pkg, s, device_neigh=True, use_previous=True)
         config["config1_36k"] = sub_config(torch, pkg, wl, 1, steps=max(args.steps, 10), warmup=args.warmup)
         config["config4_529k_one_gpu"] = sub_config(torch, pkg, wl, 4, steps=min(args.steps, 5), warmup=1, device_neigh=True)
     if not args.no_cpu_baseline:
