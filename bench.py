@@ -102,16 +102,16 @@ def roofline(s, out, ms_solve, launches, steps, pkg):
     achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
     # HBM traffic per launch from PMC counters: read from the committed profile of THIS kernel generation on THIS
     # workload (tools/pmc_traffic.sh writes it); null when the file does not match the built library
-    traffic, src = None, None
+    traffic, src, low = None, None, None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as fh:
             t = json.load(fh)
         if t.get("kernel_version") == pkg.kernel_version() and t.get("natoms") == s.nlocal:
-            traffic, src = float(t["bytes_per_launch"]), t.get("source")
+            traffic, src, low = float(t["bytes_per_launch"]), t.get("source"), t.get("bytes_per_launch_low")
     except (OSError, ValueError, KeyError):
         pass
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; {pkg.kernel_version()})",
+            "traffic": traffic, "traffic_low": low, "traffic_source": src, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; {pkg.kernel_version()})",
             "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch, "launches_per_step": launches / max(steps, 1)}
 
 

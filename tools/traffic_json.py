@@ -23,8 +23,16 @@ fetch_kb, write_kb = mean.get("FETCH_SIZE", 0.0), mean.get("WRITE_SIZE", 0.0)
 # doubled, as the guide prescribes for such streams; the 64-byte quad gathers of this kernel are served by L2 hits for the
 # most part (TCC hit rate below), so the memory-side traffic is dominated by the 16-byte-per-lane index stream
 traffic = (2.0 * fetch_kb + write_kb) * 1024.0
+# Calibration on this access pattern (tools/calib_fetch.hip, profiles/r02_fetch_size_calibration.txt): FETCH_SIZE = 64 B x
+# memory-side requests; a request is a 128-byte line for the coalesced stream and for two quads of one gather instruction
+# that ask for the two halves of one line, and ONE 64-byte half-line for a lone quad gather.  So 2 x FETCH_SIZE is exact for
+# the index stream and an UPPER bound for the gathers; the lower bound counts every non-stream request as 64 bytes.
+idx_bytes = 4.0 * (line["config"]["dd_pairs"] / max(line["config"]["colors"], 1)) if line else 0.0
+req = fetch_kb * 1024.0 / 64.0
+gather_req = max(req - idx_bytes / 128.0, 0.0)
+traffic_low = idx_bytes + 64.0 * gather_req + write_kb * 1024.0
 out = {"kernel_version": ver, "natoms": line["config"]["natoms"] if line else None, "kernel": pat,
-       "bytes_per_launch": traffic, "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
+       "bytes_per_launch": traffic, "bytes_per_launch_low": traffic_low, "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
        "launches_sampled": len(acc.get("FETCH_SIZE", [])), "counters_mean": mean,
        "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"] if line else None,
        "source": f"profiles/r02_{ver}_traffic_pmc.txt (tools/pmc_traffic.sh: separate --pmc passes of bench.py --no-extras)"}
@@ -34,5 +42,6 @@ with open(os.path.join(ROOT, "profiles", f"r02_{ver}_traffic_pmc.txt"), "w") as 
     fh.write(f"# {pat}, bench headline (BASELINE configs[2], {out['natoms']} atoms), kernel version {ver}; means per launch\n")
     for k, v in sorted(mean.items()):
         fh.write(f"{k:28s} n={len(acc[k]):5d} mean={v:16.1f}\n")
+    fh.write(f"# calibrated bracket (tools/calib_fetch.hip): {traffic_low / 1e6:.1f} MB (lone 64-byte gather requests) ... {traffic / 1e6:.1f} MB (all requests 128-byte lines)\n")
     fh.write(f"# traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB = {traffic / 1e6:.1f} MB per launch; algorithmic {out['algorithmic_bytes_per_launch'] / 1e6 if out['algorithmic_bytes_per_launch'] else 0:.1f} MB per launch\n")
 print(json.dumps(out, indent=1))
