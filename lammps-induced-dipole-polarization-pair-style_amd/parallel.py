@@ -514,7 +514,15 @@ def bench_distributed(args, rank, world, local_rank):
     cut = B.CUT_COUL
     sg = B.build_workload(wl, reps, args.extra, build_list=False, solver=cfg["solver"])   # atoms + ghosts, no host list
     n_total = sg.nlocal
-    counts, offs = split_rows(n_total, world)
+    if os.environ.get("POLAR_DIST_SPLIT", "slabs") == "rows":
+        counts, offs = split_rows(n_total, world)   # equal row ranges of the replica order (cuts through replica cells)
+    else:
+        # geometric z slabs of equal atom counts; a sorbate molecule stays on one rank (workload.slab_order): two peers per
+        # rank and the thinnest halo whatever the number of ranks (row ranges cut replica cells in the middle unless the
+        # ranks divide the replicas, which leaves three peers and half-cells of interleaved atoms)
+        order, key, glue = wl.slab_order(sg, axis=2)
+        sg = wl.permute_locals(sg, order)
+        counts, offs = wl.split_sorted(key[order], world, glue)
     lo, hi = int(offs[rank]), int(offs[rank + 1])
     # reach = the neighbor-list cutoff of the LJ/Coulomb rows (max cut + skin) -- it covers the dd cutoff
     reach = float(sg.extra["cutneigh"]) + 1e-6
@@ -584,7 +592,7 @@ def bench_distributed(args, rank, world, local_rank):
             "metric": "atom-steps/sec", "value": n_total * args.steps / dt, "unit": "atom-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": B.describe(cfg, n_total) + f"; {world} rank(s), {n_total // world} own atoms per GPU (z slabs), "
+            "config": {"workload": B.describe(cfg, n_total) + f"; {world} rank(s), {counts[0]} own atoms per GPU (z slabs), "
                                    f"colour-phase GS per rank + {'all-gather' if isinstance(plan, HaloPlan) else 'point-to-point exchange'} "
                                    f"of the halo dipoles per sweep ({'RCCL' if backend_name == 'nccl' else 'REHEARSAL: ' + backend_name + ', host-staged, ranks sharing a GPU'}), "
                                    "LJ/Coulomb lists built on the device",
@@ -593,6 +601,7 @@ def bench_distributed(args, rank, world, local_rank):
                        "ms_per_dipole_iteration": 1e3 * dt / args.steps / max(out["sweeps"], 1),
                        "ms_device_rank0": {k2: out[k2] for k2 in ("ms_total", "ms_list", "ms_ljcoul", "ms_static", "ms_solve", "ms_force")},
                        "atoms_held_rank0": n_held, "halo_rows_per_rank": plan.counts, "rows_per_rank": counts,
+                       "peers_rank0": len(plan.peers(0)) if hasattr(plan, "peers") else None,
                        "kernel_version": pkg.kernel_version()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; rank 0; {pkg.kernel_version()})",

@@ -475,6 +475,67 @@ def compact_shard_geometric(s, own, halo, reach):
         owner=np.asarray(s.owner)[keep], name=s.name + "_shard", extra=dict(s.extra, n_own=len(own)))
 
 
+def slab_order(s, axis=2, small=16):
+    """(order, key, glue) for a slab decomposition along ``axis``: the local atoms by coordinate, a small molecule (<= ``small`` atoms: a
+    rigid sorbate) moving as one with the coordinate of its first atom -- its sites are a fraction of an angstrom apart and
+    must not end up on two ranks, where they would see each other one sweep late.  Stable, so equal keys keep their order;
+    ``glue[k]``: sorted atom k is a site of the same small molecule as sorted atom k - 1 (for split_sorted)."""
+    n = s.nlocal
+    key = np.array(s.x[:n, axis], dtype=np.float64)
+    mol = np.asarray(s.molecule[:n])
+    is_small = np.zeros(n, dtype=bool)
+    if len(mol) and mol.max() > 0:
+        counts = np.bincount(mol)
+        is_small = (mol > 0) & (counts[mol] <= small)
+        first = {}
+        for i in np.nonzero(is_small)[0]:
+            m = mol[i]
+            if m not in first:
+                first[m] = key[i]
+            key[i] = first[m]
+    order = np.argsort(key, kind="stable")
+    ms, sm = mol[order], is_small[order]
+    glue = np.zeros(n, dtype=bool)
+    if n > 1:
+        glue[1:] = sm[1:] & (ms[1:] == ms[:-1])
+    return order, key, glue
+
+
+def split_sorted(key_sorted, world, glue=None):
+    """Equal-count split of a sorted key into ``world`` contiguous ranges.  ``glue[k]`` (optional) says that element k belongs
+    with element k - 1 (two sites of one small molecule): a boundary that would fall between them moves up."""
+    n = len(key_sorted)
+    offs = [0]
+    for r in range(1, world):
+        o = max((r * n) // world, offs[-1])
+        while glue is not None and 0 < o < n and glue[o]:
+            o += 1
+        offs.append(o)
+    offs.append(n)
+    offs = np.asarray(offs, dtype=int)
+    return [int(offs[r + 1] - offs[r]) for r in range(world)], offs
+
+
+def permute_locals(s, order):
+    """The same system with its local atoms in the order ``order`` (systems made with ``build_list=False`` only: there is no
+    neighbor list to re-index).  Ghosts keep their places; their ``owner`` entries follow the locals."""
+    if len(s.neigh) or s.extra.get("special"):
+        raise ValueError("permute_locals: the system carries lists indexed by atom")
+    n, nall = s.nlocal, s.nlocal + s.nghost
+    order = np.asarray(order, dtype=np.int64)
+    inv = np.empty(n, dtype=np.int64)
+    inv[order] = np.arange(n)
+    full = np.concatenate([order, np.arange(n, nall)])
+    owner = np.asarray(s.owner)
+    new_owner = inv[owner[full]]
+    return PolarSystem(
+        nlocal=n, nghost=s.nghost, x=np.ascontiguousarray(s.x[full]), q=s.q[full].copy(), alpha=s.alpha[full].copy(),
+        type=s.type[full].copy(), molecule=s.molecule[full].copy(), boxlo=s.boxlo, prd=s.prd, ntypes=s.ntypes,
+        tables=s.tables, coul=s.coul, g_ewald=s.g_ewald, qqrd2e=s.qqrd2e, special_lj=s.special_lj,
+        special_coul=s.special_coul, ilist=s.ilist, numneigh=s.numneigh, firstneigh=s.firstneigh, neigh=s.neigh,
+        settings=s.settings, owner=new_owner, name=s.name, tilt=s.tilt, triclinic=s.triclinic, extra=dict(s.extra))
+
+
 def lammps_special_arrays(n, special):
     """{(i,j): which} -> atom->nspecial [n][3] (cumulative 1-2, 1-3, 1-4 counts) and atom->special
     [n][maxspecial] (partner TAGS = index + 1, ordered 1-2 | 1-3 | 1-4), the layout

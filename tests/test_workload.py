@@ -1,0 +1,32 @@
+"""CPU tests of the input scaffolding that only the multi-GPU bench uses (workload.slab_order / split_sorted / permute_locals)."""
+import numpy as np
+import pytest
+
+
+def test_slab_order_keeps_molecules_whole_and_permutation_consistent(wl):
+    """Geometric slabs for the multi-GPU bench: locals sorted along z, a sorbate molecule as one; equal-count split that never
+    separates equal keys; the permuted system is the same system (ghosts still point at their owners)."""
+    import os
+    from helpers import GOLD
+    s = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 1, 1, 3, extra_args=["dd_cutoff", "12.8345"], build_list=False)
+    order, key, glue = wl.slab_order(s, axis=2)
+    assert sorted(order.tolist()) == list(range(s.nlocal)) and np.all(np.diff(key[order]) >= 0)
+    counts, offs = wl.split_sorted(key[order], 4, glue)
+    assert sum(counts) == s.nlocal and max(counts) - min(counts) <= 16
+    sp = wl.permute_locals(s, order)
+    n = s.nlocal
+    assert np.array_equal(sp.x[:n], s.x[order]) and np.array_equal(sp.x[n:], s.x[n:])
+    g = np.arange(n, n + s.nghost)
+    for name in ("q", "alpha", "type", "molecule"):
+        assert np.array_equal(getattr(sp, name)[g], getattr(sp, name)[sp.owner[g]]), name
+    d = sp.x[g] - sp.x[sp.owner[g]]                       # a ghost is its owner shifted by whole box vectors
+    assert np.allclose(d / s.prd, np.round(d / s.prd), atol=1e-9)
+    mol = sp.molecule[:n]
+    cnt = np.bincount(mol)
+    for r in range(4):
+        a, b = offs[r], offs[r + 1]
+        for m in np.unique(mol[a:b]):
+            if m > 0 and cnt[m] <= 16:
+                assert np.count_nonzero(mol[a:b] == m) == cnt[m]     # the whole molecule is on this rank
+    with pytest.raises(ValueError):
+        wl.permute_locals(wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 1, 1, 1), np.arange(1349))

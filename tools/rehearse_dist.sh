@@ -25,7 +25,7 @@ for ln in sys.stdin:
   port=$((port+1))
 done
 unset POLAR_DIST_BACKEND
-for cfg in 3; do
+for cfg in ${REH_SINGLE:-3}; do
   timeout -k 10 300 python bench.py --config $cfg --steps 2 --warmup 1 --no-extras --no-cpu-baseline > $out/${tag}_single_c$cfg.log 2>&1
   echo "single config $cfg rc=$?"
   grep '"metric"' $out/${tag}_single_c$cfg.log | python -c "
