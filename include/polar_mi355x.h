@@ -223,6 +223,10 @@ int polar_set_list_style(polar_handle *h, int full);
  * handle's rows tallied: the shards' arrays add up to the unsharded ones. */
 int polar_step_begin(polar_handle *h, int eflag, int vflag);
 int polar_step_sweep(polar_handle *h); /* one sweep over the owned rows */
+/* one sweep in `nparts` pieces: piece `part` runs its share of the colour phases (colour-phase Gauss-Seidel of list mode only),
+ * so that a driver can exchange halo dipoles INSIDE a sweep -- neighbours then see the phases already done one piece, not one
+ * sweep, late.  Calling all pieces 0 .. nparts-1 in order equals polar_step_sweep. */
+int polar_step_sweep_part(polar_handle *h, int part, int nparts);
 /* end-of-sweep control (PS.cpp:1193-1236) on the device; dev_global_change = all-reduced sum of
  * (dmu)^2 in device memory, or NULL to use this handle's own sum */
 int polar_step_sweep_end(polar_handle *h, const double *dev_global_change);

@@ -116,6 +116,7 @@ EXPORTS = {
     "polar_restart_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "polar_step_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "polar_step_sweep": (C.c_int, [C.c_void_p]),
+    "polar_step_sweep_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "polar_step_sweep_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "polar_step_state": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
     "polar_step_finish": (C.c_int, [C.c_void_p, C.POINTER(Result)]),

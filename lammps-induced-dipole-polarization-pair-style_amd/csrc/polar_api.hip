@@ -183,6 +183,7 @@ struct polar_handle {
   int user_full_list = 0;    // polar_set_list_style for uploaded lists
   long long lj_pitch = 0;
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
+  int part_k = 0, part_n = 1;    // polar_step_sweep_part: which share of the colour phases the next sweep_once runs
   int lp_wg_per_cu = 0;          // lab (POLAR_LP_WG_PER_CU): workgroups of k_field_lp resident per CU, capped through the LDS size
   int lp_quad_major = 1;         // slot order of the lp index stream (lp_slot), POLAR_LP_QM=0: lane = entry
   int quad_block = POLAR_BLOCK;  // workgroup size of k_field_quad / k_field_lp (POLAR_QUAD_BLOCK)
@@ -851,7 +852,8 @@ void sweep_once(polar_handle *h, bool ap) {
   if (!ap && h->sweep_kernel == 2) {
     if (!gs) { launch_field_lp<EP_JACOBI>(h, own_n(h), h->d_lpdesc.p); return; }
     const int ncol = (int)h->color_off.size() - 1;
-    for (int c = 0; c < ncol; c++)
+    const int c0 = h->part_n > 1 ? ncol * h->part_k / h->part_n : 0, c1 = h->part_n > 1 ? ncol * (h->part_k + 1) / h->part_n : ncol;
+    for (int c = c0; c < c1; c++)  // (polar_step_sweep_part: a window of the colour phases)
       launch_field_lp<EP_INPLACE>(h, h->color_off[c + 1] - h->color_off[c], h->d_lpdesc.p + h->color_off[c]);
     return;
   }
@@ -1878,6 +1880,19 @@ int polar_step_sweep(polar_handle *h) {
   return guarded(h, [&]() {
     if (!h->in_step) throw std::runtime_error("polar_step_sweep outside polar_step_begin/finish");
     sweep_once(h, false);
+    return POLAR_OK;
+  });
+}
+int polar_step_sweep_part(polar_handle *h, int part, int nparts) {
+  return guarded(h, [&]() {
+    if (!h->in_step) throw std::runtime_error("polar_step_sweep_part outside polar_step_begin/finish");
+    if (nparts < 1 || part < 0 || part >= nparts) throw InputError("polar_step_sweep_part: bad part");
+    const polar_settings &st = h->ph.st;
+    if (nparts > 1 && !(st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && h->sweep_kernel == 2))
+      throw InputError("polar_step_sweep_part: parts exist for the colour-phase Gauss-Seidel sweep of list mode only");
+    h->part_k = part; h->part_n = nparts;
+    sweep_once(h, false);
+    h->part_k = 0; h->part_n = 1;
     return POLAR_OK;
   });
 }

@@ -69,6 +69,9 @@ class HipShardBackend:
     def sweep(self):
         self.pair._ck(self.pair.L.polar_step_sweep(self.pair.h))
 
+    def sweep_part(self, part, nparts):
+        self.pair._ck(self.pair.L.polar_step_sweep_part(self.pair.h, part, nparts))
+
     def local_change(self):
         self.pair._ck(self.pair.L.polar_change_export(self.pair.h, C.c_void_p(self.chg.data_ptr())))
         return self.chg
@@ -517,10 +520,11 @@ def bench_distributed(args, rank, world, local_rank):
     if os.environ.get("POLAR_DIST_SPLIT", "slabs") == "rows":
         counts, offs = split_rows(n_total, world)   # equal row ranges of the replica order (cuts through replica cells)
     else:
-        # geometric z slabs of equal atom counts; a sorbate molecule stays on one rank (workload.slab_order): two peers per
-        # rank and the thinnest halo whatever the number of ranks (row ranges cut replica cells in the middle unless the
-        # ranks divide the replicas, which leaves three peers and half-cells of interleaved atoms)
-        order, key, glue = wl.slab_order(sg, axis=2)
+        # geometric z slabs of equal atom counts; a sorbate molecule and a cluster of bonded framework atoms (< 1.6 A
+        # apart: the strongest couplings) stay on one rank (workload.slab_order): two peers per rank and the thinnest halo
+        # whatever the number of ranks (row ranges cut replica cells in the middle unless the ranks divide the replicas,
+        # which leaves three peers and half-cells of interleaved atoms), and 37 instead of 40 sweeps on 8 slabs
+        order, key, glue = wl.slab_order(sg, axis=2, glue_dist=float(os.environ.get("POLAR_DIST_GLUE", "1.6")))
         sg = wl.permute_locals(sg, order)
         counts, offs = wl.split_sorted(key[order], world, glue)
     lo, hi = int(offs[rank]), int(offs[rank + 1])

@@ -475,29 +475,54 @@ def compact_shard_geometric(s, own, halo, reach):
         owner=np.asarray(s.owner)[keep], name=s.name + "_shard", extra=dict(s.extra, n_own=len(own)))
 
 
-def slab_order(s, axis=2, small=16):
-    """(order, key, glue) for a slab decomposition along ``axis``: the local atoms by coordinate, a small molecule (<= ``small`` atoms: a
-    rigid sorbate) moving as one with the coordinate of its first atom -- its sites are a fraction of an angstrom apart and
-    must not end up on two ranks, where they would see each other one sweep late.  Stable, so equal keys keep their order;
-    ``glue[k]``: sorted atom k is a site of the same small molecule as sorted atom k - 1 (for split_sorted)."""
+def slab_order(s, axis=2, small=16, glue_dist=0.0, max_cluster=64):
+    """(order, key, glue) for a slab decomposition along ``axis``: the local atoms by coordinate, with groups of atoms that
+    must not end up on two ranks -- where they would see each other's dipoles one sweep late, Jacobi-fashion -- moving as one
+    (all members get the coordinate of the group's first atom):
+      * a small molecule (<= ``small`` atoms: a rigid sorbate, sites a fraction of an angstrom apart);
+      * with ``glue_dist`` > 0, clusters of atoms connected by distances below it (bonded neighbours of a framework: the
+        strongest couplings of the dipole field matrix), up to ``max_cluster`` atoms and not reaching around the periodic box.
+    Stable; ``glue[k]``: sorted atom k belongs to the same group as sorted atom k - 1 (for split_sorted)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
     n = s.nlocal
     key = np.array(s.x[:n, axis], dtype=np.float64)
     mol = np.asarray(s.molecule[:n])
-    is_small = np.zeros(n, dtype=bool)
-    if len(mol) and mol.max() > 0:
+    rows, cols = [], []
+    if len(mol) and mol.max() > 0:   # consecutive sites of one small molecule
         counts = np.bincount(mol)
-        is_small = (mol > 0) & (counts[mol] <= small)
-        first = {}
-        for i in np.nonzero(is_small)[0]:
-            m = mol[i]
-            if m not in first:
-                first[m] = key[i]
-            key[i] = first[m]
+        idx = np.nonzero((mol > 0) & (counts[mol] <= small))[0]
+        by_mol = idx[np.argsort(mol[idx], kind="stable")]
+        same = mol[by_mol[1:]] == mol[by_mol[:-1]]
+        rows.append(by_mol[:-1][same]); cols.append(by_mol[1:][same])
+    if glue_dist > 0.0:
+        from scipy.spatial import cKDTree
+        prd = np.asarray(s.prd, dtype=np.float64)
+        xw = np.mod(np.asarray(s.x[:n]) - np.asarray(s.boxlo), prd)
+        xw = np.where(xw >= prd, 0.0, xw)
+        pairs = cKDTree(xw, boxsize=prd).query_pairs(glue_dist, output_type="ndarray")
+        rows.append(pairs[:, 0]); cols.append(pairs[:, 1])
+    group = np.arange(n)
+    if rows and sum(len(r) for r in rows):
+        r, c = np.concatenate(rows), np.concatenate(cols)
+        _, lab = connected_components(coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)), directed=False)
+        size = np.bincount(lab)
+        zmin = np.full(len(size), np.inf); zmax = np.full(len(size), -np.inf)
+        np.minimum.at(zmin, lab, key); np.maximum.at(zmax, lab, key)
+        first = np.full(len(size), n, dtype=np.int64)
+        np.minimum.at(first, lab, np.arange(n))
+        ok = (size > 1) & (size <= max(max_cluster, small)) & (zmax - zmin < 0.5 * float(s.prd[axis]))
+        member = ok[lab]
+        key[member] = key[first[lab[member]]]
+        group = np.where(member, first[lab], np.arange(n))
     order = np.argsort(key, kind="stable")
-    ms, sm = mol[order], is_small[order]
+    # members of a group share a key; make them adjacent even when another atom happens to have exactly that coordinate
+    order = order[np.lexsort((group[order], key[order]))]
+    go = group[order]
     glue = np.zeros(n, dtype=bool)
     if n > 1:
-        glue[1:] = sm[1:] & (ms[1:] == ms[:-1])
+        glue[1:] = go[1:] == go[:-1]
     return order, key, glue
 
 

@@ -276,6 +276,33 @@ def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
     assert np.max(np.abs(vir - ref["virial"])) < max(tol, 1e-9) * np.max(np.abs(ref["virial"]))
 
 
+def test_sweep_in_parts_equals_the_whole_sweep(wl, pkg, oracle):
+    """polar_step_sweep_part: a sweep run as two (or four) windows of its colour phases is the same sweep."""
+    import importlib
+    par = importlib.import_module(pkg.__name__ + ".parallel")
+    extra = ["use_previous", "no", "dd_cutoff", "9.0", "fixed_iteration", "yes", "max_iterations", "12"]
+    s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"), extra_args=extra)
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    for nparts in (1, 2, 4):
+        p = pkg.pair_from_system(s)
+        be = par.HipShardBackend(p, 0, s.nlocal, 0)
+        be.begin(1, 2)
+        for sw in range(be.max_it + 1):
+            for part in range(nparts):
+                be.sweep_part(part, nparts)
+            be.sweep_end(None)
+        out = be.finish()
+        mu = p.download("mu", 3 * s.nlocal).reshape(-1, 3)
+        assert out["sweeps"] == ref["sweeps"] and out["status"] == 0
+        assert np.max(np.abs(mu - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+        p.close()
+    with pytest.raises(pkg.PolarError, match="bad part"):
+        p2 = pkg.pair_from_system(s)
+        b2 = par.HipShardBackend(p2, 0, s.nlocal, 0)
+        b2.begin(1, 2)
+        b2.sweep_part(2, 2)
+
+
 def test_row_sharded_handles_tally_per_atom(wl, pkg, oracle):
     """eflag & 2 / vflag & 4 through the stepwise interface: the shards' eatom / vatom add up to the per-atom
     tallies of the reference's ev_tally (oracle, LAMMPS half list; ghosts folded onto their owners)."""

@@ -28,5 +28,17 @@ def test_slab_order_keeps_molecules_whole_and_permutation_consistent(wl):
         for m in np.unique(mol[a:b]):
             if m > 0 and cnt[m] <= 16:
                 assert np.count_nonzero(mol[a:b] == m) == cnt[m]     # the whole molecule is on this rank
+    # clusters of bonded framework atoms (< 1.6 A) stay whole as well
+    order2, key2, glue2 = wl.slab_order(s, axis=2, glue_dist=1.6)
+    from scipy.spatial import cKDTree
+    xw = np.mod(s.x[:n] - s.boxlo, s.prd)
+    pairs = cKDTree(xw, boxsize=s.prd).query_pairs(1.6, output_type="ndarray")
+    pos = np.empty(n, dtype=int); pos[order2] = np.arange(n)
+    c2, o2 = wl.split_sorted(key2[order2], 4, glue2)
+    rank_of = np.searchsorted(o2[1:], pos, side="right")
+    split = rank_of[pairs[:, 0]] != rank_of[pairs[:, 1]]
+    zext = np.abs(s.x[pairs[:, 0], 2] - s.x[pairs[:, 1], 2])
+    assert np.count_nonzero(split & (zext < 2.0)) == 0       # only pairs that reach around the periodic box may be cut
+    assert max(c2) - min(c2) <= 64
     with pytest.raises(ValueError):
         wl.permute_locals(wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 1, 1, 1), np.arange(1349))

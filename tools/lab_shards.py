@@ -5,7 +5,9 @@ the protocol of parallel.bench_distributed.  Used to try exchange variants befor
 
   LAB_REPS  "2x2x8"     replication of the MOF5+H2 cell (z slabs: one rank per z range)
   LAB_WORLD "8"
-  LAB_W     "0,0.3,0.5,adaptive"   extrapolation weights for the received halo dipoles
+  LAB_GLUE  "-1"        >= 0: geometric slabs with clusters below this distance kept on one rank (workload.slab_order)
+  LAB_W     "0,0.3,0.5,adaptive"   extrapolation weights for the received halo dipoles; "parts2" / "parts4": exchange
+            inside the sweep, after every half / every colour phase (polar_step_sweep_part)
 """
 import importlib
 import os
@@ -35,7 +37,14 @@ mu_ref = p.download("mu", 3 * n_total).reshape(-1, 3)
 p.close()
 print(f"single handle: {n_total} atoms, sweeps {ref['sweeps']}, E_pol {ref['eng_pol']:.9f}", flush=True)
 
-counts, offs = par.split_rows(n_total, world)
+glue_dist = float(os.environ.get("LAB_GLUE", "-1"))   # >= 0: geometric slabs (workload.slab_order) with this cluster distance
+if glue_dist >= 0.0:
+    order, key, glue = wl.slab_order(sg, axis=2, glue_dist=glue_dist)
+    sg = wl.permute_locals(sg, order)
+    mu_ref = mu_ref[order]
+    counts, offs = wl.split_sorted(key[order], world, glue)
+else:
+    counts, offs = par.split_rows(n_total, world)
 reach = float(sg.extra["cutneigh"]) + 1e-6
 plan = par.P2PHaloPlan(sg.x[:sg.nlocal], sg.prd, offs, reach)
 bes, bufs = [], []
@@ -75,15 +84,25 @@ for wspec in ws:
     exchange(0.0)
     changes = []
     sweeps = 0
+    nparts = int(wspec[5:]) if wspec.startswith("parts") else 1
     for sw in range(bes[0].max_it + 1):
-        for be in bes:
-            be.sweep()
+        if nparts > 1:
+            for part in range(nparts):
+                for be in bes:
+                    be.sweep_part(part, nparts)
+                if part < nparts - 1:
+                    exchange(0.0)
+        else:
+            for be in bes:
+                be.sweep()
         tot = sum(be.local_change().clone() for be in bes)
         for be in bes:
             be.sweep_end(tot)
         changes.append(float(tot.item()))
         sweeps += 1
-        if wspec == "adaptive":
+        if nparts > 1:
+            w = 0.0
+        elif wspec == "adaptive":
             w = min(0.9, (changes[-1] / changes[-2]) ** 0.5) if len(changes) >= 3 else 0.0
         else:
             w = float(wspec) if sw >= 1 else 0.0
