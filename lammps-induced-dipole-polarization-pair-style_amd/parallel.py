@@ -296,6 +296,7 @@ class SweepTimer:
 
 
 POLAR_RETRY_STEP = 2  # include/polar_mi355x.h
+REDUCE_EVERY = max(1, int(os.environ.get("POLAR_DIST_REDUCE_EVERY", "2")))  # sweeps per all-reduce of the stop rule
 
 
 def run_step(backend, dist, rank, world, counts, offs, eflag=1, vflag=2, check_every=4, gather_buf=None,
@@ -395,12 +396,12 @@ def _run_step_once(backend, dist, rank, world, counts, offs, eflag, vflag, check
             if timer is not None:
                 timer.stop()
             if world > 1 and not backend.fixed:
-                # the stop rule (PS.cpp:1194-1210) needs the sum over all ranks: one all-reduced double.  It is taken only
-                # on the sweeps after which the host looks at the state anyway (every `check_every`-th); in between the
-                # end-of-sweep logic is told "not converged yet" (+inf), which saves three of four all-reduce latencies per
-                # sweep -- a sizeable share of a ~0.1 ms sweep -- for at most check_every - 1 sweeps past the point where
-                # the rule would have stopped (they only converge the dipoles further)
-                if (sw % check_every) == check_every - 1 or sw >= backend.max_it:
+                # the stop rule (PS.cpp:1194-1210) needs the sum over all ranks: one all-reduced double.  It is taken on every
+                # second sweep only; in between the end-of-sweep logic is told "not converged yet" (+inf).  That saves half of
+                # the all-reduce latencies -- a sizeable share of a ~0.1 ms sweep -- for at most one sweep past the point where
+                # the rule would have stopped (it only converges the dipoles further).  With S = sweeps x all-reduce latency
+                # and C = the time of a sweep the best cadence is sqrt(2 S / C): 2.7 - 3.6 for 17 - 30 us against 170 us
+                if (sw % REDUCE_EVERY) == REDUCE_EVERY - 1 or sw >= backend.max_it:
                     chg = backend.local_change()
                     dist.all_reduce(chg)
                     backend.sweep_end(chg)
@@ -499,7 +500,7 @@ def bench_distributed(args, rank, world, local_rank):
     N = 2, 4 and configs[4] (7x7x8 = 528,808 atoms) for N = 8, ranked GS to precision 1e-11 -- one rank per GPU,
     contiguous row ranges (z slabs: the replicas are stored z-outermost), every rank holding only
     [own | halo | ghosts], LJ/Coulomb lists of the own rows built on the device, halo dipoles exchanged
-    point-to-point with the slab neighbours once per sweep, one all-reduced double every fourth sweep for the stop rule."""
+    point-to-point with the slab neighbours once per sweep, one all-reduced double every second sweep for the stop rule."""
     import torch
     import torch.distributed as dist
 
