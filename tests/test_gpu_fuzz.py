@@ -55,8 +55,11 @@ def _system(wl, seed):
 def test_random_system_matches_oracle(seed, wl, pkg, oracle):
     from helpers import force_rel_err, rel
     s = _system(wl, seed)
-    ref = oracle.compute(s, eflag=1, vflag=2)
-    out = pkg.pair_from_system(s).compute(eflag=1, vflag=2)
+    peratom = seed % 4 == 2                # per-atom tallies on every fourth system
+    device_neigh = seed % 5 == 1           # LJ/Coulomb list built on the device on every fifth
+    ef, vf = (3, 6) if peratom else (1, 2)
+    ref = oracle.compute(s, eflag=ef, vflag=vf)
+    out = pkg.pair_from_system(s, device_neigh=device_neigh).compute(eflag=ef, vflag=vf)
     assert out["status"] == ref["status"], (out["status"], ref["status"])
     if ref["status"] != 0:            # both walked into the divergence fallback mu = alpha E (PS.cpp:1227-1235)
         assert out["warning"] != ""
@@ -69,3 +72,8 @@ def test_random_system_matches_oracle(seed, wl, pkg, oracle):
     for k in ("eng_vdwl", "eng_coul", "eng_pol"):
         assert rel(out[k], ref[k], 1e-9) < TOL, k
     assert np.max(np.abs(out["virial"] - ref["virial"])) < TOL * max(np.max(np.abs(ref["virial"])), 1e-30)
+    if peratom:
+        for k in ("eatom", "vatom"):
+            a = oracle.fold_ghost_forces(out[k], s.owner, s.nlocal)
+            b = oracle.fold_ghost_forces(ref[k], s.owner, s.nlocal)
+            assert np.max(np.abs(a - b)) < TOL * max(np.max(np.abs(b)), 1e-30), k
