@@ -183,6 +183,7 @@ struct polar_handle {
   int user_full_list = 0;    // polar_set_list_style for uploaded lists
   long long lj_pitch = 0;
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
+  int pol_first = 1;             // polarizable atoms first inside a cell (POLAR_POL_FIRST=0: arrival order)
   int part_k = 0, part_n = 1;    // polar_step_sweep_part: which share of the colour phases the next sweep_once runs
   int lp_wg_per_cu = 0;          // lab (POLAR_LP_WG_PER_CU): workgroups of k_field_lp resident per CU, capped through the LDS size
   int lp_quad_major = 1;         // slot order of the lp index stream (lp_slot), POLAR_LP_QM=0: lane = entry
@@ -316,12 +317,13 @@ void build_cells(polar_handle *h) {
   }
   h->ncell = ncell;
   hipStream_t s = h->stream;
-  h->d_cell_id.ensure(n); h->d_cell_cnt.ensure(ncell + 1); h->d_cell_fill.ensure(ncell + 1);
+  h->d_cell_id.ensure(n); h->d_cell_cnt.ensure(ncell + 1); h->d_cell_fill.ensure(2 * (ncell + 1));
   h->d_cell_first.ensure(ncell + 2); h->d_perm.ensure(n + 1); h->d_inv.ensure(n + 1);
-  zero_many(s, {{h->d_cell_cnt.p, (size_t)(ncell + 1) * sizeof(int)}, {h->d_cell_fill.p, (size_t)(ncell + 1) * sizeof(int)}});
+  zero_many(s, {{h->d_cell_cnt.p, (size_t)(ncell + 1) * sizeof(int)}, {h->d_cell_fill.p, 2 * (size_t)(ncell + 1) * sizeof(int)}});
   k_cell_count<<<nblk(n, 256), 256, 0, s>>>(n, h->d_x.p, g, h->box, h->d_cell_id.p, h->d_cell_cnt.p);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>(ncell, h->d_cell_cnt.p, h->d_cell_first.p);
-  k_cell_fill<<<nblk(n, 256), 256, 0, s>>>(n, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_fill.p, h->d_perm.p, h->d_inv.p);
+  k_cell_fill<<<nblk(n, 256), 256, 0, s>>>(n, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_fill.p,
+                                           h->pol_first ? h->d_cell_fill.p + ncell + 1 : nullptr, h->d_alpha.p, h->d_perm.p, h->d_inv.p);
   h->sorted = true;
   if (sharded(h)) {
     h->d_ownrows.ensure(own_n(h) + 1);
@@ -1307,6 +1309,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
+  if (const char *e = getenv("POLAR_POL_FIRST")) h->pol_first = atoi(e) != 0;
   if (const char *e = getenv("POLAR_LP_WG_PER_CU")) h->lp_wg_per_cu = atoi(e);
   if (const char *e = getenv("POLAR_LP_QM")) h->lp_quad_major = atoi(e) != 0;
   if (const char *e = getenv("POLAR_LP_TILES")) h->lp_tiles = atoi(e) == 1 ? 1 : 2;

@@ -79,12 +79,18 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(long long n, const T *_
 
 // counting-sort fill: perm[s] = orig index of the atom stored at sorted position s, inv = inverse.
 // (Order inside a cell follows the atomics, i.e. it only permutes floating-point summation order.)
+// Inside a cell the polarizable atoms come first (filled from the front), the others last (from the back): the dipole lists
+// then hold long runs of CONSECUTIVE records -- gathers of neighbouring records merge into whole 128-byte lines and run
+// 20 % faster than scattered ones (tools/calib_gather48.hip: 246 against 203 G records/s from an L2-resident table).
 __global__ void k_cell_fill(int n, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
-                            int *__restrict__ fill, int *__restrict__ perm, int *__restrict__ inv) {
+                            int *__restrict__ fill, int *__restrict__ fill_back, const double *__restrict__ alpha,
+                            int *__restrict__ perm, int *__restrict__ inv) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = cell_id[i];
-  const int s = (int)cell_first[c] + atomicAdd(&fill[c], 1);
+  int s;
+  if (!fill_back || alpha[i] != 0.0) s = (int)cell_first[c] + atomicAdd(&fill[c], 1);
+  else s = (int)cell_first[c + 1] - 1 - atomicAdd(&fill_back[c], 1);
   perm[s] = i;
   inv[i] = s;
 }
