@@ -536,9 +536,17 @@ def bench_distributed(args, rank, world, local_rank):
         # apart: the strongest couplings) stay on one rank (workload.slab_order): two peers per rank and the thinnest halo
         # whatever the number of ranks (row ranges cut replica cells in the middle unless the ranks divide the replicas,
         # which leaves three peers and half-cells of interleaved atoms), and 37 instead of 40 sweeps on 8 slabs
-        order, key, glue = wl.slab_order(sg, axis=2, glue_dist=float(os.environ.get("POLAR_DIST_GLUE", "1.6")))
-        sg = wl.permute_locals(sg, order)
-        counts, offs = wl.split_sorted(key[order], world, glue)
+        glue_dist = float(os.environ.get("POLAR_DIST_GLUE", "1.6"))
+        grid = [int(v) for v in os.environ.get("POLAR_DIST_GRID", "").replace("x", ",").split(",") if v]
+        if len(grid) == 3 and grid[0] * grid[1] * grid[2] == world and (grid[0] > 1 or grid[1] > 1):
+            # bricks (opt-in): recursive bisection into equal counts; up to 7 peers per rank at 2 x 2 x 2 instead of 2
+            order, offs = wl.brick_order(sg, grid, glue_dist=glue_dist)
+            sg = wl.permute_locals(sg, order)
+            counts = [int(offs[r + 1] - offs[r]) for r in range(world)]
+        else:
+            order, key, glue = wl.slab_order(sg, axis=2, glue_dist=glue_dist)
+            sg = wl.permute_locals(sg, order)
+            counts, offs = wl.split_sorted(key[order], world, glue)
     lo, hi = int(offs[rank]), int(offs[rank + 1])
     # reach = the neighbor-list cutoff of the LJ/Coulomb rows (max cut + skin) -- it covers the dd cutoff
     reach = float(sg.extra["cutneigh"]) + 1e-6

@@ -526,6 +526,44 @@ def slab_order(s, axis=2, small=16, glue_dist=0.0, max_cluster=64):
     return order, key, glue
 
 
+def brick_order(s, grid, small=16, glue_dist=0.0, max_cluster=64):
+    """(order, offs) for a brick decomposition grid = (gx, gy, gz): recursive coordinate bisection into equal atom counts --
+    gz slabs along z, each cut into gy along y, each of those into gx along x -- with the same groups kept whole as
+    slab_order (a group moves with the coordinates of its first atom).  Rank r = (iz * gy + iy) * gx + ix owns
+    order[offs[r]:offs[r+1]]."""
+    gx, gy, gz = (int(v) for v in grid)
+    n = s.nlocal
+    # group representative coordinates along every axis (slab_order computes the groups once per axis; they are the same)
+    keys, glues = [], None
+    for axis in range(3):
+        o, key, glue = slab_order(s, axis=axis, small=small, glue_dist=glue_dist, max_cluster=max_cluster)
+        keys.append(key)
+    # group id = index of the first atom with the same representative triple (members share all three keys)
+    rep = np.stack(keys, axis=1)
+    _, group = np.unique(rep, axis=0, return_inverse=True)
+    group = group.reshape(-1)
+
+    def split(idx, axis, parts):
+        """idx (atom indices) into `parts` pieces of equal count along `axis`, groups whole"""
+        k = keys[axis][idx]
+        o = np.lexsort((group[idx], k))
+        idx = idx[o]
+        g = group[idx]
+        glue = np.zeros(len(idx), dtype=bool)
+        if len(idx) > 1:
+            glue[1:] = (g[1:] == g[:-1]) & (k[o][1:] == k[o][:-1])
+        _, offs = split_sorted(k[o], parts, glue)
+        return [idx[offs[r]:offs[r + 1]] for r in range(parts)]
+
+    pieces = []
+    for zs in split(np.arange(n), 2, gz):
+        for ys in split(zs, 1, gy):
+            pieces.extend(split(ys, 0, gx))
+    order = np.concatenate(pieces) if pieces else np.zeros(0, dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum([len(q) for q in pieces])]).astype(int)
+    return order, offs
+
+
 def split_sorted(key_sorted, world, glue=None):
     """Equal-count split of a sorted key into ``world`` contiguous ranges.  ``glue[k]`` (optional) says that element k belongs
     with element k - 1 (two sites of one small molecule): a boundary that would fall between them moves up."""

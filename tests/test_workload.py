@@ -42,3 +42,25 @@ def test_slab_order_keeps_molecules_whole_and_permutation_consistent(wl):
     assert max(c2) - min(c2) <= 64
     with pytest.raises(ValueError):
         wl.permute_locals(wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 1, 1, 1), np.arange(1349))
+
+
+def test_brick_order_partitions_into_equal_bricks_with_molecules_whole(wl):
+    import os
+    from helpers import GOLD
+    s = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 2, 2, 2, extra_args=["dd_cutoff", "12.8345"], build_list=False)
+    order, offs = wl.brick_order(s, (2, 2, 2), glue_dist=1.6)
+    n = s.nlocal
+    assert sorted(order.tolist()) == list(range(n)) and len(offs) == 9 and offs[-1] == n
+    counts = np.diff(offs)
+    assert counts.max() - counts.min() <= 64
+    rank = np.empty(n, dtype=int)
+    for r in range(8):
+        rank[order[offs[r]:offs[r + 1]]] = r
+    mol = s.molecule[:n]
+    cnt = np.bincount(mol)
+    for m in np.unique(mol[(mol > 0) & (cnt[mol] <= 16)])[::7]:
+        assert len(set(rank[mol == m])) == 1
+    # rank r = (iz * 2 + iy) * 2 + ix: the bricks are ordered along x fastest
+    cx = [np.median(s.x[order[offs[r]:offs[r + 1]], 0]) for r in range(8)]
+    cz = [np.median(s.x[order[offs[r]:offs[r + 1]], 2]) for r in range(8)]
+    assert cx[0] < cx[1] and cx[2] < cx[3] and max(cz[:4]) < min(cz[4:])

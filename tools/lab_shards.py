@@ -38,7 +38,13 @@ p.close()
 print(f"single handle: {n_total} atoms, sweeps {ref['sweeps']}, E_pol {ref['eng_pol']:.9f}", flush=True)
 
 glue_dist = float(os.environ.get("LAB_GLUE", "-1"))   # >= 0: geometric slabs (workload.slab_order) with this cluster distance
-if glue_dist >= 0.0:
+grid = [int(v) for v in os.environ.get("LAB_GRID", "").split("x") if v]   # e.g. "2x2x2": bricks instead of z slabs
+if len(grid) == 3:
+    order, offs = wl.brick_order(sg, grid, glue_dist=max(glue_dist, 0.0))
+    sg = wl.permute_locals(sg, order)
+    mu_ref = mu_ref[order]
+    counts = [int(offs[r + 1] - offs[r]) for r in range(world)]
+elif glue_dist >= 0.0:
     order, key, glue = wl.slab_order(sg, axis=2, glue_dist=glue_dist)
     sg = wl.permute_locals(sg, order)
     mu_ref = mu_ref[order]
@@ -55,7 +61,7 @@ for r in range(world):
     be = par.HipShardBackend(pr, 0, hi - lo, 0, global_count=n_total)
     bes.append(be)
     bufs.append(par.p2p_buffers(be, plan, r, compact_lo=lo))
-print(f"{world} shards: own {counts[0]}, halo {plan.counts[0]}", flush=True)
+print(f"{world} shards: own {counts[0]}, halo {plan.counts[0]}, peers of rank 0: {len(plan.peers(0))}", flush=True)
 prev = [torch.zeros_like(b["recv"]) for b in bufs]
 raw = [torch.zeros_like(b["recv"]) for b in bufs]
 
@@ -78,7 +84,7 @@ def exchange(w):
         be.scatter_idx(bufs[r]["idx_in"], bufs[r]["recv"])
 
 
-for wspec in ws:
+for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have enlarged a row pitch: POLAR_RETRY_STEP)
     for be in bes:
         be.begin(1, 2)
     exchange(0.0)
