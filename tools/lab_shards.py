@@ -90,6 +90,7 @@ for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have e
     exchange(0.0)
     changes = []
     sweeps = 0
+    sweep_events = []
     nparts = int(wspec[5:]) if wspec.startswith("parts") else 1
     for sw in range(bes[0].max_it + 1):
         if nparts > 1:
@@ -99,8 +100,12 @@ for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have e
                 if part < nparts - 1:
                     exchange(0.0)
         else:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
             for be in bes:
                 be.sweep()
+            e1.record()
+            sweep_events.append((e0, e1))
         tot = sum(be.local_change().clone() for be in bes)
         for be in bes:
             be.sweep_end(tot)
@@ -123,5 +128,10 @@ for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have e
         mu[lo:hi] = be.pair.download("mu", 3 * (hi - lo)).reshape(-1, 3)
     err = np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref))
     rate = (changes[-1] / changes[-6]) ** 0.1 if len(changes) > 6 else float("nan")
+    if sweep_events:   # the shards run one after the other on this GPU: time of all / world = what ONE rank computes per sweep
+        us = 1e3 * sum(a.elapsed_time(b) for a, b in sweep_events) / len(sweep_events) / world
+        o0 = outs[0]
+        print(f"           per rank: {us:6.1f} us of sweep kernels per sweep; rank 0 device ms: list {o0['ms_list']:.2f} ljcoul {o0['ms_ljcoul']:.2f} "
+              f"static {o0['ms_static']:.2f} force {o0['ms_force']:.2f}", flush=True)
     print(f"w={wspec:9s} sweeps {sweeps:3d}  status {[o['status'] for o in outs][:2]}  E_pol {sum(o['eng_pol'] for o in outs):.9f}  "
           f"mu vs single {err:.2e}  contraction/sweep {rate:.3f}", flush=True)
