@@ -53,8 +53,9 @@ PairLJCutCoulLongPolarizationMI355X::PairLJCutCoulLongPolarizationMI355X(LAMMPS 
   const char *dev = getenv("POLAR_DEVICE");
   int ndev = polar_device_count();
   int rc = polar_create(dev ? atoi(dev) : (ndev > 0 ? comm->me % ndev : 0), &h);
-  if (rc < 0 || polar_device_count() < 1)
-    error->all(FLERR,"Pair style lj/cut/coul/long/polarization (MI355X) found no usable HIP device");
+  if (rc < 0) error->all(FLERR,"Pair style lj/cut/coul/long/polarization (MI355X): cannot create the library handle");
+  // (a machine without a GPU may still parse a deck, read and write restart files and call single(): the host mirror of
+  //  the library needs no device.  init_style refuses to go on without one, and every compute entry point fails loudly.)
 }
 
 PairLJCutCoulLongPolarizationMI355X::~PairLJCutCoulLongPolarizationMI355X()
@@ -432,6 +433,8 @@ void PairLJCutCoulLongPolarizationMI355X::init_style()
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization requires atom attribute polarizability");
   if (strstr(update->integrate_style,"respa"))
     error->all(FLERR,"Pair style lj/cut/coul/long/polarization does not support rRESPA");  // respa_enable = 0
+  if (polar_device_count() < 1 && !getenv("POLAR_HOST_PATHS_ONLY"))   // (the variable: tests of the host-side paths)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization (MI355X) found no usable HIP device");
   int irequest = neighbor->request(this,instance_me);     // default half list, newton on
   polar_settings pst;
   check(polar_get_settings(h,&pst));

@@ -1,0 +1,71 @@
+"""The host-side paths of the LAMMPS shim run INSIDE the reference's own Pair base class, next to the reference's pair style
+(tests/shim_host/shim_host_harness.cpp): init / cutsq / single() / extract() must agree with the reference's, and the restart
+records must be interchangeable with the reference's in both directions.  Build container only (needs /root/reference and
+the built library); no GPU needed."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/src"
+PKG = os.path.join(ROOT, "lammps-induced-dipole-polarization-pair-style_amd")
+LIB = os.path.join(PKG, "libpolar_mi355x.so")
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF) or not os.path.exists(LIB), reason="needs the reference tree and the built library")
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    d = tmp_path_factory.mktemp("shimhost")
+    so = str(d / "libshimhost.so")
+    cmd = ["g++", "-O1", "-fPIC", "-shared", "-std=c++11", "-w", f"-I{REF}", f"-I{REF}/STUBS", f"-I{ROOT}/include",
+           f"-I{ROOT}/lammps_shim", f"-I{ROOT}/oracle/ref_seam", "-o", so,
+           os.path.join(ROOT, "tests", "shim_host", "shim_host_harness.cpp"),
+           os.path.join(ROOT, "lammps_shim", "pair_lj_cut_coul_long_polarization_mi355x.cpp"),
+           f"{REF}/pair_lj_cut_coul_long_polarization.cpp", f"{REF}/pair.cpp", f"{REF}/memory.cpp",
+           "-x", "c", f"{REF}/STUBS/mpi.c", "-x", "none", f"-L{PKG}", "-lpolar_mi355x", f"-Wl,-rpath,{PKG}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    os.environ["POLAR_HOST_PATHS_ONLY"] = "1"   # init_style would otherwise (rightly) refuse a machine without a GPU
+    L = C.CDLL(so)
+    L.shimhost_check.restype = C.c_int
+    return L, str(d)
+
+
+def _strs(a):
+    arr = (C.c_char_p * len(a))(*[s.encode() for s in a])
+    return arr
+
+
+CASES = {
+    "mof_like": (["2.5", "12.8345", "precision", "1e-11", "max_iterations", "100", "damp_type", "exponential", "damp", "2.1304",
+                  "polar_gs_ranked", "yes", "debug", "no", "use_previous", "yes"], [],
+                 ["1 1 0.123980 2.462000 6.155000", "1 2 0.086237 2.790000 6.975000", "2 2 0.059984 3.118000 7.795000",
+                  "2 3 0.051368 2.844500", "3 3 0.043989 2.571000 6.427500", "1 3 0.0 1.0"]),
+    "mixed_shifted_notable": (["9.0", "10.5"], ["mix", "arithmetic", "shift", "yes", "table", "0"],
+                              ["1 1 0.10 3.0", "2 2 0.20 3.5 8.0", "3 3 0.05 2.8"]),
+    "tabinner": (["2.5", "9.0", "damp_type", "none"], ["table", "10", "tabinner", "2.0", "mix", "geometric"],
+                 ["* * 0.07 3.1", "2 3 0.2 2.0 12.0"]),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_shim_host_paths_agree_with_the_reference(case, harness):
+    L, tmp = harness
+    style, mod, rows = CASES[case]
+    rep = (C.c_double * 7)()
+    msg = C.create_string_buffer(512)
+    rc = L.shimhost_check(tmp.encode(), 3, C.c_double(0.195492), C.c_double(332.06371), len(style), _strs(style),
+                          len(mod), _strs(mod), len(rows), _strs(rows), rep, msg, 512)
+    assert rc == 0, msg.value.decode()
+    r = list(rep)
+    # cutsq identical, single() to rounding (the library evaluates the same formulas and reads the base class's own tables)
+    assert 0.0 <= r[0] < 1e-14, r
+    assert 0.0 <= r[1] < 1e-14, r     # the reference's restart file read by the shim
+    assert 0.0 <= r[2] < 1e-14, r     # the shim's restart file read by the reference
+    assert r[3] == 0.0, r             # restart_polar yes: every polarization keyword came back
+    assert r[5] > 1.0 and r[6] > 1.0, r   # the comparisons saw real energies and forces (kcal/mol, charges 0.4 / -0.7)
+    assert r[4] == 0.0, r             # extract("cut_coul" | "epsilon" | "sigma") as the reference's, unknown names -> NULL
