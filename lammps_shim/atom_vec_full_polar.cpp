@@ -153,7 +153,12 @@ int AtomVecFullPolar::pack_restart(int i, double *buf)
 
 int AtomVecFullPolar::unpack_restart(double *buf)
 {
+  // the stock routine hands EVERYTHING between its own fields and buf[0] to the fixes' per-atom restart data
+  // (atom->extra, src/MOLECULE/atom_vec_full.cpp:890-894): our four values must be outside that span while it runs
+  const double total = buf[0];
+  buf[0] = total - 4.0;
   int m = AtomVecFull::unpack_restart(buf);
+  buf[0] = total;
   const int i = atom->nlocal - 1;
   static_polarizability[i] = buf[m++];
   mu_induced[i][0] = buf[m++];

@@ -69,3 +69,24 @@ def test_shim_host_paths_agree_with_the_reference(case, harness):
     assert r[3] == 0.0, r             # restart_polar yes: every polarization keyword came back
     assert r[5] > 1.0 and r[6] > 1.0, r   # the comparisons saw real energies and forces (kcal/mol, charges 0.4 / -0.7)
     assert r[4] == 0.0, r             # extract("cut_coul" | "epsilon" | "sigma") as the reference's, unknown names -> NULL
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree")
+@pytest.mark.parametrize("sanitize", [False, True], ids=["plain", "asan"])
+def test_atom_style_round_trips_inside_the_reference_atom_vec(sanitize, tmp_path):
+    """lammps_shim/atom_vec_full_polar.cpp on top of the reference's AtomVec / AtomVecFull (tests/shim_host/
+    atom_vec_harness.cpp): grow, copy, exchange, border (with velocities, with a grow inside the stock unpack), restart records
+    with and without fixes' per-atom data behind the stock fields, create_atom, property names."""
+    exe = str(tmp_path / "atomvec_check")
+    main = tmp_path / "main.cpp"
+    main.write_text('#include <stdio.h>\nextern "C" int atomvec_check(char*,int);\n'
+                    'int main(){ char m[2048]; int r = atomvec_check(m, 2048); printf("%d %s\\n", r, m); return r; }\n')
+    flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if sanitize else ["-O1"]
+    cmd = ["g++", "-std=c++11", "-w"] + flags + [f"-I{REF}", f"-I{REF}/MOLECULE", f"-I{REF}/STUBS", f"-I{ROOT}/lammps_shim", "-o", exe,
+           str(main), os.path.join(ROOT, "tests", "shim_host", "atom_vec_harness.cpp"),
+           os.path.join(ROOT, "lammps_shim", "atom_vec_full_polar.cpp"), f"{REF}/MOLECULE/atom_vec_full.cpp",
+           f"{REF}/atom_vec.cpp", f"{REF}/memory.cpp", "-x", "c", f"{REF}/STUBS/mpi.c"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and r.stdout.split()[0] == "0", (r.stdout, r.stderr[-3000:])
