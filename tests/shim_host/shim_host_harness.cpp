@@ -92,11 +92,12 @@ extern "C" {
 /* report[0] init/cutsq/single: shim vs reference              report[1] reference-written restart read by the shim
  * report[2] shim-written (default format) restart read by the reference
  * report[3] shim restart_polar yes -> shim: 0 if every polarization keyword came back, else a positive code
- * report[4] extract() mismatches (0 expected)       report[5], report[6] largest |energy| and |fforce| the comparisons saw */
+ * report[4] extract() mismatches (0 expected)       report[5], report[6] largest |energy| and |fforce| the comparisons saw
+ * report[7] 0 if write_data / write_data_all produce the reference's text byte for byte */
 int shimhost_check(const char *tmpdir, int ntypes, double g_ewald, double qqrd2e, int nstyle, const char *const *style,
                    int nmod, const char *const *mod, int ncoeff, const char *const *rows, double *report, char *msg, int nmsg) {
   g_last_error.clear();
-  for (int k = 0; k < 7; k++) report[k] = -1.0;
+  for (int k = 0; k < 8; k++) report[k] = -1.0;
   g_max_energy = g_max_force = 0.0;
   HostCtx H;
   H.lmp = make_lammps(ntypes, g_ewald, qqrd2e);
@@ -131,6 +132,14 @@ int shimhost_check(const char *tmpdir, int ntypes, double g_ewald, double qqrd2e
       int dn = 0;
       if (shim->extract("nonsense", dn) != NULL) bad++;
       report[4] = bad;
+    }
+    {  /* write_data / write_data_all: the "PairIJ Coeffs" sections of a data file (PS.cpp:1013-1031) */
+      auto slurp = [](const std::string &p) { std::string t; FILE *f = fopen(p.c_str(), "rb"); int c; while ((c = fgetc(f)) != EOF) t.push_back((char)c); fclose(f); return t; };
+      std::string a = std::string(tmpdir) + "/ref.data", b = std::string(tmpdir) + "/shim.data";
+      FILE *fa = fopen(a.c_str(), "wb"); ref->write_data(fa); ref->write_data_all(fa); fclose(fa);
+      FILE *fb = fopen(b.c_str(), "wb"); shim->write_data(fb); shim->write_data_all(fb); fclose(fb);
+      const std::string ta = slurp(a), tb = slurp(b);
+      report[7] = (ta == tb && ta.size() > 20) ? 0.0 : 1.0;
     }
     std::string f1 = std::string(tmpdir) + "/ref.restart", f2 = std::string(tmpdir) + "/shim.restart",
                 f3 = std::string(tmpdir) + "/shim_polar.restart";

@@ -56,7 +56,7 @@ CASES = {
 def test_shim_host_paths_agree_with_the_reference(case, harness):
     L, tmp = harness
     style, mod, rows = CASES[case]
-    rep = (C.c_double * 7)()
+    rep = (C.c_double * 8)()
     msg = C.create_string_buffer(512)
     rc = L.shimhost_check(tmp.encode(), 3, C.c_double(0.195492), C.c_double(332.06371), len(style), _strs(style),
                           len(mod), _strs(mod), len(rows), _strs(rows), rep, msg, 512)
@@ -68,6 +68,7 @@ def test_shim_host_paths_agree_with_the_reference(case, harness):
     assert 0.0 <= r[2] < 1e-14, r     # the shim's restart file read by the reference
     assert r[3] == 0.0, r             # restart_polar yes: every polarization keyword came back
     assert r[5] > 1.0 and r[6] > 1.0, r   # the comparisons saw real energies and forces (kcal/mol, charges 0.4 / -0.7)
+    assert r[7] == 0.0, r             # write_data / write_data_all: the reference's text
     assert r[4] == 0.0, r             # extract("cut_coul" | "epsilon" | "sigma") as the reference's, unknown names -> NULL
 
 
