@@ -192,4 +192,28 @@ int shimhost_check(const char *tmpdir, int ntypes, double g_ewald, double qqrd2e
   snprintf(msg, nmsg, "%s", g_last_error.c_str());
   return rc;
 }
+
+/* The same (possibly faulty) input through the reference's pair style (which = 0) or the shim (which = 1): settings, coeff
+ * rows, Pair::init.  Returns 0 and an empty message when everything was accepted, else -1 and the text error->all was given.
+ * flags: bit 0 clears atom->q_flag, bit 1 clears atom->static_polarizability_flag, bit 2 removes the KSpace style. */
+int shimhost_message(int which, int ntypes, int flags, int nstyle, const char *const *style, int ncoeff,
+                     const char *const *rows, int do_init, char *msg, int nmsg) {
+  g_last_error.clear();
+  HostCtx H;
+  H.lmp = make_lammps(ntypes, 0.2, 332.06371);
+  if (flags & 1) H.lmp->atom->q_flag = 0;
+  if (flags & 2) H.lmp->atom->static_polarizability_flag = 0;
+  if (flags & 4) H.lmp->force->kspace = NULL;
+  int rc = 0;
+  try {
+    Pair *p = which ? (Pair *)new PairLJCutCoulLongPolarizationMI355X(H.lmp) : (Pair *)new PairLJCutCoulLongPolarization(H.lmp);
+    if (which) feed(H, (PairLJCutCoulLongPolarizationMI355X *)p, nstyle, style, 0, NULL, ncoeff, rows);
+    else feed(H, (PairLJCutCoulLongPolarization *)p, nstyle, style, 0, NULL, ncoeff, rows);
+    if (do_init) { H.lmp->force->pair = p; p->init(); }
+  } catch (SeamError &e) {
+    g_last_error = e.msg; rc = -1;
+  }
+  snprintf(msg, nmsg, "%s", g_last_error.c_str());
+  return rc;
+}
 }

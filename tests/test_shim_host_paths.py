@@ -72,6 +72,40 @@ def test_shim_host_paths_agree_with_the_reference(case, harness):
     assert r[4] == 0.0, r             # extract("cut_coul" | "epsilon" | "sigma") as the reference's, unknown names -> NULL
 
 
+FAULTS = [
+    ([], [], 0, 0),
+    (["9", "9", "zodid", "yes"], [], 0, 0),
+    (["9", "9", "polar_gs", "yes"], [], 0, 0),
+    (["9", "precision", "1e-8"], [], 0, 0),
+    (["9", "9", "damp_type", "thole"], [], 0, 0),
+    (["9", "9", "debug", "maybe"], [], 0, 0),
+    (["9", "9", "max_iterations", "3.5"], [], 0, 0),
+    (["9", "9", "nonsense", "1"], [], 0, 0),
+    (["9", "9"], ["1 1 0.1"], 0, 0),
+    (["9", "9"], ["1 4 0.1 3.0"], 0, 0),
+    (["9", "9"], ["1 1 0.1 3.0 x"], 0, 0),
+    (["9", "9"], ["1 1 0.1 3.0"], 1, 0),                      # init with unset coefficients
+    (["9", "9"], ["* * 0.1 3.0"], 1, 1),                      # no charges
+    (["9", "9"], ["* * 0.1 3.0"], 1, 2),                      # no polarizability attribute
+    (["9", "9"], ["* * 0.1 3.0"], 1, 4),                      # no KSpace style
+    (["9", "9", "polar_gs_ranked", "no", "polar_gs", "yes"], ["* * 0.1 3.0", "1 2 0.2 3.1 7.0"], 1, 0),   # accepted by both
+]
+
+
+@pytest.mark.parametrize("style,rows,do_init,flags", FAULTS)
+def test_faulty_input_gets_the_reference_error_text(style, rows, do_init, flags, harness):
+    """The same input through the reference's pair style and through the shim, in one process: both accept it, or both stop
+    with the same error->all text."""
+    L, _ = harness
+    L.shimhost_message.restype = C.c_int
+    out = []
+    for which in (0, 1):
+        msg = C.create_string_buffer(512)
+        rc = L.shimhost_message(which, 3, flags, len(style), _strs(style), len(rows), _strs(rows), do_init, msg, 512)
+        out.append((rc, msg.value.decode()))
+    assert out[0] == out[1], out
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree")
 @pytest.mark.parametrize("sanitize", [False, True], ids=["plain", "asan"])
 def test_atom_style_round_trips_inside_the_reference_atom_vec(sanitize, tmp_path):
