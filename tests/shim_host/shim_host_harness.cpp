@@ -8,9 +8,11 @@
  * The object graph and the framework stubs are the link seam's (oracle/ref_seam/seam_harness.cpp), included here. */
 #define private public
 #define protected public
+#include "atom.h"   /* (map_array is set up by hand below) */
 #include "pair_lj_cut_coul_long_polarization_mi355x.h"
 #undef private
 #undef protected
+#include <algorithm>
 #include "../../oracle/ref_seam/seam_harness.cpp"
 
 int LAMMPS_NS::Atom::map_find_hash(int) { return -1; }
@@ -215,5 +217,72 @@ int shimhost_message(int which, int ntypes, int flags, int nstyle, const char *c
   }
   snprintf(msg, nmsg, "%s", g_last_error.c_str());
   return rc;
+}
+
+/* build_halo_map (one MPI rank per GPU): LAMMPS order -> library order [own | halo: one ghost per foreign tag | other ghosts]
+ * and the half list re-indexed accordingly, special bits kept.  A small hand-made rank: 4 local atoms (tags 11..14), ghosts =
+ * two images of local atoms, three foreign atoms of which one appears twice.  Returns 0 when every invariant holds. */
+int shimhost_halo_map(char *msg, int nmsg) {
+  g_last_error.clear();
+  std::string log;
+  int bad = 0;
+  auto expect = [&](bool ok, const char *what) { if (!ok) { bad++; log += what; log += "; "; } };
+  try {
+    LAMMPS *lmp = make_lammps(1, 0.2, 332.06371);
+    Atom *atom = lmp->atom;
+    const int nlocal = 4, nghost = 6, nall = 10;
+    atom->nlocal = nlocal; atom->nghost = nghost; atom->nmax = nall;
+    lmp->memory->create(atom->tag, nall, "tag");
+    const int tags[nall] = {11, 12, 13, 14, /* ghosts: */ 12, 21, 22, 21, 14, 23};
+    for (int i = 0; i < nall; i++) atom->tag[i] = tags[i];
+    atom->map_style = 1;
+    lmp->memory->create(atom->map_array, 32, "map");
+    for (int t = 0; t < 32; t++) atom->map_array[t] = -1;
+    for (int i = nall - 1; i >= 0; i--) atom->map_array[tags[i]] = i;   // locals win over their images, first ghost of a foreign tag wins
+    PairLJCutCoulLongPolarizationMI355X *shim = new PairLJCutCoulLongPolarizationMI355X(lmp);
+    /* half list of the rank: rows = locals; entries carry special bits in bits 30-31 */
+    NeighList *list = blank<NeighList>();
+    static int il[4] = {0, 1, 2, 3};
+    static int nn[4] = {3, 2, 2, 1};
+    static int r0[3] = {1, 5 | (1 << 30), 7}, r1[2] = {4, 6 | (3 << 30)}, r2[2] = {9, 8}, r3[1] = {5};
+    static int *first[4] = {r0, r1, r2, r3};
+    list->inum = 4; list->ilist = il; list->numneigh = nn; list->firstneigh = first;
+    shim->list = list;
+    shim->device_neigh = 0;
+    shim->build_halo_map();
+    expect(shim->nhalo == 3 && shim->sh_n == nlocal + 3, "halo = one ghost per foreign tag");
+    std::vector<int> seen(nall, 0);
+    for (int a = 0; a < nall; a++) {
+      const int k = shim->lib_of_lammps[a];
+      expect(k >= 0 && k < nall && shim->lammps_of_lib[k] == a, "the two maps are inverse");
+      if (k >= 0 && k < nall) seen[k]++;
+    }
+    for (int k = 0; k < nall; k++) expect(seen[k] == 1, "library order is a permutation");
+    for (int i = 0; i < nlocal; i++) expect(shim->lib_of_lammps[i] == i, "own atoms keep their indices");
+    /* halo slots: tags 21, 22, 23 once each; images of own atoms (tags 12, 14) and the second image of 21 are plain ghosts */
+    std::vector<int> halo_tags;
+    for (int k = nlocal; k < nlocal + shim->nhalo; k++) halo_tags.push_back(tags[shim->lammps_of_lib[k]]);
+    std::sort(halo_tags.begin(), halo_tags.end());
+    expect(halo_tags.size() == 3 && halo_tags[0] == 21 && halo_tags[1] == 22 && halo_tags[2] == 23, "halo tags");
+    for (int k = nlocal + shim->nhalo; k < nall; k++) {
+      const int t = tags[shim->lammps_of_lib[k]];
+      expect(t == 12 || t == 14 || t == 21, "plain ghosts");
+    }
+    /* the re-indexed list: same pairs, same special bits */
+    long long at = 0;
+    for (int i = 0; i < nlocal; i++) {
+      expect(shim->sh_nn[i] == nn[i] && shim->sh_first[i] == at, "row layout");
+      for (int k = 0; k < nn[i]; k++) {
+        const int e = shim->sh_flat[at + k], o = first[i][k];
+        expect((e & ~0x3FFFFFFF) == (o & ~0x3FFFFFFF), "special bits kept");
+        expect(shim->lammps_of_lib[e & 0x3FFFFFFF] == (o & 0x3FFFFFFF), "neighbor re-indexed");
+      }
+      at += nn[i];
+    }
+  } catch (SeamError &e) {
+    bad++; log += "LAMMPS error: " + e.msg;
+  }
+  snprintf(msg, nmsg, "%s", log.c_str());
+  return bad;
 }
 }

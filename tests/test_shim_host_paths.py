@@ -106,6 +106,13 @@ def test_faulty_input_gets_the_reference_error_text(style, rows, do_init, flags,
     assert out[0] == out[1], out
 
 
+def test_halo_map_of_the_one_rank_per_gpu_path(harness):
+    """build_halo_map: LAMMPS order -> [own | one ghost per foreign tag | other ghosts], half list re-indexed, special bits kept."""
+    L, _ = harness
+    msg = C.create_string_buffer(1024)
+    assert L.shimhost_halo_map(msg, 1024) == 0, msg.value.decode()
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree")
 @pytest.mark.parametrize("sanitize", [False, True], ids=["plain", "asan"])
 def test_atom_style_round_trips_inside_the_reference_atom_vec(sanitize, tmp_path):
