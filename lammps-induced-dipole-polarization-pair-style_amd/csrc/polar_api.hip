@@ -1893,9 +1893,12 @@ int polar_step_sweep_part(polar_handle *h, int part, int nparts) {
     const polar_settings &st = h->ph.st;
     if (nparts > 1 && !(st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && h->sweep_kernel == 2))
       throw InputError("polar_step_sweep_part: parts exist for the colour-phase Gauss-Seidel sweep of list mode only");
+    struct Window {  // restored on every way out: a failed launch must not leave the next full sweep truncated
+      polar_handle *h;
+      ~Window() { h->part_k = 0; h->part_n = 1; }
+    } window{h};
     h->part_k = part; h->part_n = nparts;
     sweep_once(h, false);
-    h->part_k = 0; h->part_n = 1;
     return POLAR_OK;
   });
 }
