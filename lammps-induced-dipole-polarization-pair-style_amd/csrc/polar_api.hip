@@ -151,7 +151,7 @@ struct polar_handle {
   double cluster_dist = 2.0;    // A: largest distance between two members (POLAR_CLUSTER_DIST)
   int cluster_max = 4;          // members per cluster, 1..4 (POLAR_CLUSTER_MAX)
   long long cl_slots = 0;       // entries of the union lists (gathered records per sweep)
-  DBuf<double4> d_xq, d_pos4;
+  DBuf<double4> d_xq, d_pos4, d_xq_s;
   long long nl_pairs = 0, dd_pairs = 0;
   long long nl_pitch = 0, dd_pitch = 0;   // pitched row lists (see polar_kernels.hpp RowList)
   DBuf<int> d_overflow;
@@ -183,6 +183,7 @@ struct polar_handle {
   int user_full_list = 0;    // polar_set_list_style for uploaded lists
   long long lj_pitch = 0;
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
+  int static_xq = 1;             // the static-field rows gather 32-byte {x, y, z, q} records instead of whole AtomRecs (POLAR_STATIC_XQ=0)
   int pol_first = 1;             // polarizable atoms first inside a cell (POLAR_POL_FIRST=0: arrival order)
   int part_k = 0, part_n = 1;    // polar_step_sweep_part: which share of the colour phases the next sweep_once runs
   int lp_wg_per_cu = 0;          // lab (POLAR_LP_WG_PER_CU): workgroups of k_field_lp resident per CU, capped through the LDS size
@@ -1166,9 +1167,9 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
       h->sorted = true;
     }
   }
-  if (!ap) { build_cells(h); h->d_pos4.ensure(n + 1); }  // cell order: perm / inv
+  if (!ap) { build_cells(h); h->d_pos4.ensure(n + 1); if (h->static_xq) h->d_xq_s.ensure(n + 2); }  // cell order: perm / inv
   k_pack<<<nblk(n + 1, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_x.p, h->d_q.p, h->d_alpha.p, h->d_mol.p, mu0,
-                                      h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p);
+                                      h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p, (!ap && h->static_xq) ? h->d_xq_s.p : nullptr);
   if (!ap) {
     if (h->colors_valid && h->sweep_kernel != 3) map_color_rows(h);  // the colour rows in this step's cell order
     if (h->sweep_kernel == 2) compute_slots(h);
@@ -1189,8 +1190,8 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   {  // a4 + a5
     dim3 grid(nblk(own_n(h), POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
     const double ccs = st.cut_coul * st.cut_coul, e2s = std::sqrt(h->P.qqrd2e);
-    if (ap) k_static_field<true><<<grid, block, 0, s>>>(nullptr, n, n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{nullptr, 0}, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
-    else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p);
+    if (ap) k_static_field<true><<<grid, block, 0, s>>>(nullptr, n, n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{nullptr, 0}, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p, nullptr);
+    else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p, h->static_xq ? h->d_xq_s.p : nullptr);
   }
   HIPCHECK(hipEventRecord(h->ev[4], s));
   if (lj_late) launch_lj();
@@ -1309,6 +1310,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
+  if (const char *e = getenv("POLAR_STATIC_XQ")) h->static_xq = atoi(e) != 0;
   if (const char *e = getenv("POLAR_POL_FIRST")) h->pol_first = atoi(e) != 0;
   if (const char *e = getenv("POLAR_LP_WG_PER_CU")) h->lp_wg_per_cu = atoi(e);
   if (const char *e = getenv("POLAR_LP_QM")) h->lp_quad_major = atoi(e) != 0;

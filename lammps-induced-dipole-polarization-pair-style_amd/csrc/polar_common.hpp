@@ -272,6 +272,27 @@ __device__ __forceinline__ RecQuad fetch_records(const AtomRec *__restrict__ rec
   return r;
 }
 
+// The same for kernels that need only position and charge of the neighbour (static field): 32-byte records {x, y, z, q}
+// (s order), two lanes per record -- lane L of instruction r loads piece L & 1 of the record of lane 32 r + L / 2: half the
+// vector-memory instructions, half the bytes.  LDS tile with a 48-byte pitch (stride 12 banks: conflict-free b128 reads).
+struct XQ { double2 a, b; };  // {x, y} {z, q}
+__device__ __forceinline__ XQ fetch_xq(const double4 *__restrict__ xq, int j, double2 *stage, int lane) {
+  const int h2 = lane >> 1;
+  const char *base = reinterpret_cast<const char *>(xq);
+  const unsigned piece = (unsigned)(lane & 1) * 16u, k = lane & 1;
+  const unsigned j0 = __shfl(j, h2, 64), j1 = __shfl(j, 32 + h2, 64);
+  const double2 p0 = *reinterpret_cast<const double2 *>(base + ((j0 << 5) + piece));
+  const double2 p1 = *reinterpret_cast<const double2 *>(base + ((j1 << 5) + piece));
+  stage[h2 * 3 + k] = p0; stage[(32 + h2) * 3 + k] = p1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  XQ r;
+  r.a = stage[lane * 3]; r.b = stage[lane * 3 + 1];
+  __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next trip
+  return r;
+}
+
 // exp(x) for x <= 0 with its constants in SCALAR registers.  The library routine materialises a dozen
 // FP64 constants with v_mov pairs on every call (25 of the 173 vector instructions of a sweep trip);
 // here they arrive as a kernel argument (kernel arguments live in SGPRs, and an FP64 VALU instruction

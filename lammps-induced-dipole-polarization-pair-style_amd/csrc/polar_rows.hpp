@@ -12,7 +12,7 @@ namespace polar {
 __global__ void k_pack(int n, const int *__restrict__ perm, const double *__restrict__ x, const double *__restrict__ q,
                        const double *__restrict__ alpha, const int *__restrict__ mol, const double *__restrict__ mu0,
                        AtomRec *__restrict__ r0, AtomRec *__restrict__ r1, int *__restrict__ mol_s,
-                       double4 *__restrict__ pos4) {
+                       double4 *__restrict__ pos4, double4 *__restrict__ xq_s) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == n) {  // the DUMMY record the lp sweep pads its rows with: zero dipole (contributes nothing), zero
     // polarizability, a finite position (that of atom 0: the sweep floors r^2, so a coincidence is harmless)
@@ -32,6 +32,7 @@ __global__ void k_pack(int n, const int *__restrict__ perm, const double *__rest
   mol_s[i] = mol[o];
   // 32-byte {x, y, z, (molecule id, alpha != 0)} for the list build
   if (pos4) pos4[i] = make_double4(r.x, r.y, r.z, __hiloint2double(mol[o], r.a != 0.0 ? 1 : 0));
+  if (xq_s) xq_s[i] = make_double4(r.x, r.y, r.z, r.q);  // 32-byte {x, y, z, q} for the static-field rows
 }
 
 // ------------------------------------------------------------------------------------------
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restr
                                                               const int *__restrict__ nl_j, double cut_coulsq,
                                                               double e2s, double gamma, int use_previous,
                                                               double *__restrict__ ef, AtomRec *__restrict__ rec0,
-                                                              AtomRec *__restrict__ rec1) {
+                                                              AtomRec *__restrict__ rec1, const double4 *__restrict__ xq_s) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -349,13 +350,15 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restr
       const bool valid = p < end;
       const int e = valid ? nl_j[p] : i;
       const int j = e & POLAR_NL_MASK;
-      const RecQuad rj = fetch_records(rec, j, stage, lane);
+      double xj, yj, zj, qj;
+      if (xq_s) { const XQ t = fetch_xq(xq_s, j, stage, lane); xj = t.a.x; yj = t.a.y; zj = t.b.x; qj = t.b.y; }
+      else { const RecQuad rj = fetch_records(rec, j, stage, lane); xj = rj.a.x; yj = rj.b.x; zj = rj.c.x; qj = rj.d.x; }
       double dx, dy, dz;
-      pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, rj.a.x, rj.b.x, rj.c.x, dx, dy, dz);
+      pair_del<ALLPAIRS>(box, ri.x, ri.y, ri.z, xj, yj, zj, dx, dy, dz);
       const double rsq = dx * dx + dy * dy + dz * dz;
       if (valid && j != i && rsq <= cut_coulsq && !(e & POLAR_NL_SAMEMOL)) {  // note <=, PS.cpp:342
         const double rinv = rsqrt(rsq);
-        const double ef_temp = (rinv * rinv + f_shift) * rinv * rj.d.x;
+        const double ef_temp = (rinv * rinv + f_shift) * rinv * qj;
         ex += ef_temp * dx; ey += ef_temp * dy; ez += ef_temp * dz;
       }
     }
