@@ -183,6 +183,8 @@ struct polar_handle {
   int user_full_list = 0;    // polar_set_list_style for uploaded lists
   long long lj_pitch = 0;
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
+  int lj_typed = 1;              // LJ/Coulomb list entries carry the partner's type (POLAR_LJ_TYPED=0)
+  bool sym_typed = false, dev_typed = false;
   int static_xq = 1;             // the static-field rows gather 32-byte {x, y, z, q} records instead of whole AtomRecs (POLAR_STATIC_XQ=0)
   int pol_first = 1;             // polarizable atoms first inside a cell (POLAR_POL_FIRST=0: arrival order)
   int part_k = 0, part_n = 1;    // polar_step_sweep_part: which share of the colour phases the next sweep_once runs
@@ -1110,8 +1112,9 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
       HIPCHECK(hipMemsetAsync(h->d_sym_fill.p, 0, (nall + 1) * sizeof(int), s));
       k_sym_count<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_cnt.p);
       k_exclusive_scan<int><<<1, 1024, 0, s>>>(nall, h->d_sym_cnt.p, h->d_sym_first.p);
+      h->sym_typed = h->lj_typed && nall < (1 << 24) && h->ntypes < 64;
       k_sym_fill<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_first.p,
-                                      h->d_sym_fill.p, h->d_sym_j.p);
+                                      h->d_sym_fill.p, h->d_sym_j.p, h->sym_typed ? h->d_type.p : nullptr);
       h->sym_valid = true;
     }
     // newton off: ghosts receive no force and tally nothing (PS.cpp:293, ev_tally's 0.5 per LOCAL atom), so only the
@@ -1119,6 +1122,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     const int nrows_lj = symmetrise ? (h->newton_pair ? nall : n) : h->inum;
     dim3 grid(nblk(nrows_lj, POLAR_ROWS_PER_BLOCK));
     if (symmetrise) P.full_list = 1;  // rows of the symmetrised list: force on the row atom only, tallies halved
+    P.typed_list = symmetrise ? (h->sym_typed ? 1 : 0) : (h->device_list && h->dev_typed ? 1 : 0);
     const int *il = symmetrise ? nullptr : h->d_ilist.p;
     const int *nn = symmetrise ? nullptr : h->d_numneigh.p;
     const long long *fi = symmetrise ? h->d_sym_first.p : h->d_first.p;
@@ -1310,6 +1314,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
+  if (const char *e = getenv("POLAR_LJ_TYPED")) h->lj_typed = atoi(e) != 0;
   if (const char *e = getenv("POLAR_STATIC_XQ")) h->static_xq = atoi(e) != 0;
   if (const char *e = getenv("POLAR_POL_FIRST")) h->pol_first = atoi(e) != 0;
   if (const char *e = getenv("POLAR_LP_WG_PER_CU")) h->lp_wg_per_cu = atoi(e);
@@ -1682,6 +1687,7 @@ int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *
       h->lj_pitch = (((long long)(1.3 * mean) + 64) / 64 + 1) * 64;
     }
     h->d_numneigh.ensure(n + 1); h->d_ilist.ensure(n + 1); h->d_first.ensure(n + 1);
+    h->dev_typed = h->lj_typed && nall < (1 << 24) && h->ntypes < 64;
     const size_t lds = (size_t)w * w * sizeof(double);
     if (lds > 64 * 1024) throw InputError("too many atom types for the LDS-resident cutoff table");
     for (int attempt = 0;; attempt++) {
@@ -1691,7 +1697,7 @@ int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *
       k_lj_nl_build<<<nblk(nown, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, lds, s>>>(
           own_lo(h), nown, h->ntypes, h->d_x.p, h->d_type.p, h->d_mol.p, h->d_ljpos.p, h->d_ljaux.p, g, h->d_ljcell_first.p,
           h->d_cutneighsq.p, h->box, exclude_molecule_intra, d_nsp, d_sp, maxspecial, special_flag[1], special_flag[2],
-          special_flag[3], h->lj_pitch, h->d_numneigh.p, h->d_neigh.p, h->d_overflow.p, h->d_ddtot.p);
+          special_flag[3], h->lj_pitch, h->d_numneigh.p, h->d_neigh.p, h->d_overflow.p, h->d_ddtot.p, h->dev_typed ? 1 : 0);
       HIPCHECK(hipMemcpyAsync(h->h_flags, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
       HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
       HIPCHECK(hipStreamSynchronize(s));

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int row_lo, int nro
                                                              const int *__restrict__ special, int maxspecial, int sf1,
                                                              int sf2, int sf3, long long pitch, int *__restrict__ cnt,
                                                              int *__restrict__ out_j, int *__restrict__ overflow,
-                                                             unsigned long long *__restrict__ total) {
+                                                             unsigned long long *__restrict__ total, int typed) {
   extern __shared__ double cn_lds[];
   const int w = ntypes + 1;
   for (int t = threadIdx.x; t < w * w; t += blockDim.x) cn_lds[t] = cutneighsq[t];
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int row_lo, int nro
           const double rsq = dx * dx + dy * dy + dz * dz;
           keep = aj.x != i && rsq <= cn[jtype];
           if (keep && exclude_intra && imol == jmol) keep = false;
-          entry = aj.x;
+          entry = typed ? (aj.x | (jtype << 24)) : aj.x;  // typed lists: the partner's type in bits 24-29 (k_ljcoul)
           if (keep && n3 > 0) {
             int which = 0;
             for (int k = 0; k < n3; k++)
