@@ -424,11 +424,16 @@ void build_lists(polar_handle *h) {
     h->d_color_s.ensure(n + 1);
     k_color_map<<<nblk(n, 256), 256, 0, s>>>(n, h->d_perm.p, h->d_color_orig.p, h->d_color_s.p);
   }
-  k_nl_build<<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
-      rows, nr, h->d_pos4.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,
-      h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, fuse ? r2p : nullptr, fuse ? 1 : 0, lp ? (6 | (h->lp_quad_major << 8)) : 0, lp ? n : -1,
-      lp ? h->d_dd_wrap.p : nullptr, recheck ? h->d_color_s.p : nullptr, h->color_keep * h->color_keep, h->d_overflow.p + 8,
-      lp ? h->d_slot.p : nullptr, h->d_overflow.p, h->d_ddtot.p);
+#define NLB(TRI, RC)                                                                                                          \
+  k_nl_build<TRI, RC><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(                                                 \
+      rows, nr, h->d_pos4.p, h->box, g, h->d_cell_first.p, cutallsq, ddsq, h->nl_pitch, h->dd_pitch, h->d_nl_cnt.p,            \
+      h->d_dd_cnt.p, h->d_nl_j.p, h->d_dd_j.p, fuse ? r2p : nullptr, fuse ? 1 : 0, lp ? (6 | (h->lp_quad_major << 8)) : 0,    \
+      lp ? n : -1, lp ? h->d_dd_wrap.p : nullptr, recheck ? h->d_color_s.p : nullptr, h->color_keep * h->color_keep,           \
+      h->d_overflow.p + 8, lp ? h->d_slot.p : nullptr, h->d_overflow.p, h->d_ddtot.p)
+  // the box shape and "colours are being re-validated" are compile-time: the kernel is bound by its vector instructions
+  if (h->box.triclinic) { if (recheck) NLB(true, true); else NLB(true, false); }
+  else                  { if (recheck) NLB(false, true); else NLB(false, false); }
+#undef NLB
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
   if (fuse || mode == 4) {
     // modes 1 and 2: the list build wrote r^2 (mode 1) and the padding itself; mode 4: no per-atom dd rows at all

@@ -212,6 +212,24 @@ __device__ __forceinline__ void min_image_rint(const Box &b, double xi, double y
   ex = fma(-b.prd[0], nx, ex);
   dx = ex; dy = ey; dz = ez;
 }
+// The same for the list build, with the box shape known at compile time (orthogonal boxes drop the three tilt FMAs) and
+// "a lattice vector was taken off" reported from the rounded multiples themselves (the build marks rows whose pairs all
+// lie inside the box: their sweeps skip the minimum image).
+template <bool TRI>
+__device__ __forceinline__ bool min_image_rint_w(const Box &b, double xi, double yi, double zi, double xj, double yj,
+                                                 double zj, double &dx, double &dy, double &dz) {
+  double ex = xi - xj, ey = yi - yj, ez = zi - zj;
+  const double nz = b.periodic[2] ? rint(ez * b.inv[2]) : 0.0;
+  ez = fma(-b.prd[2], nz, ez);
+  if (TRI) { ey = fma(-b.yz, nz, ey); ex = fma(-b.xz, nz, ex); }
+  const double ny = b.periodic[1] ? rint(ey * b.inv[1]) : 0.0;
+  ey = fma(-b.prd[1], ny, ey);
+  if (TRI) ex = fma(-b.xy, ny, ex);
+  const double nx = b.periodic[0] ? rint(ex * b.inv[0]) : 0.0;
+  ex = fma(-b.prd[0], nx, ex);
+  dx = ex; dy = ey; dz = ez;
+  return nz != 0.0 || ny != 0.0 || nx != 0.0;
+}
 // fractional ("lamda") coordinates of a point, src/domain.cpp x2lamda: orthogonal boxes divide by the box lengths,
 // tilted boxes back-substitute through the triangular cell matrix
 __host__ __device__ __forceinline__ void frac_coords(const Box &b, const double lo[3], double x, double y, double z, double fr[3]) {

@@ -122,6 +122,7 @@ __global__ void k_map_range(int lo, int n, const int *__restrict__ inv, int *__r
 //   nl : every j with rsq <= cutallsq                      (static field, forces, rank metric)
 //   dd : alpha_i != 0, alpha_j != 0 and rsq < ddcutsq      (the dipole sweep stream)
 // cnt[] receives the TRUE counts; writes stop at the pitch and *overflow is raised.
+template <bool TRI, bool RECHECK>
 __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict__ rows, int nrows,
                                                           const double4 *__restrict__ pos4, Box box, CellGrid g,
                                                           const long long *__restrict__ cell_first, double cutallsq,
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   const int imol = __double2hiint(ri.w), ipol = __double2loint(ri.w);
   // colour re-validation on reneighbor steps (color_s != NULL): the colouring of the previous list stays in use unless
   // two polarizable atoms of one colour have come closer than the colour distance
-  const int icol = (color_s && ipol) ? color_s[i] : -2;
-  bool clash = color_s && ipol && icol < 0;  // a polarizable atom without a colour
+  const int icol = (RECHECK && color_s && ipol) ? color_s[i] : -2;
+  bool clash = RECHECK && color_s && ipol && icol < 0;  // a polarizable atom without a colour
   // home cell and the position inside it in cell units (same arithmetic as cell_of)
   int cc[3];
   double uu[3], edge[3];
@@ -231,12 +232,12 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
         if (p < b && j != i) {
           const double4 rj = pos4[j];  // consecutive lanes read consecutive 32-byte entries
           double ex, ey, ez;
-          min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
+          const bool shifted = min_image_rint_w<TRI>(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
           rsq = ex * ex + ey * ey + ez * ez;
           in_nl = rsq <= cutallsq;
           in_dd = ipol && slot_i >= 0 && __double2loint(rj.w) && (rsq < ddcutsq);
-          if (icol >= 0 && rsq < colordistsq && __double2loint(rj.w) && color_s[j] == icol) clash = true;
-          wrap_lane |= in_dd && (ex != ri.x - rj.x || ey != ri.y - rj.y || ez != ri.z - rj.z);
+          if (RECHECK && icol >= 0 && rsq < colordistsq && __double2loint(rj.w) && color_s[j] == icol) clash = true;
+          wrap_lane |= in_dd && shifted;
           same = (imol != 0 && imol == __double2hiint(rj.w)) ? POLAR_NL_SAMEMOL : 0;
         }
         const unsigned long long m_nl = __ballot(in_nl), m_dd = __ballot(in_dd);
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
       if (dd_r2) dd_r2[dd0 + k] = 1e60;  // s3 ~ 1e-90, and d = 0 kills the s5 term: contributes nothing
     }
   }
-  if (color_s && __ballot(clash) != 0ull && lane == 0) atomicOr(color_conflict, 1);
+  if (RECHECK && color_s && __ballot(clash) != 0ull && lane == 0) atomicOr(color_conflict, 1);
   const unsigned long long anywrap = __ballot(wrap_lane);  // all lanes are back together here
   if (lane == 0) {
     nl_cnt[i] = ncount; dd_cnt[i] = dcount;
