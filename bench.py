@@ -236,6 +236,17 @@ def main():
     p = pkg.pair_from_system(s, device=0)
     out, dt, ms_solve, launches = timed_steps(torch, p, args.steps, args.warmup)
     p.close()
+    # The same sweeps with the chip to themselves: in the timed region above a3 (LJ + Ewald-real) runs beside them on its
+    # low-priority side stream -- it shortens the step and stretches the sweeps, whose launch time therefore says less about
+    # the kernel the faster the other kernels get.  A few extra steps with a3 kept on the main stream (POLAR_NO_OVERLAP):
+    # reported as roofline.alone, never as the headline.
+    os.environ["POLAR_NO_OVERLAP"] = "1"
+    try:
+        p2 = pkg.pair_from_system(s, device=0)
+        out2, dt2, ms_solve2, launches2 = timed_steps(torch, p2, 5, 2)
+        p2.close()
+    finally:
+        os.environ.pop("POLAR_NO_OVERLAP", None)
 
     n = s.nlocal
     config = {"workload": workload, "natoms": n, "sweeps": out["sweeps"], "iterations": out["iterations"], "colors": out["ncolors"],
@@ -249,6 +260,10 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": config,
         "roofline": roofline(s, out, ms_solve, launches, args.steps, pkg),
     }
+    alone = roofline(s, out2, ms_solve2, launches2, 5, pkg)
+    line["roofline"]["alone"] = {"what": "the same launches with a3 kept off its side stream (5 extra steps): the sweep kernel by itself",
+                                 "ms_per_launch": alone["ms_per_launch"], "achieved": alone["achieved"], "frac": alone["frac"],
+                                 "ms_per_step": 1e3 * dt2 / 5}
     if not args.no_extras and not args.synth and not args.reps:
         config["md_leg"] = md_leg(pkg, s)
         config["md_leg_device_neigh"] = md_leg(pkg, s, device_neigh=True)
