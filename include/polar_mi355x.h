@@ -54,6 +54,11 @@ typedef struct {
    * stock record (polar_restart_pack); off by default, so restart files keep the reference's layout (PS.cpp:976-985),
    * which stores none of them.  The dipoles persist through the atom style (AtomVecFullPolar::pack_restart). */
   int restart_polar;
+  /* deterministic yes|no (extension keyword, list mode): no sweep launch reads a dipole that another wave of the same
+   * launch writes -- updates are committed between launches and between the sub-phases of a tile -- so that a run,
+   * `fixed_iteration` runs included, is reproducible bit for bit like the reference's serial loop (PS.cpp:1158-1180).
+   * Off by default: the in-place update converges to the same fixed point and saves the commit launches. */
+  int deterministic;
 } polar_settings;
 
 typedef struct {

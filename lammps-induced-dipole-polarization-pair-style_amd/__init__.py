@@ -56,7 +56,7 @@ class Settings(C.Structure):
                 ("polar_damp", C.c_double), ("polar_gamma", C.c_double), ("iterations_max", C.c_int),
                 ("damping_type", C.c_int), ("zodid", C.c_int), ("fixed_iteration", C.c_int), ("polar_gs", C.c_int),
                 ("polar_gs_ranked", C.c_int), ("use_previous", C.c_int), ("debug", C.c_int), ("dd_cutoff", C.c_double),
-                ("device_neigh", C.c_int), ("restart_polar", C.c_int)]
+                ("device_neigh", C.c_int), ("restart_polar", C.c_int), ("deterministic", C.c_int)]
 
 
 class Result(C.Structure):
@@ -317,6 +317,8 @@ class PolarPair:
             args += ["polar_gs_ranked", "yes"]
         if st.dd_cutoff > 0:
             args += ["dd_cutoff", repr(st.dd_cutoff)]
+        if getattr(st, "deterministic", 0):
+            args += ["deterministic", "yes"]
         self.settings(args)
         if modify_args:
             self.modify(list(modify_args))

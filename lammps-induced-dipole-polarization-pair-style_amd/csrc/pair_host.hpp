@@ -44,6 +44,7 @@ inline void settings_defaults(polar_settings &s) {  // PS.cpp:65-78
   s.dd_cutoff = 0.0;
   s.device_neigh = 0;
   s.restart_polar = 0;
+  s.deterministic = 0;
 }
 
 // Force::numeric / Force::inumeric behaviour: whole token must parse.
@@ -146,6 +147,7 @@ class PairHost {
       else if (strcmp("dd_cutoff", k) == 0) st.dd_cutoff = numeric(v);  // extension keyword
       else if (strcmp("device_neigh", k) == 0) st.device_neigh = yesno(v);  // extension keyword
       else if (strcmp("restart_polar", k) == 0) st.restart_polar = yesno(v);  // extension keyword
+      else if (strcmp("deterministic", k) == 0) st.deterministic = yesno(v);  // extension keyword
       else throw InputError("Illegal pair_style command");
       iarg += 2;
     }

@@ -168,6 +168,8 @@ struct polar_handle {
   double color_keep = 2.0;      // A (POLAR_COLOR_KEEP): a colouring built at color_dist stays in use on later lists while
                                 // every same-colour pair is still farther apart than this (hysteresis: atoms move)
   bool slots_by_color = false;  // the dd rows of the current lists are laid out in colour-phase order (compute_slots)
+  long long color_epoch = 0;    // counts colourings (build_colors); the dd rows are usable only while laid out for the current one
+  long long slots_epoch = -1;   // the colouring compute_slots laid the rows out for
   bool colors_recheck = false;  // a new neighbor list arrived: keep the colouring if it still separates every same-colour pair
   std::vector<int> h_color;     // colour of every atom (orig ids), -1: none
   DBuf<int> d_color_orig, d_color_s;
@@ -196,9 +198,27 @@ struct polar_handle {
   int cache_r2 = -1;      // sweep stream (POLAR_CACHE_R2): 0 cached (s3,s5), 20 B/pair; 1 cached r^2, 12 B/pair; 2 nothing,
                           // 4 B/pair (r^2 rebuilt from the gathered positions); -1: 1 or 2 by size, see build_lists
   int stream_mode = 1;    // the choice in force for the current lists
-  int sweep_kernel = 2;   // list-mode sweep (POLAR_SWEEP_KERNEL): 2 k_field_lp (lane-per-pair, LDS-DMA gathers; default), 0 k_field_quad
-                          // (component-per-lane, round 1), 1 k_field (register-staged lane-per-pair), 3 k_field_cl (cluster rows, experimental)
+  int sweep_kernel = 2;   // list-mode sweep (POLAR_SWEEP_KERNEL): 4 k_field_tile (one workgroup per cell, neighbour records staged in LDS),
+                          // 2 k_field_lp (one wave per row, LDS-DMA gathers), 0 k_field_quad (component-per-lane, round 1),
+                          // 1 k_field (register-staged lane-per-pair), 3 k_field_cl (cluster rows, experimental)
   int ablate = 0;  // lab switches for k_field (POLAR_ABLATE), 0 in production
+  // tile sweep (sweep_kernel 4, polar_tiles.hpp): sweep records, tile headers, row table, union lists, 16-bit row lists
+  DBuf<SRec> d_srec0, d_srec1;
+  DBuf<TileHdr> d_thdr;
+  DBuf<int2> d_trow;
+  DBuf<int> d_un_j;
+  DBuf<unsigned short> d_dd16;
+  DBuf<double> d_pend;             // `deterministic yes`: dipoles of a launch's rows until k_tile_commit
+  int un_pitch = 0;                // union entries per tile (pitch of d_un_j)
+  int un_lds = 0;                  // records (dummy included) the sweep's LDS request holds; the builder refuses larger unions
+  long long pitch16 = 0;           // entries per row of d_dd16 (a multiple of 512 = 8 trips)
+  int tile_max_u = 0;              // largest union of the last step
+  double dens = 0.0;               // atoms per A^3 of the occupied part of the box (first list build)
+  std::vector<TileLaunch> tile_launches;  // Gauss-Seidel: one launch per tile colour; tile_all: every cell (Jacobi)
+  TileLaunch tile_all{};
+  size_t tile_lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // dynamic-LDS limit already raised per kernel instance
+  size_t tile_build_lds_attr = 0;
+  int deterministic = 0;           // POLAR_DETERMINISTIC / `deterministic yes`: no sweep reads a dipole another wave of the same launch writes
   Scal *h_scal = nullptr;  // pinned
   hipEvent_t ev[8] = {};
   // a3 runs on its own stream beside the list build / static field / dipole solve (it only shares the
@@ -296,6 +316,16 @@ inline int own_lo(const polar_handle *h) { return h->row_lo; }
 inline int own_n(const polar_handle *h) { return (h->row_hi < 0 ? h->nlocal : h->row_hi) - h->row_lo; }
 inline int norm_count(const polar_handle *h) { return (int)(h->global_count > 0 ? h->global_count : h->nlocal); }
 inline bool sharded(const polar_handle *h) { return own_n(h) != h->nlocal; }
+// the dd rows of the current lists sit in the launch order of the colouring in force (a colouring rebuilt after the
+// lists were laid out -- a clash found on a reneighbor step, a changed alpha pattern -- makes them stale)
+inline bool slots_current(const polar_handle *h) { return h->slots_by_color && h->slots_epoch == h->color_epoch; }
+inline bool deterministic(const polar_handle *h) { return h->deterministic || h->ph.st.deterministic; }
+inline bool tile_mode(const polar_handle *h) { return h->ph.st.dd_cutoff > 0.0 && h->sweep_kernel == 4; }
+// where the dipoles live during a solve (exchange and debug kernels): the sweep records in tile mode, else the AtomRecs
+inline MuView mu_view(const polar_handle *h) {
+  if (tile_mode(h)) return MuView{reinterpret_cast<char *>(h->d_srec0.p), reinterpret_cast<char *>(h->d_srec1.p), (int)sizeof(SRec)};
+  return MuView{reinterpret_cast<char *>(h->d_rec0.p), reinterpret_cast<char *>(h->d_rec1.p), (int)sizeof(AtomRec)};
+}
 // rows a per-row kernel should visit: nullptr = all rows 0..n-1 (identity)
 inline const int *own_rows(const polar_handle *h) { return (h->sorted && sharded(h)) ? h->d_ownrows.p : nullptr; }
 
@@ -314,11 +344,36 @@ void build_cells(polar_handle *h) {
   long long ncell = 1;
   for (int k = 0; k < 3; k++) {
     g.nc[k] = std::max(1, (int)std::floor(width[k] / (0.5 * cutall)));  // cell height >= cutoff/2: +-2 stencil
+    // tile sweep: the launches are the parity classes of the cells; an even count in a periodic dimension needs no third
+    // class for the seam (cells grow by at most 1/6)
+    if (h->sweep_kernel == 4 && h->box.periodic[k] && g.nc[k] >= 7 && (g.nc[k] & 1)) g.nc[k] -= 1;
     g.lo[k] = h->boxlo[k];
     g.inv[k] = g.nc[k] / h->box.prd[k];
     ncell *= g.nc[k];
   }
   h->ncell = ncell;
+  if (h->sweep_kernel == 4) {  // tile colours: per dimension the even cells, the odd cells and -- odd count, periodic -- the last cell
+    struct Cls { int start, stride, count; };
+    std::vector<Cls> cls[3];
+    for (int k = 0; k < 3; k++) {
+      const int nc = g.nc[k];
+      const bool seam = h->box.periodic[k] && (nc & 1) && nc > 1;
+      const int lim = seam ? nc - 1 : nc;
+      if ((lim + 1) / 2 > 0) cls[k].push_back(Cls{0, 2, (lim + 1) / 2});
+      if (lim / 2 > 0) cls[k].push_back(Cls{1, 2, lim / 2});
+      if (seam) cls[k].push_back(Cls{nc - 1, 1, 1});
+    }
+    h->tile_launches.clear();
+    for (const Cls &cz : cls[2]) for (const Cls &cy : cls[1]) for (const Cls &cx : cls[0]) {
+      TileLaunch L;
+      L.start[0] = cx.start; L.stride[0] = cx.stride; L.count[0] = cx.count;
+      L.start[1] = cy.start; L.stride[1] = cy.stride; L.count[1] = cy.count;
+      L.start[2] = cz.start; L.stride[2] = cz.stride; L.count[2] = cz.count;
+      for (int k = 0; k < 3; k++) L.nc[k] = g.nc[k];
+      h->tile_launches.push_back(L);
+    }
+    for (int k = 0; k < 3; k++) { h->tile_all.start[k] = 0; h->tile_all.stride[k] = 1; h->tile_all.count[k] = g.nc[k]; h->tile_all.nc[k] = g.nc[k]; }
+  }
   hipStream_t s = h->stream;
   h->d_cell_id.ensure(n); h->d_cell_cnt.ensure(ncell + 1); h->d_cell_fill.ensure(2 * (ncell + 1));
   h->d_cell_first.ensure(ncell + 2); h->d_perm.ensure(n + 1); h->d_inv.ensure(n + 1);
@@ -326,7 +381,7 @@ void build_cells(polar_handle *h) {
   k_cell_count<<<nblk(n, 256), 256, 0, s>>>(n, h->d_x.p, g, h->box, h->d_cell_id.p, h->d_cell_cnt.p);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>(ncell, h->d_cell_cnt.p, h->d_cell_first.p);
   k_cell_fill<<<nblk(n, 256), 256, 0, s>>>(n, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_fill.p,
-                                           h->pol_first ? h->d_cell_fill.p + ncell + 1 : nullptr, h->d_alpha.p, h->d_perm.p, h->d_inv.p);
+                                           (h->pol_first || h->sweep_kernel == 4) ? h->d_cell_fill.p + ncell + 1 : nullptr, h->d_alpha.p, h->d_perm.p, h->d_inv.p);
   h->sorted = true;
   if (sharded(h)) {
     h->d_ownrows.ensure(own_n(h) + 1);
@@ -348,6 +403,7 @@ void compute_slots(polar_handle *h) {
     const int tot = h->color_off.empty() ? 0 : h->color_off.back();
     if (tot > 0) k_slot_from_rows<<<nblk(tot, 256), 256, 0, s>>>(tot, h->d_rows.p, h->d_slot.p);
     h->slots_by_color = true;
+    h->slots_epoch = h->color_epoch;
   } else {
     k_slot_from_rows<<<nblk(own_n(h), 256), 256, 0, s>>>(own_n(h), own_rows(h), h->d_slot.p);
     h->slots_by_color = false;
@@ -384,13 +440,17 @@ void build_lists(polar_handle *h) {
       for (char v : occ) filled += v;
       if (filled > 0) vol *= (double)filled / (double)tot;
     }
+    h->dens = n / vol;
     double mean = n / vol * 4.18879020478639 * cutall * cutall * cutall;
     h->nl_pitch = h->dd_pitch = (((long long)(1.5 * mean) + 64) / 64 + 1) * 64;
   }
   if (h->sweep_kernel == 2) h->dd_pitch = ((h->dd_pitch + 255) / 256) * 256;  // whole 4-trip chunks (k_field_lp)
+  // the lp / cluster index streams hold byte offsets j << 6 in 32-bit words: the record table must stay below 2^31 bytes
+  if ((h->sweep_kernel == 2 || h->sweep_kernel == 3) && ((long long)n + 1) * (long long)sizeof(AtomRec) >= (1ll << 31))
+    throw InputError("more than 2^25 atoms on one handle: the 32-bit record offsets of the sweep's index stream would wrap (shard the system)");
   h->d_nl_cnt.ensure(n + 1); h->d_dd_cnt.ensure(n + 1);
   h->d_nl_j.ensure((size_t)n * h->nl_pitch + 64);
-  if (h->sweep_kernel != 3) h->d_dd_j.ensure((size_t)n * h->dd_pitch + 1024);  // slack: k_field_lp requests two index chunks per row up front
+  if (h->sweep_kernel < 3) h->d_dd_j.ensure((size_t)n * h->dd_pitch + 1024);  // slack: k_field_lp requests two index chunks per row up front
   else h->d_dd_j.ensure(64);
   // What the sweep streams per pair.  Measured (tools/exp_nocache.sh): while index + r^2 of all pairs
   // (12 B/pair) stay resident in the 256 MB Infinity Cache between sweeps the cached r^2 wins (36k atoms,
@@ -399,7 +459,7 @@ void build_lists(polar_handle *h) {
   int mode = h->cache_r2;
   if (h->sweep_kernel == 1) mode = 0;
   if (h->sweep_kernel == 2) mode = 3;  // lane-per-pair sweep: only the index (as a byte offset) is streamed
-  if (h->sweep_kernel == 3) mode = 4;  // cluster sweep: the dd lists are the clusters' union lists (build_cluster_lists)
+  if (h->sweep_kernel >= 3) mode = 4;  // cluster sweep: the dd lists are the clusters' union lists (build_cluster_lists); tile sweep: build_tiles
   if (mode < 0) {
     const double est_pairs = h->dd_pairs > 0 ? (double)h->dd_pairs : 0.35 * (double)own_n(h) * (double)h->dd_pitch;
     mode = (12.0 * est_pairs < 200.0e6) ? 1 : 2;
@@ -418,7 +478,7 @@ void build_lists(polar_handle *h) {
                 {h->d_overflow.p, 16 * sizeof(int)}, {h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long)}});
   const bool lp = mode == 3;
   if (lp) h->d_dd_wrap.ensure(n + 1);
-  const bool recheck = h->colors_valid && h->colors_recheck && h->sweep_kernel != 3 && (int)h->h_color.size() == n;
+  const bool recheck = h->colors_valid && h->colors_recheck && h->sweep_kernel < 3 && (int)h->h_color.size() == n;
   if (h->colors_recheck && !recheck) { h->colors_valid = false; h->colors_recheck = false; }
   if (recheck) {
     h->d_color_s.ensure(n + 1);
@@ -596,6 +656,7 @@ void build_cluster_colors(polar_handle *h, const std::vector<double> &rank, cons
     for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
     fprintf(stderr, "\n");
   }
+  h->color_epoch++;
   h->colors_valid = true;
 }
 
@@ -728,6 +789,7 @@ void build_colors(polar_handle *h, const std::vector<double> &rank) {
     for (int i : cell)
       if (mine(i)) rows[fill[color[i]]++] = i;
   h->h_rows = rows;
+  h->color_epoch++;  // the launch order changed: dd rows laid out for an earlier colouring are stale (slots_current)
   h->h_color.assign(color.begin(), color.end());
   h->d_color_orig.ensure((size_t)n + 1);
   if (n > 0) HIPCHECK(hipMemcpy(h->d_color_orig.p, h->h_color.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
@@ -810,6 +872,9 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
   const int nt = h->lp_tiles;
   size_t lds = (size_t)(qb / 64) * nt * POLAR_LP_TILE;
   if (h->lp_wg_per_cu > 0) lds = std::max(lds, std::min((size_t)64 * 1024, (size_t)160 * 1024 / h->lp_wg_per_cu));  // lab: cap the residency
+  // the launch requests dynamic LDS without raising the kernel's limit: beyond 64 KB (workgroups of more than 512 threads
+  // with two tiles per wave) it would fail, and the failure would only surface at the next read of the loop state
+  if (lds > (size_t)64 * 1024) throw InputError("k_field_lp: workgroup size x tiles needs more than 64 KB of LDS (POLAR_QUAD_BLOCK <= 512 with two tiles)");
 #define FL(D, NT) k_field_lp<EP, D, NT><<<nblk_xcd(nrows, qb / 64), qb, lds, h->stream>>>(                           \
       nrows, row0, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                               \
       st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
@@ -847,10 +912,93 @@ void launch_field_cl(polar_handle *h, int ncl, int first) {
 #undef FC
 }
 
+// ---- tile sweep: per-step tables (polar_tiles.hpp) ---------------------------------------------------
+struct TileUnavailable : std::runtime_error {
+  explicit TileUnavailable(const std::string &m) : std::runtime_error(m) {}
+};
+inline int tile_lds_cap() { return (int)((160 * 1024 - 256) / sizeof(SRec)); }  // records one workgroup can stage at all
+void build_tiles(polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  const double rc = st.dd_cutoff;
+  if (h->un_pitch == 0) {
+    long long npol = 0;
+    for (int a = 0; a < n; a++) npol += h->halpha[a] != 0.0;
+    const double dens = (h->dens > 0.0 ? h->dens : n / (h->box.prd[0] * h->box.prd[1] * h->box.prd[2])) * (double)npol / std::max(n, 1);
+    double e[3];
+    for (int k = 0; k < 3; k++) e[k] = h->box.prd[k] / h->grid.nc[k];
+    // what a cell's rows can see: the cell widened by the cutoff (Minkowski sum of a box and a sphere)
+    const double vol = e[0] * e[1] * e[2] + 2.0 * (e[0] * e[1] + e[1] * e[2] + e[0] * e[2]) * rc + M_PI * (e[0] + e[1] + e[2]) * rc * rc +
+                       4.18879020478639 * rc * rc * rc;
+    h->un_pitch = (int)(((long long)(1.25 * dens * vol) + 64 + 63) / 64 * 64);
+    h->pitch16 = ((long long)(1.5 * dens * 4.18879020478639 * rc * rc * rc) + 64 + 511) / 512 * 512;
+    if (const char *ip = getenv("POLAR_INIT_PITCH")) {  // tests: force the overflow paths
+      h->un_pitch = std::max(64, atoi(ip) / 64 * 64);
+      h->pitch16 = 512;
+    }
+    h->un_lds = 0;
+  }
+  if (h->un_pitch > tile_lds_cap()) throw TileUnavailable("tile sweep: a cell's neighbourhood does not fit the LDS of a compute unit");
+  if (h->un_lds <= 0 || h->un_lds > h->un_pitch) h->un_lds = h->un_pitch;
+  const long long ncell = h->ncell;
+  h->d_thdr.ensure((size_t)ncell + 1); h->d_trow.ensure((size_t)n + 1);
+  h->d_un_j.ensure((size_t)ncell * h->un_pitch + 64);
+  h->d_dd16.ensure((size_t)std::max(n, 1) * h->pitch16 + 1024);
+  h->d_srec0.ensure((size_t)n + 1); h->d_srec1.ensure((size_t)n + 1);
+  if (deterministic(h)) h->d_pend.ensure(3 * (size_t)n + 3);
+  // (build_lists has just zeroed the flag words and the pair totals; its own k_nl_build lists no dd pair in this mode)
+  const size_t lds = 24 * (size_t)h->un_pitch + (128 + 128 + 2 * POLAR_TILE_MAXROWS) * sizeof(int) + 6 * sizeof(double) + 16;
+  if (lds > h->tile_build_lds_attr) {
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->tile_build_lds_attr = lds;
+  }
+  const int cap = std::min(h->un_pitch, h->un_lds);
+  k_tile_build<<<(int)ncell, 256, lds, s>>>(h->grid, h->box, h->d_pos4.p, h->d_cell_first.p, h->d_cell_fill.p, h->d_perm.p, own_lo(h),
+                                            own_lo(h) + own_n(h), rc * rc, h->color_dist * h->color_dist, cap, h->d_un_j.p, h->pitch16,
+                                            h->d_dd16.p, h->d_thdr.p, h->d_trow.p, h->d_overflow.p, h->d_ddtot.p);
+  HIPCHECK(hipMemcpyAsync(h->h_flags + 5, h->d_overflow.p + 5, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+}
+// NOTE: the builder indexes the union lists with the pitch it is given (`cap`), so the sweep must use the same value
+inline int tile_pitch(const polar_handle *h) { return std::min(h->un_pitch, h->un_lds); }
+
+template <int EP>
+void launch_field_tile(polar_handle *h, const TileLaunch &L) {
+  const polar_settings &st = h->ph.st;
+  const long long nt = (long long)L.count[0] * L.count[1] * L.count[2];
+  if (nt <= 0) return;
+  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+  const bool det = deterministic(h) && EP == EP_INPLACE;
+  const size_t lds = (size_t)(tile_pitch(h) + 1) * sizeof(SRec);
+  const int inst = (EP == EP_JACOBI ? 0 : (det ? 2 : 1)) * 2 + (expd ? 0 : 1);
+#define FT(D, DT)                                                                                                              \
+  {                                                                                                                            \
+    if (lds > h->tile_lds_attr[inst]) {                                                                                        \
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_tile<EP, D, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      h->tile_lds_attr[inst] = lds;                                                                                            \
+    }                                                                                                                          \
+    k_field_tile<EP, D, DT><<<nblk_xcd(nt, 1), 256, lds, h->stream>>>(L, h->d_thdr.p, h->d_trow.p, h->d_un_j.p, tile_pitch(h),   \
+        h->d_dd16.p, h->pitch16, h->d_srec0.p, h->d_srec1.p, h->d_pend.p, h->d_rec0.p, h->d_ef_s.p, h->box, st.polar_damp,       \
+        make_expcoef(), h->d_scal.p, h->d_slots.p);                                                                              \
+  }
+  if (det) { if (expd) FT(0, true) else FT(1, true) }
+  else     { if (expd) FT(0, false) else FT(1, false) }
+#undef FT
+  if (det) k_tile_commit<<<(int)nt, 64, 0, h->stream>>>(L, h->d_thdr.p, h->d_trow.p, h->d_pend.p, h->d_srec0.p, h->d_scal.p);
+}
+
 // one sweep over the rows this handle owns (Jacobi, or the colour phases)
 void sweep_once(polar_handle *h, bool ap) {
   const polar_settings &st = h->ph.st;
   const bool gs = st.polar_gs || st.polar_gs_ranked;
+  if (!ap && h->sweep_kernel == 4) {
+    if (!gs) { launch_field_tile<EP_JACOBI>(h, h->tile_all); return; }
+    const int ncol = (int)h->tile_launches.size();
+    const int c0 = h->part_n > 1 ? ncol * h->part_k / h->part_n : 0, c1 = h->part_n > 1 ? ncol * (h->part_k + 1) / h->part_n : ncol;
+    for (int c = c0; c < c1; c++) launch_field_tile<EP_INPLACE>(h, h->tile_launches[c]);  // (polar_step_sweep_part: a window of the tile colours)
+    return;
+  }
   if (!ap && h->sweep_kernel == 3) {
     const int ncol = (int)h->color_off.size() - 1;
     for (int c = 0; c < ncol; c++) {
@@ -969,7 +1117,8 @@ void debug_trace(polar_handle *h, int sw, bool /*jacobi*/) {
   if (!h->ph.st.debug) return;
   h->d_trace.ensure((size_t)h->ph.st.iterations_max + 8);
   if (sw > h->ph.st.iterations_max + 1) return;
-  k_debug_upolar<<<1, 1024, 0, h->stream>>>(h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p, h->d_trace.p, sw, 0);  // Jacobi: like the reference, the value is formed BEFORE "mu = mu_new" (jacobi unused)
+  const MuView mv = mu_view(h);
+  k_debug_upolar<<<1, 1024, 0, h->stream>>>(h->nlocal, h->d_scal.p, mv.a, mv.b, mv.stride, h->d_ef_s.p, h->d_trace.p, sw, 0);  // Jacobi: like the reference, the value is formed BEFORE "mu = mu_new" (jacobi unused)
   h->ntrace = sw + 1;
 }
 
@@ -984,11 +1133,11 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
   out->ncolors = 0;
 
   if (!gs || !ap) {  // Jacobi (reference "polar_gs no") or colour-phase Gauss-Seidel over the dd list
-    const bool clm = !ap && h->sweep_kernel == 3;
-    if (!ap) resolve_colors(h);
-    if ((gs || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
-    if (!ap && gs && h->sweep_kernel == 2 && !h->slots_by_color) { compute_slots(h); build_lists(h); }  // rows into launch order
-    if (gs) out->ncolors = (int)h->color_off.size() - 1;
+    const bool clm = !ap && h->sweep_kernel == 3, tile = !ap && h->sweep_kernel == 4;  // tile sweep: no host-side colours at all
+    if (!ap && !tile) resolve_colors(h);
+    if (!tile && (gs || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
+    if (!ap && gs && h->sweep_kernel == 2 && !slots_current(h)) { compute_slots(h); build_lists(h); }  // rows into launch order
+    if (gs) out->ncolors = tile ? (int)h->tile_launches.size() : (int)h->color_off.size() - 1;
     if (!ap && h->sweep_kernel == 2) prepare_lp(h);
     // fixed-iteration GS takes no decision between sweeps: its end-of-sweep logic is applied in two
     // launches (all sweeps but the last, then the last one, whose sum |dmu|^2 is the one reported)
@@ -1065,8 +1214,8 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   const int n = h->nlocal, nall = h->nlocal + h->nghost;
   const bool ap = !(st.dd_cutoff > 0.0);
   if (ap && own_n(h) != n) throw InputError("row sharding needs dd_cutoff > 0 (exact all-pairs mode runs as replicas only)");
-  if (!ap && h->box.triclinic && (h->sweep_kernel != 2 || h->lp_depth != 0))
-    throw InputError("dd_cutoff (list) mode in a triclinic box needs the default sweep kernel (k_field_lp)");
+  if (!ap && h->box.triclinic && !(h->sweep_kernel == 4 || (h->sweep_kernel == 2 && h->lp_depth == 0)))
+    throw InputError("dd_cutoff (list) mode in a triclinic box needs the tile sweep or the row sweep (k_field_tile, k_field_lp)");
   const int vmode = vflag % 4;
   hipStream_t s = h->stream;
   h->warn.clear();
@@ -1180,15 +1329,16 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   k_pack<<<nblk(n + 1, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_x.p, h->d_q.p, h->d_alpha.p, h->d_mol.p, mu0,
                                       h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p, (!ap && h->static_xq) ? h->d_xq_s.p : nullptr);
   if (!ap) {
-    if (h->colors_valid && h->sweep_kernel != 3) map_color_rows(h);  // the colour rows in this step's cell order
+    if (h->colors_valid && h->sweep_kernel < 3) map_color_rows(h);  // the colour rows in this step's cell order
     if (h->sweep_kernel == 2) compute_slots(h);
     build_lists(h);
     if (h->colors_valid && h->sweep_kernel == 3) build_cluster_lists(h);
+    if (h->sweep_kernel == 4) build_tiles(h);
   }
   HIPCHECK(hipEventRecord(h->ev[1], s));
 
   // a2: every step in exact mode (reference); in cutoff mode only when the colour phases are rebuilt
-  if (st.polar_gs_ranked && (ap || !h->colors_valid) && !ranked_done) {
+  if (st.polar_gs_ranked && (ap || (!h->colors_valid && h->sweep_kernel != 4)) && !ranked_done) {
     if (ap) { launch_rank<true>(h, 1); launch_rank<true>(h, 2); }
     else    { launch_rank<false>(h, 1); launch_rank<false>(h, 2); }
   }
@@ -1202,6 +1352,9 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     if (ap) k_static_field<true><<<grid, block, 0, s>>>(nullptr, n, n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{nullptr, 0}, nullptr, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p, nullptr);
     else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p, h->static_xq ? h->d_xq_s.p : nullptr);
   }
+  // tile sweep: the solve works on 48-byte sweep records {position, dipole}; the initial dipoles are in the AtomRecs now
+  if (!ap && h->sweep_kernel == 4 && !st.zodid)
+    k_srec_pack<<<nblk(n, 256), 256, 0, s>>>(n, h->d_rec0.p, h->d_srec0.p, h->d_srec1.p);
   HIPCHECK(hipEventRecord(h->ev[4], s));
   if (lj_late) launch_lj();
 }
@@ -1214,6 +1367,8 @@ int phase_finish(polar_handle *h, polar_result *out) {
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
   const int eflag = h->step_eflag, vmode = h->step_vflag % 4;
   hipStream_t s = h->stream;
+  if (!ap && h->sweep_kernel == 4 && !st.zodid)  // the solved dipoles back into the AtomRecs the remaining kernels read
+    k_srec_unpack<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_srec0.p, h->d_srec1.p, h->d_rec0.p, h->d_rec1.p);
   k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p);
   HIPCHECK(hipEventRecord(h->ev[5], s));
   double *vatom = (h->step_vflag / 4) ? h->d_vatom.p : nullptr;
@@ -1271,27 +1426,61 @@ int phase_finish(polar_handle *h, polar_result *out) {
   return out->status;
 }
 
+// end-of-step flags of the pitched lists (pinned, copied at the end of the list builds): true = a list did not fit, the
+// pitches have been enlarged and the step must be repeated
+void clear_flags(polar_handle *h) { for (int k = 0; k < 16; k++) h->h_flags[k] = 0; }
+void tile_fallback(polar_handle *h) {
+  h->sweep_kernel = 2;
+  h->colors_valid = false; h->slots_by_color = false;
+  h->nl_pitch = h->dd_pitch = 0;  // the cell grid changes with the sweep kernel
+  h->warn = "tile sweep unavailable for this system (cell neighbourhood beyond the LDS, or a cell beyond the builder's limits): row sweep in use";
+}
+bool grow_pitches(polar_handle *h) {
+  bool again = false;
+  if (h->h_flags[0] != 0) {
+    const long long need = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
+    h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
+    again = true;
+  }
+  if (h->h_flags[4] != 0) { h->cl_pitch = (((long long)(1.25 * h->h_flags[4]) + 255) / 256) * 256; again = true; }
+  if (h->sweep_kernel == 4) {
+    if (h->h_flags[7] != 0) { tile_fallback(h); return true; }
+    if (h->h_flags[5] != 0) {  // a union list beyond the pitch, or beyond what the sweep's LDS request holds
+      const int need = (int)(((long long)(1.15 * h->h_flags[5]) + 16 + 63) / 64 * 64);
+      if (need > tile_lds_cap()) { tile_fallback(h); return true; }
+      h->un_pitch = std::max(h->un_pitch, need); h->un_lds = h->un_pitch;
+      again = true;
+    }
+    if (h->h_flags[6] != 0) { h->pitch16 = ((long long)(1.25 * h->h_flags[6]) + 511) / 512 * 512; again = true; }
+    if (!again && h->h_flags[9] > 0) {  // next step: ask only for the LDS the unions need (two workgroups per CU below 80 KB)
+      h->tile_max_u = h->h_flags[9];
+      h->un_lds = std::min(h->un_pitch, (int)((long long)(1.06 * (h->tile_max_u + 1)) + 8 + 7) / 8 * 8);
+    }
+  }
+  return again;
+}
+
 int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, polar_result *out) {
   memset(out, 0, sizeof(*out));
   const bool ap = !(h->ph.st.dd_cutoff > 0.0);
   int rc = 0;
-  for (int attempt = 0; attempt < 4; attempt++) {
-    h->h_flags[0] = 0; h->h_flags[4] = 0;
-    phase_begin(h, eflag, vflag, mu_host);
+  bool done = false;
+  for (int attempt = 0; attempt < 5; attempt++) {
+    clear_flags(h);
+    try {
+      phase_begin(h, eflag, vflag, mu_host);
+    } catch (const TileUnavailable &) {  // density beyond what a workgroup can stage: the row sweep takes over
+      tile_fallback(h);
+      continue;
+    }
     if (!h->ph.st.zodid) solve(h, ap, out);  // a6 + a7 (PS.cpp:389)
     const int nc = out->ncolors;
     rc = phase_finish(h, out);
     out->ncolors = nc;
-    if (ap || (h->h_flags[0] == 0 && h->h_flags[4] == 0)) break;
-    // a row did not fit its pitch: grow it to the reported need (+25 %) and redo the step
-    if (h->h_flags[0] != 0) {
-      const long long need = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
-      h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
-    }
-    if (h->h_flags[4] != 0) h->cl_pitch = (((long long)(1.25 * h->h_flags[4]) + 255) / 256) * 256;
-    memset(out, 0, sizeof(*out));
+    if (ap || !grow_pitches(h)) { done = true; break; }
+    memset(out, 0, sizeof(*out));  // a row did not fit its pitch: the pitches have grown, redo the step
   }
-  if (!ap && (h->h_flags[0] != 0 || h->h_flags[4] != 0)) throw std::runtime_error("neighbor list pitch overflow persists");
+  if (!done) throw std::runtime_error("neighbor list pitch overflow persists");
   return rc;
 }
 
@@ -1318,6 +1507,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_COLOR_KEEP")) h->color_keep = atof(e);
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
+  if (const char *e = getenv("POLAR_DETERMINISTIC")) h->deterministic = atoi(e) != 0;
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
   if (const char *e = getenv("POLAR_LJ_TYPED")) h->lj_typed = atoi(e) != 0;
   if (const char *e = getenv("POLAR_STATIC_XQ")) h->static_xq = atoi(e) != 0;
@@ -1382,6 +1572,7 @@ int polar_destroy(polar_handle *h) {
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_slot.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_trace.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
+    h->d_srec0.release(); h->d_srec1.release(); h->d_thdr.release(); h->d_trow.release(); h->d_un_j.release(); h->d_dd16.release(); h->d_pend.release();
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     if (h->h_ddtot) (void)hipHostFree(h->h_ddtot);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -1397,7 +1588,7 @@ const char *polar_last_error(const polar_handle *h) { return h ? h->err.c_str() 
 const char *polar_last_warning(const polar_handle *h) { return h ? h->warn.c_str() : ""; }
 
 int polar_pair_settings(polar_handle *h, int narg, const char *const *arg) {
-  return guarded(h, [&]() { h->ph.settings(narg, arg); h->colors_valid = false; h->nl_pitch = h->dd_pitch = 0; h->cl_pitch = 0; return POLAR_OK; });
+  return guarded(h, [&]() { h->ph.settings(narg, arg); h->colors_valid = false; h->nl_pitch = h->dd_pitch = 0; h->cl_pitch = 0; h->un_pitch = 0; h->pitch16 = 0; return POLAR_OK; });
 }
 int polar_pair_coeff(polar_handle *h, int ntypes, int narg, const char *const *arg) {
   return guarded(h, [&]() { h->ph.coeff(ntypes, narg, arg); return POLAR_OK; });
@@ -1497,7 +1688,7 @@ int polar_restart_unpack(polar_handle *h, const void *buf, int nbytes) {
     if (s.zodid && (s.polar_gs || s.polar_gs_ranked)) throw InputError("Zodid doesn't work with polar_gs or polar_gs_ranked");
     if (s.polar_gs && s.polar_gs_ranked) throw InputError("polar_gs and polar_gs_ranked are mutually exclusive");
     h->ph.st = s;
-    h->colors_valid = false; h->nl_pitch = h->dd_pitch = 0; h->cl_pitch = 0;
+    h->colors_valid = false; h->nl_pitch = h->dd_pitch = 0; h->cl_pitch = 0; h->un_pitch = 0; h->pitch16 = 0;
     return POLAR_OK;
   });
 }
@@ -1880,13 +2071,18 @@ int polar_set_list_style(polar_handle *h, int full) {
 int polar_step_begin(polar_handle *h, int eflag, int vflag) {
   return guarded(h, [&]() {
     HIPCHECK(hipSetDevice(h->device));
-    h->h_flags[0] = 0; h->h_flags[4] = 0;
-    phase_begin(h, eflag, vflag, nullptr);
+    clear_flags(h);
+    try {
+      phase_begin(h, eflag, vflag, nullptr);
+    } catch (const TileUnavailable &) {
+      tile_fallback(h);
+      phase_begin(h, eflag, vflag, nullptr);
+    }
     const polar_settings &st = h->ph.st;
-    const bool clm = st.dd_cutoff > 0.0 && h->sweep_kernel == 3;
-    if (st.dd_cutoff > 0.0) resolve_colors(h);
-    if (!st.zodid && (st.polar_gs || st.polar_gs_ranked || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
-    if (!st.zodid && st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && h->sweep_kernel == 2 && !h->slots_by_color) { compute_slots(h); build_lists(h); }
+    const bool clm = st.dd_cutoff > 0.0 && h->sweep_kernel == 3, tile = tile_mode(h);
+    if (st.dd_cutoff > 0.0 && !tile) resolve_colors(h);
+    if (!tile && !st.zodid && (st.polar_gs || st.polar_gs_ranked || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
+    if (!st.zodid && st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && h->sweep_kernel == 2 && !slots_current(h)) { compute_slots(h); build_lists(h); }
     if (!st.zodid && st.dd_cutoff > 0.0 && h->sweep_kernel == 2) prepare_lp(h);
     h->in_step = true;
     return POLAR_OK;
@@ -1904,7 +2100,7 @@ int polar_step_sweep_part(polar_handle *h, int part, int nparts) {
     if (!h->in_step) throw std::runtime_error("polar_step_sweep_part outside polar_step_begin/finish");
     if (nparts < 1 || part < 0 || part >= nparts) throw InputError("polar_step_sweep_part: bad part");
     const polar_settings &st = h->ph.st;
-    if (nparts > 1 && !(st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && h->sweep_kernel == 2))
+    if (nparts > 1 && !(st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && (h->sweep_kernel == 2 || h->sweep_kernel == 4)))
       throw InputError("polar_step_sweep_part: parts exist for the colour-phase Gauss-Seidel sweep of list mode only");
     struct Window {  // restored on every way out: a failed launch must not leave the next full sweep truncated
       polar_handle *h;
@@ -1943,12 +2139,9 @@ int polar_step_finish(polar_handle *h, polar_result *out) {
     if (!h->in_step) throw std::runtime_error("polar_step_finish without polar_step_begin");
     memset(out, 0, sizeof(*out));
     int rc = phase_finish(h, out);
-    out->ncolors = (h->ph.st.polar_gs || h->ph.st.polar_gs_ranked) ? (int)h->color_off.size() - 1 : 0;
+    out->ncolors = (h->ph.st.polar_gs || h->ph.st.polar_gs_ranked) ? (tile_mode(h) ? (int)h->tile_launches.size() : (int)h->color_off.size() - 1) : 0;
     h->in_step = false;
-    if (h->h_flags[0] != 0 || h->h_flags[4] != 0) {  // the driver must redo the step (all ranks see their own flag)
-      if (h->h_flags[4] != 0) h->cl_pitch = (((long long)(1.25 * h->h_flags[4]) + 255) / 256) * 256;
-      const long long need = ((long long)(1.25 * h->h_flags[0]) / 64 + 1) * 64;
-      if (h->h_flags[0] != 0) h->nl_pitch = h->dd_pitch = std::max(need, h->nl_pitch + 64);
+    if (grow_pitches(h)) {  // the driver must redo the step (all ranks see their own flag)
       out->status = POLAR_RETRY_STEP;
       h->warn = "neighbor list pitch overflow: pitch enlarged, repeat the step";
       return POLAR_RETRY_STEP;
@@ -1959,28 +2152,28 @@ int polar_step_finish(polar_handle *h, polar_result *out) {
 int polar_mu_gather(polar_handle *h, long long lo, long long hi, double *dev_dst) {
   return guarded(h, [&]() {
     need_device(h);
-    if (hi > lo) k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst);
+    if (hi > lo) k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, mu_view(h), dev_dst);
     return POLAR_OK;
   });
 }
 int polar_mu_scatter(polar_handle *h, long long lo, long long hi, const double *dev_src) {
   return guarded(h, [&]() {
     need_device(h);
-    if (hi > lo) k_mu_scatter<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src);
+    if (hi > lo) k_mu_scatter<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, mu_view(h), dev_src);
     return POLAR_OK;
   });
 }
 int polar_mu_gather_idx(polar_handle *h, const int *dev_idx, long long n, double *dev_dst) {
   return guarded(h, [&]() {
     need_device(h);
-    if (n > 0) k_mu_gather_idx<<<nblk(n, 256), 256, 0, h->stream>>>(n, dev_idx, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_dst);
+    if (n > 0) k_mu_gather_idx<<<nblk(n, 256), 256, 0, h->stream>>>(n, dev_idx, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, mu_view(h), dev_dst);
     return POLAR_OK;
   });
 }
 int polar_mu_scatter_idx(polar_handle *h, const int *dev_idx, long long n, const double *dev_src) {
   return guarded(h, [&]() {
     need_device(h);
-    if (n > 0) k_mu_scatter_idx<<<nblk(n, 256), 256, 0, h->stream>>>(n, dev_idx, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, dev_src, own_lo(h), own_lo(h) + own_n(h));
+    if (n > 0) k_mu_scatter_idx<<<nblk(n, 256), 256, 0, h->stream>>>(n, dev_idx, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, mu_view(h), dev_src, own_lo(h), own_lo(h) + own_n(h));
     return POLAR_OK;
   });
 }
@@ -1999,7 +2192,7 @@ int polar_step_mu_get(polar_handle *h, long long lo, long long hi, double *mu_ho
     const size_t cnt = 3 * (size_t)(hi - lo);
     if (cnt == 0) return (int)POLAR_OK;
     h->d_xchg.ensure(cnt);
-    k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_xchg.p);
+    k_mu_gather<<<nblk(hi - lo, 256), 256, 0, h->stream>>>(lo, hi, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, mu_view(h), h->d_xchg.p);
     HIPCHECK(hipMemcpyAsync(mu_host, h->d_xchg.p, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     return (int)POLAR_OK;
@@ -2015,7 +2208,7 @@ int polar_step_mu_put_idx(polar_handle *h, long long n, const int *idx_host, con
     h->d_xchg.ensure(3 * (size_t)n); h->d_xidx.ensure((size_t)n);
     HIPCHECK(hipMemcpyAsync(h->d_xidx.p, idx_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->d_xchg.p, mu_host, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    k_mu_scatter_idx<<<nblk(n, 256), 256, 0, h->stream>>>(n, h->d_xidx.p, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_xchg.p, own_lo(h), own_lo(h) + own_n(h));
+    k_mu_scatter_idx<<<nblk(n, 256), 256, 0, h->stream>>>(n, h->d_xidx.p, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, mu_view(h), h->d_xchg.p, own_lo(h), own_lo(h) + own_n(h));
     HIPCHECK(hipStreamSynchronize(h->stream));  // the host buffers may be reused by the caller
     return (int)POLAR_OK;
   });

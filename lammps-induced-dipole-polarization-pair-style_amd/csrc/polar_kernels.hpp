@@ -17,12 +17,14 @@
 // Reference line numbers ("PS.cpp") are into
 // /root/reference/src/pair_lj_cut_coul_long_polarization.cpp.
 //
-// The kernels live in four headers: polar_common.hpp (types, wave helpers, image rules),
+// The kernels live in five headers: polar_common.hpp (types, wave helpers, image rules),
 // polar_rows.hpp (the per-row kernels of a step), polar_solver.hpp (the dipole solver),
-// polar_lists.hpp (list mode: cells, neighbor lists, exchange).
+// polar_lists.hpp (list mode: cells, neighbor lists, exchange), polar_tiles.hpp (list mode: the tile sweep
+// -- one workgroup per cell, neighbour records staged in LDS -- and its builder).
 #pragma once
 
 #include "polar_common.hpp"
 #include "polar_rows.hpp"
 #include "polar_solver.hpp"
 #include "polar_lists.hpp"
+#include "polar_tiles.hpp"

@@ -552,47 +552,49 @@ __global__ void k_lj_rows(int row_lo, int nrows, long long pitch, int *__restric
   first[row_lo + r] = (long long)(row_lo + r) * pitch;
 }
 
-// multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers
-__global__ void k_mu_gather(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
-                            const AtomRec *__restrict__ recA, const AtomRec *__restrict__ recB,
+// multi-GPU plumbing: dipoles of a contiguous row range <-> packed [n][3] buffers.  The dipoles live in the record table
+// the sweep works on: 64-byte AtomRecs, or the 48-byte sweep records of the tile sweep -- component k of record s is
+// double 2k + 1 of the record at base + s * stride (MuView).
+struct MuView {
+  char *a, *b;  // the two buffers (Jacobi ping-pong; scal->cur picks)
+  int stride;
+};
+__device__ __forceinline__ double *mu_of(const MuView &v, const Scal *scal, long long s) {
+  return reinterpret_cast<double *>((scal->cur ? v.b : v.a) + s * v.stride);
+}
+__global__ void k_mu_gather(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal, MuView v,
                             double *__restrict__ dst) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
-  const long long s = inv ? inv[i] : i;
-  const AtomRec *r = scal->cur ? recB : recA;
-  dst[3 * (i - lo)] = r[s].mx; dst[3 * (i - lo) + 1] = r[s].my; dst[3 * (i - lo) + 2] = r[s].mz;
+  const double *r = mu_of(v, scal, inv ? inv[i] : i);
+  dst[3 * (i - lo)] = r[1]; dst[3 * (i - lo) + 1] = r[3]; dst[3 * (i - lo) + 2] = r[5];
 }
-__global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal,
-                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src) {
+__global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal, MuView v,
+                             const double *__restrict__ src) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
-  const long long s = inv ? inv[i] : i;
-  AtomRec *r = scal->cur ? recB : recA;
-  r[s].mx = src[3 * (i - lo)]; r[s].my = src[3 * (i - lo) + 1]; r[s].mz = src[3 * (i - lo) + 2];
+  double *r = mu_of(v, scal, inv ? inv[i] : i);
+  r[1] = src[3 * (i - lo)]; r[3] = src[3 * (i - lo) + 1]; r[5] = src[3 * (i - lo) + 2];
 }
 
 // halo exchange by index list (orig ids; negative entries are padding and skipped)
 __global__ void k_mu_gather_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
-                                const AtomRec *__restrict__ recA, const AtomRec *__restrict__ recB,
-                                double *__restrict__ dst) {
+                                MuView v, double *__restrict__ dst) {
   long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (t >= n) return;
   const int o = idx[t];
   if (o < 0) return;
-  const AtomRec *r = scal->cur ? recB : recA;
-  const int s = inv ? inv[o] : o;
-  dst[3 * t] = r[s].mx; dst[3 * t + 1] = r[s].my; dst[3 * t + 2] = r[s].mz;
+  const double *r = mu_of(v, scal, inv ? inv[o] : o);
+  dst[3 * t] = r[1]; dst[3 * t + 1] = r[3]; dst[3 * t + 2] = r[5];
 }
 __global__ void k_mu_scatter_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
-                                 AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, const double *__restrict__ src,
-                                 int own_lo, int own_hi) {
+                                 MuView v, const double *__restrict__ src, int own_lo, int own_hi) {
   long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (t >= n) return;
   const int o = idx[t];
   if (o < 0 || (o >= own_lo && o < own_hi)) return;  // padding, or a row this handle owns itself
-  AtomRec *r = scal->cur ? recB : recA;
-  const int s = inv ? inv[o] : o;
-  r[s].mx = src[3 * t]; r[s].my = src[3 * t + 1]; r[s].mz = src[3 * t + 2];
+  double *r = mu_of(v, scal, inv ? inv[o] : o);
+  r[1] = src[3 * t]; r[3] = src[3 * t + 1]; r[5] = src[3 * t + 2];
 }
 
 // small utilities

@@ -1243,16 +1243,20 @@ __global__ void k_zero_slots(double *__restrict__ slots, Scal *s) {
   ((unsigned long long *)slots)[(size_t)t * POLAR_SLOT_STRIDE + SL_RMIN] = (unsigned long long)__double_as_longlong(1000.0);
 }
 
-// `debug yes`: u_polar = -1/2 sum_i E_static,i . mu_i after a sweep (PS.cpp:1182-1191 prints it per iteration)
-__global__ __launch_bounds__(1024) void k_debug_upolar(int n, const Scal *scal, const AtomRec *__restrict__ recA,
-                                                       const AtomRec *__restrict__ recB, const double *__restrict__ ef,
-                                                       double *__restrict__ trace, int slot, int jacobi_next) {
+// `debug yes`: u_polar = -1/2 sum_i E_static,i . mu_i after a sweep (PS.cpp:1182-1191 prints it per iteration).
+// The dipoles are read where the sweep keeps them: component k of record i = double 2k + 1 at base + i * stride.
+__global__ __launch_bounds__(1024) void k_debug_upolar(int n, const Scal *scal, const char *recA, const char *recB, int stride,
+                                                       const double *__restrict__ ef, double *__restrict__ trace, int slot,
+                                                       int jacobi_next) {
   if (scal->done) return;  // a launch past the end of a finished solve (the host looks at the state every 4 sweeps)
   __shared__ double red[16];
   // Jacobi: the sweep that just ran wrote the OTHER buffer (the copy "mu = mu_new" happens in k_solver_step)
-  const AtomRec *r = (scal->cur ^ jacobi_next) ? recB : recA;
+  const char *base = (scal->cur ^ jacobi_next) ? recB : recA;
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) v += ef[3 * i] * r[i].mx + ef[3 * i + 1] * r[i].my + ef[3 * i + 2] * r[i].mz;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double *r = reinterpret_cast<const double *>(base + (size_t)i * stride);
+    v += ef[3 * i] * r[1] + ef[3 * i + 1] * r[3] + ef[3 * i + 2] * r[5];
+  }
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();

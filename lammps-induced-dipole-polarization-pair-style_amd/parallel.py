@@ -296,7 +296,9 @@ class SweepTimer:
 
 
 POLAR_RETRY_STEP = 2  # include/polar_mi355x.h
-REDUCE_EVERY = max(1, int(os.environ.get("POLAR_DIST_REDUCE_EVERY", "2")))  # sweeps per all-reduce of the stop rule
+# sweeps per all-reduce of the stop rule.  1 = the reference's rule after every sweep (PS.cpp:1194-1210): the iteration and
+# sweep counts then equal the single-process ones.  bench_distributed raises it to 2 (and says so in its JSON line).
+REDUCE_EVERY = max(1, int(os.environ.get("POLAR_DIST_REDUCE_EVERY", "1")))
 
 
 def run_step(backend, dist, rank, world, counts, offs, eflag=1, vflag=2, check_every=4, gather_buf=None,
@@ -508,6 +510,9 @@ def bench_distributed(args, rank, world, local_rank):
     wl = importlib.import_module(__package__ + ".workload")
     import bench as B  # repo root is on sys.path (bench.py put it there)
 
+    global REDUCE_EVERY
+    if "POLAR_DIST_REDUCE_EVERY" not in os.environ:
+        REDUCE_EVERY = 2   # bench cadence: at most one sweep past the stop rule for half of the all-reduce latencies
     backend_name = os.environ.get("POLAR_DIST_BACKEND", "nccl")
     if backend_name == "nccl":
         torch.cuda.set_device(local_rank)
@@ -626,6 +631,7 @@ def bench_distributed(args, rank, world, local_rank):
                        "ms_device_rank0": {k2: out[k2] for k2 in ("ms_total", "ms_list", "ms_ljcoul", "ms_static", "ms_solve", "ms_force")},
                        "atoms_held_rank0": n_held, "halo_rows_per_rank": plan.counts, "rows_per_rank": counts,
                        "peers_rank0": len(plan.peers(0)) if hasattr(plan, "peers") else None,
+                       "stop_rule_allreduce_every_sweeps": REDUCE_EVERY,
                        "kernel_version": pkg.kernel_version()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; rank 0; {pkg.kernel_version()})",

@@ -346,6 +346,7 @@ class PolarSettings:
     dd_cutoff: float = 0.0  # extension: <=0 exact all-pairs (reference), >0 truncated
     device_neigh: int = 0   # extension: the LAMMPS shim builds the LJ/coul list on the device
     restart_polar: int = 0  # extension: restart files carry the polarization keywords
+    deterministic: int = 0  # extension: sweeps commit their updates between launches (bit-reproducible runs)
 
 
 @dataclass
@@ -752,6 +753,10 @@ def parse_pair_style_args(args, base=None):
             st.dd_cutoff = float(v)
         elif k == "device_neigh":  # extension keyword (not in the reference)
             st.device_neigh = yn[v]
+        elif k == "restart_polar":  # extension keyword (not in the reference)
+            st.restart_polar = yn[v]
+        elif k == "deterministic":  # extension keyword (not in the reference)
+            st.deterministic = yn[v]
         else:
             raise ValueError("Illegal pair_style command")
         i += 2

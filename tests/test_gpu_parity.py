@@ -332,7 +332,8 @@ def test_row_sharded_handles_tally_per_atom(wl, pkg, oracle):
                                   "POLAR_SWEEP_KERNEL=0;POLAR_CACHE_R2=1", "POLAR_SWEEP_KERNEL=0;POLAR_CACHE_R2=2",
                                   "POLAR_SWEEP_KERNEL=2;POLAR_LP_TILES=1", "POLAR_SWEEP_KERNEL=2;POLAR_LP_QM=0",
                                   "POLAR_SWEEP_KERNEL=2;POLAR_LP_DEPTH=2",
-                                  "POLAR_SWEEP_KERNEL=2;POLAR_LP_DEPTH=3", "POLAR_SWEEP_KERNEL=3",
+                                  "POLAR_SWEEP_KERNEL=2;POLAR_LP_DEPTH=3", "POLAR_SWEEP_KERNEL=4",
+                                  "POLAR_SWEEP_KERNEL=4;POLAR_DETERMINISTIC=1", "POLAR_SWEEP_KERNEL=2", "POLAR_SWEEP_KERNEL=3",
                                   "POLAR_SWEEP_KERNEL=3;POLAR_CLUSTER_MAX=2"])
 def test_alternative_sweep_kernels_agree(knob, wl, pkg, oracle, monkeypatch):
     """The list sweep exists in several forms besides the default (k_field_lp, two LDS tiles): the register-staged

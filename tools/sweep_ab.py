@@ -22,6 +22,7 @@ wl = importlib.import_module(bench.PKG + ".workload")
 cases = os.environ.get("LAB_CASES", "3x3x3:fixed,5x5x4:prec").split(",")
 kernels = os.environ.get("LAB_KERNELS", "quad=POLAR_SWEEP_KERNEL=0,lp=POLAR_SWEEP_KERNEL=2").split(",")
 steps = int(os.environ.get("LAB_STEPS", "5"))
+print(f"LAB_CASES={','.join(cases)}  LAB_KERNELS={','.join(kernels)}  LAB_STEPS={steps}  library {pkg.kernel_version()}", flush=True)
 touched = set()
 for case in cases:
     reps, mode = case.split(":")
