@@ -205,7 +205,7 @@ struct polar_handle {
   // tile sweep (sweep_kernel 4, polar_tiles.hpp): sweep records, tile headers, row table, union lists, 16-bit row lists
   DBuf<SRec> d_srec0, d_srec1;
   DBuf<TileHdr> d_thdr;
-  DBuf<int2> d_trow;
+  DBuf<TileRowEnt> d_trow;
   DBuf<int> d_un_j;
   DBuf<unsigned short> d_dd16;
   DBuf<double> d_pend;             // `deterministic yes`: dipoles of a launch's rows until k_tile_commit
@@ -213,6 +213,7 @@ struct polar_handle {
   int un_lds = 0;                  // records (dummy included) the sweep's LDS request holds; the builder refuses larger unions
   long long pitch16 = 0;           // entries per row of d_dd16 (a multiple of 512 = 8 trips)
   int tile_max_u = 0;              // largest union of the last step
+  bool tile_reported = false;
   double dens = 0.0;               // atoms per A^3 of the occupied part of the box (first list build)
   std::vector<TileLaunch> tile_launches;  // Gauss-Seidel: one launch per tile colour; tile_all: every cell (Jacobi)
   TileLaunch tile_all{};
@@ -916,7 +917,8 @@ void launch_field_cl(polar_handle *h, int ncl, int first) {
 struct TileUnavailable : std::runtime_error {
   explicit TileUnavailable(const std::string &m) : std::runtime_error(m) {}
 };
-inline int tile_lds_cap() { return (int)((160 * 1024 - 256) / sizeof(SRec)); }  // records one workgroup can stage at all
+inline size_t tile_lds_bytes(int records) { return POLAR_TILE_LDS_REC + (size_t)(records + 1) * sizeof(SRec) + POLAR_TILE_LDS_SLACK; }
+inline int tile_lds_cap() { return (int)((160 * 1024 - POLAR_TILE_LDS_REC - POLAR_TILE_LDS_SLACK - 256) / sizeof(SRec)) - 1; }  // records one workgroup can stage at all
 void build_tiles(polar_handle *h) {
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
@@ -948,15 +950,15 @@ void build_tiles(polar_handle *h) {
   h->d_srec0.ensure((size_t)n + 1); h->d_srec1.ensure((size_t)n + 1);
   if (deterministic(h)) h->d_pend.ensure(3 * (size_t)n + 3);
   // (build_lists has just zeroed the flag words and the pair totals; its own k_nl_build lists no dd pair in this mode)
-  const size_t lds = 24 * (size_t)h->un_pitch + (128 + 128 + 2 * POLAR_TILE_MAXROWS) * sizeof(int) + 6 * sizeof(double) + 16;
+  const size_t lds = 24 * (size_t)h->un_pitch + (4 * 128 + 2 * POLAR_TILE_MAXROWS) * sizeof(int) + 24 * sizeof(double) + 12 * sizeof(int) + 16;
   if (lds > h->tile_build_lds_attr) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->tile_build_lds_attr = lds;
   }
   const int cap = std::min(h->un_pitch, h->un_lds);
   k_tile_build<<<(int)ncell, 256, lds, s>>>(h->grid, h->box, h->d_pos4.p, h->d_cell_first.p, h->d_cell_fill.p, h->d_perm.p, own_lo(h),
-                                            own_lo(h) + own_n(h), rc * rc, h->color_dist * h->color_dist, cap, h->d_un_j.p, h->pitch16,
-                                            h->d_dd16.p, h->d_thdr.p, h->d_trow.p, h->d_overflow.p, h->d_ddtot.p);
+                                            own_lo(h) + own_n(h), rc * rc, h->color_dist * h->color_dist, 4 /* waves of a sweep workgroup */, cap, h->d_un_j.p, h->pitch16,
+                                            h->d_dd16.p, h->d_thdr.p, h->d_trow.p, h->d_rec0.p, h->d_overflow.p, h->d_ddtot.p);
   HIPCHECK(hipMemcpyAsync(h->h_flags + 5, h->d_overflow.p + 5, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 }
@@ -970,7 +972,8 @@ void launch_field_tile(polar_handle *h, const TileLaunch &L) {
   if (nt <= 0) return;
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
   const bool det = deterministic(h) && EP == EP_INPLACE;
-  const size_t lds = (size_t)(tile_pitch(h) + 1) * sizeof(SRec);
+  size_t lds = tile_lds_bytes(tile_pitch(h));
+  if (const char *e = getenv("POLAR_TILE_LDS_PAD")) lds += (size_t)atoi(e);  // LAB (temporary): residency experiment
   const int inst = (EP == EP_JACOBI ? 0 : (det ? 2 : 1)) * 2 + (expd ? 0 : 1);
 #define FT(D, DT)                                                                                                              \
   {                                                                                                                            \
@@ -979,7 +982,7 @@ void launch_field_tile(polar_handle *h, const TileLaunch &L) {
       h->tile_lds_attr[inst] = lds;                                                                                            \
     }                                                                                                                          \
     k_field_tile<EP, D, DT><<<nblk_xcd(nt, 1), 256, lds, h->stream>>>(L, h->d_thdr.p, h->d_trow.p, h->d_un_j.p, tile_pitch(h),   \
-        h->d_dd16.p, h->pitch16, h->d_srec0.p, h->d_srec1.p, h->d_pend.p, h->d_rec0.p, h->d_ef_s.p, h->box, st.polar_damp,       \
+        h->d_dd16.p, h->pitch16, h->d_srec0.p, h->d_srec1.p, h->d_pend.p, h->d_ef_s.p, h->box, st.polar_damp,       \
         make_expcoef(), h->d_scal.p, h->d_slots.p);                                                                              \
   }
   if (det) { if (expd) FT(0, true) else FT(1, true) }
@@ -1327,7 +1330,8 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   }
   if (!ap) { build_cells(h); h->d_pos4.ensure(n + 1); if (h->static_xq) h->d_xq_s.ensure(n + 2); }  // cell order: perm / inv
   k_pack<<<nblk(n + 1, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_x.p, h->d_q.p, h->d_alpha.p, h->d_mol.p, mu0,
-                                      h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p, (!ap && h->static_xq) ? h->d_xq_s.p : nullptr);
+                                      h->d_rec0.p, h->d_rec1.p, h->d_mol_s.p, ap ? nullptr : h->d_pos4.p, (!ap && h->static_xq) ? h->d_xq_s.p : nullptr,
+                                      (!ap && h->sweep_kernel == 4) ? 1 : 0, h->box, h->boxlo[0], h->boxlo[1], h->boxlo[2]);
   if (!ap) {
     if (h->colors_valid && h->sweep_kernel < 3) map_color_rows(h);  // the colour rows in this step's cell order
     if (h->sweep_kernel == 2) compute_slots(h);
@@ -1455,6 +1459,12 @@ bool grow_pitches(polar_handle *h) {
     if (!again && h->h_flags[9] > 0) {  // next step: ask only for the LDS the unions need (two workgroups per CU below 80 KB)
       h->tile_max_u = h->h_flags[9];
       h->un_lds = std::min(h->un_pitch, (int)((long long)(1.06 * (h->tile_max_u + 1)) + 8 + 7) / 8 * 8);
+      if (getenv("POLAR_DEBUG") && !h->tile_reported) {
+        h->tile_reported = true;
+        fprintf(stderr, "[polar] tile sweep: %lld cells (%d x %d x %d), %d launches per sweep, largest union %d records, union pitch %d, "
+                "LDS request %zu bytes (%d records), row pitch %lld entries\n", h->ncell, h->grid.nc[0], h->grid.nc[1], h->grid.nc[2],
+                (int)h->tile_launches.size(), h->tile_max_u, h->un_pitch, tile_lds_bytes(std::min(h->un_pitch, h->un_lds)), h->un_lds, h->pitch16);
+      }
     }
   }
   return again;

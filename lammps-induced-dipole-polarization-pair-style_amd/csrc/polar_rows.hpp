@@ -12,7 +12,8 @@ namespace polar {
 __global__ void k_pack(int n, const int *__restrict__ perm, const double *__restrict__ x, const double *__restrict__ q,
                        const double *__restrict__ alpha, const int *__restrict__ mol, const double *__restrict__ mu0,
                        AtomRec *__restrict__ r0, AtomRec *__restrict__ r1, int *__restrict__ mol_s,
-                       double4 *__restrict__ pos4, double4 *__restrict__ xq_s) {
+                       double4 *__restrict__ pos4, double4 *__restrict__ xq_s, int wrap, Box box, double lo0, double lo1,
+                       double lo2) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == n) {  // the DUMMY record the lp sweep pads its rows with: zero dipole (contributes nothing), zero
     // polarizability, a finite position (that of atom 0: the sweep floors r^2, so a coincidence is harmless)
@@ -25,6 +26,16 @@ __global__ void k_pack(int n, const int *__restrict__ perm, const double *__rest
   const int o = perm ? perm[i] : i;
   AtomRec r;
   r.x = x[3 * o]; r.y = x[3 * o + 1]; r.z = x[3 * o + 2]; r.q = q[o];
+  if (wrap) {
+    // tile sweep: the records hold the image INSIDE the box (LAMMPS lets atoms drift out of it between reneighborings);
+    // the builder then finds every partner's image from cell offsets alone.  Whole lattice vectors c, b, a come off.
+    const double lo[3] = {lo0, lo1, lo2};
+    double fr[3];
+    frac_coords(box, lo, r.x, r.y, r.z, fr);
+    const double n2 = box.periodic[2] ? floor(fr[2]) : 0.0, n1 = box.periodic[1] ? floor(fr[1]) : 0.0,
+                 n0 = box.periodic[0] ? floor(fr[0]) : 0.0;
+    r.z -= n2 * box.prd[2]; r.y -= n2 * box.yz + n1 * box.prd[1]; r.x -= n2 * box.xz + n1 * box.xy + n0 * box.prd[0];
+  }
   r.mx = mu0 ? mu0[3 * o] : 0.0; r.my = mu0 ? mu0[3 * o + 1] : 0.0; r.mz = mu0 ? mu0[3 * o + 2] : 0.0;
   r.a = alpha[o];
   r0[i] = r;

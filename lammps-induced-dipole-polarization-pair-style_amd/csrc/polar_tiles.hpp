@@ -30,15 +30,22 @@ struct __attribute__((aligned(16))) SRec {
 };
 
 #define POLAR_TILE_MAXSUB 11   // sub-phases (in-tile colours) a tile header can describe
-#define POLAR_TILE_MAXROWS 256 // polarizable atoms of one cell the builder can colour
+#define POLAR_TILE_MAXROWS 128 // polarizable atoms of one cell the builder can colour (and the sweep's LDS row table holds)
 #define POLAR_TILE_RECMASK 0x03FFFFFF  // union entry = record index | image code << 26 (code = (sx+1) + 3 (sy+1) + 9 (sz+1))
 
 struct __attribute__((aligned(64))) TileHdr {
   int r0;     // first record of the cell (s space); local row m is record r0 + m
   int nrows;  // rows of this tile (polarizable atoms this handle owns); 0: nothing to do
   int U;      // entries of the union list = staged records (the dummy sits at position U)
-  int nsub;   // sub-phases
+  int nsub;   // sub-phases (low byte) | 0x100: some union entry is another periodic image
   int sub_off[POLAR_TILE_MAXSUB + 1];  // rows of sub-phase p: trow[r0 + sub_off[p] .. r0 + sub_off[p + 1])
+};
+
+// row table entry (16 bytes): rows of a tile in sub-phase order
+struct __attribute__((aligned(16))) TileRowEnt {
+  int mT;        // local row m (record r0 + m) | trips << 16
+  int self;      // position of the row atom's own record in the union list
+  double alpha;  // its polarizability (the sweep's epilogue needs it: mu = alpha (E_static + E_ind))
 };
 
 // tiles of one launch: cells c_k = start_k + stride_k * i_k, i_k < count_k
@@ -90,19 +97,21 @@ __global__ void k_srec_unpack(int n, const Scal *scal, const SRec *__restrict__ 
 __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const double4 *__restrict__ pos4,
                                                     const long long *__restrict__ cell_first,
                                                     const int *__restrict__ npol, const int *__restrict__ perm,
-                                                    int own_lo, int own_hi, double ddcutsq, double colordistsq,
+                                                    int own_lo, int own_hi, double ddcutsq, double colordistsq, int subcap,
                                                     int un_pitch, int *__restrict__ un_j, long long pitch16,
                                                     unsigned short *__restrict__ dd16, TileHdr *__restrict__ hdr,
-                                                    int2 *__restrict__ trow, int *__restrict__ flags,
-                                                    unsigned long long *__restrict__ dd_total) {
+                                                    TileRowEnt *__restrict__ trow, const AtomRec *__restrict__ rec,
+                                                    int *__restrict__ flags, unsigned long long *__restrict__ dd_total) {
   extern __shared__ __attribute__((aligned(16))) char tb_lds[];
   double *ux = reinterpret_cast<double *>(tb_lds), *uy = ux + un_pitch, *uz = uy + un_pitch;
-  int *cnt = reinterpret_cast<int *>(uz + un_pitch);  // [128] entries per stencil cell
-  int *off = cnt + 128;                               // [128] their prefix
-  int *rowT = off + 128;                              // [MAXROWS] trips of local row m, -1: not a row of this handle
+  int *cnt = reinterpret_cast<int *>(uz + un_pitch);  // [128] candidates per stencil cell; later: accepted per (round, wave)
+  int *off = cnt + 128;                               // [128] prefix of the candidates
+  int *sca = off + 128;                               // [128] first record of a stencil cell's polarizable run
+  int *scc = sca + 128;                               // [128] its periodic-image code
+  int *rowT = scc + 128;                              // [MAXROWS] trips of local row m, -1: not a row of this handle
   int *col = rowT + POLAR_TILE_MAXROWS;               // [MAXROWS] sub-phase
-  double *bb = reinterpret_cast<double *>(col + POLAR_TILE_MAXROWS);  // [6] bounding box of the rows
-  int *misc = reinterpret_cast<int *>(bb + 6);        // [4] U, rows
+  double *bb = reinterpret_cast<double *>(col + POLAR_TILE_MAXROWS);  // [4 waves][6] partial, then [6] bounding box of the rows
+  int *misc = reinterpret_cast<int *>(bb + 24);       // [12] U, rows, shifted entries, selfbase, rows per wave [4..7], candidates [8]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
   const int c = blockIdx.x;
   const int n0 = g.nc[0], n1 = g.nc[1], n2 = g.nc[2];
@@ -113,44 +122,14 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
     if (tid == 0) { atomicMax(flags + 7, P); H->r0 = r0; H->nrows = 0; H->U = 0; H->nsub = 0; }
     return;
   }
-  for (int m = tid; m < POLAR_TILE_MAXROWS; m += blockDim.x) {
-    bool row = false;
-    if (m < P) { const int o = perm[r0 + m]; row = o >= own_lo && o < own_hi; }
-    rowT[m] = row ? 0 : -1;
-    col[m] = -1;
-  }
-  __syncthreads();
-  if (wv == 0) {  // bounding box of the rows
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    int rows = 0;
-    for (int mb = 0; mb < P; mb += 64) {
-      const int m = mb + lane;
-      const bool is = m < P && rowT[m] >= 0;
-      if (is) {
-        const double4 p = pos4[r0 + m];
-        lo[0] = fmin(lo[0], p.x); lo[1] = fmin(lo[1], p.y); lo[2] = fmin(lo[2], p.z);
-        hi[0] = fmax(hi[0], p.x); hi[1] = fmax(hi[1], p.y); hi[2] = fmax(hi[2], p.z);
-      }
-      rows += __popcll(__ballot(is));
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) { lo[k] = wave_min(lo[k]); hi[k] = -wave_min(-hi[k]); }
-    if (lane == 0) {
-      for (int k = 0; k < 3; k++) { bb[k] = lo[k]; bb[3 + k] = hi[k]; }
-      misc[1] = rows;
-    }
-  }
-  __syncthreads();
-  if (misc[1] == 0) {  // no row of this handle in the cell
-    if (tid == 0) { H->r0 = r0; H->nrows = 0; H->U = 0; H->nsub = 0; }
-    return;
-  }
-  const double b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  // the two sweeps over the 125 stencil cells (FILL = 0: count, 1: write)
-  auto stencil_pass = [&](const int fill) {
-    for (int q = wv; q < 125; q += nwv) {
-      int bq[3] = {c0 + q % 5 - 2, c1 + (q / 5) % 5 - 2, c2 + q / 25 - 2};
+  // ---- round 1 of memory requests, all at once: the 125 stencil cells (thread q: cell q), and the tile's own atoms
+  //      (thread m: is atom m a row of this handle, where is it).  A workgroup that walked the stencil cell by cell paid two
+  //      dependent memory latencies per cell and pass: 250 of them, a millisecond per step at 135k atoms.
+  {
+    int a = 0, np = 0, code = 13;
+    if (tid < 125) {
+      int bq[3] = {c0 + tid % 5 - 2, c1 + (tid / 5) % 5 - 2, c2 + tid / 25 - 2};
       int sh[3] = {0, 0, 0};
       const int nn[3] = {n0, n1, n2};
       bool ok = true;
@@ -160,40 +139,45 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
         else if (bq[k] >= nn[k]) { ok = ok && box.periodic[k]; bq[k] -= nn[k]; sh[k] = 1; }
         ok = ok && bq[k] >= 0 && bq[k] < nn[k];  // (a dimension with fewer than 3 cells cannot be periodic in list mode)
       }
-      int count = 0;
       if (ok) {
         const int cj = (bq[2] * n1 + bq[1]) * n0 + bq[0];
-        const int a = (int)cell_first[cj], np = npol[cj];
-        const double sx = sh[0] * box.prd[0] + sh[1] * box.xy + sh[2] * box.xz, sy = sh[1] * box.prd[1] + sh[2] * box.yz,
-                     sz = sh[2] * box.prd[2];
-        const int code = (sh[0] + 1) + 3 * (sh[1] + 1) + 9 * (sh[2] + 1);
-        const int base0 = fill ? off[q] : 0;
-        for (int b = 0; b < np; b += 64) {
-          const int j = a + b + lane;
-          bool in = false;
-          double px = 0, py = 0, pz = 0;
-          if (b + lane < np) {
-            const double4 p = pos4[j];
-            px = p.x + sx; py = p.y + sy; pz = p.z + sz;
-            const double ex = fmax(fmax(b0 - px, px - b3), 0.0), ey = fmax(fmax(b1 - py, py - b4), 0.0),
-                         ez = fmax(fmax(b2 - pz, pz - b5), 0.0);
-            in = q == 62 || (ex * ex + ey * ey + ez * ez) < ddcutsq;  // the home cell is listed whole: row m sits at off[62] + m
-          }
-          const unsigned long long mk = __ballot(in);
-          if (fill && in) {
-            const int k = base0 + count + __popcll(mk & below);
-            ux[k] = px; uy[k] = py; uz[k] = pz;
-            un_j[(size_t)c * un_pitch + k] = j | (code << 26);
-          }
-          count += __popcll(mk);
-        }
+        a = (int)cell_first[cj]; np = npol[cj];
+        code = (sh[0] + 1) + 3 * (sh[1] + 1) + 9 * (sh[2] + 1);
       }
-      if (!fill && lane == 0) cnt[q] = count;
     }
-  };
-  stencil_pass(0);
+    bool row = false;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    if (tid < P) {
+      const int o = perm[r0 + tid];
+      row = o >= own_lo && o < own_hi;
+      if (row) {
+        const double4 p = pos4[r0 + tid];
+        lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
+      }
+    }
+    if (tid < 128) { cnt[tid] = np; sca[tid] = a; scc[tid] = code; }
+    if (tid < POLAR_TILE_MAXROWS) { rowT[tid] = row ? 0 : -1; col[tid] = -1; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = wave_min(lo[k]); hi[k] = -wave_min(-hi[k]); }
+    const int rows = __popcll(__ballot(row));
+    if (lane == 0) {
+      for (int k = 0; k < 3; k++) { bb[6 * wv + k] = lo[k]; bb[6 * wv + 3 + k] = hi[k]; }
+      misc[4 + wv] = rows;
+    }
+  }
   __syncthreads();
-  if (wv == 0) {  // exclusive prefix of the 125 counts
+  const int nrow_tile = misc[4] + misc[5] + misc[6] + misc[7];
+  if (nrow_tile == 0) {  // no row of this handle in the cell
+    if (tid == 0) { H->r0 = r0; H->nrows = 0; H->U = 0; H->nsub = 0; }
+    return;
+  }
+  double b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
+#pragma unroll
+  for (int w = 1; w < 4; w++) {
+    b0 = fmin(b0, bb[6 * w]); b1 = fmin(b1, bb[6 * w + 1]); b2 = fmin(b2, bb[6 * w + 2]);
+    b3 = fmax(b3, bb[6 * w + 3]); b4 = fmax(b4, bb[6 * w + 4]); b5 = fmax(b5, bb[6 * w + 5]);
+  }
+  if (wv == 0) {  // exclusive prefix of the 125 candidate counts
     const int v0 = cnt[lane], v1 = lane + 64 < 125 ? cnt[lane + 64] : 0;
     int i0 = v0, i1 = v1;
 #pragma unroll
@@ -203,18 +187,85 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
     }
     const int t0 = __shfl(i0, 63, 64), t1 = __shfl(i1, 63, 64);
     off[lane] = i0 - v0;
-    off[64 + lane] = t0 + i1 - v1;
-    if (lane == 0) misc[0] = t0 + t1;
+    off[64 + lane] = t0 + i1 - v1;  // (entries 125..127: the total)
+    if (lane == 0) { misc[8] = t0 + t1; misc[0] = 0; misc[1] = nrow_tile; misc[2] = 0; misc[3] = 0; }
   }
   __syncthreads();
+  // ---- round 2: the candidates, flattened (candidate idx of the concatenated runs -> its cell by bisection of the prefix),
+  //      NBC per thread with all their position loads in flight at once; accepted = within the cutoff of the rows' bounding
+  //      box (the home cell is taken whole: row m then sits at selfbase + m).  Ordered compaction: counts per (round, wave),
+  //      one prefix, then every thread writes its accepted candidates -- the union keeps candidate order, run to run.
+  const int C = misc[8];
+  constexpr int NBC = 8;
+  for (int base = 0; base < C; base += NBC * 256) {
+    int ej[NBC];
+    double4 pp[NBC];
+#pragma unroll
+    for (int u = 0; u < NBC; u++) {
+      const int idx = base + u * 256 + tid;
+      int q = 0;
+      if (idx < C) {
+#pragma unroll
+        for (int stp = 64; stp > 0; stp >>= 1) if (q + stp < 125 && off[q + stp] <= idx) q += stp;  // last q with off[q] <= idx
+      }
+      const int j = idx < C ? sca[q] + idx - off[q] : 0;
+      ej[u] = idx < C ? (j | (scc[q] << 26)) : -1;
+      pp[u] = pos4[j];
+    }
+    unsigned inmask = 0u;
+#pragma unroll
+    for (int u = 0; u < NBC; u++) {
+      bool in = false;
+      if (ej[u] >= 0) {
+        const int code = ej[u] >> 26;
+        double sx, sy, sz;
+        tile_shift(box, code, sx, sy, sz);
+        pp[u].x += sx; pp[u].y += sy; pp[u].z += sz;
+        const double ex = fmax(fmax(b0 - pp[u].x, pp[u].x - b3), 0.0), ey = fmax(fmax(b1 - pp[u].y, pp[u].y - b4), 0.0),
+                     ez = fmax(fmax(b2 - pp[u].z, pp[u].z - b5), 0.0);
+        const int idx = base + u * 256 + tid;
+        const bool home = idx >= off[62] && idx < off[63];
+        in = home || (ex * ex + ey * ey + ez * ez) < ddcutsq;
+      }
+      const unsigned long long mk = __ballot(in);
+      if (in) inmask |= 1u << u;
+      if (lane == 0) cnt[u * 4 + wv] = __popcll(mk);
+    }
+    __syncthreads();
+    if (wv == 0) {  // prefix over (round, wave) in candidate order, on top of what earlier chunks accepted
+      const int v = lane < NBC * 4 ? cnt[lane] : 0;
+      int inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+      }
+      const int ubase = misc[0];
+      if (lane < NBC * 4) cnt[32 + lane] = ubase + inc - v;
+      if (lane == 63) misc[0] = ubase + inc;
+    }
+    __syncthreads();
+    if (misc[0] + 1 > un_pitch) break;  // (uniform) does not fit: reported below
+#pragma unroll
+    for (int u = 0; u < NBC; u++) {
+      const bool in = (inmask >> u) & 1u;
+      const unsigned long long mk = __ballot(in);
+      if (in) {
+        const int k = cnt[32 + u * 4 + wv] + __popcll(mk & below);
+        ux[k] = pp[u].x; uy[k] = pp[u].y; uz[k] = pp[u].z;
+        un_j[(size_t)c * un_pitch + k] = ej[u];
+        if ((ej[u] >> 26) != 13) misc[2] = 1;  // (every writer stores the same value)
+        if (base + u * 256 + tid == off[62]) misc[3] = k;  // first atom of the home cell
+      }
+    }
+    __syncthreads();
+  }
   const int U = misc[0];
   if (U + 1 > un_pitch) {
     if (tid == 0) { atomicMax(flags + 5, U + 1); H->r0 = r0; H->nrows = 0; H->U = 0; H->nsub = 0; }
     return;
   }
-  stencil_pass(1);
-  __syncthreads();
-  const int selfbase = off[62];
+  const int selfbase = misc[3];
   // pass 2: the rows' partner lists
   for (int m = wv; m < P; m += nwv) {
     if (rowT[m] < 0) continue;
@@ -248,6 +299,12 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
   // pass 3: greedy colouring of the rows in cell order -- a row takes the lowest sub-phase no earlier row within the colour
   // distance holds (atoms that close must not be relaxed Jacobi-fashion against each other)
   int nsub = 0;
+  int *filled = cnt;  // rows per sub-phase so far (the stencil counts are no longer needed)
+  const int cap = subcap * ((misc[1] + 8 * subcap - 1) / (8 * subcap));  // rows per sub-phase: at most 8 sub-phases' worth
+  if (lane < POLAR_TILE_MAXSUB) filled[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int m = 0; m < P; m++) {
     if (rowT[m] < 0) continue;
     const int self = selfbase + m;
@@ -260,11 +317,15 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
         if ((dx * dx + dy * dy + dz * dz) < colordistsq) used |= 1u << col[j];
       }
     }
+    // ... and no sub-phase takes more rows than the sweep's workgroup has waves (times a whole number for crowded cells):
+    // every wave then has the same number of rows per sub-phase -- rows of a tile are about equally long -- and the waves
+    // reach the barrier together
+    if (lane < POLAR_TILE_MAXSUB && filled[lane] >= cap) used |= 1u << lane;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) used |= (unsigned)__shfl_xor((int)used, o, 64);
     int cm = __ffs((int)~used) - 1;
     if (cm >= POLAR_TILE_MAXSUB) { if (lane == 0) atomicMax(flags + 7, cm + 1); cm = POLAR_TILE_MAXSUB - 1; }
-    if (lane == 0) col[m] = cm;
+    if (lane == 0) { col[m] = cm; filled[cm] += 1; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -278,13 +339,17 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
       const int m = mb + lane;
       const bool is = m < P && rowT[m] >= 0 && col[m] == s;
       const unsigned long long mk = __ballot(is);
-      if (is) trow[r0 + k + __popcll(mk & below)] = make_int2(m | (rowT[m] << 16), selfbase + m);
+      if (is) {
+        TileRowEnt e;
+        e.mT = m | (rowT[m] << 16); e.self = selfbase + m; e.alpha = rec[r0 + m].a;
+        trow[r0 + k + __popcll(mk & below)] = e;
+      }
       k += __popcll(mk);
     }
   }
   if (lane == 0) {
     H->sub_off[nsub] = k;
-    H->r0 = r0; H->nrows = k; H->U = U; H->nsub = nsub;
+    H->r0 = r0; H->nrows = k; H->U = U; H->nsub = nsub | (misc[2] ? 0x100 : 0);
     atomicMax(flags + 9, U);
   }
 }
@@ -316,14 +381,68 @@ __device__ __forceinline__ void tile_read(const char *lds, unsigned pos, double2
   C = *reinterpret_cast<const double2 *>(p + 32);
 }
 
+// LDS image of a workgroup: [tile header, 64 B][row table, MAXROWS x 16 B][records, (U + 1) x 48 B][slack]
+#define POLAR_TILE_LDS_ROWS 64
+#define POLAR_TILE_LDS_REC (POLAR_TILE_LDS_ROWS + 16 * POLAR_TILE_MAXROWS)
+#define POLAR_TILE_LDS_SLACK 1024  // the last DMA instruction of the staging pass writes a whole 64-piece block
+
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's global loads and stores
+// (vmcnt(0)): here that would expose, at every sub-phase, the latency of the index stream requested for the NEXT row.
+// Other waves read this wave's dipole out of LDS, never out of memory, inside a launch.
+__device__ __forceinline__ void tile_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// What a wave asks for one row ahead: the first two chunks of the row's index stream (16 trips) and the row's E_static.
+// The loads are inline assembly and the waits are counted by hand: hipcc's own waits lose count at a loop header and
+// would drain the queue -- the next row's prefetch included -- before the first trip of every row.
+typedef unsigned tile_u4 __attribute__((ext_vector_type(4)));
+struct TileRow {
+  tile_u4 Ja, Jb;
+  double ef, alpha;
+  const tile_u4 *pc;
+  int i, T;
+  unsigned self;
+};
+__device__ __forceinline__ tile_u4 tile_ld128(const void *p) {
+  tile_u4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ double tile_ld64(const void *p) {
+  double v;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// THREE vector-memory instructions, always: tile_settle<3> below leaves exactly these in flight
+__device__ __forceinline__ TileRow tile_prefetch(const char *lds, int r0, int k, const unsigned short *dd16, long long pitch16,
+                                                 const double *ef, int lane) {
+  TileRow R;
+  const TileRowEnt tr = *reinterpret_cast<const TileRowEnt *>(lds + POLAR_TILE_LDS_ROWS + 16 * k);  // same address in every lane
+  const int m = __builtin_amdgcn_readfirstlane(tr.mT & 0xFFFF);
+  R.T = __builtin_amdgcn_readfirstlane(tr.mT >> 16);
+  R.self = (unsigned)__builtin_amdgcn_readfirstlane(tr.self);
+  R.alpha = tr.alpha;
+  R.i = r0 + m;
+  R.pc = reinterpret_cast<const tile_u4 *>(dd16 + (size_t)R.i * pitch16) + lane;
+  R.Ja = tile_ld128(R.pc);
+  R.Jb = tile_ld128(R.pc + 64);  // (rows of one chunk: the next row's first chunk, or the slack behind the table)
+  R.ef = tile_ld64(ef + 3 * (size_t)R.i + (lane < 3 ? lane : 2));
+  return R;
+}
+// everything but the N youngest vector-memory operations of this wave has completed; the row's prefetched values are
+// tied to the wait so that no use of them can be scheduled above it
+template <int N>
+__device__ __forceinline__ void tile_settle(TileRow &R) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(R.Ja), "+v"(R.Jb), "+v"(R.ef) : "n"(N) : "memory");
+}
+
 template <int EP, int DAMP, bool DET>
-__global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr *__restrict__ hdr, const int2 *__restrict__ trow,
+__global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr *__restrict__ hdr, const TileRowEnt *__restrict__ trow,
                                                     const int *__restrict__ un_j, int un_pitch,
                                                     const unsigned short *__restrict__ dd16, long long pitch16, SRec *s0,
-                                                    SRec *s1, double *pend, const AtomRec *__restrict__ rec,
-                                                    const double *__restrict__ ef, Box box, double pd, ExpCoef K,
-                                                    const Scal *scal, double *__restrict__ slots) {
+                                                    SRec *s1, double *pend, const double *__restrict__ ef, Box box, double pd,
+                                                    ExpCoef K, const Scal *scal, double *__restrict__ slots) {
   extern __shared__ __attribute__((aligned(16))) char tl_lds[];
+  char *const recs = tl_lds + POLAR_TILE_LDS_REC;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
   const int ntile = L.count[0] * L.count[1] * L.count[2];
@@ -338,126 +457,172 @@ __global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr 
   const int cur = EP == EP_JACOBI ? scal->cur : 0;
   const SRec *src = (EP == EP_JACOBI && cur) ? s1 : s0;
   SRec *dst = (EP == EP_JACOBI) ? (cur ? s0 : s1) : s0;
-  const int U = H->U, r0 = H->r0;
-  // ---- stage the union: piece g = 3 e + p of entry e, 16 bytes each, lane-linear in LDS ----
+  const int U = H->U, r0 = H->r0, hsub = H->nsub;
+  // ---- stage: header and row table (every later per-row decision then comes out of LDS, not out of a chain of
+  //      dependent memory reads), then the union: piece g = 3 e + p of entry e (16 bytes: {position_p, dipole_p}) goes to
+  //      byte 16 g of the record area.  All of a thread's entry words are requested first, then all of its record pieces as
+  //      LDS-DMA (no destination registers, lane-linear landing = piece order): a tile pays two memory latencies for its
+  //      whole neighbourhood.  The DMA is inline assembly: beside a compiler-issued global_load_lds hipcc drains the whole
+  //      queue (vmcnt(0)) before every use of an ordinary load's result, i.e. once per piece.  Entries of another periodic
+  //      image get their lattice vector added in place afterwards (tiles at a periodic face only).
   {
+    if (tid <= POLAR_TILE_MAXSUB) reinterpret_cast<int *>(tl_lds)[4 + tid] = H->sub_off[tid];
+    for (int k = tid; k < nrows; k += blockDim.x)
+      *reinterpret_cast<TileRowEnt *>(tl_lds + POLAR_TILE_LDS_ROWS + 16 * k) = trow[r0 + k];
     const int *uj = un_j + (size_t)c * un_pitch;
     const char *sb = reinterpret_cast<const char *>(src);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)recs;
     const int np = 3 * U, step = blockDim.x;
-    for (int g0 = tid; g0 < np; g0 += 4 * step) {
-      int ent[4];
-      double2 v[4];
+    constexpr int NB = 16;  // pieces per thread and round: 4,096 pieces = 1,365 records per round of a 256-thread workgroup
+    for (int gb = 0; gb < np; gb += NB * step) {
+      int ent[NB];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int gq = g0 + u * step;
-        ent[u] = gq < np ? uj[gq / 3] : 0;
+      for (int u = 0; u < NB; u++) {
+        const int gq = gb + u * step + tid;
+        ent[u] = uj[(gq < np ? gq : 0) / 3];
       }
+      // (the entry words pass through an empty asm statement: the compiler then waits for them HERE, and places none of
+      //  its counted waits -- which do not know of the DMAs -- between the DMA instructions below)
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int gq = g0 + u * step, p = gq % 3;
-        v[u] = make_double2(0.0, 0.0);
-        if (gq < np) v[u] = *reinterpret_cast<const double2 *>(sb + (size_t)(ent[u] & POLAR_TILE_RECMASK) * 48 + p * 16);
+      for (int u = 0; u < NB; u++) asm volatile("" : "+v"(ent[u]));
+#pragma unroll
+      for (int u = 0; u < NB; u++) {
+        const int gw = __builtin_amdgcn_readfirstlane(gb + u * step + (tid & ~63));  // first piece of this wave's instruction
+        const int gq = gw + lane, p = gq % 3;
+        if (gw < np) {  // wave-uniform; lanes past the end fetch a valid piece into the slack behind the dummy
+          const unsigned voff = (unsigned)(ent[u] & POLAR_TILE_RECMASK) * 48u + (unsigned)p * 16u;
+          lpa_dma(sb, voff, lds0 + (unsigned)gw * 16u);
+        }
       }
+      if (hsub >> 8) {  // some entry of this tile is another periodic image: its lattice vector goes onto the position words.
+        // Every thread patches the pieces it fetched itself (their entry words are still in registers; a loop that read them
+        // again cost a tile fifteen dependent memory round trips), once its own DMAs have landed.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int gq = g0 + u * step, p = gq % 3, code = ent[u] >> 26;
-        if (gq < np) {
-          if (code != 13) {
-            double sx, sy, sz;
-            tile_shift(box, code, sx, sy, sz);
-            v[u].x += p == 0 ? sx : (p == 1 ? sy : sz);
+        for (int u = 0; u < NB; u++) {
+          const int gq = gb + u * step + tid, code = ent[u] >> 26;
+          if (gq < np && code != 13) {
+            const int p = gq % 3;
+            const int s0_ = code % 3 - 1, s1_ = (code / 3) % 3 - 1, s2_ = code / 9 - 1;
+            const double sh = p == 0 ? s0_ * box.prd[0] + s1_ * box.xy + s2_ * box.xz : (p == 1 ? s1_ * box.prd[1] + s2_ * box.yz : s2_ * box.prd[2]);
+            *reinterpret_cast<double *>(recs + (size_t)gq * 16) += sh;
           }
-          *reinterpret_cast<double2 *>(tl_lds + (size_t)gq * 16) = v[u];
         }
       }
     }
-    if (tid < 3) *reinterpret_cast<double2 *>(tl_lds + (size_t)U * 48 + tid * 16) = make_double2(0.0, 0.0);  // the dummy
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < 3) *reinterpret_cast<double2 *>(recs + (size_t)U * 48 + tid * 16) = make_double2(0.0, 0.0);  // the dummy (overhang of the last DMA block lands here first)
   }
   __syncthreads();
-  double chg = 0.0;
-  const int nsub = EP == EP_JACOBI ? 1 : H->nsub;
-  for (int sp = 0; sp < nsub; sp++) {
-    const int kb = EP == EP_JACOBI ? 0 : H->sub_off[sp], ke = EP == EP_JACOBI ? nrows : H->sub_off[sp + 1];
-    for (int k = kb + wv; k < ke; k += nwv) {
-      const int2 tr = trow[r0 + k];
-      const int m = __builtin_amdgcn_readfirstlane(tr.x & 0xFFFF), T = __builtin_amdgcn_readfirstlane(tr.x >> 16);
-      const unsigned self = (unsigned)__builtin_amdgcn_readfirstlane(tr.y);
-      const int i = r0 + m;
-      const uint4 *pc = reinterpret_cast<const uint4 *>(dd16 + (size_t)i * pitch16) + lane;
-      uint4 Ja = pc[0];
-      // the row atom: position out of the staged copy (same in every lane -> scalar registers), epilogue inputs in lanes 0..2
-      const char *sp_ = tl_lds + self * 48u;
-      const double xi = wave_uniform(*reinterpret_cast<const double *>(sp_)),
-                   yi = wave_uniform(*reinterpret_cast<const double *>(sp_ + 16)),
-                   zi = wave_uniform(*reinterpret_cast<const double *>(sp_ + 32));
-      double mu_old = 0.0, alpha = 0.0, efk = 0.0;
-      if (lane < 3) {
-        mu_old = *reinterpret_cast<const double *>(sp_ + lane * 16 + 8);
-        alpha = rec[i].a;
-        efk = ef[3 * (size_t)i + lane];
-      }
-      double ax = 0.0, ay = 0.0, az = 0.0;
-      if (T > 0) {
-        double2 A, B, C, An, Bn, Cn;
-        tile_read(tl_lds, Ja.x & 0xFFFFu, A, B, C);
-        const int NC = (T + 7) >> 3;
-#define POLAR_TILE_TRIP(UU, NEXTPOS)                                        \
-  {                                                                        \
-    const bool more = t0 + (UU) + 1 < T;                                   \
-    if (more) tile_read(tl_lds, (NEXTPOS), An, Bn, Cn);                    \
-    tile_pair<DAMP>(xi, yi, zi, A, B, C, pd, K, ax, ay, az);               \
-    if (!more) break;                                                      \
-    A = An; B = Bn; C = Cn;                                                \
-  }
-        for (int cc = 0; cc < NC; cc++) {
-          const int t0 = 8 * cc;
-          uint4 Jn = Ja;
-          if (cc + 1 < NC) Jn = pc[64 * (cc + 1)];
-          POLAR_TILE_TRIP(0, Ja.x >> 16)
-          POLAR_TILE_TRIP(1, Ja.y & 0xFFFFu)
-          POLAR_TILE_TRIP(2, Ja.y >> 16)
-          POLAR_TILE_TRIP(3, Ja.z & 0xFFFFu)
-          POLAR_TILE_TRIP(4, Ja.z >> 16)
-          POLAR_TILE_TRIP(5, Ja.w & 0xFFFFu)
-          POLAR_TILE_TRIP(6, Ja.w >> 16)
-          POLAR_TILE_TRIP(7, Jn.x & 0xFFFFu)
-          Ja = Jn;
-        }
-#undef POLAR_TILE_TRIP
-      }
-      // the three wave sums in one butterfly (lp_finish): lanes 0, 1, 2 end with E_x, E_y, E_z of the row
-      const double v = cl_reduce3(ax, ay, az, lane);
-      if (lane < 3) {
-        const double mu_new = alpha * (efk + v);  // PS.cpp:1170-1180
-        const double d = mu_new - mu_old;
-        chg = fma(d, d, chg);
-        if (DET) {
-          pend[3 * (size_t)i + lane] = mu_new;  // committed below (LDS copy) and by k_tile_commit (record table)
-        } else {
-          reinterpret_cast<double *>(dst + i)[2 * lane + 1] = mu_new;
-          if (EP != EP_JACOBI) *reinterpret_cast<double *>(tl_lds + self * 48u + lane * 16 + 8) = mu_new;
-        }
-      }
-    }
-    if (EP != EP_JACOBI) {
+  // ---- the rows.  Wave w takes rows w, w + nwv, ... of every sub-phase, in sub-phase order; while it works on a row it
+  //      has the NEXT row's index stream and E_static in flight (a row is ~9 trips = ~1 us: one memory latency).
+  const int nsub = EP == EP_JACOBI ? 1 : (hsub & 0xFF);
+  const int *soff = reinterpret_cast<const int *>(tl_lds) + 4;  // sub_off[0 .. nsub] (LDS copy)
+  auto first_row = [&](int sp) { return EP == EP_JACOBI ? wv : soff[sp] + wv; };
+  auto end_row = [&](int sp) { return EP == EP_JACOBI ? nrows : soff[sp + 1]; };
+  auto settle = [&](int &sp, int &k) {  // (sp, k) -> the first existing row at or after it in this wave's sequence
+    while (sp < nsub && k >= end_row(sp)) { sp++; if (sp < nsub) k = first_row(sp); }
+  };
+  // leaving sub-phase `from` for `to` (or for the end): the barriers in between; DET commits this wave's rows of `from`
+  // into the LDS copy between two barriers (every row of the sub-phase has read what it needed; then everybody sees it)
+  auto cross = [&](int from, int to) {
+    if (EP == EP_JACOBI) return;
+    for (int s = from; s < to; s++) {
       if (DET) {
-        __syncthreads();  // every row of the sub-phase has read what it needed
-        for (int k = kb + wv; k < ke; k += nwv) {  // this wave's rows again: their pending dipoles into the LDS copy
-          const int2 tr = trow[r0 + k];
-          if (lane < 3)
-            *reinterpret_cast<double *>(tl_lds + (unsigned)tr.y * 48u + lane * 16 + 8) = pend[3 * (size_t)(r0 + (tr.x & 0xFFFF)) + lane];
-        }
+        tile_barrier();
+        if (s == from)
+          for (int k = first_row(s); k < end_row(s); k += nwv) {
+            const TileRowEnt tr = *reinterpret_cast<const TileRowEnt *>(tl_lds + POLAR_TILE_LDS_ROWS + 16 * k);
+            if (lane < 3)
+              *reinterpret_cast<double *>(recs + (unsigned)tr.self * 48u + lane * 16 + 8) = pend[3 * (size_t)(r0 + (tr.mT & 0xFFFF)) + lane];
+          }
       }
-      if (sp + 1 < nsub) __syncthreads();
+      tile_barrier();
     }
+  };
+  double chg = 0.0;
+  int sp = 0, k = first_row(0);
+  settle(sp, k);
+  int at = 0;  // sub-phase whose start this wave has reached (barriers passed)
+  TileRow R{};
+  if (sp < nsub) { R = tile_prefetch(tl_lds, r0, k, dd16, pitch16, ef, lane); tile_settle<0>(R); }
+  while (sp < nsub) {
+    cross(at, sp);
+    at = sp;
+    int sp2 = sp, k2 = k + nwv;
+    settle(sp2, k2);
+    const bool has_next = sp2 < nsub;
+    TileRow N{};
+    if (has_next) N = tile_prefetch(tl_lds, r0, k2, dd16, pitch16, ef, lane);  // in flight while this row is computed
+    // the row atom: position out of the staged copy (same in every lane -> scalar registers), old dipole in lanes 0..2
+    const char *sp_ = recs + R.self * 48u;
+    const double xi = wave_uniform(*reinterpret_cast<const double *>(sp_)),
+                 yi = wave_uniform(*reinterpret_cast<const double *>(sp_ + 16)),
+                 zi = wave_uniform(*reinterpret_cast<const double *>(sp_ + 32));
+    const double mu_old = *reinterpret_cast<const double *>(sp_ + (lane < 3 ? lane : 2) * 16 + 8);
+    double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0;
+    const int T = R.T;
+    if (T > 0) {
+      // TWO trips per step, as two independent dependency chains (a workgroup's LDS footprint leaves a SIMD two waves, so
+      // the latency of the ~45-deep FP64 chain of a pair has to be covered inside the wave), and two register sets used
+      // alternately: a step computes out of one while the records of the next step land in the other
+      double2 PA0, PB0, PC0, PA1, PB1, PC1, QA0, QB0, QC0, QA1, QB1, QC1;
+      tile_read(recs, R.Ja.x & 0xFFFFu, PA0, PB0, PC0);
+      if (T > 1) tile_read(recs, R.Ja.x >> 16, PA1, PB1, PC1);
+      const int NC = (T + 7) >> 3;
+      tile_u4 J = R.Ja, Jn = R.Jb;
+#define POLAR_TILE_STEP(QQ, XA0, XB0, XC0, XA1, XB1, XC1, YA0, YB0, YC0, YA1, YB1, YC1, NEXT0, NEXT1) \
+  {                                                                                                   \
+    const int t = t0 + 2 * (QQ);                                                                      \
+    if (t + 2 < T) tile_read(recs, (NEXT0), YA0, YB0, YC0);                                           \
+    if (t + 3 < T) tile_read(recs, (NEXT1), YA1, YB1, YC1);                                           \
+    if (t + 1 < T) {                                                                                  \
+      tile_pair<DAMP>(xi, yi, zi, XA0, XB0, XC0, pd, K, ax, ay, az);                                  \
+      tile_pair<DAMP>(xi, yi, zi, XA1, XB1, XC1, pd, K, bx, by, bz);                                  \
+    } else {                                                                                          \
+      tile_pair<DAMP>(xi, yi, zi, XA0, XB0, XC0, pd, K, ax, ay, az);                                  \
+    }                                                                                                 \
+    if (t + 2 >= T) break;                                                                            \
   }
+      for (int cc = 0; cc < NC; cc++) {
+        const int t0 = 8 * cc;
+        tile_u4 Jf = Jn;  // chunk cc + 2 (rows longer than 16 trips only): requested here, needed two chunks on
+        if (cc + 2 < NC) Jf = tile_ld128(R.pc + 64 * (cc + 2));
+        POLAR_TILE_STEP(0, PA0, PB0, PC0, PA1, PB1, PC1, QA0, QB0, QC0, QA1, QB1, QC1, J.y & 0xFFFFu, J.y >> 16)
+        POLAR_TILE_STEP(1, QA0, QB0, QC0, QA1, QB1, QC1, PA0, PB0, PC0, PA1, PB1, PC1, J.z & 0xFFFFu, J.z >> 16)
+        POLAR_TILE_STEP(2, PA0, PB0, PC0, PA1, PB1, PC1, QA0, QB0, QC0, QA1, QB1, QC1, J.w & 0xFFFFu, J.w >> 16)
+        if (cc + 2 < NC) asm volatile("s_waitcnt vmcnt(0)" : "+v"(Jf) : : "memory");  // (long rows: the chunk requested above)
+        POLAR_TILE_STEP(3, QA0, QB0, QC0, QA1, QB1, QC1, PA0, PB0, PC0, PA1, PB1, PC1, Jn.x & 0xFFFFu, Jn.x >> 16)
+        J = Jn; Jn = Jf;
+      }
+#undef POLAR_TILE_STEP
+      ax += bx; ay += by; az += bz;
+    }
+    // the three wave sums in one butterfly (lp_finish): lanes 0, 1, 2 end with E_x, E_y, E_z of the row
+    const double v = cl_reduce3(ax, ay, az, lane);
+    if (lane < 3) {
+      const double mu_new = R.alpha * (R.ef + v);  // PS.cpp:1170-1180
+      const double d = mu_new - mu_old;
+      chg = fma(d, d, chg);
+      if (DET) {
+        pend[3 * (size_t)R.i + lane] = mu_new;  // committed in cross() (LDS copy) and by k_tile_commit (record table)
+      } else {
+        reinterpret_cast<double *>(dst + R.i)[2 * lane + 1] = mu_new;
+        if (EP != EP_JACOBI) *reinterpret_cast<double *>(recs + R.self * 48u + lane * 16 + 8) = mu_new;
+      }
+    }
+    if (has_next) tile_settle<1>(N);  // everything but the dipole store just issued: the next row's prefetch has landed
+    R = N; sp = sp2; k = k2;             // (before these registers are copied: a copy of a register a load is still to write is stale)
+  }
+  cross(at, nsub - (DET ? 0 : 1));  // the barriers the other waves still wait at (DET: the last sub-phase's pair too)
   chg += dpp_full<0xB1>(chg);
   chg += dpp_full<0x4E>(chg);
   if (lane == 0 && chg != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), chg);
 }
 
 // DET: fold the pending dipoles of a launch's rows into the record table (the launch itself only read the table)
-__global__ void k_tile_commit(TileLaunch L, const TileHdr *__restrict__ hdr, const int2 *__restrict__ trow,
+__global__ void k_tile_commit(TileLaunch L, const TileHdr *__restrict__ hdr, const TileRowEnt *__restrict__ trow,
                               const double *__restrict__ pend, SRec *s0, const Scal *scal) {
   if (scal->done) return;
   const int ntile = L.count[0] * L.count[1] * L.count[2];
@@ -469,7 +634,7 @@ __global__ void k_tile_commit(TileLaunch L, const TileHdr *__restrict__ hdr, con
   const int nrows = H->nrows, r0 = H->r0;
   for (int t = threadIdx.x; t < 3 * nrows; t += blockDim.x) {
     const int k = t / 3, comp = t - 3 * k;
-    const int i = r0 + (trow[r0 + k].x & 0xFFFF);
+    const int i = r0 + (trow[r0 + k].mT & 0xFFFF);
     reinterpret_cast<double *>(s0 + i)[2 * comp + 1] = pend[3 * (size_t)i + comp];
   }
 }

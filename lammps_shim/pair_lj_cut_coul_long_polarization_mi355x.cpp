@@ -107,7 +107,13 @@ void PairLJCutCoulLongPolarizationMI355X::debug_prints(const polar_result &res)
 void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
 {
   if (eflag || vflag) ev_setup(eflag,vflag);
-  else evflag = vflag_fdotr = 0;
+  else {
+    // PS.cpp:126-127 clears only evflag and vflag_fdotr and then reads its ARGUMENTS; this function reads the flags
+    // ev_setup derives from them, which would otherwise still hold the last thermo step's values (Pair::ev_unset)
+    evflag = vflag_fdotr = 0;
+    eflag_either = eflag_global = eflag_atom = 0;
+    vflag_either = vflag_global = vflag_atom = 0;
+  }
   if (comm->nprocs > 1) { compute_sharded(eflag,vflag); return; }
   // what compute() reads through domain->, atom-> and list-> (PS.cpp:125-188)
   double tilt[3] = {domain->xy,domain->xz,domain->yz};

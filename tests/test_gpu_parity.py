@@ -556,3 +556,75 @@ def test_synthetic_box_list_mode_matches_oracle(wl, pkg, oracle):
         assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
         for k in ("eng_vdwl", "eng_coul", "eng_pol"):
             assert rel(out[k], ref[k], 1e-9) < TOL
+
+
+def _relabelled_fixture(wl, case, extra, order):
+    """The fixture with its atoms stored in the order ``order`` (what a LAMMPS atom sort or an exchange does to the
+    arrays a pair style sees): same physics, every per-atom array, the bonds and the neighbor list re-indexed."""
+    import json
+
+    z = np.load(os.path.join(GOLD, case + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    st = wl.parse_pair_style_args(list(meta["pair_style_args"]) + list(extra))
+    rows = [[str(int(r[0])), str(int(r[1])), repr(float(r[2])), repr(float(r[3])), repr(float(r[4]))] for r in z["pair_coeff"]]
+    inv = np.empty(len(order), dtype=np.int64)
+    inv[order] = np.arange(len(order))
+    return wl.make_system(z["x"][order], z["q"][order], z["alpha"][order], z["type"][order], z["molecule"][order], z["boxlo"],
+                          z["prd"], meta["ntypes"], rows, st, meta["known"]["g_ewald"], bonds=inv[z["bonds"]],
+                          exclude_intra=meta["exclude_intra"], name=meta["name"])
+
+
+@pytest.mark.parametrize("kernel", ["2", "4"])
+def test_colour_clash_on_a_reneighbor_step_relays_the_rows(kernel, wl, pkg, oracle, monkeypatch):
+    """a colouring invalidated AFTER the lists of the step were laid out in its launch order (two atoms of
+    one colour closer than the keep distance on a reneighbor step -- here: the polarizable atoms relabelled among
+    themselves, as an atom sort does, so that the stored colours belong to other atoms) must have the dd rows laid out
+    again for the new colouring.  Second step on the same handle against the oracle on the relabelled system."""
+    monkeypatch.setenv("POLAR_SWEEP_KERNEL", kernel)
+    extra = ["use_previous", "no", "precision", "1e-13", "max_iterations", "200", "dd_cutoff", "9.0"]
+    s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"), extra_args=extra)
+    p = pkg.pair_from_system(s)
+    first = p.compute()
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    assert np.max(np.abs(first["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+    rng = np.random.default_rng(5)
+    order = np.arange(s.nlocal)
+    pol = np.nonzero(s.alpha[:s.nlocal])[0]
+    order[pol] = rng.permutation(pol)            # the alpha pattern stays: set_atoms alone does not drop the colours
+    s2 = _relabelled_fixture(wl, "mof5_h2", extra, order)
+    assert np.array_equal(s2.alpha[:s2.nlocal] != 0, s.alpha[:s.nlocal] != 0)
+    p.set_system(s2)                              # set_box + set_atoms + set_neighbors_csr: a reneighbor step
+    out = p.compute()
+    ref2 = oracle.compute(s2, eflag=1, vflag=2)
+    assert out["status"] == 0
+    assert np.max(np.abs(out["mu"] - ref2["mu"])) / np.max(np.abs(ref2["mu"])) < TOL
+    f = oracle.fold_ghost_forces(out["f"], s2.owner, s2.nlocal)
+    fr = oracle.fold_ghost_forces(ref2["f"], s2.owner, s2.nlocal)
+    assert force_rel_err(f, fr) < TOL
+    assert rel(out["eng_pol"], ref2["eng_pol"]) < TOL
+    if kernel == "2":
+        assert out["ms_color_host"] > 0.0         # the clash was seen and the colouring rebuilt in this step
+    p.close()
+
+
+@pytest.mark.parametrize("variant", ["ranked", "gs", "config0_max30", "nodamp_fallback30"])
+def test_matrix_free_exact_gauss_seidel_matches_reference_golden(variant, wl, pkg, oracle, monkeypatch):
+    """The exact-order Gauss-Seidel WITHOUT the HBM-resident tensor (k_gs_block_seq / k_gs_block_push: what a system
+    beyond 9,128 atoms gets, e.g. the 10,792-atom replica BASELINE.md quotes a reference timing for), forced on MOF5+H2
+    with POLAR_NO_DENSE_GS: same reference goldens, same iteration counts (30 of 30 on the knife-edge deck)."""
+    monkeypatch.setenv("POLAR_NO_DENSE_GS", "1")
+    hits = [(pth, info) for pth, info in golden_refs("mof5_h2") if info["variant"] == variant]
+    assert len(hits) == 1, variant
+    path, info = hits[0]
+    z = np.load(path)
+    s, _ = load_ref_system(wl, info)
+    out = _run(pkg, s, info)
+    f = oracle.fold_ghost_forces(out["f"], s.owner, s.nlocal)
+    assert force_rel_err(f, z["f"]) < TOL
+    assert np.max(np.abs(out["mu"] - z["mu"])) / max(np.max(np.abs(z["mu"])), 1e-30) < TOL
+    assert rel(out["eng_pol"], z["energies"][2], 1e-6) < TOL
+    assert (out["status"] == 1) == bool(info["warnings"])
+    if "iterations" in z.files and not info["warnings"]:
+        assert out["iterations"] == int(z["iterations"])
+    if variant == "config0_max30":
+        assert out["iterations"] == 30 and out["status"] == 0

