@@ -217,8 +217,11 @@ struct polar_handle {
   double dens = 0.0;               // atoms per A^3 of the occupied part of the box (first list build)
   std::vector<TileLaunch> tile_launches;  // Gauss-Seidel: one launch per tile colour; tile_all: every cell (Jacobi)
   TileLaunch tile_all{};
-  size_t tile_lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // dynamic-LDS limit already raised per kernel instance
+  size_t tile_lds_attr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // dynamic-LDS limit already raised per kernel instance
   size_t tile_build_lds_attr = 0;
+  int tile_waves = 4;              // waves of a sweep workgroup = rows of a tile's sub-phase (POLAR_TILE_WAVES: 4 or 8)
+  int tile_wide = 0;               // cells of a whole cutoff in x (tiles of ~30 rows) instead of half a cutoff (~15) (POLAR_TILE_WIDE)
+  int tile_sw[3] = {2, 2, 2};      // stencil half-widths of the tile builder, in cells
   int deterministic = 0;           // POLAR_DETERMINISTIC / `deterministic yes`: no sweep reads a dipole another wave of the same launch writes
   Scal *h_scal = nullptr;  // pinned
   hipEvent_t ev[8] = {};
@@ -347,7 +350,9 @@ void build_cells(polar_handle *h) {
     g.nc[k] = std::max(1, (int)std::floor(width[k] / (0.5 * cutall)));  // cell height >= cutoff/2: +-2 stencil
     // tile sweep: the launches are the parity classes of the cells; an even count in a periodic dimension needs no third
     // class for the seam (cells grow by at most 1/6)
+    if (h->sweep_kernel == 4 && k == 0 && h->tile_wide) g.nc[k] = std::max(1, (int)std::floor(width[k] / cutall));
     if (h->sweep_kernel == 4 && h->box.periodic[k] && g.nc[k] >= 7 && (g.nc[k] & 1)) g.nc[k] -= 1;
+    h->tile_sw[k] = std::max(1, std::min(2, (int)std::ceil(st.dd_cutoff / (width[k] / g.nc[k]) - 1e-9)));
     g.lo[k] = h->boxlo[k];
     g.inv[k] = g.nc[k] / h->box.prd[k];
     ncell *= g.nc[k];
@@ -945,7 +950,11 @@ void build_tiles(polar_handle *h) {
   if (h->un_lds <= 0 || h->un_lds > h->un_pitch) h->un_lds = h->un_pitch;
   const long long ncell = h->ncell;
   h->d_thdr.ensure((size_t)ncell + 1); h->d_trow.ensure((size_t)n + 1);
-  h->d_un_j.ensure((size_t)ncell * h->un_pitch + 64);
+  {  // the sweep requests entry words before it knows how many a tile holds: the table never contains stale garbage
+    const int *before = h->d_un_j.p;
+    h->d_un_j.ensure((size_t)ncell * h->un_pitch + 64);
+    if (h->d_un_j.p != before) HIPCHECK(hipMemsetAsync(h->d_un_j.p, 0, h->d_un_j.cap * sizeof(int), s));
+  }
   h->d_dd16.ensure((size_t)std::max(n, 1) * h->pitch16 + 1024);
   h->d_srec0.ensure((size_t)n + 1); h->d_srec1.ensure((size_t)n + 1);
   if (deterministic(h)) h->d_pend.ensure(3 * (size_t)n + 3);
@@ -957,7 +966,7 @@ void build_tiles(polar_handle *h) {
   }
   const int cap = std::min(h->un_pitch, h->un_lds);
   k_tile_build<<<(int)ncell, 256, lds, s>>>(h->grid, h->box, h->d_pos4.p, h->d_cell_first.p, h->d_cell_fill.p, h->d_perm.p, own_lo(h),
-                                            own_lo(h) + own_n(h), rc * rc, h->color_dist * h->color_dist, 4 /* waves of a sweep workgroup */, cap, h->d_un_j.p, h->pitch16,
+                                            own_lo(h) + own_n(h), rc * rc, h->color_dist * h->color_dist, h->tile_waves, h->tile_sw[0], h->tile_sw[1], h->tile_sw[2], cap, h->d_un_j.p, h->pitch16,
                                             h->d_dd16.p, h->d_thdr.p, h->d_trow.p, h->d_rec0.p, h->d_overflow.p, h->d_ddtot.p);
   HIPCHECK(hipMemcpyAsync(h->h_flags + 5, h->d_overflow.p + 5, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -974,19 +983,21 @@ void launch_field_tile(polar_handle *h, const TileLaunch &L) {
   const bool det = deterministic(h) && EP == EP_INPLACE;
   size_t lds = tile_lds_bytes(tile_pitch(h));
   if (const char *e = getenv("POLAR_TILE_LDS_PAD")) lds += (size_t)atoi(e);  // LAB (temporary): residency experiment
-  const int inst = (EP == EP_JACOBI ? 0 : (det ? 2 : 1)) * 2 + (expd ? 0 : 1);
-#define FT(D, DT)                                                                                                              \
+  const int inst = ((EP == EP_JACOBI ? 0 : (det ? 2 : 1)) * 2 + (expd ? 0 : 1)) * 2 + (h->tile_waves == 8 ? 1 : 0);
+#define FT(D, DT, W)                                                                                                           \
   {                                                                                                                            \
     if (lds > h->tile_lds_attr[inst]) {                                                                                        \
-      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_tile<EP, D, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_tile<EP, D, DT, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       h->tile_lds_attr[inst] = lds;                                                                                            \
     }                                                                                                                          \
-    k_field_tile<EP, D, DT><<<nblk_xcd(nt, 1), 256, lds, h->stream>>>(L, h->d_thdr.p, h->d_trow.p, h->d_un_j.p, tile_pitch(h),   \
+    k_field_tile<EP, D, DT, W><<<nblk_xcd(nt, 1), 64 * W, lds, h->stream>>>(L, h->d_thdr.p, h->d_trow.p, h->d_un_j.p, tile_pitch(h),   \
         h->d_dd16.p, h->pitch16, h->d_srec0.p, h->d_srec1.p, h->d_pend.p, h->d_ef_s.p, h->box, st.polar_damp,       \
         make_expcoef(), h->d_scal.p, h->d_slots.p);                                                                              \
   }
-  if (det) { if (expd) FT(0, true) else FT(1, true) }
-  else     { if (expd) FT(0, false) else FT(1, false) }
+#define FW(D, DT) { if (h->tile_waves == 8) FT(D, DT, 8) else FT(D, DT, 4) }
+  if (det) { if (expd) FW(0, true) else FW(1, true) }
+  else     { if (expd) FW(0, false) else FW(1, false) }
+#undef FW
 #undef FT
   if (det) k_tile_commit<<<(int)nt, 64, 0, h->stream>>>(L, h->d_thdr.p, h->d_trow.p, h->d_pend.p, h->d_srec0.p, h->d_scal.p);
 }
@@ -1518,6 +1529,8 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_DETERMINISTIC")) h->deterministic = atoi(e) != 0;
+  if (const char *e = getenv("POLAR_TILE_WAVES")) h->tile_waves = atoi(e) == 8 ? 8 : 4;
+  if (const char *e = getenv("POLAR_TILE_WIDE")) h->tile_wide = atoi(e) != 0;
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
   if (const char *e = getenv("POLAR_LJ_TYPED")) h->lj_typed = atoi(e) != 0;
   if (const char *e = getenv("POLAR_STATIC_XQ")) h->static_xq = atoi(e) != 0;

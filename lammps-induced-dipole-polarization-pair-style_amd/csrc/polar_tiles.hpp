@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
                                                     const long long *__restrict__ cell_first,
                                                     const int *__restrict__ npol, const int *__restrict__ perm,
                                                     int own_lo, int own_hi, double ddcutsq, double colordistsq, int subcap,
-                                                    int un_pitch, int *__restrict__ un_j, long long pitch16,
+                                                    int sw0, int sw1, int sw2, int un_pitch, int *__restrict__ un_j, long long pitch16,
                                                     unsigned short *__restrict__ dd16, TileHdr *__restrict__ hdr,
                                                     TileRowEnt *__restrict__ trow, const AtomRec *__restrict__ rec,
                                                     int *__restrict__ flags, unsigned long long *__restrict__ dd_total) {
@@ -123,13 +123,15 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
     return;
   }
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  // ---- round 1 of memory requests, all at once: the 125 stencil cells (thread q: cell q), and the tile's own atoms
+  // stencil: +-sw_k cells in dimension k (2 for cells of half a cutoff, 1 for cells of a whole one), at most 5 x 5 x 5
+  const int nx = 2 * sw0 + 1, ny = 2 * sw1 + 1, nq = nx * ny * (2 * sw2 + 1), qh = sw0 + nx * (sw1 + ny * sw2);
+  // ---- round 1 of memory requests, all at once: the stencil cells (thread q: cell q), and the tile's own atoms
   //      (thread m: is atom m a row of this handle, where is it).  A workgroup that walked the stencil cell by cell paid two
   //      dependent memory latencies per cell and pass: 250 of them, a millisecond per step at 135k atoms.
   {
     int a = 0, np = 0, code = 13;
-    if (tid < 125) {
-      int bq[3] = {c0 + tid % 5 - 2, c1 + (tid / 5) % 5 - 2, c2 + tid / 25 - 2};
+    if (tid < nq) {
+      int bq[3] = {c0 + tid % nx - sw0, c1 + (tid / nx) % ny - sw1, c2 + tid / (nx * ny) - sw2};
       int sh[3] = {0, 0, 0};
       const int nn[3] = {n0, n1, n2};
       bool ok = true;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
     b3 = fmax(b3, bb[6 * w + 3]); b4 = fmax(b4, bb[6 * w + 4]); b5 = fmax(b5, bb[6 * w + 5]);
   }
   if (wv == 0) {  // exclusive prefix of the 125 candidate counts
-    const int v0 = cnt[lane], v1 = lane + 64 < 125 ? cnt[lane + 64] : 0;
+    const int v0 = cnt[lane], v1 = lane + 64 < nq ? cnt[lane + 64] : 0;
     int i0 = v0, i1 = v1;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
     }
     const int t0 = __shfl(i0, 63, 64), t1 = __shfl(i1, 63, 64);
     off[lane] = i0 - v0;
-    off[64 + lane] = t0 + i1 - v1;  // (entries 125..127: the total)
+    off[64 + lane] = t0 + i1 - v1;  // (entries nq .. 127: the total)
     if (lane == 0) { misc[8] = t0 + t1; misc[0] = 0; misc[1] = nrow_tile; misc[2] = 0; misc[3] = 0; }
   }
   __syncthreads();
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
       int q = 0;
       if (idx < C) {
 #pragma unroll
-        for (int stp = 64; stp > 0; stp >>= 1) if (q + stp < 125 && off[q + stp] <= idx) q += stp;  // last q with off[q] <= idx
+        for (int stp = 64; stp > 0; stp >>= 1) if (q + stp < nq && off[q + stp] <= idx) q += stp;  // last q with off[q] <= idx
       }
       const int j = idx < C ? sca[q] + idx - off[q] : 0;
       ej[u] = idx < C ? (j | (scc[q] << 26)) : -1;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
         const double ex = fmax(fmax(b0 - pp[u].x, pp[u].x - b3), 0.0), ey = fmax(fmax(b1 - pp[u].y, pp[u].y - b4), 0.0),
                      ez = fmax(fmax(b2 - pp[u].z, pp[u].z - b5), 0.0);
         const int idx = base + u * 256 + tid;
-        const bool home = idx >= off[62] && idx < off[63];
+        const bool home = idx >= off[qh] && idx < off[qh + 1];
         in = home || (ex * ex + ey * ey + ez * ez) < ddcutsq;
       }
       const unsigned long long mk = __ballot(in);
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const d
         ux[k] = pp[u].x; uy[k] = pp[u].y; uz[k] = pp[u].z;
         un_j[(size_t)c * un_pitch + k] = ej[u];
         if ((ej[u] >> 26) != 13) misc[2] = 1;  // (every writer stores the same value)
-        if (base + u * 256 + tid == off[62]) misc[3] = k;  // first atom of the home cell
+        if (base + u * 256 + tid == off[qh]) misc[3] = k;  // first atom of the home cell
       }
     }
     __syncthreads();
@@ -435,8 +437,85 @@ __device__ __forceinline__ void tile_settle(TileRow &R) {
   asm volatile("s_waitcnt vmcnt(%3)" : "+v"(R.Ja), "+v"(R.Jb), "+v"(R.ef) : "n"(N) : "memory");
 }
 
-template <int EP, int DAMP, bool DET>
-__global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr *__restrict__ hdr, const TileRowEnt *__restrict__ trow,
+// The trips of one row, two at a time: TWO independent dependency chains per step (a four-wave workgroup's LDS footprint leaves
+// a SIMD two waves, so the latency of the ~45-deep FP64 chain of a pair has to be covered inside the wave), and two register
+// sets used alternately: a step computes out of one while the records of the next step land in the other.
+template <int DAMP>
+__device__ __forceinline__ void tile_row_pairs2(const TileRow &R, const char *recs, double xi, double yi, double zi, double pd,
+                                                const ExpCoef &K, double &ax, double &ay, double &az) {
+  const int T = R.T;
+  if (T <= 0) return;
+  double bx = 0.0, by = 0.0, bz = 0.0;
+  double2 PA0, PB0, PC0, PA1, PB1, PC1, QA0, QB0, QC0, QA1, QB1, QC1;
+  tile_read(recs, R.Ja.x & 0xFFFFu, PA0, PB0, PC0);
+  if (T > 1) tile_read(recs, R.Ja.x >> 16, PA1, PB1, PC1);
+  const int NC = (T + 7) >> 3;
+  tile_u4 J = R.Ja, Jn = R.Jb;
+#define POLAR_TILE_STEP(QQ, XA0, XB0, XC0, XA1, XB1, XC1, YA0, YB0, YC0, YA1, YB1, YC1, NEXT0, NEXT1) \
+  {                                                                                                   \
+    const int t = t0 + 2 * (QQ);                                                                      \
+    if (t + 2 < T) tile_read(recs, (NEXT0), YA0, YB0, YC0);                                           \
+    if (t + 3 < T) tile_read(recs, (NEXT1), YA1, YB1, YC1);                                           \
+    if (t + 1 < T) {                                                                                  \
+      tile_pair<DAMP>(xi, yi, zi, XA0, XB0, XC0, pd, K, ax, ay, az);                                  \
+      tile_pair<DAMP>(xi, yi, zi, XA1, XB1, XC1, pd, K, bx, by, bz);                                  \
+    } else {                                                                                          \
+      tile_pair<DAMP>(xi, yi, zi, XA0, XB0, XC0, pd, K, ax, ay, az);                                  \
+    }                                                                                                 \
+    if (t + 2 >= T) break;                                                                            \
+  }
+  for (int cc = 0; cc < NC; cc++) {
+    const int t0 = 8 * cc;
+    tile_u4 Jf = Jn;  // chunk cc + 2 (rows longer than 16 trips only): requested here, needed two chunks on
+    if (cc + 2 < NC) Jf = tile_ld128(R.pc + 64 * (cc + 2));
+    POLAR_TILE_STEP(0, PA0, PB0, PC0, PA1, PB1, PC1, QA0, QB0, QC0, QA1, QB1, QC1, J.y & 0xFFFFu, J.y >> 16)
+    POLAR_TILE_STEP(1, QA0, QB0, QC0, QA1, QB1, QC1, PA0, PB0, PC0, PA1, PB1, PC1, J.z & 0xFFFFu, J.z >> 16)
+    POLAR_TILE_STEP(2, PA0, PB0, PC0, PA1, PB1, PC1, QA0, QB0, QC0, QA1, QB1, QC1, J.w & 0xFFFFu, J.w >> 16)
+    if (cc + 2 < NC) asm volatile("s_waitcnt vmcnt(0)" : "+v"(Jf) : : "memory");  // (long rows: the chunk requested above)
+    POLAR_TILE_STEP(3, QA0, QB0, QC0, QA1, QB1, QC1, PA0, PB0, PC0, PA1, PB1, PC1, Jn.x & 0xFFFFu, Jn.x >> 16)
+    J = Jn; Jn = Jf;
+  }
+#undef POLAR_TILE_STEP
+  ax += bx; ay += by; az += bz;
+}
+// the same, one trip per step (eight-wave workgroups: four waves per SIMD cover the chain's latency, registers are scarce)
+template <int DAMP>
+__device__ __forceinline__ void tile_row_pairs1(const TileRow &R, const char *recs, double xi, double yi, double zi, double pd,
+                                                const ExpCoef &K, double &ax, double &ay, double &az) {
+  const int T = R.T;
+  if (T <= 0) return;
+  double2 A0, B0, C0, A1, B1, C1;
+  tile_read(recs, R.Ja.x & 0xFFFFu, A0, B0, C0);
+  const int NC = (T + 7) >> 3;
+  tile_u4 J = R.Ja, Jn = R.Jb;
+#define POLAR_TILE_TRIP(UU, PA, PB, PC, QA, QB, QC, NEXTPOS)               \
+  {                                                                        \
+    const bool more = t0 + (UU) + 1 < T;                                   \
+    if (more) tile_read(recs, (NEXTPOS), QA, QB, QC);                      \
+    tile_pair<DAMP>(xi, yi, zi, PA, PB, PC, pd, K, ax, ay, az);            \
+    if (!more) break;                                                      \
+  }
+  for (int cc = 0; cc < NC; cc++) {
+    const int t0 = 8 * cc;
+    tile_u4 Jf = Jn;
+    if (cc + 2 < NC) Jf = tile_ld128(R.pc + 64 * (cc + 2));
+    POLAR_TILE_TRIP(0, A0, B0, C0, A1, B1, C1, J.x >> 16)
+    POLAR_TILE_TRIP(1, A1, B1, C1, A0, B0, C0, J.y & 0xFFFFu)
+    POLAR_TILE_TRIP(2, A0, B0, C0, A1, B1, C1, J.y >> 16)
+    POLAR_TILE_TRIP(3, A1, B1, C1, A0, B0, C0, J.z & 0xFFFFu)
+    POLAR_TILE_TRIP(4, A0, B0, C0, A1, B1, C1, J.z >> 16)
+    POLAR_TILE_TRIP(5, A1, B1, C1, A0, B0, C0, J.w & 0xFFFFu)
+    POLAR_TILE_TRIP(6, A0, B0, C0, A1, B1, C1, J.w >> 16)
+    if (cc + 2 < NC) asm volatile("s_waitcnt vmcnt(0)" : "+v"(Jf) : : "memory");
+    POLAR_TILE_TRIP(7, A1, B1, C1, A0, B0, C0, Jn.x & 0xFFFFu)
+    J = Jn; Jn = Jf;
+  }
+#undef POLAR_TILE_TRIP
+}
+
+// NW = waves of the workgroup (4: two workgroups per CU leave a SIMD two waves; 8: four)
+template <int EP, int DAMP, bool DET, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_field_tile(TileLaunch L, const TileHdr *__restrict__ hdr, const TileRowEnt *__restrict__ trow,
                                                     const int *__restrict__ un_j, int un_pitch,
                                                     const unsigned short *__restrict__ dd16, long long pitch16, SRec *s0,
                                                     SRec *s1, double *pend, const double *__restrict__ ef, Box box, double pd,
@@ -444,12 +523,30 @@ __global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr 
   extern __shared__ __attribute__((aligned(16))) char tl_lds[];
   char *const recs = tl_lds + POLAR_TILE_LDS_REC;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = NW;
   const int ntile = L.count[0] * L.count[1] * L.count[2];
   const int lb = xcd_block(blockIdx.x, ntile);
   if (lb < 0) return;
   const int i0 = lb % L.count[0], i1 = (lb / L.count[0]) % L.count[1], i2 = lb / (L.count[0] * L.count[1]);
   const int c = ((L.start[2] + L.stride[2] * i2) * L.nc[1] + (L.start[1] + L.stride[1] * i1)) * L.nc[0] + L.start[0] + L.stride[0] * i0;
+  // ---- prologue: THREE memory latencies for everything a tile needs before its first trip.
+  //   1: the tile header (scalar loads) and, not waiting for it, this thread's entry words of the union list;
+  //   2: the row table (into LDS: every later per-row decision then comes out of LDS, not out of a chain of dependent memory
+  //      reads) and this wave's first row;
+  //   3: the union records as LDS-DMA -- piece g = 3 e + p of entry e (16 bytes: {position_p, dipole_p}) goes to byte 16 g of
+  //      the record area, no destination registers, lane-linear landing = piece order -- and the first row's index stream.
+  // The DMA is inline assembly: beside a compiler-issued global_load_lds hipcc drains the whole queue (vmcnt(0)) before every
+  // use of an ordinary load's result, i.e. once per piece.  Entries of another periodic image get their lattice vector added
+  // in place afterwards by the thread that fetched them (tiles at a periodic face only).
+  const int *uj = un_j + (size_t)c * un_pitch;
+  const int step = 64 * NW;
+  constexpr int NB = 16;  // pieces per thread and round: 4,096 (8,192) pieces = 1,365 (2,730) records per round of 256 (512) threads
+  int ent[NB];
+#pragma unroll
+  for (int u = 0; u < NB; u++) {
+    const int e = (u * step + tid) / 3;
+    ent[u] = uj[e < un_pitch ? e : un_pitch - 1];
+  }
   const TileHdr *H = hdr + c;
   const int nrows = H->nrows;
   if (nrows == 0) return;
@@ -458,28 +555,26 @@ __global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr 
   const SRec *src = (EP == EP_JACOBI && cur) ? s1 : s0;
   SRec *dst = (EP == EP_JACOBI) ? (cur ? s0 : s1) : s0;
   const int U = H->U, r0 = H->r0, hsub = H->nsub;
-  // ---- stage: header and row table (every later per-row decision then comes out of LDS, not out of a chain of
-  //      dependent memory reads), then the union: piece g = 3 e + p of entry e (16 bytes: {position_p, dipole_p}) goes to
-  //      byte 16 g of the record area.  All of a thread's entry words are requested first, then all of its record pieces as
-  //      LDS-DMA (no destination registers, lane-linear landing = piece order): a tile pays two memory latencies for its
-  //      whole neighbourhood.  The DMA is inline assembly: beside a compiler-issued global_load_lds hipcc drains the whole
-  //      queue (vmcnt(0)) before every use of an ordinary load's result, i.e. once per piece.  Entries of another periodic
-  //      image get their lattice vector added in place afterwards (tiles at a periodic face only).
+  const int nsub = EP == EP_JACOBI ? 1 : (hsub & 0xFF);
+  const int end0 = EP == EP_JACOBI ? nrows : H->sub_off[1];  // rows of the first sub-phase: wave w starts with row w of it
+  if (tid <= POLAR_TILE_MAXSUB) reinterpret_cast<int *>(tl_lds)[4 + tid] = H->sub_off[tid];
+  for (int k = tid; k < nrows; k += step)
+    *reinterpret_cast<TileRowEnt *>(tl_lds + POLAR_TILE_LDS_ROWS + 16 * k) = trow[r0 + k];
+  TileRow R{};
+  const bool early = wv < end0;  // (wave-uniform) this wave's first row is row wv: ask for it beside the records
+  TileRowEnt tr0{};
+  if (early) tr0 = trow[r0 + wv];
   {
-    if (tid <= POLAR_TILE_MAXSUB) reinterpret_cast<int *>(tl_lds)[4 + tid] = H->sub_off[tid];
-    for (int k = tid; k < nrows; k += blockDim.x)
-      *reinterpret_cast<TileRowEnt *>(tl_lds + POLAR_TILE_LDS_ROWS + 16 * k) = trow[r0 + k];
-    const int *uj = un_j + (size_t)c * un_pitch;
     const char *sb = reinterpret_cast<const char *>(src);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)recs;
-    const int np = 3 * U, step = blockDim.x;
-    constexpr int NB = 16;  // pieces per thread and round: 4,096 pieces = 1,365 records per round of a 256-thread workgroup
+    const int np = 3 * U;
     for (int gb = 0; gb < np; gb += NB * step) {
-      int ent[NB];
+      if (gb > 0) {  // (unions beyond one round: the next entry words)
 #pragma unroll
-      for (int u = 0; u < NB; u++) {
-        const int gq = gb + u * step + tid;
-        ent[u] = uj[(gq < np ? gq : 0) / 3];
+        for (int u = 0; u < NB; u++) {
+          const int gq = gb + u * step + tid;
+          ent[u] = uj[(gq < np ? gq : 0) / 3];
+        }
       }
       // (the entry words pass through an empty asm statement: the compiler then waits for them HERE, and places none of
       //  its counted waits -- which do not know of the DMAs -- between the DMA instructions below)
@@ -490,9 +585,21 @@ __global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr 
         const int gw = __builtin_amdgcn_readfirstlane(gb + u * step + (tid & ~63));  // first piece of this wave's instruction
         const int gq = gw + lane, p = gq % 3;
         if (gw < np) {  // wave-uniform; lanes past the end fetch a valid piece into the slack behind the dummy
-          const unsigned voff = (unsigned)(ent[u] & POLAR_TILE_RECMASK) * 48u + (unsigned)p * 16u;
+          // (the entry words were requested before U was known: beyond the list they are whatever the table held)
+          const unsigned voff = (gq < np ? (unsigned)(ent[u] & POLAR_TILE_RECMASK) : 0u) * 48u + (unsigned)p * 16u;
           lpa_dma(sb, voff, lds0 + (unsigned)gw * 16u);
         }
+      }
+      if (gb == 0 && early) {  // the first row's index stream and E_static travel with the records
+        asm volatile("" : "+v"(tr0.mT), "+v"(tr0.self), "+v"(tr0.alpha));
+        R.T = __builtin_amdgcn_readfirstlane(tr0.mT >> 16);
+        R.self = (unsigned)__builtin_amdgcn_readfirstlane(tr0.self);
+        R.alpha = tr0.alpha;
+        R.i = r0 + __builtin_amdgcn_readfirstlane(tr0.mT & 0xFFFF);
+        R.pc = reinterpret_cast<const tile_u4 *>(dd16 + (size_t)R.i * pitch16) + lane;
+        R.Ja = tile_ld128(R.pc);
+        R.Jb = tile_ld128(R.pc + 64);
+        R.ef = tile_ld64(ef + 3 * (size_t)R.i + (lane < 3 ? lane : 2));
       }
       if (hsub >> 8) {  // some entry of this tile is another periodic image: its lattice vector goes onto the position words.
         // Every thread patches the pieces it fetched itself (their entry words are still in registers; a loop that read them
@@ -510,14 +617,13 @@ __global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr 
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R.Ja), "+v"(R.Jb), "+v"(R.ef) : : "memory");
     __syncthreads();
     if (tid < 3) *reinterpret_cast<double2 *>(recs + (size_t)U * 48 + tid * 16) = make_double2(0.0, 0.0);  // the dummy (overhang of the last DMA block lands here first)
   }
   __syncthreads();
   // ---- the rows.  Wave w takes rows w, w + nwv, ... of every sub-phase, in sub-phase order; while it works on a row it
   //      has the NEXT row's index stream and E_static in flight (a row is ~9 trips = ~1 us: one memory latency).
-  const int nsub = EP == EP_JACOBI ? 1 : (hsub & 0xFF);
   const int *soff = reinterpret_cast<const int *>(tl_lds) + 4;  // sub_off[0 .. nsub] (LDS copy)
   auto first_row = [&](int sp) { return EP == EP_JACOBI ? wv : soff[sp] + wv; };
   auto end_row = [&](int sp) { return EP == EP_JACOBI ? nrows : soff[sp + 1]; };
@@ -545,8 +651,7 @@ __global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr 
   int sp = 0, k = first_row(0);
   settle(sp, k);
   int at = 0;  // sub-phase whose start this wave has reached (barriers passed)
-  TileRow R{};
-  if (sp < nsub) { R = tile_prefetch(tl_lds, r0, k, dd16, pitch16, ef, lane); tile_settle<0>(R); }
+  if (sp < nsub && !early) { R = tile_prefetch(tl_lds, r0, k, dd16, pitch16, ef, lane); tile_settle<0>(R); }  // (a wave whose first row is not row wv of sub-phase 0)
   while (sp < nsub) {
     cross(at, sp);
     at = sp;
@@ -561,44 +666,9 @@ __global__ __launch_bounds__(256) void k_field_tile(TileLaunch L, const TileHdr 
                  yi = wave_uniform(*reinterpret_cast<const double *>(sp_ + 16)),
                  zi = wave_uniform(*reinterpret_cast<const double *>(sp_ + 32));
     const double mu_old = *reinterpret_cast<const double *>(sp_ + (lane < 3 ? lane : 2) * 16 + 8);
-    double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0;
-    const int T = R.T;
-    if (T > 0) {
-      // TWO trips per step, as two independent dependency chains (a workgroup's LDS footprint leaves a SIMD two waves, so
-      // the latency of the ~45-deep FP64 chain of a pair has to be covered inside the wave), and two register sets used
-      // alternately: a step computes out of one while the records of the next step land in the other
-      double2 PA0, PB0, PC0, PA1, PB1, PC1, QA0, QB0, QC0, QA1, QB1, QC1;
-      tile_read(recs, R.Ja.x & 0xFFFFu, PA0, PB0, PC0);
-      if (T > 1) tile_read(recs, R.Ja.x >> 16, PA1, PB1, PC1);
-      const int NC = (T + 7) >> 3;
-      tile_u4 J = R.Ja, Jn = R.Jb;
-#define POLAR_TILE_STEP(QQ, XA0, XB0, XC0, XA1, XB1, XC1, YA0, YB0, YC0, YA1, YB1, YC1, NEXT0, NEXT1) \
-  {                                                                                                   \
-    const int t = t0 + 2 * (QQ);                                                                      \
-    if (t + 2 < T) tile_read(recs, (NEXT0), YA0, YB0, YC0);                                           \
-    if (t + 3 < T) tile_read(recs, (NEXT1), YA1, YB1, YC1);                                           \
-    if (t + 1 < T) {                                                                                  \
-      tile_pair<DAMP>(xi, yi, zi, XA0, XB0, XC0, pd, K, ax, ay, az);                                  \
-      tile_pair<DAMP>(xi, yi, zi, XA1, XB1, XC1, pd, K, bx, by, bz);                                  \
-    } else {                                                                                          \
-      tile_pair<DAMP>(xi, yi, zi, XA0, XB0, XC0, pd, K, ax, ay, az);                                  \
-    }                                                                                                 \
-    if (t + 2 >= T) break;                                                                            \
-  }
-      for (int cc = 0; cc < NC; cc++) {
-        const int t0 = 8 * cc;
-        tile_u4 Jf = Jn;  // chunk cc + 2 (rows longer than 16 trips only): requested here, needed two chunks on
-        if (cc + 2 < NC) Jf = tile_ld128(R.pc + 64 * (cc + 2));
-        POLAR_TILE_STEP(0, PA0, PB0, PC0, PA1, PB1, PC1, QA0, QB0, QC0, QA1, QB1, QC1, J.y & 0xFFFFu, J.y >> 16)
-        POLAR_TILE_STEP(1, QA0, QB0, QC0, QA1, QB1, QC1, PA0, PB0, PC0, PA1, PB1, PC1, J.z & 0xFFFFu, J.z >> 16)
-        POLAR_TILE_STEP(2, PA0, PB0, PC0, PA1, PB1, PC1, QA0, QB0, QC0, QA1, QB1, QC1, J.w & 0xFFFFu, J.w >> 16)
-        if (cc + 2 < NC) asm volatile("s_waitcnt vmcnt(0)" : "+v"(Jf) : : "memory");  // (long rows: the chunk requested above)
-        POLAR_TILE_STEP(3, QA0, QB0, QC0, QA1, QB1, QC1, PA0, PB0, PC0, PA1, PB1, PC1, Jn.x & 0xFFFFu, Jn.x >> 16)
-        J = Jn; Jn = Jf;
-      }
-#undef POLAR_TILE_STEP
-      ax += bx; ay += by; az += bz;
-    }
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (NW == 4) tile_row_pairs2<DAMP>(R, recs, xi, yi, zi, pd, K, ax, ay, az);
+    else tile_row_pairs1<DAMP>(R, recs, xi, yi, zi, pd, K, ax, ay, az);
     // the three wave sums in one butterfly (lp_finish): lanes 0, 1, 2 end with E_x, E_y, E_z of the row
     const double v = cl_reduce3(ax, ay, az, lane);
     if (lane < 3) {
