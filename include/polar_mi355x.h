@@ -59,6 +59,11 @@ typedef struct {
    * `fixed_iteration` runs included, is reproducible bit for bit like the reference's serial loop (PS.cpp:1158-1180).
    * Off by default: the in-place update converges to the same fixed point and saves the commit launches. */
   int deterministic;
+  /* polar_sor <omega> (extension keyword, list mode with polar_gs / polar_gs_ranked): successive over-relaxation of the
+   * Gauss-Seidel update, mu <- mu + omega (alpha (E_static + E_ind) - mu).  1 (default) is the reference's update
+   * (PS.cpp:1170-1180); 1.1 - 1.2 reaches the same fixed point under the same stop rule in about 30 % fewer sweeps on the MOF
+   * boxes (profiles/r03_lab_sor.txt).  0 < omega < 2. */
+  double polar_sor;
 } polar_settings;
 
 typedef struct {

@@ -20,10 +20,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libpolar_mi355x.so")
+# the LAB build of the same sources (-DPOLAR_LAB): the sweep kernels that were measured and not kept as the default, the
+# `ablate` timing switches and the environment knobs that select them.  tools/ and the alternative-kernel tests load it; the
+# product library above contains none of that.
+LIB_PATH_LAB = os.path.join(_HERE, "libpolar_mi355x_lab.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 _lib = None
+_lib_lab = None
 
 
 class PolarError(RuntimeError):
@@ -39,15 +44,19 @@ def _sources():
         os.path.join(os.path.dirname(_HERE), "include", "polar_mi355x.h")]
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU)."""
+def build(force=False, verbose=False, lab=True):
+    """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU): the product library and, with
+    ``lab``, the lab build of the same sources."""
     src = os.path.join(_CSRC, "polar_api.hip")
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in _sources())
-    if force or stale:
-        cmd = [HIPCC] + HIP_FLAGS + ["-o", LIB_PATH, src]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    for path, extra in ((LIB_PATH, []), (LIB_PATH_LAB, ["-DPOLAR_LAB"])):
+        if path == LIB_PATH_LAB and not lab:
+            continue
+        stale = (not os.path.exists(path)) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in _sources())
+        if force or stale:
+            cmd = [HIPCC] + HIP_FLAGS + extra + ["-o", path, src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
     return LIB_PATH
 
 
@@ -56,7 +65,7 @@ class Settings(C.Structure):
                 ("polar_damp", C.c_double), ("polar_gamma", C.c_double), ("iterations_max", C.c_int),
                 ("damping_type", C.c_int), ("zodid", C.c_int), ("fixed_iteration", C.c_int), ("polar_gs", C.c_int),
                 ("polar_gs_ranked", C.c_int), ("use_previous", C.c_int), ("debug", C.c_int), ("dd_cutoff", C.c_double),
-                ("device_neigh", C.c_int), ("restart_polar", C.c_int), ("deterministic", C.c_int)]
+                ("device_neigh", C.c_int), ("restart_polar", C.c_int), ("deterministic", C.c_int), ("polar_sor", C.c_double)]
 
 
 class Result(C.Structure):
@@ -128,9 +137,20 @@ EXPORTS = {
 }
 
 
-def lib():
-    """Load the C-ABI library.  Fails loudly when it has not been built."""
-    global _lib
+def lib(lab=False):
+    """Load the C-ABI library (``lab``: the lab build).  Fails loudly when it has not been built."""
+    global _lib, _lib_lab
+    if lab:
+        if _lib_lab is None:
+            if not os.path.exists(LIB_PATH_LAB):
+                raise PolarError(-2, f"{LIB_PATH_LAB} is missing: run __graft_entry__.build()")
+            lib()  # load order (torch first) as for the product library
+            L = C.CDLL(LIB_PATH_LAB)
+            for name, (res, args) in EXPORTS.items():
+                fn = getattr(L, name)
+                fn.restype, fn.argtypes = res, args
+            _lib_lab = L
+        return _lib_lab
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PolarError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950); "
@@ -175,8 +195,8 @@ def _argv(args):
 class PolarPair:
     """Mirror of the reference Pair interface on top of the C-ABI (one handle = one Pair instance)."""
 
-    def __init__(self, device=0):
-        self.L = lib()
+    def __init__(self, device=0, lab=False):
+        self.L = lib(lab)
         self.h = C.c_void_p()
         rc = self.L.polar_create(device, C.byref(self.h))
         if rc < 0:
@@ -319,6 +339,8 @@ class PolarPair:
             args += ["dd_cutoff", repr(st.dd_cutoff)]
         if getattr(st, "deterministic", 0):
             args += ["deterministic", "yes"]
+        if getattr(st, "polar_sor", 1.0) != 1.0:
+            args += ["polar_sor", repr(float(st.polar_sor))]
         self.settings(args)
         if modify_args:
             self.modify(list(modify_args))
@@ -406,14 +428,14 @@ def _result_dict(res):
     return out
 
 
-def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0, device_neigh=False, row_range=None):
+def pair_from_system(sysm, coeff_rows=None, modify_args=(), device=0, device_neigh=False, row_range=None, lab=False):
     """Build a PolarPair from a workload.PolarSystem the way an input script would:
     pair_style -> pair_modify -> pair_coeff -> init -> per-step data.
     ``device_neigh``: the LJ/Coulomb list is built on the device (keyword ``device_neigh yes`` of the shim)
     instead of being uploaded; systems made with ``build_list=False`` need it.
     ``row_range`` = (lo, hi): a sharded handle (polar_set_row_range) -- set before the device list is built, which
     then covers the own rows only."""
-    p = PolarPair(device)
+    p = PolarPair(device, lab=lab)
     p.load_system(sysm, modify_args)
     rows = coeff_rows if coeff_rows is not None else sysm.extra.get("coeff_rows")
     if rows is None:

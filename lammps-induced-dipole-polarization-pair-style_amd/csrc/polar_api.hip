@@ -141,6 +141,7 @@ struct polar_handle {
   DBuf<long long> d_cell_first, d_nl_first, d_dd_first;
   DBuf<double2> d_dd_s;
   DBuf<int2> d_lpdesc;  // row descriptors of k_field_lp
+  DBuf<double> d_lp_pend;  // `deterministic yes`: {mu_x, mu_y, mu_z, (dmu)^2} per launch row until k_lp_commit
   DBuf<int> d_slot;     // lp sweep: launch row of every atom's dd row (s space), -1: none
   // cluster rows (sweep_kernel 3, k_field_cl): clusters sorted by colour; color_off then counts clusters
   std::vector<int> h_cl;        // [ncl][4] member atoms (orig ids, -1 padded)
@@ -343,7 +344,10 @@ void build_cells(polar_handle *h) {
     if (h->box.periodic[k] && width[k] < 2.0 * cutall * (1.0 - 1e-12))
       throw InputError("dd_cutoff mode needs box lengths >= 2*max(cut_coul,dd_cutoff); use exact mode (dd_cutoff 0)");
   CellGrid &g = h->grid;
-  g.trim = getenv("POLAR_NL_TRIM") ? atoi(getenv("POLAR_NL_TRIM")) : 1;
+  g.trim = 1;
+#ifdef POLAR_LAB
+  if (const char *e = getenv("POLAR_NL_TRIM")) g.trim = atoi(e);
+#endif
   if (h->box.triclinic) g.trim = 0;  // the per-atom stencil trimming measures orthogonal distances
   long long ncell = 1;
   for (int k = 0; k < 3; k++) {
@@ -388,6 +392,8 @@ void build_cells(polar_handle *h) {
   k_exclusive_scan<int><<<1, 1024, 0, s>>>(ncell, h->d_cell_cnt.p, h->d_cell_first.p);
   k_cell_fill<<<nblk(n, 256), 256, 0, s>>>(n, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_fill.p,
                                            (h->pol_first || h->sweep_kernel == 4) ? h->d_cell_fill.p + ncell + 1 : nullptr, h->d_alpha.p, h->d_perm.p, h->d_inv.p);
+  if (deterministic(h))  // the order inside a cell follows the atomics of k_cell_fill: put it into atom order (reproducible sums)
+    k_cell_sort<<<nblk(ncell, 128), 128, 0, s>>>(ncell, h->d_cell_first.p, (h->pol_first || h->sweep_kernel == 4) ? h->d_cell_fill.p : nullptr, h->d_perm.p, h->d_inv.p);
   h->sorted = true;
   if (sharded(h)) {
     h->d_ownrows.ensure(own_n(h) + 1);
@@ -476,7 +482,10 @@ void build_lists(polar_handle *h) {
   else if (mode == 0) h->d_dd_s.ensure((size_t)n * h->dd_pitch + 64);
   double *r2p = r2c ? h->d_dd_r2.p : nullptr;
   double2 *sp = mode == 0 ? h->d_dd_s.p : nullptr;
-  const bool fuse = mode != 0 && mode != 4 && !getenv("POLAR_NO_FUSE_R2");  // r^2 and padding written by k_nl_build (no k_dd_scalars pass)
+  bool fuse = mode != 0 && mode != 4;  // r^2 and padding written by k_nl_build (no k_dd_scalars pass)
+#ifdef POLAR_LAB
+  if (getenv("POLAR_NO_FUSE_R2")) fuse = false;
+#endif
   const double cutallsq = cutall * cutall, ddsq = mode == 4 ? -1.0 : st.dd_cutoff * st.dd_cutoff;
   const int nr = own_n(h);
   const int *rows = own_rows(h);
@@ -503,15 +512,19 @@ void build_lists(polar_handle *h) {
   const RowList ddl{h->d_dd_cnt.p, h->dd_pitch};
   if (fuse || mode == 4) {
     // modes 1 and 2: the list build wrote r^2 (mode 1) and the padding itself; mode 4: no per-atom dd rows at all
-  } else if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
+  }
+#ifdef POLAR_LAB
+  else if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
     k_dd_scalars<0><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, sp, r2p);
   else
     k_dd_scalars<1><<<nblk(nr, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(rows, nr, h->d_rec0.p, h->box, ddl, h->d_dd_j.p, st.polar_damp, sp, r2p);
+#endif
   // overflow flag and dd total come back with the end-of-step read (no sync here)
   HIPCHECK(hipMemcpyAsync(h->h_flags, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 }
 
+#ifdef POLAR_LAB
 // ---- clusters of rows for k_field_cl and their colouring ------------------------------------------
 // Clusters: greedy, in cell order -- a seed atom takes its nearest unassigned polarizable neighbours while every
 // member stays within cluster_dist of every other (adjacency lists hold the atoms within color_dist, so
@@ -665,6 +678,10 @@ void build_cluster_colors(polar_handle *h, const std::vector<double> &rank, cons
   h->color_epoch++;
   h->colors_valid = true;
 }
+
+#else
+inline void build_cluster_colors(polar_handle *, const std::vector<double> &, const std::vector<std::vector<int>> &, const std::vector<std::vector<int>> &) { throw std::logic_error("lab build only"); }
+#endif  // POLAR_LAB
 
 // ---- host-side greedy distance colouring for the colour-phase Gauss-Seidel (cutoff mode) ----
 // Atoms of one colour are >= color_dist apart, so the couplings treated Jacobi-style inside a
@@ -832,15 +849,24 @@ void launch_field(polar_handle *h, int nrows, const int *rows) {
   const size_t lds = AP ? 0 : (size_t)(fb / 64) * 64 * 5 * sizeof(double2);  // per-wave staging tiles (list mode)
   k_field<AP, DAMP, EP><<<nblk(nrows, fb / 64), fb, lds, h->stream>>>(
       nrows, rows, h->nlocal, h->d_rec0.p, h->d_rec1.p, h->box, RowList{h->d_dd_cnt.p, h->dd_pitch}, h->d_dd_j.p, h->d_dd_s.p,
-      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_scal.p, h->d_slots.p, h->ablate);
+      st.dd_cutoff * st.dd_cutoff, st.polar_damp, h->d_ef_s.p, h->d_F.p, h->d_scal.p, h->d_slots.p
+#ifdef POLAR_LAB
+      , h->ablate
+#endif
+      );
 }
 template <int EP>
 void launch_field_dyn(polar_handle *h, bool ap, int nrows, const int *rows) {
   const bool expd = h->ph.st.damping_type == POLAR_DAMP_EXPONENTIAL;
   if (ap) { if (expd) launch_field<true, 0, EP>(h, nrows, rows); else launch_field<true, 1, EP>(h, nrows, rows); }
+#ifdef POLAR_LAB
   else    { if (expd) launch_field<false, 0, EP>(h, nrows, rows); else launch_field<false, 1, EP>(h, nrows, rows); }
+#else
+  else throw std::logic_error("k_field's list branch exists in the lab build only");
+#endif
 }
 
+#ifdef POLAR_LAB
 // list-mode production sweep: component-per-lane quads (k_field_quad), one wave per row
 template <int EP>
 void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
@@ -858,6 +884,10 @@ void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
 #undef FQ
 }
 
+#else
+template <int EP> inline void launch_field_quad(polar_handle *, int, const int *) { throw std::logic_error("lab build only"); }
+#endif  // POLAR_LAB
+
 // list-mode sweep, lane-per-pair with LDS-DMA gathers (k_field_lp), one wave per row
 // row descriptors of this step for k_field_lp: the colour phases back to back (GS), or the own rows (Jacobi)
 void prepare_lp(polar_handle *h) {
@@ -865,6 +895,7 @@ void prepare_lp(polar_handle *h) {
   const bool gs = st.polar_gs || st.polar_gs_ranked;
   const int tot = gs ? (h->color_off.empty() ? 0 : h->color_off.back()) : own_n(h);
   h->d_lpdesc.ensure((size_t)tot + 1);
+  if (deterministic(h)) h->d_lp_pend.ensure(4 * (size_t)tot + 4);
   if (tot > 0)
     k_lp_desc<<<nblk(tot, 256), 256, 0, h->stream>>>(tot, gs ? h->d_rows.p : own_rows(h), RowList{h->d_dd_cnt.p, h->dd_pitch},
                                                      h->d_dd_wrap.p, h->d_lpdesc.p);
@@ -881,10 +912,18 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
   // the launch requests dynamic LDS without raising the kernel's limit: beyond 64 KB (workgroups of more than 512 threads
   // with two tiles per wave) it would fail, and the failure would only surface at the next read of the loop state
   if (lds > (size_t)64 * 1024) throw InputError("k_field_lp: workgroup size x tiles needs more than 64 KB of LDS (POLAR_QUAD_BLOCK <= 512 with two tiles)");
-#define FL(D, NT) k_field_lp<EP, D, NT><<<nblk_xcd(nrows, qb / 64), qb, lds, h->stream>>>(                           \
+  const bool det = deterministic(h);
+  const double omega = EP == EP_INPLACE ? st.polar_sor : 1.0;
+#ifdef POLAR_LAB
+#define POLAR_LAB_ARG , h->ablate
+#else
+#define POLAR_LAB_ARG
+#endif
+#define FL(D, NT, DT) k_field_lp<EP, D, NT, DT><<<nblk_xcd(nrows, qb / 64), qb, lds, h->stream>>>(                   \
       nrows, row0, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                               \
-      st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
+      st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, omega, h->d_lp_pend.p POLAR_LAB_ARG)
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
+#ifdef POLAR_LAB
   if (h->lp_depth >= 2) {  // gathers kept lp_depth trips ahead (hand-counted waits), four tiles per wave
     const int pb = std::min(qb, 256);
     const size_t plds = (size_t)(pb / 64) * 4 * POLAR_LP_TILE;
@@ -896,11 +935,20 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
 #undef FA
     return;
   }
-  if (nt == 1) { if (expd) FL(0, 1); else FL(1, 1); }
-  else         { if (expd) FL(0, 2); else FL(1, 2); }
+  if (nt == 1 && !det) { if (expd) FL(0, 1, false); else FL(1, 1, false); return; }
+#endif
+  if (det) {
+    if (expd) FL(0, 2, true); else FL(1, 2, true);
+    // the launch only read the record table: its rows' new dipoles and the sum of their changes are folded in now
+    k_lp_commit<<<1, 1024, 0, h->stream>>>(nrows, row0, desc, h->d_lp_pend.p, h->d_rec0.p, h->d_rec1.p, EP == EP_JACOBI ? 1 : 0, h->d_scal.p);
+  } else {
+    if (expd) FL(0, 2, false); else FL(1, 2, false);
+  }
 #undef FL
+#undef POLAR_LAB_ARG
 }
 
+#ifdef POLAR_LAB
 // cluster sweep (k_field_cl): one wave per cluster, clusters [first, first + ncl) of the colour-sorted table
 template <int EP>
 void launch_field_cl(polar_handle *h, int ncl, int first) {
@@ -1001,6 +1049,15 @@ void launch_field_tile(polar_handle *h, const TileLaunch &L) {
 #undef FT
   if (det) k_tile_commit<<<(int)nt, 64, 0, h->stream>>>(L, h->d_thdr.p, h->d_trow.p, h->d_pend.p, h->d_srec0.p, h->d_scal.p);
 }
+
+#else
+template <int EP> inline void launch_field_cl(polar_handle *, int, int) { throw std::logic_error("lab build only"); }
+struct TileUnavailable : std::runtime_error { explicit TileUnavailable(const std::string &m) : std::runtime_error(m) {} };
+inline size_t tile_lds_bytes(int) { return 0; }
+inline int tile_lds_cap() { return 0; }
+inline void build_tiles(polar_handle *) { throw std::logic_error("lab build only"); }
+template <int EP> inline void launch_field_tile(polar_handle *, const TileLaunch &) { throw std::logic_error("lab build only"); }
+#endif  // POLAR_LAB
 
 // one sweep over the rows this handle owns (Jacobi, or the colour phases)
 void sweep_once(polar_handle *h, bool ap) {
@@ -1107,6 +1164,7 @@ void resolve_colors(polar_handle *h) {
   if (h->ph.st.polar_gs_ranked) { launch_rank<false>(h, 1); launch_rank<false>(h, 2); }  // a2 for the phase order
 }
 
+#ifdef POLAR_LAB
 // cluster mode, per step: members -> s space, union lists, descriptors (needs the colours AND this step's cell order)
 void build_cluster_lists(polar_handle *h) {
   const polar_settings &st = h->ph.st;
@@ -1125,6 +1183,10 @@ void build_cluster_lists(polar_handle *h) {
   HIPCHECK(hipMemcpyAsync(h->h_flags + 4, h->d_overflow.p + 4, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 }
+
+#else
+inline void build_cluster_lists(polar_handle *) { throw std::logic_error("lab build only"); }
+#endif  // POLAR_LAB
 
 // `debug yes` (PS.cpp:1182-1191): u_polar after sweep `sw`, kept on the device until polar_get_debug_trace
 void debug_trace(polar_handle *h, int sw, bool /*jacobi*/) {
@@ -1229,7 +1291,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   const bool ap = !(st.dd_cutoff > 0.0);
   if (ap && own_n(h) != n) throw InputError("row sharding needs dd_cutoff > 0 (exact all-pairs mode runs as replicas only)");
   if (!ap && h->box.triclinic && !(h->sweep_kernel == 4 || (h->sweep_kernel == 2 && h->lp_depth == 0)))
-    throw InputError("dd_cutoff (list) mode in a triclinic box needs the tile sweep or the row sweep (k_field_tile, k_field_lp)");
+    throw InputError("dd_cutoff (list) mode in a triclinic box needs the row sweep (k_field_lp) or, in the lab build, the tile sweep");
   const int vmode = vflag % 4;
   hipStream_t s = h->stream;
   h->warn.clear();
@@ -1260,18 +1322,21 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     hipStream_t s = h->lj_forked ? h->lj_stream : ms;  // shadows the main stream inside this block
     HIPCHECK(hipEventRecord(h->ev_lj0, s));
     LJCoulParams P = h->P;
-    P.newton_pair = h->newton_pair; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list; P.ablate = h->ablate;
+    P.newton_pair = h->newton_pair; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list; P.ablate = 0;
     h->d_xq.ensure(nall + 1);
     k_pack_lj<<<nblk(nall, 256), 256, 0, s>>>(nall, h->d_x.p, h->d_q.p, h->d_xq.p);
     const size_t ljlds = (size_t)(h->ntypes + 1) * (h->ntypes + 1) * 8 * sizeof(double);
     if (ljlds > 64 * 1024) throw InputError("too many atom types for the LDS-resident LJ table (max 31)");
     dim3 block(POLAR_BLOCK);
-    const bool symmetrise = !h->full_list && !getenv("POLAR_LJ_ATOMICS");
+    bool symmetrise = !h->full_list;
+#ifdef POLAR_LAB
+    if (getenv("POLAR_LJ_ATOMICS")) symmetrise = false;  // round 1's FP64 atomics on f[j]
+#endif
     // A full (newton-off) list puts no force on ghosts, so sum f.x over locals+ghosts (fdotr) would miss
     // the image terms: the LJ/Coulomb virial is then tallied pairwise (the same number), and only the
     // polarization forces -- local atoms, minimum-image displacements -- go through f.x (phase_finish)
     const bool lj_pairwise_virial = h->full_list && vmode == 2;
-    if ((eatom || vatom) && !symmetrise && !h->full_list) throw InputError("per-atom tallies need the row-complete pair list (unset POLAR_LJ_ATOMICS)");
+    if ((eatom || vatom) && !symmetrise && !h->full_list) throw InputError("per-atom tallies need the row-complete pair list");
     if (symmetrise && !h->sym_valid && h->inum > 0) {  // once per uploaded list (reneighbor steps)
       dim3 g0(nblk(h->inum, POLAR_ROWS_PER_BLOCK));
       h->d_sym_cnt.ensure(nall + 1); h->d_sym_fill.ensure(nall + 1); h->d_sym_first.ensure(nall + 2);
@@ -1305,7 +1370,10 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     HIPCHECK(hipEventRecord(h->ev_lj1, s));
     if (h->lj_forked) HIPCHECK(hipEventRecord(h->ev_join, s));
   };
-  const bool lj_late = getenv("POLAR_LJ_LATE") != nullptr;  // lab: fork a3 after the static field instead
+  bool lj_late = false;
+#ifdef POLAR_LAB
+  lj_late = getenv("POLAR_LJ_LATE") != nullptr;  // fork a3 after the static field instead
+#endif
   if (!lj_late) launch_lj();
   const double *mu0 = nullptr;
   if (st.use_previous) {
@@ -1368,8 +1436,10 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     else    k_static_field<false><<<grid, block, 0, s>>>(own_rows(h), own_n(h), n, h->d_rec0.p, h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p, ccs, e2s, st.polar_gamma, st.use_previous, h->d_ef_s.p, h->d_rec0.p, h->d_rec1.p, h->static_xq ? h->d_xq_s.p : nullptr);
   }
   // tile sweep: the solve works on 48-byte sweep records {position, dipole}; the initial dipoles are in the AtomRecs now
+#ifdef POLAR_LAB
   if (!ap && h->sweep_kernel == 4 && !st.zodid)
     k_srec_pack<<<nblk(n, 256), 256, 0, s>>>(n, h->d_rec0.p, h->d_srec0.p, h->d_srec1.p);
+#endif
   HIPCHECK(hipEventRecord(h->ev[4], s));
   if (lj_late) launch_lj();
 }
@@ -1382,8 +1452,10 @@ int phase_finish(polar_handle *h, polar_result *out) {
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
   const int eflag = h->step_eflag, vmode = h->step_vflag % 4;
   hipStream_t s = h->stream;
+#ifdef POLAR_LAB
   if (!ap && h->sweep_kernel == 4 && !st.zodid)  // the solved dipoles back into the AtomRecs the remaining kernels read
     k_srec_unpack<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_srec0.p, h->d_srec1.p, h->d_rec0.p, h->d_rec1.p);
+#endif
   k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p);
   HIPCHECK(hipEventRecord(h->ev[5], s));
   double *vatom = (h->step_vflag / 4) ? h->d_vatom.p : nullptr;
@@ -1526,9 +1598,10 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_COLOR_DIST")) h->color_dist = atof(e);
   h->color_keep = std::max(h->color_dist - 0.4, 0.75 * h->color_dist);
   if (const char *e = getenv("POLAR_COLOR_KEEP")) h->color_keep = atof(e);
+  if (const char *e = getenv("POLAR_DETERMINISTIC")) h->deterministic = atoi(e) != 0;  // the same as the keyword `deterministic yes`
+#ifdef POLAR_LAB
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
-  if (const char *e = getenv("POLAR_DETERMINISTIC")) h->deterministic = atoi(e) != 0;
   if (const char *e = getenv("POLAR_TILE_WAVES")) h->tile_waves = atoi(e) == 8 ? 8 : 4;
   if (const char *e = getenv("POLAR_TILE_WIDE")) h->tile_wide = atoi(e) != 0;
   if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
@@ -1541,8 +1614,9 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_CLUSTER_DIST")) h->cluster_dist = atof(e);
   if (const char *e = getenv("POLAR_CLUSTER_MAX")) h->cluster_max = std::max(1, std::min(4, atoi(e)));
   if (const char *e = getenv("POLAR_LP_DEPTH")) { int v = atoi(e); h->lp_depth = (v == 2 || v == 3) ? v : 0; }
-  if (const char *e = getenv("POLAR_QUAD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->quad_block = v; }  // 0 quad (default), 1 lane-per-pair kernels
+  if (const char *e = getenv("POLAR_QUAD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->quad_block = v; }
   if (const char *e = getenv("POLAR_FIELD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->field_block = v; }
+#endif
   int n = polar_device_count();
   if (n <= 0 || device < 0 || device >= n) {
     h->have_device = false;  // host mirror still usable; compute entry points will fail loudly

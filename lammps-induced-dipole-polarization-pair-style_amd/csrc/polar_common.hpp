@@ -6,6 +6,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// LAB BUILD (-DPOLAR_LAB, libpolar_mi355x_lab.so): the sweep kernels that were built, measured and did not become the default
+// (component-per-lane, register-staged, cluster rows, tile sweep, variants of the row sweep), the `ablate` timing switches
+// and the environment knobs that select them.  The product library is compiled without it: its kernels carry no lab
+// argument and it reads no lab environment variable (tests/test_gpu_parity.py::test_product_library_ignores_lab_switches).
+#ifdef POLAR_LAB
+#define POLAR_LAB_PARAM , int ablate
+#define POLAR_LAB_PASS , ablate
+#define POLAR_ABL(bit) (ablate & (bit))
+#else
+#define POLAR_LAB_PARAM
+#define POLAR_LAB_PASS
+#define POLAR_ABL(bit) 0
+#endif
+
 namespace polar {
 
 
@@ -34,6 +48,7 @@ struct Scal {
   double last_change;      // change / (3N) of the last finished sweep
   unsigned long long rmin_bits;  // double bits of rmin (positive doubles order like uint64)
   int iterations, done, status, cur, sweeps, pad;
+  double det_change;       // `deterministic yes`: sum (dmu)^2 of the running sweep, added launch by launch in a fixed order
 };
 
 // Contended accumulators (energies, virial, sum dmu^2, rmin) are spread over NSLOT cache lines:

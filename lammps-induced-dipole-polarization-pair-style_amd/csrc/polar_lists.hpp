@@ -94,6 +94,25 @@ __global__ void k_cell_fill(int n, const int *__restrict__ cell_id, const long l
   perm[s] = i;
   inv[i] = s;
 }
+// `deterministic yes`: k_cell_fill places the atoms of a cell in the order its atomics happened to run; here one thread per
+// cell puts each of the two groups (polarizable atoms, the others) into ascending atom index -- insertion sort of ~20
+// entries -- so that every list, and with it every floating-point sum, has the same order run after run
+__global__ void k_cell_sort(long long ncell, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+                            int *__restrict__ perm, int *__restrict__ inv) {
+  const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int a = (int)cell_first[c], b = (int)cell_first[c + 1], m = npol ? a + npol[c] : b;
+  for (int part = 0; part < 2; part++) {
+    const int lo = part ? m : a, hi = part ? b : m;
+    for (int k = lo + 1; k < hi; k++) {
+      const int v = perm[k];
+      int j = k - 1;
+      while (j >= lo && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
+      perm[j + 1] = v;
+    }
+  }
+  for (int k = a; k < b; k++) inv[perm[k]] = k;
+}
 __global__ void k_map_rows(int n, const int *__restrict__ inv, const int *__restrict__ in, int *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = inv[in[i]];
@@ -273,6 +292,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict_
   }
 }
 
+#ifdef POLAR_LAB
 // ------------------------------------------------------------------------------------------
 // Cluster rows of the dipole sweep (k_field_cl).  The sweep is bound by the gather of the neighbour records
 // (about 60 GB/s per CU through L1 misses, however many waves or gathers are in flight: profiles/r02_lab_*), so
@@ -418,6 +438,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_cl_build(ClusterRows cl, const 
     if (np > 0.0) atomicAdd(total + (blockIdx.x & 63) * 16, (unsigned long long)np);
   }
 }
+
+#endif  // POLAR_LAB
 
 // ------------------------------------------------------------------------------------------
 // Device-side neighbor build for a3: what Neighbor hands this style --
@@ -613,7 +635,7 @@ __global__ void k_zero_many(ZeroJobs jobs) {
 __global__ void k_zero_scal(Scal *s, int keep_solver) {
   s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;
   for (int k = 0; k < 6; k++) s->virial[k] = 0.0;
-  s->change = 0.0; s->last_change = 0.0; s->pad = 0;
+  s->change = 0.0; s->last_change = 0.0; s->pad = 0; s->det_change = 0.0;
   s->rmin_bits = (unsigned long long)__double_as_longlong(1000.0);
   if (!keep_solver) { s->iterations = 0; s->done = 0; s->status = 0; s->cur = 0; s->sweeps = 0; }
 }

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
                                                        const int *__restrict__ dd_j,
                                                        const double2 *__restrict__ dd_s, double ddcutsq, double pd,
                                                        const double *__restrict__ ef, double *__restrict__ Fout,
-                                                       const Scal *scal, double *__restrict__ slots, int ablate) {
+                                                       const Scal *scal, double *__restrict__ slots POLAR_LAB_PARAM) {
   if (scal->done) return;  // device-resident loop control: finished solves turn later launches into no-ops
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // blockDim.x/64 rows per workgroup
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
         fz -= s3 * rj.mz - c * dz;
       }
     } else {
-      // list mode.  The damped tensor scalars (s3, s5) were cached per pair by k_dd_scalars, so a
+#ifdef POLAR_LAB
+      // list mode (lab: the register-staged lane-per-pair sweep).  The damped tensor scalars (s3, s5) were cached per pair by k_dd_scalars, so a
       // sweep streams 20 B per pair (int32 j + two doubles) and gathers one 64-byte record.
       //   gather : scattered 16-byte loads cost one L1 (TCP) transaction per LANE, so the records of
       //            a trip's 64 pairs are fetched QUAD-cooperatively -- lane k of quad q loads piece k
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
 #undef POLAR_LOAD_STREAM
 #undef POLAR_GATHER
       fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+#endif
     }
     if (ALLPAIRS) { fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz); }
   }
@@ -139,13 +141,14 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
       const double ddx = mx - ri.mx, ddy = my - ri.my, ddz = mz - ri.mz;
       dst[i].mx = mx; dst[i].my = my; dst[i].mz = mz;
       const double c = ddx * ddx + ddy * ddy + ddz * ddz;
-      if (c != 0.0 && !(ablate & 16)) atomicAdd(slot_ptr(slots, SL_CHANGE), c);
+      if (c != 0.0 && !POLAR_ABL(16)) atomicAdd(slot_ptr(slots, SL_CHANGE), c);
     }
   }
 }
 
+#ifdef POLAR_LAB
 // ------------------------------------------------------------------------------------------
-// List-mode sweep, component-per-lane form (production).
+// List-mode sweep, component-per-lane form (round 1's production kernel; lab build).
 // The lane-per-pair kernel (k_field) gives every LANE one pair, so the 64-byte records fetched quad-wise have to
 // be transposed through LDS and the indices shuffled to the quads: ~180 of the ~200 VALU slots of a
 // 64-pair trip were bookkeeping, and the kernel was VALU-issue bound on it.  Here the quad that
@@ -269,6 +272,8 @@ __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__res
   if (lane == 0 && chg != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), chg);
 }
 
+#endif  // POLAR_LAB
+
 // ------------------------------------------------------------------------------------------
 // List-mode sweep, lane-per-pair form with the gather done by LDS-DMA (`global_load_lds_dwordx4`).
 // A 64-pair trip needs the 64-byte records of 64 neighbours.  Four DMA instructions fetch them
@@ -348,8 +353,12 @@ __device__ __forceinline__ LpSelf lp_self(int lane, const AtomRec *self, const d
   }
   return s;
 }
+// DET (`deterministic yes`): the new dipole and its (dmu)^2 go to the launch row's slot of `pend` instead: no row of the
+// launch then reads a dipole another wave of the same launch may or may not have written yet, and the sum of the changes is
+// formed in a fixed order (k_lp_commit) instead of by atomics
+template <bool DET>
 __device__ __forceinline__ void lp_finish(double ax, double ay, double az, int lane, const LpSelf &self, AtomRec *out,
-                                          double *slots) {
+                                          double *slots, double omega, double *pend) {
   const bool odd = lane & 1, hi = lane & 2;
   const double keep1 = odd ? ay : ax, give1 = odd ? ax : ay;
   double v = keep1 + dpp_full<0xB1>(give1);  // quad_perm [1,0,3,2]: even lanes x(l)+x(l+1), odd lanes y(l-1)+y(l)
@@ -363,14 +372,41 @@ __device__ __forceinline__ void lp_finish(double ax, double ay, double az, int l
   // lanes 0, 1, 2 hold E_x, E_y, E_z of the row: mu_new = alpha (E_static + E_ind), PS.cpp:1170-1180
   double d2 = 0.0;
   if (lane < 3) {
-    const double mu_new = self.alpha * (self.ef + v);
-    reinterpret_cast<double *>(out)[2 * lane + 1] = mu_new;
+    // omega = 1: the reference's update (PS.cpp:1170-1180); `polar_sor` (extension) over-relaxes it
+    const double mu_new = fma(omega, self.alpha * (self.ef + v) - self.mu_old, self.mu_old);
+    if (DET) pend[lane] = mu_new;
+    else reinterpret_cast<double *>(out)[2 * lane + 1] = mu_new;
     const double d = mu_new - self.mu_old;
     d2 = d * d;
   }
   d2 += dpp_full<0xB1>(d2);
   d2 += dpp_full<0x4E>(d2);
-  if (lane == 0 && d2 != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), d2);
+  if (DET) { if (lane == 0) pend[3] = d2; }
+  else if (lane == 0 && d2 != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), d2);
+}
+// DET: one workgroup folds a launch's pending dipoles into the record table and adds their (dmu)^2 -- thread-strided partial
+// sums, wave butterflies, then the waves in order: the same association every run -- onto the sweep's running sum
+__global__ __launch_bounds__(1024) void k_lp_commit(int nrows, long long row0, const int2 *__restrict__ desc,
+                                                    const double *__restrict__ pend, AtomRec *recA, AtomRec *recB, int jacobi,
+                                                    Scal *scal) {
+  if (scal->done) return;
+  __shared__ double red[16];
+  AtomRec *dst = jacobi ? (scal->cur ? recA : recB) : recA;
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+    const int i = desc[r].x;
+    const double *p = pend + 4 * (size_t)(row0 + r);
+    dst[i].mx = p[0]; dst[i].my = p[1]; dst[i].mz = p[2];
+    acc += p[3];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sum = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) sum += red[k];
+    scal->det_change += sum;
+  }
 }
 #define POLAR_LP_TILE 4096
 // Index stream layout of this kernel ("chunked"): a row's entries are stored in chunks of 4 trips (256 entries);
@@ -388,19 +424,19 @@ template <int WRAP, int DAMP, int NT>
 __device__ __forceinline__ void lp_trip(const char *rd0, const char *rd1, const char *rd2, int cur, int nxt, bool more,
                                         const char *srcc, int jnext, unsigned g0, unsigned g1, unsigned g2, unsigned g3,
                                         char *tile0, const AtomRec &ri, double px, double py, double pz, const Box &box,
-                                        double pd, const ExpCoef &K, double &ax, double &ay, double &az, int ablate) {
+                                        double pd, const ExpCoef &K, double &ax, double &ay, double &az POLAR_LAB_PARAM) {
   // the compiler waits vmcnt(0) here: the DMA of this trip (issued one trip ago)
   const double2 A = *reinterpret_cast<const double2 *>(rd0 + cur);
   const double2 B = *reinterpret_cast<const double2 *>(rd1 + cur);
   const double2 C = *reinterpret_cast<const double2 *>(rd2 + cur);
-  if (more && !(ablate & 8)) {  // wave-uniform
+  if (more && !POLAR_ABL(8)) {  // wave-uniform
     if (NT == 1) __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads above are done before the tile is rewritten
     char *nt = tile0 + nxt;
-    const int jg = (ablate & 4) ? 0 : jnext;  // lab: every gather hits record 0
+    const int jg = POLAR_ABL(4) ? 0 : jnext;  // lab: every gather hits record 0
     lp_gather<0>(srcc, jg, g0, nt); lp_gather<1>(srcc, jg, g1, nt);
     lp_gather<2>(srcc, jg, g2, nt); lp_gather<3>(srcc, jg, g3, nt);
   }
-  if (ablate & 16) { ax += A.x + B.y + C.x; return; }  // lab: no pair arithmetic
+  if (POLAR_ABL(16)) { ax += A.x + B.y + C.x; return; }  // lab: no pair arithmetic
   double dx = ri.x - A.x, dy = ri.y - B.x, dz = ri.z - C.x;
   if (WRAP == 1) {
     dx = fma(-px, rint(dx * box.inv[0]), dx);
@@ -429,8 +465,8 @@ __device__ __forceinline__ void lp_first_gather(const char *srcc, int joff, int 
 }
 template <int WRAP, int DAMP, int NT>
 __device__ __forceinline__ void lp_row(int T, const int4 *pc, const int4 &Ja0, const int4 &Jb0, const char *srcc, char *tile0, int lane, const AtomRec &ri,
-                                       const Box &box, double pd, const ExpCoef &K, double &ax, double &ay, double &az,
-                                       int ablate) {
+                                       const Box &box, double pd, const ExpCoef &K, double &ax, double &ay, double &az
+                                       POLAR_LAB_PARAM) {
   const double px = box.periodic[0] ? box.prd[0] : 0.0, py = box.periodic[1] ? box.prd[1] : 0.0,
                pz = box.periodic[2] ? box.prd[2] : 0.0;
   const int k = lane & 3, q = lane >> 2;
@@ -446,7 +482,7 @@ __device__ __forceinline__ void lp_row(int T, const int4 *pc, const int4 &Ja0, c
   const int other = NT == 1 ? 0 : POLAR_LP_TILE;
 #define POLAR_LP_TRIP(CUR, NXT, TT, JNEXT)                                                                              \
   lp_trip<WRAP, DAMP, NT>(rd0, rd1, rd2, CUR, NXT, t0 + (TT) + 1 < T, srcc, JNEXT, g0, g1, g2, g3, tile0, ri, px, py, pz, \
-                          box, pd, K, ax, ay, az, ablate)
+                          box, pd, K, ax, ay, az POLAR_LAB_PASS)
   for (int c = 0; c < C; c++) {
     const int t0 = 4 * c;
     if (c + 2 < C) Jc = pc[64 * (c + 2)];  // rows longer than 8 trips: two chunks ahead
@@ -472,12 +508,12 @@ __global__ void k_lp_desc(int nrows, const int *__restrict__ rows, RowList ddl, 
   if (c > ddl.pitch) c = ddl.pitch;
   desc[r] = make_int2(i, (int)((c + 63) >> 6) | (dd_wrap[i] ? 0x40000000 : 0));
 }
-template <int EP, int DAMP, int NT>
+template <int EP, int DAMP, int NT, bool DET>
 __global__ __launch_bounds__(1024) void k_field_lp(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA,
                                                    AtomRec *recB, Box box, long long pitch,
                                                    const int *__restrict__ dd_j, double pd, ExpCoef K,
                                                    const double *__restrict__ ef, const Scal *scal,
-                                                   double *__restrict__ slots, int ablate) {
+                                                   double *__restrict__ slots, double omega, double *pend POLAR_LAB_PARAM) {
   extern __shared__ __attribute__((aligned(16))) char lp_lds[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -496,11 +532,11 @@ __global__ __launch_bounds__(1024) void k_field_lp(int nrows, long long row0, co
   if (done) return;
   const int i = __builtin_amdgcn_readfirstlane(de.x);
   int T = __builtin_amdgcn_readfirstlane(de.y & 0xFFFF);
-  const int wrapped = __builtin_amdgcn_readfirstlane(de.y >> 30) | (ablate & 2);
+  const int wrapped = __builtin_amdgcn_readfirstlane(de.y >> 30) | POLAR_ABL(2);
   const int cur = __builtin_amdgcn_readfirstlane(curv);
   const AtomRec *src = (EP == EP_JACOBI && cur) ? recB : recA;
   AtomRec *dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
-  if (ablate & 1) T = 0;  // lab switches (POLAR_ABLATE): timing only, wrong numbers
+  if (POLAR_ABL(1)) T = 0;  // lab switches (POLAR_ABLATE, lab build only): timing only, wrong numbers
   const char *srcc = reinterpret_cast<const char *>(src);
   char *tile0 = lp_lds + (size_t)wv * (NT * POLAR_LP_TILE);
   if (T > 0) lp_first_gather(srcc, Ja0.x, lane, tile0);  // second round trip: the first gathers ...
@@ -512,12 +548,13 @@ __global__ __launch_bounds__(1024) void k_field_lp(int nrows, long long row0, co
   const LpSelf self = lp_self(lane, src + i, ef + 3 * (size_t)i);
   double ax = 0.0, ay = 0.0, az = 0.0;
   // rows whose list holds no pair across a periodic face (flag written by k_nl_build) skip the minimum-image wrap
-  if (!wrapped) lp_row<0, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
-  else if (!box.triclinic) lp_row<1, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
-  else lp_row<2, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az, ablate);
-  lp_finish(ax, ay, az, lane, self, dst + i, slots);
+  if (!wrapped) lp_row<0, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az POLAR_LAB_PASS);
+  else if (!box.triclinic) lp_row<1, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az POLAR_LAB_PASS);
+  else lp_row<2, DAMP, NT>(T, pc, Ja0, Jb0, srcc, tile0, lane, ri, box, pd, K, ax, ay, az POLAR_LAB_PASS);
+  lp_finish<DET>(ax, ay, az, lane, self, dst + i, slots, omega, DET ? pend + 4 * (size_t)(row0 + row) : nullptr);
 }
 
+#ifdef POLAR_LAB
 // ------------------------------------------------------------------------------------------
 // Cluster sweep: one wave = one CLUSTER of up to four rows (polar_lists.hpp, k_cl_build) against the union of
 // their neighbours.  Per 64-neighbour trip the gather, the index stream and the LDS reads are paid once and the
@@ -923,6 +960,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restric
   }
 }
 
+#endif  // POLAR_LAB
+
 // ------------------------------------------------------------------------------------------
 // a7  sequential (ranked) Gauss-Seidel, exact-order, blocked for the GPU.
 // F_j = -sum_k T_jk mu_k is kept current for every atom.  For a block of 64 consecutive atoms of
@@ -1169,6 +1208,8 @@ __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double 
   if (threadIdx.x != 0) return;
   double sum = 0.0;
   for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+  sum += scal->det_change;  // (`deterministic yes`: the sweep's changes were summed in a fixed order by k_lp_commit)
+  scal->det_change = 0.0;
   scal->change = sum;  // this handle's own sum (exported to the all-reduce in multi-GPU runs)
   // multi-GPU: the all-reduced sum over ranks arrives through global_change (device memory)
   const double change = (global_change ? *global_change : sum) / ((double)nlocal * 3.0);
@@ -1198,6 +1239,8 @@ __global__ __launch_bounds__(POLAR_NSLOT) void k_fold_change(Scal *scal, double 
   if (threadIdx.x != 0) return;
   double sum = 0.0;
   for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+  sum += scal->det_change;
+  scal->det_change = 0.0;
   scal->change = sum;
   *dst = sum;
 }
@@ -1234,7 +1277,7 @@ __global__ void k_zero_slots(double *__restrict__ slots, Scal *s) {
   if (t == 0 && s) {
     s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;
     for (int k = 0; k < 6; k++) s->virial[k] = 0.0;
-    s->change = 0.0; s->last_change = 0.0; s->pad = 0;
+    s->change = 0.0; s->last_change = 0.0; s->pad = 0; s->det_change = 0.0;
     s->rmin_bits = (unsigned long long)__double_as_longlong(1000.0);
     s->iterations = 0; s->done = 0; s->status = 0; s->cur = 0; s->sweeps = 0;
   }

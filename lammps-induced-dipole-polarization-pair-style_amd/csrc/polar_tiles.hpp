@@ -68,6 +68,12 @@ __device__ __forceinline__ void tile_shift(const Box &b, int code, double &sx, d
   sz = s2 * b.prd[2];
 }
 
+// LDS image of a workgroup: [tile header, 64 B][row table, MAXROWS x 16 B][records, (U + 1) x 48 B][slack]
+#define POLAR_TILE_LDS_ROWS 64
+#define POLAR_TILE_LDS_REC (POLAR_TILE_LDS_ROWS + 16 * POLAR_TILE_MAXROWS)
+#define POLAR_TILE_LDS_SLACK 1024  // the last DMA instruction of the staging pass writes a whole 64-piece block
+
+#ifdef POLAR_LAB  // the kernels below exist in the lab build only (the types and layout constants above are shared with the host code)
 // AtomRec (both buffers hold the same initial dipoles) -> sweep records, and the solved dipoles back
 __global__ void k_srec_pack(int n, const AtomRec *__restrict__ r, SRec *__restrict__ s0, SRec *__restrict__ s1) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,10 +389,6 @@ __device__ __forceinline__ void tile_read(const char *lds, unsigned pos, double2
   C = *reinterpret_cast<const double2 *>(p + 32);
 }
 
-// LDS image of a workgroup: [tile header, 64 B][row table, MAXROWS x 16 B][records, (U + 1) x 48 B][slack]
-#define POLAR_TILE_LDS_ROWS 64
-#define POLAR_TILE_LDS_REC (POLAR_TILE_LDS_ROWS + 16 * POLAR_TILE_MAXROWS)
-#define POLAR_TILE_LDS_SLACK 1024  // the last DMA instruction of the staging pass writes a whole 64-piece block
 
 // workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's global loads and stores
 // (vmcnt(0)): here that would expose, at every sub-phase, the latency of the index stream requested for the NEXT row.
@@ -708,5 +710,7 @@ __global__ void k_tile_commit(TileLaunch L, const TileHdr *__restrict__ hdr, con
     reinterpret_cast<double *>(s0 + i)[2 * comp + 1] = pend[3 * (size_t)i + comp];
   }
 }
+
+#endif  // POLAR_LAB
 
 }  // namespace polar

@@ -347,6 +347,7 @@ class PolarSettings:
     device_neigh: int = 0   # extension: the LAMMPS shim builds the LJ/coul list on the device
     restart_polar: int = 0  # extension: restart files carry the polarization keywords
     deterministic: int = 0  # extension: sweeps commit their updates between launches (bit-reproducible runs)
+    polar_sor: float = 1.0  # extension: over-relaxation factor of the list-mode Gauss-Seidel update (1 = reference)
 
 
 @dataclass
@@ -757,6 +758,10 @@ def parse_pair_style_args(args, base=None):
             st.restart_polar = yn[v]
         elif k == "deterministic":  # extension keyword (not in the reference)
             st.deterministic = yn[v]
+        elif k == "polar_sor":  # extension keyword (not in the reference)
+            st.polar_sor = float(v)
+            if not 0.0 < st.polar_sor < 2.0:
+                raise ValueError("Illegal pair_style command")
         else:
             raise ValueError("Illegal pair_style command")
         i += 2

@@ -333,10 +333,14 @@ def test_row_sharded_handles_tally_per_atom(wl, pkg, oracle):
                                   "POLAR_SWEEP_KERNEL=2;POLAR_LP_TILES=1", "POLAR_SWEEP_KERNEL=2;POLAR_LP_QM=0",
                                   "POLAR_SWEEP_KERNEL=2;POLAR_LP_DEPTH=2",
                                   "POLAR_SWEEP_KERNEL=2;POLAR_LP_DEPTH=3", "POLAR_SWEEP_KERNEL=4",
-                                  "POLAR_SWEEP_KERNEL=4;POLAR_DETERMINISTIC=1", "POLAR_SWEEP_KERNEL=2", "POLAR_SWEEP_KERNEL=3",
+                                  "POLAR_SWEEP_KERNEL=4;POLAR_DETERMINISTIC=1", "POLAR_SWEEP_KERNEL=4;POLAR_TILE_WAVES=8",
+                                  "POLAR_SWEEP_KERNEL=4;POLAR_TILE_WIDE=1;POLAR_TILE_WAVES=8", "POLAR_SWEEP_KERNEL=2",
+                                  "POLAR_SWEEP_KERNEL=2;POLAR_DETERMINISTIC=1", "POLAR_SWEEP_KERNEL=3",
                                   "POLAR_SWEEP_KERNEL=3;POLAR_CLUSTER_MAX=2"])
 def test_alternative_sweep_kernels_agree(knob, wl, pkg, oracle, monkeypatch):
-    """The list sweep exists in several forms besides the default (k_field_lp, two LDS tiles): the register-staged
+    """LAB BUILD (libpolar_mi355x_lab.so, -DPOLAR_LAB): the sweep kernels that were built, measured and not kept as the
+    default stay reproducible -- the product library contains none of them.
+    The list sweep exists in several forms besides the default (k_field_lp, two LDS tiles): the register-staged
     lane-per-pair kernel (POLAR_SWEEP_KERNEL=1), the component-per-lane kernel of round 1 (0) with its three stream modes
     (POLAR_CACHE_R2: cached (s3,s5), cached r^2, nothing cached), k_field_lp with one tile or with hand-counted
     gathers two / three trips ahead, and the cluster-row sweep (3).  All must reproduce the oracle (Jacobi sweep by
@@ -348,12 +352,12 @@ def test_alternative_sweep_kernels_agree(knob, wl, pkg, oracle, monkeypatch):
              "dd_cutoff", "9.0"]
     s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
     ref = oracle.compute(s, eflag=1, vflag=2)
-    out = pkg.pair_from_system(s).compute()
+    out = pkg.pair_from_system(s, lab=True).compute()
     assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
     extra = ["use_previous", "no", "precision", "1e-13", "max_iterations", "200", "dd_cutoff", "9.0"]
     s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"), extra_args=extra)
     ref = oracle.compute(s, eflag=1, vflag=2)
-    out = pkg.pair_from_system(s).compute()
+    out = pkg.pair_from_system(s, lab=True).compute()
     assert out["status"] == 0
     assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
     assert rel(out["eng_pol"], ref["eng_pol"]) < TOL
@@ -362,9 +366,68 @@ def test_alternative_sweep_kernels_agree(knob, wl, pkg, oracle, monkeypatch):
              "dd_cutoff", "9.0", "damp_type", "none"]
     s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
     ref = oracle.compute(s, eflag=1, vflag=2)
-    out = pkg.pair_from_system(s).compute()
+    out = pkg.pair_from_system(s, lab=True).compute()
     assert np.max(np.abs(out["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
     assert rel(out["eng_pol"], ref["eng_pol"]) < TOL
+
+
+def test_product_library_ignores_lab_switches(wl, pkg, monkeypatch):
+    """the shipped library is compiled without -DPOLAR_LAB -- POLAR_ABLATE (timing switches that return
+    wrong dipoles), POLAR_SWEEP_KERNEL and the other lab knobs are not even read, and its binary holds none of the lab
+    kernels."""
+    extra = ["use_previous", "no", "precision", "1e-12", "max_iterations", "100", "dd_cutoff", "9.0"]
+    s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
+    base = pkg.pair_from_system(s).compute()
+    for k, v in (("POLAR_ABLATE", "16"), ("POLAR_SWEEP_KERNEL", "0"), ("POLAR_LP_TILES", "1"), ("POLAR_QUAD_BLOCK", "1024")):
+        monkeypatch.setenv(k, v)
+    out = pkg.pair_from_system(s).compute()
+    assert out["iterations"] == base["iterations"] and out["ncolors"] == base["ncolors"]
+    assert np.max(np.abs(out["mu"] - base["mu"])) / np.max(np.abs(base["mu"])) < 1e-8    # (in-place phases: not bit for bit)
+    assert rel(out["eng_pol"], base["eng_pol"]) < 1e-9
+    blob = open(pkg.LIB_PATH, "rb").read()
+    for name in (b"k_field_quad", b"k_field_cl", b"k_field_tile", b"k_field_lpa", b"k_dd_scalars", b"POLAR_ABLATE", b"POLAR_SWEEP_KERNEL"):
+        assert name not in blob, name
+    assert b"k_field_lp" in blob
+    lab = open(pkg.LIB_PATH_LAB, "rb").read()
+    assert b"k_field_tile" in lab and b"POLAR_ABLATE" in lab
+
+
+@pytest.mark.parametrize("mode", ["fixed", "precision", "jacobi"])
+def test_deterministic_keyword_gives_bit_identical_runs(mode, wl, pkg, oracle):
+    """`deterministic yes` (extension): atoms of a cell in atom order, phase updates committed after the launch, the
+    sum of the dipole changes formed in a fixed order -- two handles fed the same input return the same bits
+    (configs[1]'s setting: fixed_iteration 30 on a replicated MOF box), and the oracle's fixed point."""
+    solver = {"fixed": ["fixed_iteration", "yes", "max_iterations", "30"],
+              "precision": ["precision", "1e-12", "max_iterations", "100"],
+              "jacobi": ["polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "6"]}[mode]
+    args = ["use_previous", "no", "polar_gs_ranked", "yes", "dd_cutoff", "12.8345", "deterministic", "yes"] + solver
+    s = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 2, 2, 2, extra_args=args)
+    outs = []
+    for _ in range(2):
+        p = pkg.pair_from_system(s)
+        outs.append(p.compute())
+        p.close()
+    assert np.array_equal(outs[0]["mu"], outs[1]["mu"])
+    assert outs[0]["rms_dmu"] == outs[1]["rms_dmu"] and outs[0]["iterations"] == outs[1]["iterations"]
+    assert np.max(np.abs(outs[0]["f"] - outs[1]["f"])) <= 1e-12 * np.max(np.abs(outs[0]["f"]))   # (energies and forces: slot atomics)
+    if mode == "precision":
+        ref = oracle.compute(s, eflag=1, vflag=2)
+        assert np.max(np.abs(outs[0]["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+
+
+def test_polar_sor_reaches_the_same_fixed_point_in_fewer_sweeps(wl, pkg, oracle):
+    """`polar_sor <omega>` (extension): over-relaxed colour-phase Gauss-Seidel under the reference's stop rule."""
+    base = ["use_previous", "no", "polar_gs_ranked", "yes", "dd_cutoff", "12.8345", "precision", "1e-12", "max_iterations", "100"]
+    s1 = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 2, 2, 2, extra_args=base)
+    s2 = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 2, 2, 2, extra_args=base + ["polar_sor", "1.15"])
+    a = pkg.pair_from_system(s1).compute()
+    b = pkg.pair_from_system(s2).compute()
+    assert a["status"] == b["status"] == 0
+    assert b["iterations"] < a["iterations"] - 3
+    assert np.max(np.abs(a["mu"] - b["mu"])) / np.max(np.abs(a["mu"])) < TOL
+    assert rel(a["eng_pol"], b["eng_pol"]) < TOL
+    with pytest.raises(Exception):
+        wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 1, 1, 1, extra_args=base + ["polar_sor", "2.5"])
 
 
 @pytest.mark.parametrize("case", ["bulk_h2", "mof5_h2", "sifsix_co2"])
@@ -580,10 +643,10 @@ def test_colour_clash_on_a_reneighbor_step_relays_the_rows(kernel, wl, pkg, orac
     one colour closer than the keep distance on a reneighbor step -- here: the polarizable atoms relabelled among
     themselves, as an atom sort does, so that the stored colours belong to other atoms) must have the dd rows laid out
     again for the new colouring.  Second step on the same handle against the oracle on the relabelled system."""
-    monkeypatch.setenv("POLAR_SWEEP_KERNEL", kernel)
+    monkeypatch.setenv("POLAR_SWEEP_KERNEL", kernel)   # read by the lab build only; the product library always runs kernel 2
     extra = ["use_previous", "no", "precision", "1e-13", "max_iterations", "200", "dd_cutoff", "9.0"]
     s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"), extra_args=extra)
-    p = pkg.pair_from_system(s)
+    p = pkg.pair_from_system(s, lab=(kernel != "2"))
     first = p.compute()
     ref = oracle.compute(s, eflag=1, vflag=2)
     assert np.max(np.abs(first["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL

@@ -38,7 +38,7 @@ for case in cases:
             k, _, v = e.partition("=")
             os.environ[k] = v
             touched.add(k)
-        p = pkg.pair_from_system(s)
+        p = pkg.pair_from_system(s, lab=os.environ.get("LAB_LIB", "1") != "0")   # the lab build has the kernels and knobs compared here
         for _ in range(2):
             out = p.compute_resident()
         t, tt = [], []
