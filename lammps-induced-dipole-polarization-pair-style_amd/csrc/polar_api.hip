@@ -142,6 +142,8 @@ struct polar_handle {
   DBuf<double2> d_dd_s;
   DBuf<int2> d_lpdesc;  // row descriptors of k_field_lp
   DBuf<double> d_lp_pend;  // `deterministic yes`: {mu_x, mu_y, mu_z, (dmu)^2} per launch row until k_lp_commit
+  DBuf<double> d_lp_part;  // ... and the sums of (dmu)^2 per 256 launch rows (k_solver_step adds them in order)
+  int lp_npart = 0;
   DBuf<int> d_slot;     // lp sweep: launch row of every atom's dd row (s space), -1: none
   // cluster rows (sweep_kernel 3, k_field_cl): clusters sorted by colour; color_off then counts clusters
   std::vector<int> h_cl;        // [ncl][4] member atoms (orig ids, -1 padded)
@@ -325,6 +327,9 @@ inline bool sharded(const polar_handle *h) { return own_n(h) != h->nlocal; }
 // lists were laid out -- a clash found on a reneighbor step, a changed alpha pattern -- makes them stale)
 inline bool slots_current(const polar_handle *h) { return h->slots_by_color && h->slots_epoch == h->color_epoch; }
 inline bool deterministic(const polar_handle *h) { return h->deterministic || h->ph.st.deterministic; }
+// `deterministic yes` with the row sweep: where the end-of-sweep kernels find the sweep's partial sums of (dmu)^2
+inline const double *det_part(const polar_handle *h) { return (deterministic(h) && h->ph.st.dd_cutoff > 0.0 && h->sweep_kernel == 2 && h->lp_npart > 0) ? h->d_lp_part.p : nullptr; }
+inline int det_npart(const polar_handle *h) { return det_part(h) ? h->lp_npart : 0; }
 inline bool tile_mode(const polar_handle *h) { return h->ph.st.dd_cutoff > 0.0 && h->sweep_kernel == 4; }
 // where the dipoles live during a solve (exchange and debug kernels): the sweep records in tile mode, else the AtomRecs
 inline MuView mu_view(const polar_handle *h) {
@@ -895,7 +900,14 @@ void prepare_lp(polar_handle *h) {
   const bool gs = st.polar_gs || st.polar_gs_ranked;
   const int tot = gs ? (h->color_off.empty() ? 0 : h->color_off.back()) : own_n(h);
   h->d_lpdesc.ensure((size_t)tot + 1);
-  if (deterministic(h)) h->d_lp_pend.ensure(4 * (size_t)tot + 4);
+  h->lp_npart = 0;
+  if (deterministic(h)) {  // one partial sum per 256 rows of every launch; launches are 256-aligned in the array
+    h->d_lp_pend.ensure(4 * (size_t)tot + 4);
+    const int nlaunch = gs ? (int)h->color_off.size() - 1 : 1;
+    h->lp_npart = tot / 256 + nlaunch + 1;
+    h->d_lp_part.ensure((size_t)h->lp_npart + 1);
+    HIPCHECK(hipMemsetAsync(h->d_lp_part.p, 0, (size_t)h->lp_npart * sizeof(double), h->stream));
+  }
   if (tot > 0)
     k_lp_desc<<<nblk(tot, 256), 256, 0, h->stream>>>(tot, gs ? h->d_rows.p : own_rows(h), RowList{h->d_dd_cnt.p, h->dd_pitch},
                                                      h->d_dd_wrap.p, h->d_lpdesc.p);
@@ -940,7 +952,11 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
   if (det) {
     if (expd) FL(0, 2, true); else FL(1, 2, true);
     // the launch only read the record table: its rows' new dipoles and the sum of their changes are folded in now
-    k_lp_commit<<<1, 1024, 0, h->stream>>>(nrows, row0, desc, h->d_lp_pend.p, h->d_rec0.p, h->d_rec1.p, EP == EP_JACOBI ? 1 : 0, h->d_scal.p);
+    // (launch `l` of the sweep starts at row0: its partial sums start at slot row0 / 256 + l -- disjoint for every launch)
+    int launch_no = 0;
+    if (EP == EP_INPLACE) while (launch_no + 1 < (int)h->color_off.size() && h->color_off[launch_no] < row0) launch_no++;
+    k_lp_commit<<<nblk(nrows, 256), 256, 0, h->stream>>>(nrows, row0, desc, h->d_lp_pend.p, h->d_rec0.p, h->d_rec1.p, EP == EP_JACOBI ? 1 : 0,
+                                                      h->d_scal.p, h->d_lp_part.p + row0 / 256 + launch_no);
   } else {
     if (expd) FL(0, 2, false); else FL(1, 2, false);
   }
@@ -1223,7 +1239,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
       debug_trace(h, sw, !gs);
       if (lazy && sw < max_sweeps - 2) continue;
       const int count = (lazy && sw == max_sweeps - 2) ? max_sweeps - 1 : 1;
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count, det_part(h), det_npart(h));
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
@@ -1240,7 +1256,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
         k_gs_push_T6<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, b0, h->d_T6.p, h->d_rec0.p, h->d_dmu.p, h->d_F.p, h->d_scal.p);
       }
       debug_trace(h, sw, false);
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, nullptr, 0);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
@@ -1272,7 +1288,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
         }
       }
       debug_trace(h, sw, false);
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, nullptr, 0);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
@@ -2216,7 +2232,7 @@ int polar_step_sweep_end_n(polar_handle *h, const double *dev_global_change, int
     const bool gs = st.polar_gs || st.polar_gs_ranked;
     if (count > 1 && !(gs && st.fixed_iteration)) throw InputError("polar_step_sweep_end_n: count > 1 needs fixed-iteration Gauss-Seidel");
     k_solver_step<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
-                                          gs ? 0 : 1, dev_global_change, count);
+                                          gs ? 0 : 1, dev_global_change, count, det_part(h), det_npart(h));
     return POLAR_OK;
   });
 }
@@ -2277,7 +2293,7 @@ int polar_mu_scatter_idx(polar_handle *h, const int *dev_idx, long long n, const
 int polar_change_export(polar_handle *h, double *dev_dst) {
   return guarded(h, [&]() {
     need_device(h);
-    k_fold_change<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, dev_dst);
+    k_fold_change<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, dev_dst, det_part(h), det_npart(h));
     return POLAR_OK;
   });
 }
@@ -2315,7 +2331,7 @@ int polar_step_change_get(polar_handle *h, double *sum) {
     need_device(h);
     if (!sum) throw InputError("polar_step_change_get: null pointer");
     h->d_xchg.ensure(8);
-    k_fold_change<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, h->d_xchg.p);
+    k_fold_change<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, h->d_xchg.p, det_part(h), det_npart(h));
     HIPCHECK(hipMemcpyAsync(sum, h->d_xchg.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     return (int)POLAR_OK;

@@ -384,29 +384,27 @@ __device__ __forceinline__ void lp_finish(double ax, double ay, double az, int l
   if (DET) { if (lane == 0) pend[3] = d2; }
   else if (lane == 0 && d2 != 0.0) atomicAdd(slot_ptr(slots, SL_CHANGE), d2);
 }
-// DET: one workgroup folds a launch's pending dipoles into the record table and adds their (dmu)^2 -- thread-strided partial
-// sums, wave butterflies, then the waves in order: the same association every run -- onto the sweep's running sum
-__global__ __launch_bounds__(1024) void k_lp_commit(int nrows, long long row0, const int2 *__restrict__ desc,
-                                                    const double *__restrict__ pend, AtomRec *recA, AtomRec *recB, int jacobi,
-                                                    Scal *scal) {
+// DET: fold a launch's pending dipoles into the record table; every workgroup leaves the sum of its 256 rows' (dmu)^2 --
+// wave butterflies, then the four waves in order: the same association every run -- in its own slot of `part`, which the
+// end-of-sweep kernel adds up in slot order
+__global__ __launch_bounds__(256) void k_lp_commit(int nrows, long long row0, const int2 *__restrict__ desc,
+                                                   const double *__restrict__ pend, AtomRec *recA, AtomRec *recB, int jacobi,
+                                                   const Scal *scal, double *__restrict__ part) {
   if (scal->done) return;
-  __shared__ double red[16];
+  __shared__ double red[4];
   AtomRec *dst = jacobi ? (scal->cur ? recA : recB) : recA;
+  const int r = blockIdx.x * 256 + threadIdx.x;
   double acc = 0.0;
-  for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+  if (r < nrows) {
     const int i = desc[r].x;
     const double *p = pend + 4 * (size_t)(row0 + r);
     dst[i].mx = p[0]; dst[i].my = p[1]; dst[i].mz = p[2];
-    acc += p[3];
+    acc = p[3];
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double sum = 0.0;
-    for (int k = 0; k < (int)(blockDim.x >> 6); k++) sum += red[k];
-    scal->det_change += sum;
-  }
+  if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 #define POLAR_LP_TILE 4096
 // Index stream layout of this kernel ("chunked"): a row's entries are stored in chunks of 4 trips (256 entries);
@@ -1197,19 +1195,20 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_gs_push_T6(int n, int b0, const
 __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double *__restrict__ slots, int nlocal,
                                                            int fixed_iteration, int iterations_max, double precision,
                                                            int jacobi, const double *__restrict__ global_change,
-                                                           int count) {
+                                                           int count, const double *__restrict__ part, int npart) {
   if (scal->done) return;
   __shared__ double red[POLAR_NSLOT / 64];
   double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
   slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE] = 0.0;
+  // `deterministic yes`: the sweep's changes sit in `part` (k_lp_commit), one value per 256 rows in launch order; thread t adds
+  // slots t, t + 1024, ...: a fixed association (the atomic slots above stay zero in that mode)
+  for (int k = threadIdx.x; k < npart; k += POLAR_NSLOT) v += part[k];
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x != 0) return;
   double sum = 0.0;
   for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
-  sum += scal->det_change;  // (`deterministic yes`: the sweep's changes were summed in a fixed order by k_lp_commit)
-  scal->det_change = 0.0;
   scal->change = sum;  // this handle's own sum (exported to the all-reduce in multi-GPU runs)
   // multi-GPU: the all-reduced sum over ranks arrives through global_change (device memory)
   const double change = (global_change ? *global_change : sum) / ((double)nlocal * 3.0);
@@ -1229,18 +1228,18 @@ __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double 
 }
 
 // fold the change slots into scal->change without touching the loop state (multi-GPU export)
-__global__ __launch_bounds__(POLAR_NSLOT) void k_fold_change(Scal *scal, double *__restrict__ slots, double *dst) {
+__global__ __launch_bounds__(POLAR_NSLOT) void k_fold_change(Scal *scal, double *__restrict__ slots, double *dst,
+                                                           const double *__restrict__ part, int npart) {
   __shared__ double red[POLAR_NSLOT / 64];
   double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
   slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE] = 0.0;
+  for (int k = threadIdx.x; k < npart; k += POLAR_NSLOT) v += part[k];
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x != 0) return;
   double sum = 0.0;
   for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
-  sum += scal->det_change;
-  scal->det_change = 0.0;
   scal->change = sum;
   *dst = sum;
 }

@@ -6,6 +6,7 @@
 
 For every case the first kernel is the reference: forces / dipoles of the others are compared to it.
 Scratch tool: results to stdout."""
+import copy
 import importlib
 import os
 import sys
@@ -34,11 +35,18 @@ for case in cases:
         name, _, envs = kspec.partition("=")
         for k in touched:
             os.environ.pop(k, None)
+        import dataclasses
+        sk = s
         for e in filter(None, envs.split(";")):
+            if e.startswith("kw:"):   # a pair_style keyword of the settings object, e.g. kw:polar_sor:1.15 / kw:deterministic:1
+                _, key, val = e.split(":")
+                sk = copy.copy(sk)
+                sk.settings = dataclasses.replace(sk.settings, **{key: type(getattr(sk.settings, key))(float(val))})
+                continue
             k, _, v = e.partition("=")
             os.environ[k] = v
             touched.add(k)
-        p = pkg.pair_from_system(s, lab=os.environ.get("LAB_LIB", "1") != "0")   # the lab build has the kernels and knobs compared here
+        p = pkg.pair_from_system(sk, lab=os.environ.get("LAB_LIB", "1") != "0")   # the lab build has the kernels and knobs compared here
         for _ in range(2):
             out = p.compute_resident()
         t, tt = [], []
