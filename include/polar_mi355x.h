@@ -148,6 +148,10 @@ int polar_set_box(polar_handle *h, const double boxlo[3], const double prd[3], c
 /* atom->x,q,static_polarizability,type,molecule for nlocal+nghost atoms (src/atom.h:160-163) */
 int polar_set_atoms(polar_handle *h, int nlocal, int nghost, const double *x, const double *q,
                     const double *alpha, const int *type, const int *molecule);
+/* positions only, between two neighbor-list builds (neighbor->ago != 0): LAMMPS neither reorders nor exchanges atoms on such
+ * steps, so q, static_polarizability, type and molecule on the device still hold (what PS.cpp:125-188 re-reads through atom->
+ * every step is, on these steps, only x).  Same nlocal / nghost as the last polar_set_atoms, or POLAR_ERR_INPUT. */
+int polar_set_positions(polar_handle *h, int nlocal, int nghost, const double *x);
 /* NeighList inum/ilist/numneigh/firstneigh (src/neigh_list.h:46-50); call when neighbor->ago == 0 */
 int polar_set_neighbors(polar_handle *h, int inum, const int *ilist, const int *numneigh,
                         int *const *firstneigh);

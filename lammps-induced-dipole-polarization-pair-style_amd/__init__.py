@@ -101,6 +101,7 @@ EXPORTS = {
                        + [_dp] * 8),
     "polar_set_box": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip, C.c_int]),
     "polar_set_atoms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _ip, _ip]),
+    "polar_set_positions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp]),
     "polar_set_neighbors": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.POINTER(_ip)]),
     "polar_set_neighbors_csr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _llp, _ip]),
     "polar_build_neighbors": (C.c_int, [C.c_void_p, _dp, _ip, _ip, _ip, C.c_int, _ip, C.c_int]),
@@ -298,6 +299,12 @@ class PolarPair:
         assert x.shape == (nlocal + nghost, 3) and len(q) == len(alpha) == len(typ) == len(mol) == nlocal + nghost
         self._ck(self.L.polar_set_atoms(self.h, nlocal, nghost, _dptr(x), _dptr(q), _dptr(alpha), _iptr(typ), _iptr(mol)))
         self.nlocal, self.nghost = nlocal, nghost
+
+    def set_positions(self, x):
+        """Positions only (steps between two neighbor-list builds)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.nlocal + self.nghost, 3)
+        self._ck(self.L.polar_set_positions(self.h, self.nlocal, self.nghost, _dptr(x)))
 
     def set_neighbors_csr(self, ilist, numneigh, firstneigh, neigh):
         ilist = np.ascontiguousarray(ilist, dtype=np.int32)

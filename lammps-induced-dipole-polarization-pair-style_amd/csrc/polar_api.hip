@@ -13,6 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pair_host.hpp"
@@ -164,6 +165,7 @@ struct polar_handle {
   int inum = 0;
   long long nneigh = 0;
   bool mu_resident = false;
+  bool mu_host_in_sync = false;  // the caller's mu array still holds what the last polar_compute returned (no polar_set_atoms since)
   // colour phases (cutoff-mode Gauss-Seidel)
   std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
   std::vector<int> h_rows;     // rows sorted by colour (host copy)
@@ -176,6 +178,15 @@ struct polar_handle {
   bool colors_recheck = false;  // a new neighbor list arrived: keep the colouring if it still separates every same-colour pair
   std::vector<int> h_color;     // colour of every atom (orig ids), -1: none
   DBuf<int> d_color_orig, d_color_s;
+  DBuf<int> d_cadj, d_cdeg, d_ccnt, d_cflags, d_crelabel;  // device colouring: conflict lists, degrees, rows per (colour, cell), round counters
+  DBuf<unsigned long long> d_cprio;
+  DBuf<double> d_cstat;
+  DBuf<long long> d_coff;
+  int *h_cflags = nullptr;        // pinned: round counters / fold counters of the device colouring
+  double *h_cstat = nullptr;      // pinned: rows and rank sums per colour
+  long long *h_coff = nullptr;    // pinned: first row of every phase
+  int cadj_pitch = 16;            // conflict-list entries per atom (grown when an atom has more neighbours within the colour distance)
+  int host_colors = 0;            // lab (POLAR_HOST_COLORS): rounds 1-2's host-side conflict graph + DSATUR instead of the device colouring
   int colors_reused = 0, colors_rebuilt = 0;
   double ms_color_host = 0.0;  // host time of the last colour rebuild; reported once, then cleared
   double color_dist = 2.4;  // A (POLAR_COLOR_DIST).  profiles/r01_lab_color_distance.txt: 2.4 -> 4 phases, 2.5-2.6 -> 5, with the same
@@ -278,6 +289,21 @@ double *staging(polar_handle *h, size_t count) {
 
 void need_device(polar_handle *h) {
   if (!h->have_device) throw NoDevice();
+}
+
+// host-side array work of a compute call (adding 4 MB of forces into the caller's array, copying dipoles and fields out of
+// the staging area): one thread moves ~10 GB/s, the PCIe link brings the data three times faster -- a few short-lived
+// threads, each on its own contiguous quarter
+template <typename F>
+void host_chunks(size_t total, F &&fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nt = total < (1u << 16) ? 1 : std::min<size_t>(4, hw ? hw : 1);
+  if (nt <= 1) { fn((size_t)0, total); return; }
+  std::vector<std::thread> th;
+  const size_t per = (total + nt - 1) / nt;
+  for (size_t t = 1; t < nt; t++) th.emplace_back([&, t]() { fn(std::min(total, t * per), std::min(total, (t + 1) * per)); });
+  fn((size_t)0, std::min(total, per));
+  for (auto &t : th) t.join();
 }
 
 // upload LJ tables + Coulomb tables from the host mirror (or raw setters) into P, repacked so that
@@ -688,6 +714,7 @@ void build_cluster_colors(polar_handle *h, const std::vector<double> &rank, cons
 inline void build_cluster_colors(polar_handle *, const std::vector<double> &, const std::vector<std::vector<int>> &, const std::vector<std::vector<int>> &) { throw std::logic_error("lab build only"); }
 #endif  // POLAR_LAB
 
+#ifdef POLAR_LAB
 // ---- host-side greedy distance colouring for the colour-phase Gauss-Seidel (cutoff mode) ----
 // Atoms of one colour are >= color_dist apart, so the couplings treated Jacobi-style inside a
 // phase are weak and the splitting M = D + L_colour stays convergent for the SPD dipole system
@@ -827,6 +854,129 @@ void build_colors(polar_handle *h, const std::vector<double> &rank) {
   if (!rows.empty()) HIPCHECK(hipMemcpy(h->d_rows_orig.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
   if (getenv("POLAR_DEBUG")) {
     fprintf(stderr, "[polar] %d colour phases (dist %.2f):", ncolors, h->color_dist);
+    for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
+    fprintf(stderr, "\n");
+  }
+  h->colors_valid = true;
+}
+
+#else
+inline void build_colors(polar_handle *, const std::vector<double> &) { throw std::logic_error("host-side colouring: lab build only"); }
+#endif  // POLAR_LAB
+
+// ---- the colour phases on the device (polar_lists.hpp, k_color_*): Jones-Plassmann with largest-degree-first priorities,
+//      then the highest classes dissolved into lower ones; phase order and the rows of every phase in cell order.
+//      Needs this step's cell order (phase_begin has run) and, for the ranked flavour, the rank metric in d_rank (s space).
+void build_colors_device(polar_handle *h, bool ranked) {
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  const long long ncell = h->ncell;
+  if (!h->h_cflags) {
+    HIPCHECK(hipHostMalloc((void **)&h->h_cflags, 96 * sizeof(int)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_cstat, 128 * sizeof(double)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_coff, 72 * sizeof(long long)));
+  }
+  h->d_cdeg.ensure(n + 1); h->d_cprio.ensure(n + 1);
+  h->d_color_s.ensure(n + 1); h->d_color_orig.ensure(n + 1); h->d_cflags.ensure(96); h->d_cstat.ensure(128); h->d_crelabel.ensure(64);
+  int *flags = h->d_cflags.p;  // [0] conflict-list overflow, [1..64] atoms deferred in round r, [65..] atoms that could not leave a folded class
+  HIPCHECK(hipMemsetAsync(h->d_color_orig.p, 0xFF, (size_t)(n + 1) * sizeof(int), s));
+  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
+  const double dc2 = h->color_dist * h->color_dist;
+  for (int attempt = 0;; attempt++) {  // conflict lists; an atom with more neighbours than the lists hold makes them wider
+    h->d_cadj.ensure((size_t)n * h->cadj_pitch + 16);
+    HIPCHECK(hipMemsetAsync(flags, 0, 96 * sizeof(int), s));
+    k_color_adj<<<nblk(n, 128), 128, 0, s>>>(n, h->d_pos4.p, h->d_perm.p, lo, hi, h->box, h->grid, h->d_cell_first.p, h->d_cell_fill.p, dc2,
+                                             h->cadj_pitch, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags);
+    HIPCHECK(hipMemcpyAsync(h->h_cflags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (h->h_cflags[0] <= h->cadj_pitch) break;
+    if (h->h_cflags[0] > 62 || attempt > 3) throw std::runtime_error("colouring: more than 62 polarizable atoms within the colour distance of one atom (64 colours at most): reduce POLAR_COLOR_DIST");
+    h->cadj_pitch = (h->h_cflags[0] + 4 + 7) / 8 * 8;
+  }
+  const int ap_ = h->cadj_pitch;
+  bool coloured = false;
+  int rounds = 0;
+  const int max_rounds = 4096, look_every = 32;
+  while (!coloured && rounds < max_rounds) {   // rounds (priorities, then decisions), then a look at how many atoms the last one deferred
+    const int hashed = rounds >= 1024 ? 1 : 0;  // index-ordered ties while the chains stay short (see k_color_prio)
+    for (int k = 0; k < look_every; k++) {
+      k_color_prio<<<nblk(n, 256), 256, 0, s>>>(n, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p, h->d_perm.p, h->d_cprio.p, hashed);
+      if (k == look_every - 1) HIPCHECK(hipMemsetAsync(flags + 1, 0, sizeof(int), s));
+      k_color_round<<<nblk(n, 256), 256, 0, s>>>(n, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags + 1);
+    }
+    rounds += look_every;
+    HIPCHECK(hipMemcpyAsync(h->h_cflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    coloured = h->h_cflags[1] == 0;
+  }
+  if (!coloured) throw std::runtime_error("colouring: Jones-Plassmann did not finish");
+  if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] device colouring: %d rounds\n", rounds);
+  auto stats = [&]() {  // rows and rank sums per colour -> number of colours in use
+    HIPCHECK(hipMemsetAsync(h->d_cstat.p, 0, 128 * sizeof(double), s));
+    k_color_stats<<<nblk(n, 256), 256, 0, s>>>(n, h->d_color_s.p, ranked ? h->d_rank.p : nullptr, h->d_cstat.p);
+    HIPCHECK(hipMemcpyAsync(h->h_cstat, h->d_cstat.p, 128 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    int nc = 0;
+    for (int c = 0; c < 64; c++) if (h->h_cstat[2 * c] > 0.0) nc = c + 1;
+    return nc;
+  };
+  int ncolors = stats();
+  auto fold = [&]() {  // dissolve the highest class while that works
+    for (int pass = 0; pass < 6 && ncolors > 1; pass++) {
+      k_color_fold<<<nblk(n, 256), 256, 0, s>>>(n, ap_, ncolors - 1, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p, flags + 65 + pass);
+      const int before = ncolors;
+      ncolors = stats();
+      if (ncolors == before) break;
+    }
+  };
+  fold();
+  // iterated greedy: the parallel rounds above decide many atoms on stale saturation counts and end one class above the
+  // sequential DSATUR on the MOF boxes (5 against 4); regrouping by old classes in a few different orders wins it back
+  for (int ig = 0, stale = 0; ig < 4 && stale < 2 && ncolors > 4; ig++) {
+    std::vector<int> ord((size_t)ncolors), rank(64, 0);
+    std::iota(ord.begin(), ord.end(), 0);
+    if (ig % 2 == 0) std::reverse(ord.begin(), ord.end());                                    // highest class first
+    else std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {                         // smallest / largest class first
+      return (ig % 4 == 1) ? h->h_cstat[2 * a] < h->h_cstat[2 * b] : h->h_cstat[2 * a] > h->h_cstat[2 * b]; });
+    for (int c = 0; c < ncolors; c++) rank[ord[c]] = c;
+    HIPCHECK(hipMemcpyAsync(h->d_crelabel.p, rank.data(), 64 * sizeof(int), hipMemcpyHostToDevice, s));
+    k_color_regroup<<<nblk(n, 256), 256, 0, s>>>(n, h->d_cdeg.p, h->d_crelabel.p, h->d_perm.p, h->d_color_s.p, h->d_cprio.p);
+    for (int k = 0; k < ncolors + 1; k++)
+      k_color_round<<<nblk(n, 256), 256, 0, s>>>(n, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags + 80);
+    const int before = ncolors;
+    ncolors = stats();   // (synchronises: `rank` may go)
+    fold();
+    stale = ncolors < before ? 0 : stale + 1;
+  }
+  if (ncolors > 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
+  // phase order: "ranked" flavour = colours by descending mean rank metric (PS.cpp:192-227 ranks the dipoles most likely to
+  // change first); otherwise by descending size
+  std::vector<int> ord((size_t)ncolors), relabel(64, 0);
+  std::iota(ord.begin(), ord.end(), 0);
+  auto key = [&](int c) { return ranked ? h->h_cstat[2 * c + 1] / std::max(h->h_cstat[2 * c], 1.0) : h->h_cstat[2 * c]; };
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key(a) > key(b); });
+  for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
+  HIPCHECK(hipMemcpyAsync(h->d_crelabel.p, relabel.data(), 64 * sizeof(int), hipMemcpyHostToDevice, s));
+  k_color_relabel<<<nblk(n, 256), 256, 0, s>>>(n, h->d_crelabel.p, h->d_perm.p, h->d_color_s.p, h->d_color_orig.p);
+  // rows of every phase in cell order
+  const size_t ncc = (size_t)ncolors * ncell;
+  h->d_ccnt.ensure(ncc + 1); h->d_coff.ensure(ncc + 2);
+  k_color_cellcount<<<nblk(ncell, 128), 128, 0, s>>>(ncell, ncolors, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_ccnt.p);
+  k_exclusive_scan<int><<<1, 1024, 0, s>>>((long long)ncc, h->d_ccnt.p, h->d_coff.p);
+  for (int c = 0; c <= ncolors; c++)
+    HIPCHECK(hipMemcpyAsync(h->h_coff + c, h->d_coff.p + (size_t)c * ncell, sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));  // (also: `relabel` is a stack vector)
+  h->color_off.assign((size_t)ncolors + 1, 0);
+  for (int c = 0; c <= ncolors; c++) h->color_off[c] = (int)h->h_coff[c];
+  const int tot = h->color_off[ncolors];
+  h->d_rows_orig.ensure((size_t)tot + 1); h->d_rows.ensure((size_t)tot + 1);
+  k_color_fill<<<nblk(ncell, 128), 128, 0, s>>>(ncell, ncolors, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_perm.p, h->d_coff.p,
+                                               h->d_rows_orig.p);
+  h->h_color.assign((size_t)n, 0);  // (its size says "a colouring for n atoms exists": the colours themselves live on the device)
+  h->color_epoch++;
+  h->colors_rebuilt++;
+  if (getenv("POLAR_DEBUG")) {
+    fprintf(stderr, "[polar] %d colour phases (device, dist %.2f):", ncolors, h->color_dist);
     for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
     fprintf(stderr, "\n");
   }
@@ -1147,18 +1297,24 @@ void ensure_colors(polar_handle *h) {
   if (h->colors_valid) return;
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
-  std::vector<double> rk;
-  if (st.polar_gs_ranked && !sharded(h)) {  // a sharded handle only knows its own rows' metric
-    std::vector<double> rs(n);
-    std::vector<int> perm(n);
-    rk.assign(n, 0.0);
-    HIPCHECK(hipMemcpyAsync(rs.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipMemcpyAsync(perm.data(), h->d_perm.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    for (int k = 0; k < n; k++) rk[perm[k]] = rs[k];  // rank metric was computed in s space
-  }
   const auto t0 = std::chrono::steady_clock::now();
-  build_colors(h, rk);
+  const bool on_device = h->sorted && st.dd_cutoff > 0.0 && h->sweep_kernel == 2 && !h->host_colors && h->pol_first;
+  if (on_device) {
+    build_colors_device(h, st.polar_gs_ranked != 0);
+  } else {  // lab paths (cluster rows, POLAR_HOST_COLORS): the host-side conflict graph + DSATUR of rounds 1-2
+    std::vector<double> rk;
+    if (st.polar_gs_ranked && !sharded(h)) {  // a sharded handle only knows its own rows' metric
+      std::vector<double> rs(n);
+      std::vector<int> perm(n);
+      rk.assign(n, 0.0);
+      HIPCHECK(hipMemcpyAsync(rs.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipMemcpyAsync(perm.data(), h->d_perm.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      for (int k = 0; k < n; k++) rk[perm[k]] = rs[k];  // rank metric was computed in s space
+    }
+    build_colors(h, rk);
+  }
+  // (wall time of the rebuild, host work and the waits for the device included)
   h->ms_color_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 // per step: the colour rows (orig ids) -> s space of this step's cell order
@@ -1393,7 +1549,10 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   if (!lj_late) launch_lj();
   const double *mu0 = nullptr;
   if (st.use_previous) {
-    if (mu_host) {
+    // the caller's mu_induced (PS.cpp:376-386 reads atom->mu_induced).  Between two polar_set_atoms calls the atoms keep
+    // their places and the caller's array is what the last compute call wrote into it: the resident copy is the same
+    // numbers (a caller that edits mu_induced in between goes through polar_upload_mu or polar_set_atoms)
+    if (mu_host && !(h->mu_resident && h->mu_host_in_sync)) {
       HIPCHECK(hipMemcpyAsync(h->d_mu.p, mu_host, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
       mu0 = h->d_mu.p;
     } else if (h->mu_resident) mu0 = h->d_mu.p;
@@ -1617,6 +1776,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_DETERMINISTIC")) h->deterministic = atoi(e) != 0;  // the same as the keyword `deterministic yes`
 #ifdef POLAR_LAB
   if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
+  if (const char *e = getenv("POLAR_HOST_COLORS")) h->host_colors = atoi(e) != 0;
   if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
   if (const char *e = getenv("POLAR_TILE_WAVES")) h->tile_waves = atoi(e) == 8 ? 8 : 4;
   if (const char *e = getenv("POLAR_TILE_WIDE")) h->tile_wide = atoi(e) != 0;
@@ -1685,6 +1845,10 @@ int polar_destroy(polar_handle *h) {
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_slot.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_trace.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
+    h->d_cadj.release(); h->d_cdeg.release(); h->d_ccnt.release(); h->d_cflags.release(); h->d_crelabel.release(); h->d_cprio.release(); h->d_cstat.release(); h->d_coff.release(); h->d_lp_pend.release(); h->d_lp_part.release();
+    if (h->h_cflags) (void)hipHostFree(h->h_cflags);
+    if (h->h_cstat) (void)hipHostFree(h->h_cstat);
+    if (h->h_coff) (void)hipHostFree(h->h_coff);
     h->d_srec0.release(); h->d_srec1.release(); h->d_thdr.release(); h->d_trow.release(); h->d_un_j.release(); h->d_dd16.release(); h->d_pend.release();
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     if (h->h_ddtot) (void)hipHostFree(h->h_ddtot);
@@ -1904,6 +2068,23 @@ int polar_set_atoms(polar_handle *h, int nlocal, int nghost, const double *x, co
       }
     HIPCHECK(hipStreamSynchronize(s));
     h->atoms_set = true;
+    h->mu_host_in_sync = false;  // the atoms may sit in a new order
+    return POLAR_OK;
+  });
+}
+
+int polar_set_positions(polar_handle *h, int nlocal, int nghost, const double *x) {
+  return guarded(h, [&]() {
+    need_device(h);
+    HIPCHECK(hipSetDevice(h->device));
+    if (!h->atoms_set || nlocal != h->nlocal || nghost != h->nghost) throw InputError("polar_set_positions: atom counts differ from the last polar_set_atoms");
+    if (!x) throw InputError("polar_set_positions: null pointer");
+    const size_t nall = (size_t)nlocal + nghost;
+    // through the pinned staging area: a pageable source is staged by the runtime in small pieces at a third of the rate
+    double *st = staging(h, 3 * nall + 6 * (size_t)nlocal);
+    memcpy(st, x, 3 * nall * sizeof(double));
+    HIPCHECK(hipMemcpyAsync(h->d_x.p, st, 3 * nall * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // (no synchronisation: the staging area is next written by the downloads of the compute call, which wait for the stream)
     return POLAR_OK;
   });
 }
@@ -2066,10 +2247,13 @@ int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, 
     if (ef_static) HIPCHECK(hipMemcpyAsync(st + 3 * nall + 3 * n, h->d_ef.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipEventRecord(h->ev_dl1, h->stream));
     HIPCHECK(hipEventSynchronize(h->ev_dl0));
-    for (size_t k = 0; k < 3 * nall; k++) f[k] += st[k];
+    host_chunks(3 * nall, [&](size_t a, size_t b) { for (size_t k = a; k < b; k++) f[k] += st[k]; });
     HIPCHECK(hipEventSynchronize(h->ev_dl1));
-    memcpy(mu, st + 3 * nall, 3 * n * sizeof(double));
-    if (ef_static) memcpy(ef_static, st + 3 * nall + 3 * n, 3 * n * sizeof(double));
+    host_chunks(3 * n, [&](size_t a, size_t b) {
+      memcpy(mu + a, st + 3 * nall + a, (b - a) * sizeof(double));
+      if (ef_static) memcpy(ef_static + a, st + 3 * nall + 3 * n + a, (b - a) * sizeof(double));
+    });
+    h->mu_host_in_sync = true;
     return rc;
   });
 }
@@ -2094,6 +2278,7 @@ int polar_compute_peratom(polar_handle *h, int eflag, int vflag, double *f, doub
     if (vflag / 4) add_from(h->d_vatom.p, vatom, 6 * nall);
     HIPCHECK(hipMemcpy(mu, h->d_mu.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
     if (ef_static) HIPCHECK(hipMemcpy(ef_static, h->d_ef.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    h->mu_host_in_sync = true;
     return rc;
   });
 }

@@ -136,6 +136,183 @@ __global__ void k_map_range(int lo, int n, const int *__restrict__ inv, int *__r
   if (i < n) out[i] = inv[lo + i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Colour phases of the list-mode Gauss-Seidel, built ON THE DEVICE (round 3; the host-side conflict graph + DSATUR of
+// rounds 1-2 cost 70-80 ms at 135k atoms, whenever a colouring had to be rebuilt).  Atoms of one colour must be farther
+// apart than the colour distance (they are relaxed Jacobi-fashion against each other inside a launch).
+//   k_color_adj    conflict lists: the polarizable own atoms within the colour distance (3 x 3 x 3 cells), `apitch` per atom
+//                  (an atom with more raises a flag and the lists are rebuilt wider), and the atom's degree
+//   k_color_round  Jones-Plassmann: an uncoloured atom whose priority beats every uncoloured neighbour's takes the lowest
+//                  colour none of its coloured neighbours holds.  Neighbours never decide in the same round, so no race.
+//   k_color_fold   atoms of the highest class move to a lower colour their neighbours leave free (no two atoms of one class
+//                  are adjacent, so all of them can move at once): classes dissolve from the top, 6 -> 4 on the MOF boxes
+//   k_color_stats / k_color_relabel / k_color_cellcount / k_color_fill: phase order (ranked: by mean rank metric) and the
+//                  rows of every phase in cell order
+__device__ __forceinline__ unsigned color_hash(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ void k_color_adj(int n, const double4 *__restrict__ pos4, const int *__restrict__ perm, int own_lo, int own_hi,
+                            Box box, CellGrid g, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+                            double colordistsq, int apitch, int *__restrict__ adj, int *__restrict__ deg,
+                            unsigned long long *__restrict__ prio, int *__restrict__ color_s, int *__restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double4 ri = pos4[i];
+  const int o = perm[i];
+  const bool row = __double2loint(ri.w) && o >= own_lo && o < own_hi;
+  color_s[i] = -1;
+  if (!row) { deg[i] = -1; prio[i] = 0ull; return; }
+  int cc[3];
+  {
+    double fr3[3];
+    frac_coords(box, g.lo, ri.x, ri.y, ri.z, fr3);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double fr = fr3[k];
+      fr -= floor(fr);
+      int ck = (int)(fr * g.nc[k]);
+      cc[k] = ck >= g.nc[k] ? g.nc[k] - 1 : ck;
+    }
+  }
+  int d = 0;
+  for (int dz = -1; dz <= 1; dz++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        int b[3] = {cc[0] + dx, cc[1] + dy, cc[2] + dz};
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          if (b[k] < 0 || b[k] >= g.nc[k]) {
+            if (!box.periodic[k] || g.nc[k] < 3) ok = false;  // (fewer than 3 cells: every cell is visited through offsets -1..1 already)
+            b[k] = (b[k] + g.nc[k]) % g.nc[k];
+          }
+        }
+        if (!ok) continue;
+        const long long cj = ((long long)b[2] * g.nc[1] + b[1]) * g.nc[0] + b[0];
+        const int a = (int)cell_first[cj], e = a + npol[cj];  // the polarizable atoms of a cell come first
+        for (int j = a; j < e; j++) {
+          if (j == i) continue;
+          const double4 rj = pos4[j];
+          double ex, ey, ez;
+          min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
+          if (ex * ex + ey * ey + ez * ez < colordistsq) {
+            const int oj = perm[j];
+            if (oj < own_lo || oj >= own_hi) continue;
+            if (d < apitch) adj[(size_t)i * apitch + d] = j;
+            d++;
+          }
+        }
+      }
+  if (d > apitch) { atomicMax(flags, d); d = apitch; }
+  deg[i] = d;
+  // largest degree first; ties by a hash of the atom's index in the caller's order (the same atoms get the same priorities
+  // step after step, whatever this step's cell order), then by that index
+  prio[i] = ((unsigned long long)(d < 255 ? d : 255) << 56) | ((unsigned long long)(color_hash((unsigned)o) >> 8) << 32) | (unsigned)o;
+}
+// priorities of the uncoloured atoms for the next round: (colours already seen among the neighbours, degree, hash, index) --
+// the saturation-first order of DSATUR, evaluated on a snapshot (its own launch) so that two neighbours never both think
+// they go first
+__global__ void k_color_prio(int n, int apitch, const int *__restrict__ adj, const int *__restrict__ deg, const int *__restrict__ color_s,
+                             const int *__restrict__ perm, unsigned long long *__restrict__ prio, int hashed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int d = deg[i];
+  if (d < 0 || color_s[i] >= 0) return;
+  unsigned long long used = 0ull;
+  for (int k = 0; k < d; k++) { const int cj = color_s[adj[(size_t)i * apitch + k]]; if (cj >= 0) used |= 1ull << cj; }
+  const unsigned o = (unsigned)perm[i];
+  // ties by the atom's index (`hashed` = 0): in a crystal built cell by cell the decisions then sweep through the structure in
+  // ONE consistent order, as the sequential DSATUR's do, and find its 4 classes on the MOF boxes where hashed ties end with 5;
+  // the price is rounds (a dependency chain per replica).  `hashed` = 1 breaks chains that grow too long.
+  const unsigned long long tie = hashed ? ((unsigned long long)(color_hash(o) >> 16) << 32) | o : (unsigned long long)o;
+  prio[i] = ((unsigned long long)__popcll(used) << 56) | ((unsigned long long)(d < 255 ? d : 255) << 48) | tie;
+}
+__global__ void k_color_round(int n, int apitch, const int *__restrict__ adj, const int *__restrict__ deg,
+                              const unsigned long long *__restrict__ prio, int *__restrict__ color_s, int *__restrict__ left) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int d = deg[i];
+  if (d < 0 || color_s[i] >= 0) return;
+  const unsigned long long pi = prio[i];
+  unsigned long long used = 0ull;
+  for (int k = 0; k < d; k++) {
+    const int j = adj[(size_t)i * apitch + k];
+    const int cj = color_s[j];
+    if (cj >= 0) used |= 1ull << cj;
+    else if (prio[j] > pi) { atomicAdd(left, 1); return; }  // a stronger neighbour decides first
+  }
+  color_s[i] = __ffsll((long long)~used) - 1;
+}
+__global__ void k_color_fold(int n, int apitch, int top, const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s,
+                             int *__restrict__ stay) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || deg[i] < 0 || color_s[i] != top) return;
+  unsigned long long used = 0ull;
+  for (int k = 0; k < deg[i]; k++) used |= 1ull << color_s[adj[(size_t)i * apitch + k]];  // (no neighbour has colour `top`)
+  const int c = __ffsll((long long)~used) - 1;
+  if (c < top) color_s[i] = c;
+  else atomicAdd(stay, 1);
+}
+// iterated greedy (Culberson): recolour greedily in an order that keeps every old class together -- never more colours than
+// before, often fewer.  This kernel sets the stage: priorities = (rank of the atom's old class in the new order, hash, index),
+// colours cleared; k_color_round then needs one round per old class (a class is an independent set: it decides at once).
+__global__ void k_color_regroup(int n, const int *__restrict__ deg, const int *__restrict__ class_rank, const int *__restrict__ perm,
+                                int *__restrict__ color_s, unsigned long long *__restrict__ prio) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || deg[i] < 0) return;
+  const unsigned o = (unsigned)perm[i];
+  prio[i] = ((unsigned long long)(63 - class_rank[color_s[i]]) << 56) | ((unsigned long long)(color_hash(o) >> 8) << 32) | o;
+  color_s[i] = -1;
+}
+// per colour: rows and the sum of their rank metric (phase order of the ranked flavour)
+__global__ __launch_bounds__(256) void k_color_stats(int n, const int *__restrict__ color_s, const double *__restrict__ rank,
+                                                     double *__restrict__ sums) {
+  // (summed per workgroup in LDS first: a hundred thousand FP64 atomics on five addresses took 2 ms)
+  __shared__ double part[128];
+  if (threadIdx.x < 128) part[threadIdx.x] = 0.0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = i < n ? color_s[i] : -1;
+  if (c >= 0) {
+    atomicAdd(&part[2 * c], 1.0);
+    atomicAdd(&part[2 * c + 1], rank ? rank[i] : 1.0);
+  }
+  __syncthreads();
+  if (threadIdx.x < 128 && part[threadIdx.x] != 0.0) atomicAdd(sums + threadIdx.x, part[threadIdx.x]);
+}
+__global__ void k_color_relabel(int n, const int *__restrict__ relabel, const int *__restrict__ perm, int *__restrict__ color_s,
+                                int *__restrict__ color_orig) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = color_s[i] >= 0 ? relabel[color_s[i]] : -1;
+  color_s[i] = c;
+  color_orig[perm[i]] = c;
+}
+// rows of every phase, cells in order, atoms of a cell in order: counts per (colour, cell), one scan, fill
+__global__ void k_color_cellcount(long long ncell, int ncolors, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+                                  const int *__restrict__ color_s, int *__restrict__ cnt) {
+  const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int a = (int)cell_first[c], e = a + npol[c];
+  for (int q = 0; q < ncolors; q++) {
+    int k = 0;
+    for (int j = a; j < e; j++) k += color_s[j] == q;
+    cnt[(size_t)q * ncell + c] = k;
+  }
+}
+__global__ void k_color_fill(long long ncell, int ncolors, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+                             const int *__restrict__ color_s, const int *__restrict__ perm, const long long *__restrict__ off,
+                             int *__restrict__ rows_orig) {
+  const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int a = (int)cell_first[c], e = a + npol[c];
+  for (int q = 0; q < ncolors; q++) {
+    long long w = off[(size_t)q * ncell + c];
+    for (int j = a; j < e; j++) if (color_s[j] == q) rows_orig[w++] = perm[j];
+  }
+}
+
 // One wave per atom row; lanes stride the atoms of the <=27 distinct neighbor cells (contiguous s
 // ranges); ballot + popcount compacts in order.  Single pass into the pitched lists:
 //   nl : every j with rsq <= cutallsq                      (static field, forces, rank metric)

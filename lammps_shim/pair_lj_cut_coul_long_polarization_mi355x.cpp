@@ -43,6 +43,7 @@ PairLJCutCoulLongPolarizationMI355X::PairLJCutCoulLongPolarizationMI355X(LAMMPS 
   pair_inited = 0;
   device_neigh = 0;
   debug_flag = 0;
+  atoms_sent = sent_nlocal = sent_nghost = 0;
   cut_lj_global = cut_coul = 0.0;
   h = NULL;
   // one MPI rank per GPU: the dipoles of ghost atoms travel through
@@ -119,8 +120,12 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
   double tilt[3] = {domain->xy,domain->xz,domain->yz};
   int periodic[3] = {domain->xperiodic,domain->yperiodic,domain->zperiodic};
   check(polar_set_box(h,domain->boxlo,domain->prd,tilt,periodic,domain->triclinic));
-  check(polar_set_atoms(h,atom->nlocal,atom->nghost,&atom->x[0][0],atom->q,atom->static_polarizability,
-                        atom->type,(const int *) atom->molecule));
+  // atoms are reordered, exchanged and re-ghosted only when the lists are rebuilt: in between only their positions move
+  if (neighbor->ago == 0 || !atoms_sent || atom->nlocal != sent_nlocal || atom->nghost != sent_nghost) {
+    check(polar_set_atoms(h,atom->nlocal,atom->nghost,&atom->x[0][0],atom->q,atom->static_polarizability,
+                          atom->type,(const int *) atom->molecule));
+    atoms_sent = 1; sent_nlocal = atom->nlocal; sent_nghost = atom->nghost;
+  } else check(polar_set_positions(h,atom->nlocal,atom->nghost,&atom->x[0][0]));
   if (neighbor->ago == 0) {
     check(polar_set_newton(h,force->newton_pair));       // PS.cpp:293 and the ev_tally weights read force->newton_pair
     if (device_neigh)

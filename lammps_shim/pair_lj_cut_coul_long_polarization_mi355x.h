@@ -53,6 +53,7 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   int pair_inited;
   int device_neigh;                      // extension keyword: list built by polar_build_neighbors
   int debug_flag;                        // keyword `debug yes`: the reference's prints (debug_prints)
+  int atoms_sent, sent_nlocal, sent_nghost;   // what the last polar_set_atoms handed over (positions alone travel in between)
   // one MPI rank per GPU: library order = [own | halo (one ghost per foreign tag) | other ghosts]
   int nhalo, sh_n;
   std::vector<int> lib_of_lammps, lammps_of_lib, halo_ghost, sh_nn, sh_flat, sh_idx, sh_t, sh_t2, sh_m;

@@ -97,6 +97,12 @@ int polar_set_atoms(polar_handle *, int nlocal, int nghost, const double *x, con
   R.nlocal = nlocal; R.nghost = nghost; R.x = x; R.q = q; R.alpha = alpha; R.type = type; R.mol = mol;
   return POLAR_OK;
 }
+int polar_set_positions(polar_handle *, int nlocal, int nghost, const double *x) {
+  R.calls.push_back("set_positions");
+  if (nlocal != R.nlocal || nghost != R.nghost) return POLAR_ERR_INPUT;
+  R.x = x;
+  return POLAR_OK;
+}
 int polar_set_neighbors(polar_handle *, int inum, const int *ilist, const int *numneigh, int *const *firstneigh) {
   R.calls.push_back("set_neighbors");
   R.inum = inum; R.ilist = ilist; R.numneigh = numneigh; R.firstneigh = firstneigh;
@@ -232,8 +238,9 @@ int shimcompute_check(int *ncombos, char *msg, int nmsg) {
         EXPECT(shim->no_virial_fdotr_compute == dn, "a device-built full list must keep the base class off the fdotr virial");
         EXPECT(R.modify.find("table 0") != std::string::npos && R.modify.find("mix geometric") != std::string::npos, "pair_modify state mirrored into the library: " << R.modify);
       }
+      bool first_call = true;
       for (int rcw = 0; rcw < 2; rcw++)
-      for (int ago = 0; ago <= 3; ago += 3)
+      for (int ago = 3; ago >= 0; ago -= 3)       /* (ago 3 first: the very first call must hand the atoms over all the same) */
       for (int eflag = 0; eflag <= 3; eflag++)
       for (int vflag = 0; vflag <= 6; vflag++) {
         if (vflag == 3) continue;               /* integrate::ev_set never produces 3 or 7 */
@@ -250,7 +257,9 @@ int shimcompute_check(int *ncombos, char *msg, int nmsg) {
         shim->compute(eflag, vflag);
         (*ncombos)++;
         /* ---- the call sequence (PS.cpp:125-188: everything compute() reads, lists only when they are new) ---- */
-        std::vector<std::string> want = {"set_box", "set_atoms"};
+        /* (the first call of a run and every reneighbor step hand all per-atom arrays over; steps in between only x) */
+        std::vector<std::string> want = {"set_box", (ago == 0 || first_call) ? "set_atoms" : "set_positions"};
+        first_call = false;
         if (ago == 0) { want.push_back("set_newton"); want.push_back(dn ? "build_neighbors" : "set_neighbors"); }
         const bool peratom = (eflag / 2) || (vflag / 4);
         want.push_back(peratom ? "compute_peratom" : "compute");
