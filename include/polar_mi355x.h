@@ -270,6 +270,38 @@ int polar_step_mu_put_idx(polar_handle *h, long long n, const int *idx_host, con
 int polar_step_change_get(polar_handle *h, double *sum);
 int polar_step_sweep_end_host(polar_handle *h, double global_change);
 
+/* ---- multi-GPU driver inside the library: one process (or MPI rank) per GPU, RCCL over xGMI -------------------------
+ * The capability the reference declares and never wires up (pack_comm / unpack_comm, PS.h:51-52, PS.cpp:1320-1362; the
+ * pair style is single-process, README.md:5).  A rank's handle holds [own atoms | halo atoms | ghost images] with
+ * polar_set_row_range = the own rows; the driver runs a whole Pair::compute for it: per sweep, on the handle's stream,
+ *     pack kernel -> ncclGroupStart, ncclRecv + ncclSend per peer, ncclGroupEnd -> unpack kernel
+ * and one ncclAllReduce of the stop rule's double every `reduce_every` sweeps; the host reads the device-resident loop
+ * state every `check_every` sweeps.  Energies, virial and pair counts of the result are summed over the ranks; a pitch
+ * overflow on any rank makes all ranks repeat the step.  RCCL is opened at run time (dlopen): the library has no link-time
+ * dependency on it, and a process that already holds a copy (PyTorch's) shares it.
+ *   polar_dist_unique_id   rank 0: the 128-byte ncclUniqueId, to be broadcast by the caller (MPI_Bcast, a file, a store)
+ *   polar_dist_create      ncclCommInitRank on `device` (collective over the ranks)
+ *   polar_dist_set_halo    this rank's exchange plan: for peer k (a rank; the rank itself is allowed) the handle-local
+ *                          indices of the atoms whose dipoles it sends, and of the atoms it receives dipoles for, in the
+ *                          order the peer sends them (concatenated over the peers)
+ *   polar_dist_set_cadence sweeps per all-reduce of the stop rule (1 = the reference's rule after every sweep) and
+ *                          sweeps per look at the loop state
+ *   polar_dist_step        one Pair::compute across the ranks (collective); forces, dipoles and per-atom arrays stay on the
+ *                          device (polar_download / polar_dev_ptr)
+ *   polar_dist_exchange    one dipole exchange by itself (tests) */
+#define POLAR_DIST_ID_BYTES 128
+typedef struct polar_dist polar_dist;
+int polar_dist_unique_id(void *id128);
+int polar_dist_create(const void *id128, int rank, int nranks, int device, polar_dist **out);
+int polar_dist_destroy(polar_dist *d);
+const char *polar_dist_last_error(const polar_dist *d);
+int polar_dist_set_cadence(polar_dist *d, int reduce_every, int check_every);
+int polar_dist_set_halo(polar_dist *d, int npeers, const int *peers, const int *send_count, const int *send_idx,
+                        const int *recv_count, const int *recv_idx);
+int polar_dist_exchange(polar_dist *d, polar_handle *h);
+int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_result *out);
+int polar_dist_counters(const polar_dist *d, int *exchanges, int *allreduces);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,6 +135,15 @@ EXPORTS = {
     "polar_mu_gather_idx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "polar_mu_scatter_idx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "polar_change_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "polar_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "polar_dist_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "polar_dist_destroy": (C.c_int, [C.c_void_p]),
+    "polar_dist_last_error": (C.c_char_p, [C.c_void_p]),
+    "polar_dist_set_cadence": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "polar_dist_set_halo": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _ip]),
+    "polar_dist_exchange": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "polar_dist_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Result)]),
+    "polar_dist_counters": (C.c_int, [C.c_void_p, _ip, _ip]),
 }
 
 
@@ -425,6 +434,62 @@ class PolarPair:
         a = np.zeros(n)
         self._ck(self.L.polar_download(self.h, name.encode(), _dptr(a), n))
         return a
+
+
+class PolarDist:
+    """The in-library multi-GPU driver (polar_dist_*, RCCL): one instance per rank.  ``unique_id`` = the bytes rank 0 got from
+    ``PolarDist.unique_id()`` and handed to every rank (torch.distributed broadcast, MPI_Bcast, a file)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = lib().polar_dist_unique_id(buf)
+        if rc < 0:
+            raise PolarError(rc, "polar_dist_unique_id failed (is RCCL available?)")
+        return buf.raw
+
+    def __init__(self, unique_id, rank, nranks, device=0):
+        self.L = lib()
+        self.d = C.c_void_p()
+        self.rank, self.nranks = rank, nranks
+        rc = self.L.polar_dist_create(C.c_char_p(bytes(unique_id)), rank, nranks, device, C.byref(self.d))
+        if rc < 0:
+            raise PolarError(rc, self.L.polar_dist_last_error(self.d).decode())
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise PolarError(rc, self.L.polar_dist_last_error(self.d).decode())
+        return rc
+
+    def set_cadence(self, reduce_every=1, check_every=4):
+        self._ck(self.L.polar_dist_set_cadence(self.d, reduce_every, check_every))
+
+    def set_halo(self, peers, send_lists, recv_lists):
+        """peers[k] = rank; send_lists[k] / recv_lists[k] = handle-local atom indices (int arrays)."""
+        peers = np.ascontiguousarray(peers, dtype=np.int32)
+        sc = np.array([len(a) for a in send_lists], dtype=np.int32)
+        rc_ = np.array([len(a) for a in recv_lists], dtype=np.int32)
+        si = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32) for a in send_lists]) if len(send_lists) else np.zeros(0, np.int32))
+        ri = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32) for a in recv_lists]) if len(recv_lists) else np.zeros(0, np.int32))
+        self._ck(self.L.polar_dist_set_halo(self.d, len(peers), _iptr(peers), _iptr(sc), _iptr(si) if len(si) else None,
+                                            _iptr(rc_), _iptr(ri) if len(ri) else None))
+
+    def exchange(self, pair):
+        self._ck(self.L.polar_dist_exchange(self.d, pair.h))
+
+    def step(self, pair, eflag=1, vflag=2):
+        res = Result()
+        rc = self._ck(self.L.polar_dist_step(self.d, pair.h, eflag, vflag, C.byref(res)))
+        out = _result_dict(res)
+        ex, ar = C.c_int(), C.c_int()
+        self.L.polar_dist_counters(self.d, C.byref(ex), C.byref(ar))
+        out.update(status=rc, warning=pair.L.polar_last_warning(pair.h).decode(), exchanges=ex.value, allreduces=ar.value)
+        return out
+
+    def close(self):
+        if self.d:
+            self.L.polar_dist_destroy(self.d)
+            self.d = C.c_void_p()
 
 
 def _result_dict(res):

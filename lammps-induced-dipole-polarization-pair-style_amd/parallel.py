@@ -596,15 +596,40 @@ def bench_distributed(args, rank, world, local_rank):
         dist.all_reduce(t)
         torch.cuda.synchronize()
     gbuf = None
+    # The per-sweep loop: the library's own C++ driver (polar_dist_*: RCCL calls enqueued by the library on its compute
+    # stream, no Python between two sweeps) whenever the backend is RCCL and the exchange is point-to-point; the Python loop
+    # below (run_step) remains for the rehearsal backends (gloo: ranks sharing a GPU, exchanges staged through the host) and
+    # for the all-gather variant.
+    driver = None
+    if backend_name == "nccl" and isinstance(plan, P2PHaloPlan) and os.environ.get("POLAR_DIST_DRIVER", "cpp") == "cpp":
+        ids = [pkg.PolarDist.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        driver = pkg.PolarDist(ids[0], rank, world, device=local_rank)
+        peers = plan.peers(rank)
+        n_own = hi - lo
+        send_lists = [(np.asarray(plan.send[rank][r]) - lo).astype(np.int32) for r in peers]
+        recv_lists, at = [], n_own
+        for r in peers:
+            m = len(plan.send[r][rank])
+            recv_lists.append(np.arange(at, at + m, dtype=np.int32))
+            at += m
+        driver.set_halo(peers, send_lists, recv_lists)
+        driver.set_cadence(REDUCE_EVERY, 4)
+
+    def one_step(timer=None):
+        if driver is not None:
+            return driver.step(p, 1, 2)
+        return run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo, timer=timer)
+
     for _ in range(max(args.warmup, 1)):
-        out = run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo)
+        out = one_step()
     dist.barrier()
     torch.cuda.synchronize()
     timer = SweepTimer(torch)
     t0 = time.perf_counter()
     for it in range(args.steps):  # the event pairs cost ~5 % of a step: only the last timed step carries them
-        out = run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo,
-                       timer=timer if it == args.steps - 1 else None)
+        out = one_step(timer if it == args.steps - 1 else None)
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.dev)
@@ -613,6 +638,9 @@ def bench_distributed(args, rank, world, local_rank):
     # roofline of the dominant kernel on this rank (same accounting as the single-GPU line, bench.py)
     launches = max(len(timer.pairs), 1) * max(out["ncolors"], 1)
     ms_launch = timer.total_ms() / launches
+    if driver is not None:  # the library's own events around the solve of the last step (exchanges and all-reduces included)
+        launches = max(out["sweeps"], 1) * max(out["ncolors"], 1)
+        ms_launch = out["ms_solve"] / launches
     pairs_rank = out["dd_pairs"] / world          # dd_pairs was all-reduced; equal shares of a uniform box
     bytes_launch = (4.0 * pairs_rank + 112.0 * rows_own) / max(out["ncolors"], 1)
     achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
@@ -632,6 +660,10 @@ def bench_distributed(args, rank, world, local_rank):
                        "atoms_held_rank0": n_held, "halo_rows_per_rank": plan.counts, "rows_per_rank": counts,
                        "peers_rank0": len(plan.peers(0)) if hasattr(plan, "peers") else None,
                        "stop_rule_allreduce_every_sweeps": REDUCE_EVERY,
+                       "sweep_loop": ("in-library C++ driver (polar_dist_step): pack kernel, ncclGroupStart/Send/Recv/End, unpack kernel and the "
+                                      "all-reduced stop rule enqueued on the compute stream, state read every 4 sweeps") if driver is not None
+                                     else "Python loop over the stepwise C-ABI (torch.distributed collectives)",
+                       "exchanges_last_step": out.get("exchanges"), "allreduces_last_step": out.get("allreduces"),
                        "kernel_version": pkg.kernel_version()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; rank 0; {pkg.kernel_version()})",

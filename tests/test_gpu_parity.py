@@ -691,3 +691,43 @@ def test_matrix_free_exact_gauss_seidel_matches_reference_golden(variant, wl, pk
         assert out["iterations"] == int(z["iterations"])
     if variant == "config0_max30":
         assert out["iterations"] == 30 and out["status"] == 0
+
+
+@pytest.mark.parametrize("mode", ["precision", "fixed", "jacobi"])
+def test_in_library_rccl_driver_with_one_rank(mode, wl, pkg, oracle):
+    """the C++ multi-GPU driver (polar_dist_*: RCCL opened by the library itself, per sweep pack ->
+    ncclGroupStart / ncclRecv + ncclSend / ncclGroupEnd -> unpack on the compute stream, the stop rule's double all-reduced)
+    run for real with the one rank a test box has: the rank exchanges a third of its rows WITH ITSELF (RCCL allows a
+    self send / receive inside a group) and all-reduces over a communicator of one.  Same numbers as the oracle; the
+    counters show that every sweep exchanged and, in precision mode, all-reduced."""
+    solver = {"precision": ["precision", "1e-12", "max_iterations", "100"],
+              "fixed": ["fixed_iteration", "yes", "max_iterations", "12"],
+              "jacobi": ["polar_gs_ranked", "no", "fixed_iteration", "yes", "max_iterations", "5"]}[mode]
+    extra = ["use_previous", "no", "dd_cutoff", "9.0"] + solver
+    s, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=extra)
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    p = pkg.pair_from_system(s)
+    p._ck(p.L.polar_set_list_style(p.h, 0))
+    d = pkg.PolarDist(pkg.PolarDist.unique_id(), 0, 1, device=0)
+    rows = np.arange(0, s.nlocal, 3, dtype=np.int32)
+    d.set_halo([0], [rows], [rows])
+    d.set_cadence(reduce_every=1, check_every=4)
+    out = d.step(p, eflag=1, vflag=2)
+    mu = p.download("mu", 3 * s.nlocal).reshape(-1, 3)
+    f = p.download("f", 3 * (s.nlocal + s.nghost)).reshape(-1, 3)
+    assert out["status"] == ref["status"] == 0
+    assert out["sweeps"] == ref["sweeps"] or mode == "precision"
+    assert np.max(np.abs(mu - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+    assert force_rel_err(oracle.fold_ghost_forces(f, s.owner, s.nlocal), oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)) < TOL
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert rel(out[k], ref[k], 1e-9) < TOL
+    assert out["exchanges"] >= out["sweeps"] + 1
+    if mode == "precision":
+        assert out["allreduces"] >= out["sweeps"]
+    # a second step on the same communicator, cadence 2: at most one sweep past the stop rule
+    d.set_cadence(reduce_every=2, check_every=4)
+    out2 = d.step(p, eflag=1, vflag=2)
+    assert out2["status"] == 0 and out2["sweeps"] <= out["sweeps"] + 1
+    assert np.max(np.abs(p.download("mu", 3 * s.nlocal).reshape(-1, 3) - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+    d.close()
+    p.close()
