@@ -35,6 +35,8 @@ PKG = "lammps-induced-dipole-polarization-pair-style_amd"
 
 CUT_COUL = 12.8345
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak; the sweep has no matrix work
+FLOP_PER_PAIR = 60.0     # ~45 FP64 flop + exp + rsqrt per directed pair of a sweep
 FIXED30 = ["fixed_iteration", "yes", "max_iterations", "30"]
 PREC11 = ["fixed_iteration", "no", "precision", "1e-11", "max_iterations", "100"]
 CONFIGS = {  # BASELINE.json configs[k] -> replication of the 1,349-atom MOF5+H2 cell, solver keywords
@@ -102,27 +104,35 @@ def roofline(s, out, ms_solve, launches, steps, pkg):
     achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
     # HBM traffic per launch from PMC counters: read from the committed profile of THIS kernel generation on THIS
     # workload (tools/pmc_traffic.sh writes it); null when the file does not match the built library
-    traffic, src, low = None, None, None
+    traffic, src, low, valu_busy, issue_busy, waves = None, None, None, None, None, None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as fh:
             t = json.load(fh)
         if t.get("kernel_version") == pkg.kernel_version() and t.get("natoms") == s.nlocal:
             traffic, src, low = float(t["bytes_per_launch"]), t.get("source"), t.get("bytes_per_launch_low")
+            valu_busy, issue_busy, waves = t.get("valu_busy"), t.get("issue_busy"), t.get("waves_per_simd")
     except (OSError, ValueError, KeyError):
         pass
+    # the other roof SURVEY 8(d) asks for: FP64 vector rate of the pair arithmetic (60 flop-equivalents per directed pair)
+    tflops = FLOP_PER_PAIR * out["dd_pairs"] / ncol / (ms_launch * 1e-3) / 1e12
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_low": low, "traffic_source": src, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; {pkg.kernel_version()})",
-            "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch, "launches_per_step": launches / max(steps, 1)}
+            "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch, "launches_per_step": launches / max(steps, 1),
+            "fp64_tflops": tflops, "fp64_frac": tflops / FP64_PEAK_TFLOPS,
+            "valu_busy": valu_busy, "issue_busy": issue_busy, "waves_per_simd": waves,
+            "note": "valu_busy / issue_busy / waves_per_simd: SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_ANY, SQ_WAVE_CYCLES over the chip's quad-cycles, from the "
+                    "committed PMC passes of this kernel version (null when profiles/traffic_pmc.json is of another build): the sweep is bound by "
+                    "instruction issue (FP64 at 4 cycles per wave instruction), not by HBM bytes"}
 
 
-def sub_config(torch, pkg, wl, k, steps, warmup, device_neigh=False):
+def sub_config(torch, pkg, wl, k, steps, warmup, device_neigh=False, extra=()):
     cfg = CONFIGS[k]
-    s = build_workload(wl, cfg["reps"], solver=cfg["solver"], build_list=not device_neigh)
+    s = build_workload(wl, cfg["reps"], extra=extra, solver=cfg["solver"], build_list=not device_neigh)
     p = pkg.pair_from_system(s, device_neigh=device_neigh)
     out, dt, ms_solve, launches = timed_steps(torch, p, steps, warmup)
     rf = roofline(s, out, ms_solve, launches, steps, pkg)
     p.close()
-    return {"workload": describe(cfg, s.nlocal) + (", LJ/Coulomb list built on the device" if device_neigh else ""),
+    return {"workload": describe(cfg, s.nlocal) + (", LJ/Coulomb list built on the device" if device_neigh else "") + ("; extra keywords: " + " ".join(extra) if extra else ""),
             "natoms": s.nlocal, "steps": steps, "ms_per_step": 1e3 * dt / steps, "atom_steps_per_s": s.nlocal * steps / dt,
             "sweeps": out["sweeps"], "colors": out["ncolors"], "dd_pairs": out["dd_pairs"],
             "ms_per_dipole_iteration": ms_solve / steps / max(out["sweeps"], 1), "ms_solve": ms_solve / steps,
@@ -297,6 +307,9 @@ def main():
         config["md_leg_ballistic"] = md_leg(pkg, s, steps=200, device_neigh=True, motion="ballistic", temperature=300.0)
         config["config1_36k"] = sub_config(torch, pkg, wl, 1, steps=max(args.steps, 10), warmup=args.warmup)
         config["config4_529k_one_gpu"] = sub_config(torch, pkg, wl, 4, steps=min(args.steps, 5), warmup=1, device_neigh=True)
+        # opt-in extension keywords on the headline box (NOT the headline: the reference has neither)
+        config["config2_polar_sor_1p15"] = sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("polar_sor", "1.15"))
+        config["config2_deterministic"] = sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("deterministic", "yes"))
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(wl, cfg["solver"])
     print(json.dumps(line))

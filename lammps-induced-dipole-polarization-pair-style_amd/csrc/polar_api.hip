@@ -24,7 +24,7 @@
 using namespace polar;
 
 // bump when a kernel on the hot path changes: PMC files under profiles/ are keyed by it (bench.py, roofline.traffic)
-#define POLAR_KERNEL_VERSION "r02-lp2-v4"
+#define POLAR_KERNEL_VERSION "r03-lp3-v1"
 
 namespace {
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/<tag>_pmc*/ (tools/pmc_traffic.sh) -> profiles/traffic_pmc.json + profiles/r02_<version>_traffic_pmc.txt"""
+"""gpurun_out/<tag>_pmc*/ (tools/pmc_traffic.sh) -> profiles/traffic_pmc.json + profiles/<round>_<version>_traffic_pmc.txt"""
 import collections, csv, glob, importlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,17 +31,26 @@ idx_bytes = 4.0 * (line["config"]["dd_pairs"] / max(line["config"]["colors"], 1)
 req = fetch_kb * 1024.0 / 64.0
 gather_req = max(req - idx_bytes / 128.0, 0.0)
 traffic_low = idx_bytes + 64.0 * gather_req + write_kb * 1024.0
-out = {"kernel_version": ver, "natoms": line["config"]["natoms"] if line else None, "kernel": pat,
+# issue-side occupancy of the chip by this kernel: SQ_ACTIVE_INST_* count quad-cycles summed over all waves; the chip offers
+# (launch length in cycles = GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs / 4 quad-cycles per launch
+cap = mean.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 * 1024.0 / 4.0
+valu_busy = mean.get("SQ_ACTIVE_INST_VALU", 0.0) / cap if cap else None
+issue_busy = mean.get("SQ_ACTIVE_INST_ANY", 0.0) / cap if cap else None
+waves_per_simd = mean.get("SQ_WAVE_CYCLES", 0.0) / cap if cap else None
+rnd = ver.split("-")[0] if ver[:1] == "r" else "r03"
+out = {"kernel_version": ver, "valu_busy": valu_busy, "issue_busy": issue_busy, "waves_per_simd": waves_per_simd, "natoms": line["config"]["natoms"] if line else None, "kernel": pat,
        "bytes_per_launch": traffic, "bytes_per_launch_low": traffic_low, "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
        "launches_sampled": len(acc.get("FETCH_SIZE", [])), "counters_mean": mean,
        "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"] if line else None,
-       "source": f"profiles/r02_{ver}_traffic_pmc.txt (tools/pmc_traffic.sh: separate --pmc passes of bench.py --no-extras)"}
+       "source": f"profiles/{rnd}_{ver}_traffic_pmc.txt (tools/pmc_traffic.sh: separate --pmc passes of bench.py --no-extras)"}
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_pmc.json"), "w"), indent=1)
-with open(os.path.join(ROOT, "profiles", f"r02_{ver}_traffic_pmc.txt"), "w") as fh:
+with open(os.path.join(ROOT, "profiles", f"{rnd}_{ver}_traffic_pmc.txt"), "w") as fh:
     fh.write(f"# {pat}, bench headline (BASELINE configs[2], {out['natoms']} atoms), kernel version {ver}; means per launch\n")
     for k, v in sorted(mean.items()):
         fh.write(f"{k:28s} n={len(acc[k]):5d} mean={v:16.1f}\n")
     fh.write(f"# calibrated bracket (tools/calib_fetch.hip): {traffic_low / 1e6:.1f} MB (lone 64-byte gather requests) ... {traffic / 1e6:.1f} MB (all requests 128-byte lines)\n")
+    if cap:
+        fh.write(f"# issue side: VALU busy {valu_busy:.3f}, any instruction {issue_busy:.3f} of the chip's quad-cycles; {waves_per_simd:.2f} waves resident per SIMD on average\n")
     fh.write(f"# traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB = {traffic / 1e6:.1f} MB per launch; algorithmic {out['algorithmic_bytes_per_launch'] / 1e6 if out['algorithmic_bytes_per_launch'] else 0:.1f} MB per launch\n")
 print(json.dumps(out, indent=1))
