@@ -180,6 +180,7 @@ struct polar_handle {
   bool colors_recheck = false;  // a new neighbor list arrived: keep the colouring if it still separates every same-colour pair
   std::vector<int> h_color;     // colour of every atom (orig ids), -1: none
   DBuf<int> d_color_orig, d_color_s;
+  DBuf<int> d_klist;              // device colouring: rows of the top class and their repair states (k_color_kempe)
   DBuf<int> d_cadj, d_cdeg, d_ccnt, d_cflags, d_crelabel;  // device colouring: conflict lists, degrees, rows per (colour, cell), round counters
   DBuf<unsigned long long> d_cprio;
   DBuf<double> d_cstat;
@@ -880,7 +881,7 @@ void build_colors_device(polar_handle *h, bool ranked) {
   }
   h->d_cdeg.ensure(n + 1); h->d_cprio.ensure(n + 1);
   h->d_color_s.ensure(n + 1); h->d_color_orig.ensure(n + 1); h->d_cflags.ensure(96); h->d_cstat.ensure(128); h->d_crelabel.ensure(64);
-  int *flags = h->d_cflags.p;  // [0] conflict-list overflow, [1..64] atoms deferred in round r, [65..] atoms that could not leave a folded class
+  int *flags = h->d_cflags.p;  // [0] conflict-list overflow, [1] atoms deferred in the last round, [2] a row that saw 64 colours, [65..] atoms that could not leave a folded class
   HIPCHECK(hipMemsetAsync(h->d_color_orig.p, 0xFF, (size_t)(n + 1) * sizeof(int), s));
   const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
   const double dc2 = h->color_dist * h->color_dist;
@@ -896,19 +897,47 @@ void build_colors_device(polar_handle *h, bool ranked) {
     h->cadj_pitch = (h->h_cflags[0] + 4 + 7) / 8 * 8;
   }
   const int ap_ = h->cadj_pitch;
+  // sequential DSATUR cell by cell (k_color_cells): one launch per parity class of the cell grid -- per dimension the even
+  // cells, the odd cells and, when a periodic dimension has an odd count, its last cell on its own.  Safe while two cells of
+  // a class (a whole cell apart) cannot hold neighbours: colour distance below the shortest cell edge.
+  const double min_edge = std::min({h->box.prd[0] / h->grid.nc[0], h->box.prd[1] / h->grid.nc[1], h->box.prd[2] / h->grid.nc[2]});
+  bool cell_pass = h->color_dist < min_edge;
+#ifdef POLAR_LAB
+  if (getenv("POLAR_COLOR_JP")) cell_pass = false;  // lab: Jones-Plassmann alone (the round-3 first version: 5 classes)
+#endif
+  if (cell_pass) {
+    struct Cls { int start, stride, count; };
+    std::vector<Cls> cls[3];
+    for (int k = 0; k < 3; k++) {
+      const int nc = h->grid.nc[k];
+      const bool seam = h->box.periodic[k] && (nc & 1) && nc > 1;
+      const int lim = seam ? nc - 1 : nc;
+      if ((lim + 1) / 2 > 0) cls[k].push_back(Cls{0, 2, (lim + 1) / 2});
+      if (lim / 2 > 0) cls[k].push_back(Cls{1, 2, lim / 2});
+      if (seam) cls[k].push_back(Cls{nc - 1, 1, 1});
+    }
+    for (const Cls &cz : cls[2]) for (const Cls &cy : cls[1]) for (const Cls &cx : cls[0])
+      k_color_cells<<<cx.count * cy.count * cz.count, 64, 0, s>>>(cx.start, cy.start, cz.start, cx.stride, cy.stride, cz.stride, cx.count, cy.count,
+                                                                  cz.count, h->grid.nc[0], h->grid.nc[1], h->d_cell_first.p, h->d_cell_fill.p, ap_,
+                                                                  h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p, flags + 2);
+  }
+  // Jones-Plassmann rounds for whatever is still uncoloured (nothing after the cell pass; everything without it): an uncoloured
+  // row whose priority beats every uncoloured neighbour's takes the lowest free colour.  First look after one round.
   bool coloured = false;
   int rounds = 0;
   const int max_rounds = 4096, look_every = 32;
   while (!coloured && rounds < max_rounds) {   // rounds (priorities, then decisions), then a look at how many atoms the last one deferred
     const int hashed = rounds >= 1024 ? 1 : 0;  // index-ordered ties while the chains stay short (see k_color_prio)
-    for (int k = 0; k < look_every; k++) {
+    const int batch = rounds == 0 ? 1 : look_every;
+    for (int k = 0; k < batch; k++) {
       k_color_prio<<<nblk(n, 256), 256, 0, s>>>(n, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p, h->d_perm.p, h->d_cprio.p, hashed);
-      if (k == look_every - 1) HIPCHECK(hipMemsetAsync(flags + 1, 0, sizeof(int), s));
+      if (k == batch - 1) HIPCHECK(hipMemsetAsync(flags + 1, 0, sizeof(int), s));
       k_color_round<<<nblk(n, 256), 256, 0, s>>>(n, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags + 1);
     }
-    rounds += look_every;
-    HIPCHECK(hipMemcpyAsync(h->h_cflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    rounds += batch;
+    HIPCHECK(hipMemcpyAsync(h->h_cflags, flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    if (h->h_cflags[2] >= 1000) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
     coloured = h->h_cflags[1] == 0;
   }
   if (!coloured) throw std::runtime_error("colouring: Jones-Plassmann did not finish");
@@ -932,6 +961,25 @@ void build_colors_device(polar_handle *h, bool ranked) {
     }
   };
   fold();
+  // local repair of a small top class (k_color_ball): the cell-by-cell pass leaves about one row per unit cell in a fifth
+  // class on the MOF boxes; first balls of one conflict step, then of two
+  const int kcap = 8192;
+  for (int hops = 1; hops <= 2 && ncolors > 2 && h->h_cstat[2 * (ncolors - 1)] <= (double)kcap; hops++) {
+    h->d_klist.ensure(4 * (size_t)kcap + 8);
+    int *raw = h->d_klist.p, *list = raw + kcap, *st0 = raw + 2 * kcap, *st1 = raw + 3 * kcap, *cnt = raw + 4 * kcap;
+    HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int), s));
+    k_color_collect<<<nblk(n, 256), 256, 0, s>>>(n, ncolors - 1, h->d_color_s.p, kcap, raw, cnt);
+    k_sort_small<<<8, 256, 0, s>>>(cnt, kcap, raw, list, st0, st1);
+    const int waves = (int)h->h_cstat[2 * (ncolors - 1)];
+    const double reach = (2 * hops + 1) * h->color_dist;
+    for (int round = 0; round < 6; round++)
+      k_color_ball<<<waves, 64, 0, s>>>(cnt, kcap, list, (round & 1) ? st1 : st0, (round & 1) ? st0 : st1, h->d_pos4.p, h->box, reach * reach,
+                                        ncolors - 1, hops, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p);
+    const int before = ncolors;
+    ncolors = stats();
+    if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] colour repair (%d-step balls): %d rows in the top class, %d classes -> %d\n", hops, waves, before, ncolors);
+    if (ncolors < before) break;
+  }
   // iterated greedy: the parallel rounds above decide many atoms on stale saturation counts and end one class above the
   // sequential DSATUR on the MOF boxes (5 against 4); regrouping by old classes in a few different orders wins it back
   for (int ig = 0, stale = 0; ig < 4 && stale < 2 && ncolors > 4; ig++) {
@@ -1847,7 +1895,7 @@ int polar_destroy(polar_handle *h) {
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_slot.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_trace.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
-    h->d_cadj.release(); h->d_cdeg.release(); h->d_ccnt.release(); h->d_cflags.release(); h->d_crelabel.release(); h->d_cprio.release(); h->d_cstat.release(); h->d_coff.release(); h->d_lp_pend.release(); h->d_lp_part.release();
+    h->d_cadj.release(); h->d_cdeg.release(); h->d_ccnt.release(); h->d_cflags.release(); h->d_crelabel.release(); h->d_klist.release(); h->d_cprio.release(); h->d_cstat.release(); h->d_coff.release(); h->d_lp_pend.release(); h->d_lp_part.release();
     if (h->h_cflags) (void)hipHostFree(h->h_cflags);
     if (h->h_cstat) (void)hipHostFree(h->h_cstat);
     if (h->h_coff) (void)hipHostFree(h->h_coff);

@@ -210,6 +210,52 @@ __global__ void k_color_adj(int n, const double4 *__restrict__ pos4, const int *
   // step after step, whatever this step's cell order), then by that index
   prio[i] = ((unsigned long long)(d < 255 ? d : 255) << 56) | ((unsigned long long)(color_hash((unsigned)o) >> 8) << 32) | (unsigned)o;
 }
+// Sequential DSATUR, cell by cell: one wave colours the rows of ONE cell in saturation order (always the uncoloured row that
+// sees the most colours; ties by degree, then by position in the cell), every decision made on up-to-date colours.  Cells of
+// one launch are never adjacent (parity classes of the cell grid; a cell edge is at least half a cutoff, far beyond the colour
+// distance), so no two waves of a launch ever colour neighbours: 8 launches walk the whole box.  The parallel rounds of
+// Jones-Plassmann decide many neighbours-of-neighbours on stale saturation counts and end with 5 classes on the MOF boxes;
+// this order finds the 4 the host-side DSATUR of rounds 1-2 found.  cells: c_k = start_k + stride_k * i_k, i_k < count_k.
+__global__ __launch_bounds__(64) void k_color_cells(int s0, int s1, int s2, int t0, int t1, int t2, int m0, int m1, int m2, int n0, int n1,
+                                                    const long long *__restrict__ cell_first, const int *__restrict__ npol, int apitch,
+                                                    const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s,
+                                                    int *__restrict__ flags) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int i0 = b % m0, i1 = (b / m0) % m1, i2 = b / (m0 * m1);
+  if (i2 >= m2) return;
+  const long long c = ((long long)(s2 + t2 * i2) * n1 + (s1 + t1 * i1)) * n0 + (s0 + t0 * i0);
+  const int a = (int)cell_first[c], np = npol[c];
+  for (int base = 0; base < np; base += 64) {   // (cells with more than 64 rows: 64 at a time)
+    const int i = a + base + lane;
+    const bool row = base + lane < np && deg[i] >= 0;
+    int mine = row ? color_s[i] : 0;            // >= 0: done (or not a row)
+    const int todo = __popcll(__ballot(row && mine < 0));
+    for (int it = 0; it < todo; it++) {
+      unsigned long long used = 0ull;
+      int d = 0;
+      if (row && mine < 0) {
+        d = deg[i];
+        for (int k = 0; k < d; k++) { const int cj = color_s[adj[(size_t)i * apitch + k]]; if (cj >= 0) used |= 1ull << cj; }
+      }
+      // key = (saturation, degree, first in the cell); 0 for lanes with nothing to colour
+      unsigned key = (row && mine < 0) ? (((unsigned)__popcll(used) + 1u) << 16) | ((unsigned)(d < 255 ? d : 255) << 8) | (unsigned)(63 - lane) : 0u;
+      unsigned best = key;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const unsigned v = (unsigned)__shfl_xor((int)best, o, 64); best = v > best ? v : best; }
+      if (key == best && key != 0u) {           // exactly one lane (the lane number is part of the key)
+        const int cm = __ffsll((long long)~used) - 1;
+        if (cm >= 64) atomicMax(flags, 1000);
+        mine = cm < 64 ? cm : 63;
+        color_s[i] = mine;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next pick reads this colour through the conflict lists
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
+}
+
 // priorities of the uncoloured atoms for the next round: (colours already seen among the neighbours, degree, hash, index) --
 // the saturation-first order of DSATUR, evaluated on a snapshot (its own launch) so that two neighbours never both think
 // they go first
@@ -253,6 +299,106 @@ __global__ void k_color_fold(int n, int apitch, int top, const int *__restrict__
   const int c = __ffsll((long long)~used) - 1;
   if (c < top) color_s[i] = c;
   else atomicAdd(stay, 1);
+}
+// Local repair of a small top class.  A row v stuck in the top class sees every lower colour among its neighbours; the ball of
+// rows within `hops` conflict-graph steps of v is uncoloured and coloured again with the lower colours only, by exhaustive
+// search (depth first, at most 64 rows, a bounded number of steps) against the fixed colours around the ball.  If the search
+// fails nothing changes.  k_color_collect lists the rows of the top class (then sorted by index: k_sort_small), k_color_ball
+// gives one wave to each; a wave waits while an earlier, still untried row of the list lies within `reach` (the balls write up
+// to `hops` steps from their centres and read one step further), so the result does not depend on the order the waves run in.
+// `state` 0 = untried, 1 = tried; `prev` = the states before this launch.
+__global__ void k_color_collect(int n, int top, const int *__restrict__ color_s, int cap, int *__restrict__ list, int *__restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || color_s[i] != top) return;
+  const int k = atomicAdd(count, 1);
+  if (k < cap) list[k] = i;
+}
+__global__ __launch_bounds__(256) void k_sort_small(const int *__restrict__ count, int cap, const int *__restrict__ in, int *__restrict__ out,
+                                                    int *__restrict__ state_a, int *__restrict__ state_b) {
+  const int m = *count;
+  if (m > cap) return;   // (the host skips the repair as well)
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
+    const int v = in[k];
+    int r = 0;
+    for (int q = 0; q < m; q++) r += in[q] < v;
+    out[r] = v;
+    state_a[k] = 0; state_b[k] = 0;
+  }
+}
+__global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count, int cap, const int *__restrict__ list, const int *__restrict__ prev,
+                                                   int *__restrict__ state, const double4 *__restrict__ pos4, Box box, double reachsq, int top, int hops,
+                                                   int apitch, const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s) {
+  __shared__ int ball[64];
+  __shared__ unsigned long long inball[64], allowed[64];
+  __shared__ int col[64];
+  __shared__ int found;
+  const int m_all = *count;
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if (m_all > cap || w >= m_all) return;
+  if (prev[w]) { if (lane == 0) state[w] = 1; return; }
+  const int v = list[w];
+  const double4 rv = pos4[v];
+  bool blocked = false;
+  for (int q = lane; q < w; q += 64) {
+    if (prev[q]) continue;
+    const double4 rq = pos4[list[q]];
+    double dx, dy, dz;
+    min_image_del(box, rv.x, rv.y, rv.z, rq.x, rq.y, rq.z, dx, dy, dz);
+    blocked |= dx * dx + dy * dy + dz * dz < reachsq;
+  }
+  if (__ballot(blocked)) { if (lane == 0) state[w] = 0; return; }
+  if (lane == 0) state[w] = 1;
+  // the ball, breadth first
+  if (lane == 0) ball[0] = v;
+  int m = 1, level0 = 0;
+  __syncthreads();
+  for (int hop = 0; hop < hops; hop++) {
+    const int level1 = m;
+    for (int q = level0; q < level1 && m < 64; q++) {
+      const int node = ball[q];
+      const int d = deg[node];
+      int j = lane < d ? adj[(size_t)node * apitch + lane] : -1;
+      if (j >= 0) for (int k = 0; k < m; k++) if (ball[k] == j) { j = -1; break; }
+      const unsigned long long fresh = __ballot(j >= 0);
+      const int at = m + __popcll(fresh & ((1ull << lane) - 1ull));
+      if (j >= 0 && at < 64) ball[at] = j;
+      m = min(64, m + __popcll(fresh));
+      __syncthreads();
+    }
+    level0 = level1;
+  }
+  // per ball row: the colours its neighbours outside the ball hold, and its neighbours inside
+  if (lane < m) {
+    const int node = ball[lane];
+    unsigned long long used = 0ull, in = 0ull;
+    const int d = deg[node];
+    for (int k = 0; k < d; k++) {
+      const int j = adj[(size_t)node * apitch + k];
+      int at = -1;
+      for (int q = 0; q < m; q++) if (ball[q] == j) { at = q; break; }
+      if (at >= 0) in |= 1ull << at;
+      else used |= 1ull << color_s[j];
+    }
+    inball[lane] = in;
+    allowed[lane] = ~used & ((1ull << top) - 1ull);
+    col[lane] = -1;
+  }
+  if (lane == 0) found = 0;
+  __syncthreads();
+  if (lane == 0) {   // depth-first search, rows in ball order (the centre first, then by distance)
+    int k = 0;
+    for (int step = 0; step < 200000 && k >= 0 && k < m; step++) {
+      unsigned long long ok = allowed[k];
+      const unsigned long long earlier = inball[k] & ((1ull << k) - 1ull);
+      for (int q = 0; q < k; q++) if ((earlier >> q) & 1ull) ok &= ~(1ull << col[q]);
+      ok &= col[k] >= 0 ? ~((2ull << col[k]) - 1ull) : ~0ull;   // colours above the one tried last
+      if (ok) { col[k] = __ffsll((long long)ok) - 1; k++; if (k < m) col[k] = -1; }
+      else { col[k] = -1; k--; }
+    }
+    found = k >= m ? 1 : 0;
+  }
+  __syncthreads();
+  if (found && lane < m) color_s[ball[lane]] = col[lane];
 }
 // iterated greedy (Culberson): recolour greedily in an order that keeps every old class together -- never more colours than
 // before, often fewer.  This kernel sets the stage: priorities = (rank of the atom's old class in the new order, hash, index),
