@@ -211,6 +211,7 @@ struct polar_handle {
   int lp_quad_major = 1;         // slot order of the lp index stream (lp_slot), POLAR_LP_QM=0: lane = entry
   int quad_block = POLAR_BLOCK;  // workgroup size of k_field_quad / k_field_lp (POLAR_QUAD_BLOCK)
   int lp_tiles = 2;              // LDS tiles per wave of k_field_lp (POLAR_LP_TILES: 1 or 2)
+  int lp_rows = 1;               // launch rows per wave (k_field_lpr when > 1; POLAR_LP_ROWS)
   int lp_depth = 0;              // >= 2: k_field_lpa with the gathers that many trips ahead (POLAR_LP_DEPTH: 0, 2, 3)
   int cache_r2 = -1;      // sweep stream (POLAR_CACHE_R2): 0 cached (s3,s5), 20 B/pair; 1 cached r^2, 12 B/pair; 2 nothing,
                           // 4 B/pair (r^2 rebuilt from the gathered positions); -1: 1 or 2 by size, see build_lists
@@ -1149,6 +1150,25 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
   }
   if (nt == 1 && !det) { if (expd) FL(0, 1, false); else FL(1, 1, false); return; }
 #endif
+#ifdef POLAR_LAB
+  if (h->lp_rows > 1 && qb <= 256) {  // several launch rows per wave (k_field_lpr)
+    const int R = h->lp_rows;
+    const size_t rlds = (size_t)(qb / 64) * 2 * POLAR_LP_TILE;
+#define FR(D, DT) k_field_lpr<EP, D, DT><<<nblk_xcd(nrows, (qb / 64) * R), qb, rlds, h->stream>>>(                         \
+      nrows, row0, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                               \
+      st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, omega, h->d_lp_pend.p, R)
+    if (det) { if (expd) FR(0, true); else FR(1, true); }
+    else     { if (expd) FR(0, false); else FR(1, false); }
+#undef FR
+    if (det) {
+      int launch_no = 0;
+      if (EP == EP_INPLACE) while (launch_no + 1 < (int)h->color_off.size() && h->color_off[launch_no] < row0) launch_no++;
+      k_lp_commit<<<nblk(nrows, 256), 256, 0, h->stream>>>(nrows, row0, desc, h->d_lp_pend.p, h->d_rec0.p, h->d_rec1.p, EP == EP_JACOBI ? 1 : 0,
+                                                        h->d_scal.p, h->d_lp_part.p + row0 / 256 + launch_no);
+    }
+    return;
+  }
+#endif
   if (det) {
     if (expd) FL(0, 2, true); else FL(1, 2, true);
     // the launch only read the record table: its rows' new dipoles and the sum of their changes are folded in now
@@ -1837,6 +1857,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_LP_WG_PER_CU")) h->lp_wg_per_cu = atoi(e);
   if (const char *e = getenv("POLAR_LP_QM")) h->lp_quad_major = atoi(e) != 0;
   if (const char *e = getenv("POLAR_LP_TILES")) h->lp_tiles = atoi(e) == 1 ? 1 : 2;
+  if (const char *e = getenv("POLAR_LP_ROWS")) h->lp_rows = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("POLAR_CLUSTER_DIST")) h->cluster_dist = atof(e);
   if (const char *e = getenv("POLAR_CLUSTER_MAX")) h->cluster_max = std::max(1, std::min(4, atoi(e)));
   if (const char *e = getenv("POLAR_LP_DEPTH")) { int v = atoi(e); h->lp_depth = (v == 2 || v == 3) ? v : 0; }

@@ -556,6 +556,175 @@ __global__ __launch_bounds__(1024) void k_field_lp(int nrows, long long row0, co
 
 #ifdef POLAR_LAB
 // ------------------------------------------------------------------------------------------
+// k_field_lpr: the same row sweep, `R` consecutive launch rows per wave, the next row's start hidden behind the current
+// row's trips.  A row of k_field_lp begins with two dependent round trips (descriptor + index chunks, then the row atom's
+// record + the first gathers) and ends with a reduction: with rows only ~8 trips long a wave computes for about half of its
+// life.  Here trip 0 of a row also requests the next row's descriptor and first two index chunks, trip 1 its record and
+// static field, and the LAST trip issues the next row's first gathers into the tile it would have used for "the next trip" --
+// across a row boundary the wave sees one uninterrupted stream of trips, and the epilogue of row r runs while the gathers of
+// row r+1 are in flight.  Tiles alternate per trip, so after a row with an odd number of trips the two tile roles swap.
+// LAB ONLY -- it loses: 246 / 250 / 261 / 291 us per sweep at R = 2 / 3 / 4 / 6 against 229.5 for k_field_lp at 135k atoms
+// (profiles/r03_lab_lpr_rows_per_wave.txt): 115 registers (four waves per SIMD instead of six) and a longer drain cost more
+// than the hidden row starts return -- the sweep is not waiting on its row prologues.
+struct LpNext { int2 de; int4 Ja, Jb; double x, y, z; LpSelf self; };
+__device__ __forceinline__ void lpr_gather4(const char *srcc, int joff, unsigned g0, unsigned g1, unsigned g2, unsigned g3, char *tile) {
+  lp_gather<0>(srcc, joff, g0, tile); lp_gather<1>(srcc, joff, g1, tile);
+  lp_gather<2>(srcc, joff, g2, tile); lp_gather<3>(srcc, joff, g3, tile);
+}
+template <int WRAP, int DAMP>
+__device__ __forceinline__ void lp_pair_math(const double2 &A, const double2 &B, const double2 &C, double rix, double riy, double riz,
+                                             double px, double py, double pz, const Box &box, double pd, const ExpCoef &K,
+                                             double &ax, double &ay, double &az) {
+  double dx = rix - A.x, dy = riy - B.x, dz = riz - C.x;
+  if (WRAP == 1) {
+    dx = fma(-px, rint(dx * box.inv[0]), dx);
+    dy = fma(-py, rint(dy * box.inv[1]), dy);
+    dz = fma(-pz, rint(dz * box.inv[2]), dz);
+  } else if (WRAP == 2) {
+    const double nz = pz != 0.0 ? rint(dz * box.inv[2]) : 0.0;
+    dz = fma(-pz, nz, dz); dy = fma(-box.yz, nz, dy); dx = fma(-box.xz, nz, dx);
+    const double ny = py != 0.0 ? rint(dy * box.inv[1]) : 0.0;
+    dy = fma(-py, ny, dy); dx = fma(-box.xy, ny, dx);
+    dx = fma(-px, rint(dx * box.inv[0]), dx);
+  }
+  const double r2 = fmax(fma(dx, dx, fma(dy, dy, dz * dz)), 1e-12);  // the dummy record may coincide with the row atom
+  double s3, s5;
+  tensor_scalars_lp<DAMP>(r2, pd, K, s3, s5);
+  const double dot = fma(A.y, dx, fma(B.y, dy, C.y * dz));
+  const double cc = s5 * dot;
+  ax = fma(cc, dx, fma(-s3, A.y, ax));
+  ay = fma(cc, dy, fma(-s3, B.y, ay));
+  az = fma(cc, dz, fma(-s3, C.y, az));
+}
+// next row, stage 1 (needs only the launch row number) and stage 2 (needs the descriptor)
+__device__ __forceinline__ void lpr_stage1(LpNext &N, const int2 *descN, const int4 *pcN) {
+  N.de = *descN; N.Ja = pcN[0]; N.Jb = pcN[64];
+}
+__device__ __forceinline__ void lpr_stage2(LpNext &N, int lane, const AtomRec *src, const double *ef) {
+  const int iN = __builtin_amdgcn_readfirstlane(N.de.x);
+  const double *r = reinterpret_cast<const double *>(src + iN);
+  N.x = r[0]; N.y = r[2]; N.z = r[4];
+  N.self = lp_self(lane, src + iN, ef + 3 * (size_t)iN);
+}
+template <int WRAP, int DAMP>
+__device__ __forceinline__ void lpr_row(int T, const int4 *pc, const int4 &Ja0, const int4 &Jb0, const char *srcc, char *lds, int lane,
+                                        double rix, double riy, double riz, const Box &box, double pd, const ExpCoef &K,
+                                        int oa0, int oa1, int oa2, int ob0, int ob1, int ob2, int ta, int tb, bool has_next,
+                                        const int2 *descN, const int4 *pcN, const AtomRec *src, const double *ef, LpNext &N,
+                                        bool &gatheredN, double &ax, double &ay, double &az) {
+  const double px = box.periodic[0] ? box.prd[0] : 0.0, py = box.periodic[1] ? box.prd[1] : 0.0,
+               pz = box.periodic[2] ? box.prd[2] : 0.0;
+  const int k = lane & 3;
+  const unsigned g0 = (unsigned)(k * 16), g1 = (unsigned)((k ^ 1) * 16), g2 = (unsigned)((k ^ 2) * 16), g3 = (unsigned)((k ^ 3) * 16);
+  if (T <= 0) return;
+  const int C = (T + 3) >> 2;
+  int4 Ja = Ja0, Jb = Jb0, Jc = Jb0;
+#define POLAR_LPR_TRIP(U, JNEXT)                                                                                        \
+  {                                                                                                                     \
+    const int tt = t0 + (U);                                                                                            \
+    const double2 A = *reinterpret_cast<const double2 *>(lds + (((U) & 1) ? ob0 : oa0));                                \
+    const double2 B = *reinterpret_cast<const double2 *>(lds + (((U) & 1) ? ob1 : oa1));                                \
+    const double2 Cc = *reinterpret_cast<const double2 *>(lds + (((U) & 1) ? ob2 : oa2));                               \
+    char *nt_ = lds + (((U) & 1) ? ta : tb);                                                                            \
+    if (tt + 1 < T) lpr_gather4(srcc, JNEXT, g0, g1, g2, g3, nt_);                                                      \
+    else if (has_next && tt >= 1) {  /* the last trip: the next row's first records (its stage 1 left with trip 0) */   \
+      if (__builtin_amdgcn_readfirstlane(N.de.y & 0xFFFF) > 0) lpr_gather4(srcc, N.Ja.x, g0, g1, g2, g3, nt_);          \
+      gatheredN = true;                                                                                                 \
+    }                                                                                                                   \
+    if (has_next && tt == 0) lpr_stage1(N, descN, pcN);                                                                 \
+    if (has_next && tt == 1) lpr_stage2(N, lane, src, ef);                                                              \
+    lp_pair_math<WRAP, DAMP>(A, B, Cc, rix, riy, riz, px, py, pz, box, pd, K, ax, ay, az);                              \
+  }
+  for (int c = 0; c < C; c++) {
+    const int t0 = 4 * c;
+    if (c + 2 < C) Jc = pc[64 * (c + 2)];  // rows longer than 8 trips: two chunks ahead
+    POLAR_LPR_TRIP(0, Ja.y);
+    if (t0 + 1 >= T) break;
+    POLAR_LPR_TRIP(1, Ja.z);
+    if (t0 + 2 >= T) break;
+    POLAR_LPR_TRIP(2, Ja.w);
+    if (t0 + 3 >= T) break;
+    POLAR_LPR_TRIP(3, Jb.x);
+    Ja = Jb; Jb = Jc;
+  }
+#undef POLAR_LPR_TRIP
+}
+template <int EP, int DAMP, bool DET>
+__global__ __launch_bounds__(256) void k_field_lpr(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA,
+                                                   AtomRec *recB, Box box, long long pitch, const int *__restrict__ dd_j, double pd,
+                                                   ExpCoef K, const double *__restrict__ ef, const Scal *scal,
+                                                   double *__restrict__ slots, double omega, double *pend, int R) {
+  extern __shared__ __attribute__((aligned(16))) char lp_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rpb = blockDim.x >> 6;
+  const int per = rpb * R;
+  const int lb = xcd_block(blockIdx.x, (nrows + per - 1) / per);
+  if (lb < 0) return;
+  int row = (lb * rpb + wv) * R;  // R consecutive launch rows
+  if (row >= nrows) return;
+  const int last = min(row + R, nrows);
+  const int4 *pc = reinterpret_cast<const int4 *>(dd_j + (size_t)(row0 + row) * pitch) + lane;
+  const int2 de0 = desc[row];
+  int4 Ja = pc[0], Jb = pc[64];
+  const int done = scal->done, curv = scal->cur;
+  if (done) return;
+  int i = __builtin_amdgcn_readfirstlane(de0.x);
+  int T = __builtin_amdgcn_readfirstlane(de0.y & 0xFFFF);
+  int wrapped = __builtin_amdgcn_readfirstlane(de0.y >> 30);
+  const int cur = __builtin_amdgcn_readfirstlane(curv);
+  const AtomRec *src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+  const char *srcc = reinterpret_cast<const char *>(src);
+  const int k = lane & 3, q = lane >> 2;
+  int ta = wv * (2 * POLAR_LP_TILE), tb = ta + POLAR_LP_TILE;
+  // this lane is pair 4q+k of a trip: its record is in block k, piece p in slot 4q + (p^k)
+  int oa0 = ta + k * 1024 + (4 * q + k) * 16, oa1 = ta + k * 1024 + (4 * q + (k ^ 1)) * 16, oa2 = ta + k * 1024 + (4 * q + (k ^ 2)) * 16;
+  int ob0 = oa0 + POLAR_LP_TILE, ob1 = oa1 + POLAR_LP_TILE, ob2 = oa2 + POLAR_LP_TILE;
+  if (T > 0) lp_first_gather(srcc, Ja.x, lane, lp_lds + ta);
+  double rix, riy, riz;
+  {
+    const double *r = reinterpret_cast<const double *>(src + i);
+    rix = wave_uniform(r[0]); riy = wave_uniform(r[2]); riz = wave_uniform(r[4]);
+  }
+  LpSelf self = lp_self(lane, src + i, ef + 3 * (size_t)i);
+  const int unit = lane & 3;
+  const unsigned g0 = (unsigned)(unit * 16), g1 = (unsigned)((unit ^ 1) * 16), g2 = (unsigned)((unit ^ 2) * 16), g3 = (unsigned)((unit ^ 3) * 16);
+  for (;;) {
+    const bool has_next = row + 1 < last;
+    LpNext N;
+    N.de = make_int2(0, 0); N.Ja = Ja; N.Jb = Jb; N.x = N.y = N.z = 0.0; N.self = self;
+    bool gatheredN = false;
+    const int2 *descN = desc + row + 1;
+    const int4 *pcN = pc + (pitch >> 2);
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (!wrapped) lpr_row<0, DAMP>(T, pc, Ja, Jb, srcc, lp_lds, lane, rix, riy, riz, box, pd, K, oa0, oa1, oa2, ob0, ob1, ob2, ta, tb, has_next, descN, pcN, src, ef, N, gatheredN, ax, ay, az);
+    else if (!box.triclinic) lpr_row<1, DAMP>(T, pc, Ja, Jb, srcc, lp_lds, lane, rix, riy, riz, box, pd, K, oa0, oa1, oa2, ob0, ob1, ob2, ta, tb, has_next, descN, pcN, src, ef, N, gatheredN, ax, ay, az);
+    else lpr_row<2, DAMP>(T, pc, Ja, Jb, srcc, lp_lds, lane, rix, riy, riz, box, pd, K, oa0, oa1, oa2, ob0, ob1, ob2, ta, tb, has_next, descN, pcN, src, ef, N, gatheredN, ax, ay, az);
+    if (has_next) {  // rows shorter than two trips leave stages of the next row's start to do
+      if (T < 1) lpr_stage1(N, descN, pcN);
+      if (T < 2) lpr_stage2(N, lane, src, ef);
+      if (!gatheredN && __builtin_amdgcn_readfirstlane(N.de.y & 0xFFFF) > 0) lpr_gather4(srcc, N.Ja.x, g0, g1, g2, g3, lp_lds + ((T & 1) ? tb : ta));
+    }
+    lp_finish<DET>(ax, ay, az, lane, self, dst + i, slots, omega, DET ? pend + 4 * (size_t)(row0 + row) : nullptr);
+    if (!has_next) break;
+    if (T & 1) {  // the next row's trip 0 reads the tile this row's last trip filled
+      int t_;
+      t_ = ta; ta = tb; tb = t_;
+      t_ = oa0; oa0 = ob0; ob0 = t_; t_ = oa1; oa1 = ob1; ob1 = t_; t_ = oa2; oa2 = ob2; ob2 = t_;
+    }
+    row++;
+    pc = pcN;
+    i = __builtin_amdgcn_readfirstlane(N.de.x);
+    T = __builtin_amdgcn_readfirstlane(N.de.y & 0xFFFF);
+    wrapped = __builtin_amdgcn_readfirstlane(N.de.y >> 30);
+    Ja = N.Ja; Jb = N.Jb;
+    rix = wave_uniform(N.x); riy = wave_uniform(N.y); riz = wave_uniform(N.z);
+    self = N.self;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Cluster sweep: one wave = one CLUSTER of up to four rows (polar_lists.hpp, k_cl_build) against the union of
 // their neighbours.  Per 64-neighbour trip the gather, the index stream and the LDS reads are paid once and the
 // pair arithmetic M times (a pair outside the dd cutoff of a member is switched off through its r^2), so the bytes
