@@ -26,6 +26,7 @@ import ctypes as C
 import importlib
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -601,21 +602,34 @@ def bench_distributed(args, rank, world, local_rank):
     # below (run_step) remains for the rehearsal backends (gloo: ranks sharing a GPU, exchanges staged through the host) and
     # for the all-gather variant.
     driver = None
+    driver_fallback = None
     if backend_name == "nccl" and isinstance(plan, P2PHaloPlan) and os.environ.get("POLAR_DIST_DRIVER", "cpp") == "cpp":
         ids = [pkg.PolarDist.unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
-        driver = pkg.PolarDist(ids[0], rank, world, device=local_rank)
-        peers = plan.peers(rank)
-        n_own = hi - lo
-        send_lists = [(np.asarray(plan.send[rank][r]) - lo).astype(np.int32) for r in peers]
-        recv_lists, at = [], n_own
-        for r in peers:
-            m = len(plan.send[r][rank])
-            recv_lists.append(np.arange(at, at + m, dtype=np.int32))
-            at += m
-        driver.set_halo(peers, send_lists, recv_lists)
-        driver.set_cadence(REDUCE_EVERY, 4)
+        driver_error = None
+        try:
+            driver = pkg.PolarDist(ids[0], rank, world, device=local_rank)
+            peers = plan.peers(rank)
+            n_own = hi - lo
+            send_lists = [(np.asarray(plan.send[rank][r]) - lo).astype(np.int32) for r in peers]
+            recv_lists, at = [], n_own
+            for r in peers:
+                m = len(plan.send[r][rank])
+                recv_lists.append(np.arange(at, at + m, dtype=np.int32))
+                at += m
+            driver.set_halo(peers, send_lists, recv_lists)
+            driver.set_cadence(REDUCE_EVERY, 4)
+        except Exception as e:  # noqa: BLE001 -- the communicator could not be made on this rank: all ranks must take the same loop
+            driver_error = repr(e)
+        ok = torch.tensor([0.0 if driver_error else 1.0], dtype=torch.float64, device=be.dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:  # same HIP kernels, the sweep loop in Python over torch.distributed instead (said in the JSON line)
+            if driver is not None and not driver_error:
+                driver.close()
+            driver = None
+            driver_fallback = driver_error or "another rank could not create the RCCL communicator"
+            print(f"[rank {rank}] polar_dist driver unavailable ({driver_fallback}): Python sweep loop", file=sys.stderr, flush=True)
 
     def one_step(timer=None):
         if driver is not None:
@@ -662,7 +676,7 @@ def bench_distributed(args, rank, world, local_rank):
                        "stop_rule_allreduce_every_sweeps": REDUCE_EVERY,
                        "sweep_loop": ("in-library C++ driver (polar_dist_step): pack kernel, ncclGroupStart/Send/Recv/End, unpack kernel and the "
                                       "all-reduced stop rule enqueued on the compute stream, state read every 4 sweeps") if driver is not None
-                                     else "Python loop over the stepwise C-ABI (torch.distributed collectives)",
+                                     else "Python loop over the stepwise C-ABI (torch.distributed collectives)" + (f" -- C++ driver unavailable: {driver_fallback}" if driver_fallback else ""),
                        "exchanges_last_step": out.get("exchanges"), "allreduces_last_step": out.get("allreduces"),
                        "kernel_version": pkg.kernel_version()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
