@@ -64,6 +64,11 @@ typedef struct {
    * (PS.cpp:1170-1180); 1.1 - 1.2 reaches the same fixed point under the same stop rule in about 30 % fewer sweeps on the MOF
    * boxes (profiles/r03_lab_sor.txt).  0 < omega < 2. */
   double polar_sor;
+  /* rccl_halo yes|no (extension keyword, one MPI rank per GPU on one node): the LAMMPS shim hands the per-sweep exchange of
+   * the halo dipoles and the all-reduced stop rule to the library's own RCCL driver (polar_dist_step) instead of staging
+   * them through atom->mu_induced and Comm::forward_comm_pair -- the capability PS.h:51-52 / PS.cpp:1320-1362
+   * (pack_comm / unpack_comm, never called) was meant to provide.  Off by default. */
+  int rccl_halo;
 } polar_settings;
 
 typedef struct {

@@ -65,7 +65,7 @@ class Settings(C.Structure):
                 ("polar_damp", C.c_double), ("polar_gamma", C.c_double), ("iterations_max", C.c_int),
                 ("damping_type", C.c_int), ("zodid", C.c_int), ("fixed_iteration", C.c_int), ("polar_gs", C.c_int),
                 ("polar_gs_ranked", C.c_int), ("use_previous", C.c_int), ("debug", C.c_int), ("dd_cutoff", C.c_double),
-                ("device_neigh", C.c_int), ("restart_polar", C.c_int), ("deterministic", C.c_int), ("polar_sor", C.c_double)]
+                ("device_neigh", C.c_int), ("restart_polar", C.c_int), ("deterministic", C.c_int), ("polar_sor", C.c_double), ("rccl_halo", C.c_int)]
 
 
 class Result(C.Structure):

@@ -348,6 +348,7 @@ class PolarSettings:
     restart_polar: int = 0  # extension: restart files carry the polarization keywords
     deterministic: int = 0  # extension: sweeps commit their updates between launches (bit-reproducible runs)
     polar_sor: float = 1.0  # extension: over-relaxation factor of the list-mode Gauss-Seidel update (1 = reference)
+    rccl_halo: int = 0      # extension: the LAMMPS shim's multi-rank sweeps run through the library's RCCL driver
 
 
 @dataclass
@@ -758,6 +759,8 @@ def parse_pair_style_args(args, base=None):
             st.restart_polar = yn[v]
         elif k == "deterministic":  # extension keyword (not in the reference)
             st.deterministic = yn[v]
+        elif k == "rccl_halo":  # extension keyword (not in the reference)
+            st.rccl_halo = yn[v]
         elif k == "polar_sor":  # extension keyword (not in the reference)
             st.polar_sor = float(v)
             if not 0.0 < st.polar_sor < 2.0:

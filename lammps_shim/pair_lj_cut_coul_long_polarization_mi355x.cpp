@@ -51,9 +51,11 @@ PairLJCutCoulLongPolarizationMI355X::PairLJCutCoulLongPolarizationMI355X(LAMMPS 
   // (The reference declares pack_comm/unpack_comm but never calls them: it is single-process only.)
   comm_forward = 3;
   nhalo = 0;
+  dist = NULL;
   const char *dev = getenv("POLAR_DEVICE");
   int ndev = polar_device_count();
-  int rc = polar_create(dev ? atoi(dev) : (ndev > 0 ? comm->me % ndev : 0), &h);
+  device_index = dev ? atoi(dev) : (ndev > 0 ? comm->me % ndev : 0);
+  int rc = polar_create(device_index, &h);
   if (rc < 0) error->all(FLERR,"Pair style lj/cut/coul/long/polarization (MI355X): cannot create the library handle");
   // (a machine without a GPU may still parse a deck, read and write restart files and call single(): the host mirror of
   //  the library needs no device.  init_style refuses to go on without one, and every compute entry point fails loudly.)
@@ -61,6 +63,7 @@ PairLJCutCoulLongPolarizationMI355X::PairLJCutCoulLongPolarizationMI355X(LAMMPS 
 
 PairLJCutCoulLongPolarizationMI355X::~PairLJCutCoulLongPolarizationMI355X()
 {
+  if (dist) polar_dist_destroy(dist);
   if (allocated) {
     memory->destroy(setflag);
     memory->destroy(cutsq);
@@ -215,6 +218,73 @@ void PairLJCutCoulLongPolarizationMI355X::build_halo_map()
   sh_nn.swap(nn); sh_first.swap(first); sh_flat.swap(flat);
 }
 
+/* ----------------------------------------------------------------------
+   `rccl_halo yes`: the halo plan of the library's RCCL driver, rebuilt with the halo map (reneighbor steps).
+   Every rank publishes the tags of its halo atoms; the owner of a tag (atom->map gives an own index) answers with the
+   slot it will fill.  Own atoms keep their LAMMPS indices in library order, halo slot k is library atom nlocal + k.
+   The communicator is made once: rank 0 draws the RCCL id, MPI_Bcast carries it.
+------------------------------------------------------------------------- */
+
+void PairLJCutCoulLongPolarizationMI355X::build_rccl_plan()
+{
+  const int me = comm->me, np = comm->nprocs, nlocal = atom->nlocal;
+  if (!dist) {
+    char id[POLAR_DIST_ID_BYTES];
+    memset(id,0,sizeof(id));
+    int ok = 1;
+    if (me == 0) ok = polar_dist_unique_id(id) == POLAR_OK;
+    MPI_Bcast(&ok,1,MPI_INT,0,world);
+    if (!ok) error->all(FLERR,"Pair style lj/cut/coul/long/polarization rccl_halo: RCCL is not available");
+    MPI_Bcast(id,POLAR_DIST_ID_BYTES,MPI_CHAR,0,world);
+    int rc = polar_dist_create(id,me,np,device_index,&dist);
+    int bad = rc < 0 ? 1 : 0, any = 0;
+    MPI_Allreduce(&bad,&any,1,MPI_INT,MPI_MAX,world);
+    if (any) error->all(FLERR,"Pair style lj/cut/coul/long/polarization rccl_halo: cannot create the RCCL communicator");
+  }
+  // the halo tags of all ranks
+  std::vector<int> cnt(np,0), disp(np + 1,0);
+  int mine = nhalo;
+  MPI_Allgather(&mine,1,MPI_INT,cnt.data(),1,MPI_INT,world);
+  for (int r = 0; r < np; r++) disp[r + 1] = disp[r] + cnt[r];
+  std::vector<tagint> mytags(nhalo + 1), alltags((size_t) disp[np] + 1);
+  for (int k = 0; k < nhalo; k++) mytags[k] = atom->tag[halo_ghost[k]];
+  MPI_Allgatherv(mytags.data(),nhalo,MPI_LMP_TAGINT,alltags.data(),cnt.data(),disp.data(),MPI_LMP_TAGINT,world);
+  // the slots of the others' halos that this rank fills, and with which own atoms
+  std::vector<int> scount(np,0), sdisp(np + 1,0), rcount(np,0), rdisp(np + 1,0), sslot, sidx;
+  for (int r = 0; r < np; r++) {
+    if (r != me)
+      for (int k = 0; k < cnt[r]; k++) {
+        const int a = atom->map(alltags[(size_t) disp[r] + k]);
+        if (a >= 0 && a < nlocal) { sslot.push_back(k); sidx.push_back(a); scount[r]++; }
+      }
+    sdisp[r + 1] = sdisp[r] + scount[r];
+  }
+  MPI_Alltoall(scount.data(),1,MPI_INT,rcount.data(),1,MPI_INT,world);
+  for (int r = 0; r < np; r++) rdisp[r + 1] = rdisp[r] + rcount[r];
+  std::vector<int> rslot((size_t) rdisp[np] + 1);
+  sslot.push_back(0);
+  MPI_Alltoallv(sslot.data(),scount.data(),sdisp.data(),MPI_INT,rslot.data(),rcount.data(),rdisp.data(),MPI_INT,world);
+  // every halo slot has exactly one owner
+  int bad = rdisp[np] != nhalo ? 1 : 0, any = 0;
+  std::vector<char> filled(nhalo + 1,0);
+  for (int k = 0; k < rdisp[np] && !bad; k++) {
+    if (rslot[k] < 0 || rslot[k] >= nhalo || filled[rslot[k]]) bad = 1;
+    else filled[rslot[k]] = 1;
+  }
+  MPI_Allreduce(&bad,&any,1,MPI_INT,MPI_MAX,world);
+  if (any) error->all(FLERR,"Pair style lj/cut/coul/long/polarization rccl_halo: a halo atom has no owner or several");
+  std::vector<int> peers, sc, rc_, sflat, rflat;
+  for (int r = 0; r < np; r++) {
+    if (scount[r] == 0 && rcount[r] == 0) continue;
+    peers.push_back(r); sc.push_back(scount[r]); rc_.push_back(rcount[r]);
+    for (int k = sdisp[r]; k < sdisp[r + 1]; k++) sflat.push_back(sidx[k]);
+    for (int k = rdisp[r]; k < rdisp[r + 1]; k++) rflat.push_back(nlocal + rslot[k]);
+  }
+  sflat.push_back(0); rflat.push_back(0); peers.push_back(0); sc.push_back(0); rc_.push_back(0);   // (never empty pointers)
+  if (polar_dist_set_halo(dist,(int) peers.size() - 1,peers.data(),sc.data(),sflat.data(),rc_.data(),rflat.data()) < 0)
+    error->one(FLERR,polar_dist_last_error(dist));
+}
+
 void PairLJCutCoulLongPolarizationMI355X::exchange_dipoles()
 {
   const int nlocal = atom->nlocal;
@@ -291,6 +361,15 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
   // eflag & 2 / vflag & 4: per-atom tallies (src/pair.cpp:760-764), fetched after the step
   const int ef = (eflag_either ? 1 : 0) | (eflag_atom ? 2 : 0), vf = (vflag_global ? 1 : 0) | (vflag_atom ? 4 : 0);
   polar_result res;
+  if (pst.rccl_halo) {
+    // the whole solve inside the library: per sweep a pack kernel, one grouped RCCL send/receive with the halo peers, an
+    // unpack kernel and (every sweep, PS.cpp:1194-1210 over all ranks) one all-reduced double, all on the compute stream;
+    // retries after a pitch overflow are agreed on by the driver itself
+    if (relist) build_rccl_plan();
+    int rc = polar_dist_step(dist,h,ef,vf,&res);
+    if (rc < 0) error->one(FLERR,polar_dist_last_error(dist));
+    check(rc);
+  } else
   for (int attempt = 0;; attempt++) {
     check(polar_step_begin(h,ef,vf));
     exchange_dipoles();                                // the other ranks' initial guess

@@ -59,6 +59,10 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   std::vector<int> lib_of_lammps, lammps_of_lib, halo_ghost, sh_nn, sh_flat, sh_idx, sh_t, sh_t2, sh_m;
   std::vector<long long> sh_first;
   std::vector<double> sh_x, sh_q, sh_a, sh_f, sh_mu;
+  // `rccl_halo yes`: the sweeps of a multi-rank step run inside the library (polar_dist_step, RCCL over xGMI)
+  polar_dist *dist;
+  int device_index;
+  void build_rccl_plan();
   void compute_sharded(int, int);
   void build_halo_map();
   void exchange_dipoles();

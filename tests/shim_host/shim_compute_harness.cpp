@@ -151,6 +151,13 @@ int polar_step_finish(polar_handle *, polar_result *) { return POLAR_ERR_STATE; 
 int polar_step_mu_get(polar_handle *, long long, long long, double *) { return POLAR_ERR_STATE; }
 int polar_step_mu_put_idx(polar_handle *, long long, const int *, const double *) { return POLAR_ERR_STATE; }
 int polar_step_change_get(polar_handle *, double *) { return POLAR_ERR_STATE; }
+// the multi-rank driver is not reached by a one-rank compute(): present so that the shim links
+int polar_dist_unique_id(void *) { return POLAR_ERR_STATE; }
+int polar_dist_create(const void *, int, int, int, polar_dist **) { return POLAR_ERR_STATE; }
+int polar_dist_destroy(polar_dist *) { return POLAR_OK; }
+const char *polar_dist_last_error(const polar_dist *) { return "stub"; }
+int polar_dist_set_halo(polar_dist *, int, const int *, const int *, const int *, const int *, const int *) { return POLAR_ERR_STATE; }
+int polar_dist_step(polar_dist *, polar_handle *, int, int, polar_result *) { return POLAR_ERR_STATE; }
 }
 
 namespace {

@@ -42,7 +42,7 @@ ARG_CASES = [
     ["9.0", "9.0", "fixed_iteration", "yes", "max_iterations", "7", "damp_type", "none"],
     ["9.0", "9.0", "dd_cutoff", "8.5"],
     ["9.0", "9.0", "dd_cutoff", "8.5", "device_neigh", "yes"],
-    ["9.0", "9.0", "dd_cutoff", "8.5", "deterministic", "yes", "polar_sor", "1.15", "restart_polar", "yes"],
+    ["9.0", "9.0", "dd_cutoff", "8.5", "deterministic", "yes", "polar_sor", "1.15", "restart_polar", "yes", "rccl_halo", "yes"],
 ]
 
 
@@ -54,7 +54,7 @@ def test_settings_parser_agrees_with_python_mirror(args, pkg, wl):
     ref = wl.parse_pair_style_args(args)
     for k in ("cut_lj_global", "cut_coul", "iterations_max", "damping_type", "zodid", "fixed_iteration", "polar_gs",
               "polar_gs_ranked", "use_previous", "debug", "polar_damp", "polar_precision", "polar_gamma", "dd_cutoff",
-              "device_neigh", "deterministic", "polar_sor", "restart_polar"):
+              "device_neigh", "deterministic", "polar_sor", "restart_polar", "rccl_halo"):
         assert getattr(s, k) == getattr(ref, k), k
 
 
