@@ -230,29 +230,42 @@ __global__ __launch_bounds__(64) void k_color_cells(int s0, int s1, int s2, int 
     const int i = a + base + lane;
     const bool row = base + lane < np && deg[i] >= 0;
     int mine = row ? color_s[i] : 0;            // >= 0: done (or not a row)
+    // One pass over the conflict list: the colours the neighbours hold now, and which of them sit in this batch (bit = lane).
+    // Neighbours outside the cell do not change during this launch (no adjacent cell is in it), those inside are tracked
+    // through the broadcast of every pick: the loop below touches no memory but the one store of the picked colour.
+    unsigned long long used = 0ull, inbatch = 0ull;
+    int d = 0;
+    if (row && mine < 0) {
+      d = deg[i];
+      for (int k = 0; k < d; k++) {
+        const int j = adj[(size_t)i * apitch + k];
+        const int cj = color_s[j];
+        if (cj >= 0) used |= 1ull << cj;
+        const int rel = j - (a + base);
+        if (rel >= 0 && rel < 64) inbatch |= 1ull << rel;
+      }
+    }
     const int todo = __popcll(__ballot(row && mine < 0));
     for (int it = 0; it < todo; it++) {
-      unsigned long long used = 0ull;
-      int d = 0;
-      if (row && mine < 0) {
-        d = deg[i];
-        for (int k = 0; k < d; k++) { const int cj = color_s[adj[(size_t)i * apitch + k]]; if (cj >= 0) used |= 1ull << cj; }
-      }
       // key = (saturation, degree, first in the cell); 0 for lanes with nothing to colour
-      unsigned key = (row && mine < 0) ? (((unsigned)__popcll(used) + 1u) << 16) | ((unsigned)(d < 255 ? d : 255) << 8) | (unsigned)(63 - lane) : 0u;
+      const unsigned key = (row && mine < 0) ? (((unsigned)__popcll(used) + 1u) << 16) | ((unsigned)(d < 255 ? d : 255) << 8) | (unsigned)(63 - lane) : 0u;
       unsigned best = key;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { const unsigned v = (unsigned)__shfl_xor((int)best, o, 64); best = v > best ? v : best; }
-      if (key == best && key != 0u) {           // exactly one lane (the lane number is part of the key)
-        const int cm = __ffsll((long long)~used) - 1;
-        if (cm >= 64) atomicMax(flags, 1000);
-        mine = cm < 64 ? cm : 63;
-        color_s[i] = mine;
+      const int wl = 63 - (int)(best & 63u);    // the picked lane (the lane number is part of the key: exactly one)
+      int cm = 0;
+      if (lane == wl) {
+        cm = __ffsll((long long)~used) - 1;
+        if (cm >= 64) { atomicMax(flags, 1000); cm = 63; }
+        mine = cm;
+        color_s[i] = cm;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next pick reads this colour through the conflict lists
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      cm = __shfl(cm, wl, 64);
+      if ((inbatch >> wl) & 1ull) used |= 1ull << cm;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // a second batch of the same cell reads these colours from memory
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
 }
 
@@ -387,7 +400,7 @@ __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count
   __syncthreads();
   if (lane == 0) {   // depth-first search, rows in ball order (the centre first, then by distance)
     int k = 0;
-    for (int step = 0; step < 200000 && k >= 0 && k < m; step++) {
+    for (int step = 0; step < 768 && k >= 0 && k < m; step++) {   // (a ball that has a colouring is found in a few hundred steps)
       unsigned long long ok = allowed[k];
       const unsigned long long earlier = inball[k] & ((1ull << k) - 1ull);
       for (int q = 0; q < k; q++) if ((earlier >> q) & 1ull) ok &= ~(1ull << col[q]);
