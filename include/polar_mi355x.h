@@ -211,6 +211,12 @@ int polar_compute_peratom(polar_handle *h, int eflag, int vflag, double *f, doub
  * returns how many sweeps were recorded (0 unless the debug keyword is on), < 0 on error. */
 int polar_get_debug_trace(polar_handle *h, double *u_polar, int max);
 
+/* Diagnostics (no reference counterpart: the reference's sweep is serial, PS.cpp:1158-1180): the colour phase of every
+ * local atom in the list-mode Gauss-Seidel of the last compute, in the caller's atom order; -1 for atoms that are not rows
+ * (not polarizable, or outside the handle's row range).  Atoms of one colour are relaxed by one launch and must lie farther
+ * apart than the colour distance (tests check exactly that).  Returns the number of colours, < 0 on error. */
+int polar_get_colors(polar_handle *h, int *color, int n);
+
 /* ---- device-resident variant (bench, multi-GPU driver): no host<->device traffic ---------- */
 /* Runs compute() on the atoms/lists already resident from polar_set_*; results stay on the
  * device (polar_dev_ptr) and only the scalars in polar_result come back. */

@@ -122,6 +122,7 @@ EXPORTS = {
     "polar_set_list_style": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_set_newton": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_get_debug_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "polar_get_colors": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "polar_restart_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "polar_restart_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "polar_step_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -429,6 +430,12 @@ class PolarPair:
         a = np.zeros(nmax)
         n = self._ck(self.L.polar_get_debug_trace(self.h, _dptr(a), nmax))
         return a[:n].copy()
+
+    def colors(self, n):
+        """(ncolors, colour of every local atom in the caller's order; -1: not a row) of the last list-mode GS compute."""
+        a = np.full(n, -1, dtype=np.int32)
+        nc = self._ck(self.L.polar_get_colors(self.h, a.ctypes.data_as(C.POINTER(C.c_int)), n))
+        return nc, a
 
     def download(self, name, n):
         a = np.zeros(n)

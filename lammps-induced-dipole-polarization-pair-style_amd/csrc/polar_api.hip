@@ -905,7 +905,9 @@ void build_colors_device(polar_handle *h, bool ranked) {
   // cells, the odd cells and, when a periodic dimension has an odd count, its last cell on its own.  Safe while two cells of
   // a class (a whole cell apart) cannot hold neighbours: colour distance below the shortest cell edge.
   const double min_edge = std::min({h->box.prd[0] / h->grid.nc[0], h->box.prd[1] / h->grid.nc[1], h->box.prd[2] / h->grid.nc[2]});
-  bool cell_pass = h->color_dist < min_edge;
+  // (tilted box: a cell's perpendicular width is below its edge along the lattice vector -- by at most 1/sqrt(1.5) at LAMMPS'
+  //  tilt limit of half a box length)
+  bool cell_pass = h->color_dist < (h->box.triclinic ? 0.5 : 1.0) * min_edge;
 #ifdef POLAR_LAB
   if (getenv("POLAR_COLOR_JP")) cell_pass = false;  // lab: Jones-Plassmann alone (the round-3 first version: 5 classes)
 #endif
@@ -2432,6 +2434,22 @@ int polar_get_debug_trace(polar_handle *h, double *u_polar, int max) {
     return (int)POLAR_OK;
   });
   return rc < 0 ? rc : n;
+}
+int polar_get_colors(polar_handle *h, int *color, int n) {
+  if (!h) return POLAR_ERR_STATE;
+  int nc = 0;
+  int rc = guarded(h, [&]() {
+    need_device(h);
+    if (!color || n < 0) throw InputError("polar_get_colors: null pointer");
+    const int m = std::min(n, h->nlocal);
+    for (int k = 0; k < n; k++) color[k] = -1;
+    if (!h->colors_valid || (int)h->color_off.size() < 2) return (int)POLAR_OK;
+    nc = (int)h->color_off.size() - 1;
+    if (h->d_color_orig.p && h->d_color_orig.cap >= (size_t)m && m > 0)   // colours by original index (both colourings leave them here)
+      HIPCHECK(hipMemcpy(color, h->d_color_orig.p, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+    return (int)POLAR_OK;
+  });
+  return rc < 0 ? rc : nc;
 }
 int polar_set_newton(polar_handle *h, int newton_pair) {
   if (!h) return POLAR_ERR_STATE;

@@ -77,3 +77,52 @@ def test_random_system_matches_oracle(seed, wl, pkg, oracle):
             a = oracle.fold_ghost_forces(out[k], s.owner, s.nlocal)
             b = oracle.fold_ghost_forces(ref[k], s.owner, s.nlocal)
             assert np.max(np.abs(a - b)) < TOL * max(np.max(np.abs(b)), 1e-30), k
+
+
+def _check_colouring(s, p, dist=2.4):
+    """No two atoms of one colour phase within the colour distance (minimum image), every own polarizable row coloured."""
+    nc, col = p.colors(s.nlocal)
+    x = np.asarray(s.x[:s.nlocal], dtype=float)
+    pol = np.asarray(s.alpha[:s.nlocal]) != 0.0
+    assert nc >= 1 and np.all(col[pol] >= 0) and np.all(col[pol] < nc) and np.all(col[~pol] < 0)
+    assert set(np.unique(col[pol])) == set(range(nc))
+    prd = np.asarray(s.prd, dtype=float)
+    worst = np.inf
+    for c in range(nc):
+        xc = x[col == c]
+        for a in range(0, len(xc), 512):
+            d = xc[a:a + 512, None, :] - xc[None, :, :]
+            d -= prd * np.rint(d / prd)
+            r2 = np.einsum("ijk,ijk->ij", d, d)
+            r2[np.arange(len(r2)), a + np.arange(len(r2))] = np.inf
+            worst = min(worst, float(r2.min()) if r2.size else np.inf)
+    assert worst > dist * dist, (np.sqrt(worst), nc)
+    return nc
+
+
+@pytest.mark.parametrize("seed", [1, 4, 5, 7, 8, 11, 13, 16, 20, 23, 29])
+def test_device_colouring_is_a_proper_colouring(seed, wl, pkg):
+    """The colour phases built on the device (cell-by-cell DSATUR, local repair, Jones-Plassmann fallback): read back through
+    polar_get_colors and checked pair by pair on random boxes (empty cells, vacuum slabs, odd cell counts, few rows)."""
+    s = _system(wl, seed)
+    if not s.settings.dd_cutoff > 0 or not (s.settings.polar_gs or s.settings.polar_gs_ranked):
+        pytest.skip("no colour phases: exact mode or Jacobi")
+    p = pkg.pair_from_system(s)
+    out = p.compute(eflag=1, vflag=2)
+    assert out["status"] == 0
+    nc = _check_colouring(s, p)
+    assert nc == out["ncolors"]
+    p.close()
+
+
+def test_device_colouring_on_the_mof_replica_has_four_phases(wl, pkg):
+    """MOF5+H2 2 x 2 x 2: the device colouring reaches the four phases of the sequential DSATUR (rounds 1-2 built it on the
+    host), and it is a proper colouring at the 2.4 A colour distance."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mof5_h2.npz")
+    s = wl.replicate_fixture(gold, 2, 2, 2, extra_args=["use_previous", "no", "dd_cutoff", "12.8345", "precision", "1e-11", "max_iterations", "100"])
+    p = pkg.pair_from_system(s)
+    out = p.compute(eflag=1, vflag=2)
+    assert out["status"] == 0 and out["ncolors"] == 4
+    assert _check_colouring(s, p) == 4
+    p.close()
