@@ -968,12 +968,12 @@ void build_colors_device(polar_handle *h, bool ranked) {
   };
   fold();
   // local repair of a small top class (k_color_ball): the cell-by-cell pass leaves about one row per unit cell in a fifth
-  // class on the MOF boxes; first balls of one conflict step, then of two
+  // class on the MOF boxes; first balls of one conflict step, then of two, then of three
   const int kcap = 8192;
   // (only a SMALL top class is worth it -- at most 2 % of the rows: where atoms overlap, e.g. sorbates flying through the
   //  framework in bench.py's ballistic leg, the extra classes are needed and no local search removes them)
   const double krows = std::min((double)kcap, 0.02 * (double)own_n(h));
-  for (int hops = 1; hops <= 2 && ncolors > 2 && h->h_cstat[2 * (ncolors - 1)] <= krows; hops++) {
+  for (int hops = 1; hops <= 3 && ncolors > 2 && h->h_cstat[2 * (ncolors - 1)] <= krows; hops++) {
     h->d_klist.ensure(4 * (size_t)kcap + 8);
     int *raw = h->d_klist.p, *list = raw + kcap, *st0 = raw + 2 * kcap, *st1 = raw + 3 * kcap, *cnt = raw + 4 * kcap;
     HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int), s));
@@ -981,9 +981,10 @@ void build_colors_device(polar_handle *h, bool ranked) {
     k_sort_small<<<8, 256, 0, s>>>(cnt, kcap, raw, list, st0, st1);
     const int waves = (int)h->h_cstat[2 * (ncolors - 1)];
     const double reach = (2 * hops + 1) * h->color_dist;
-    for (int round = 0; round < 4; round++)
+    const int budget = hops == 1 ? 768 : hops == 2 ? 2048 : 16384;   // search steps per ball: the later stages see few rows
+    for (int round = 0; round < 2 + 2 * hops; round++)
       k_color_ball<<<waves, 64, 0, s>>>(cnt, kcap, list, (round & 1) ? st1 : st0, (round & 1) ? st0 : st1, h->d_pos4.p, h->box, reach * reach,
-                                        ncolors - 1, hops, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p);
+                                        ncolors - 1, hops, budget, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p);
     const int before = ncolors;
     ncolors = stats();
     if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] colour repair (%d-step balls): %d rows in the top class, %d classes -> %d\n", hops, waves, before, ncolors);

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_sort_small(const int *__restrict__ coun
 }
 __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count, int cap, const int *__restrict__ list, const int *__restrict__ prev,
                                                    int *__restrict__ state, const double4 *__restrict__ pos4, Box box, double reachsq, int top, int hops,
-                                                   int apitch, const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s) {
+                                                   int budget, int apitch, const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s) {
   __shared__ int ball[64];
   __shared__ unsigned long long inball[64], allowed[64];
   __shared__ int col[64];
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count
   __syncthreads();
   if (lane == 0) {   // depth-first search, rows in ball order (the centre first, then by distance)
     int k = 0;
-    for (int step = 0; step < 768 && k >= 0 && k < m; step++) {   // (a ball that has a colouring is found in a few hundred steps)
+    for (int step = 0; step < budget && k >= 0 && k < m; step++) {   // (a ball that has a colouring is usually found in a few hundred steps)
       unsigned long long ok = allowed[k];
       const unsigned long long earlier = inball[k] & ((1ull << k) - 1ull);
       for (int q = 0; q < k; q++) if ((earlier >> q) & 1ull) ok &= ~(1ull << col[q]);
