@@ -24,7 +24,7 @@
 using namespace polar;
 
 // bump when a kernel on the hot path changes: PMC files under profiles/ are keyed by it (bench.py, roofline.traffic)
-#define POLAR_KERNEL_VERSION "r03-lp3-v2"
+#define POLAR_KERNEL_VERSION "r03-lp3-v3"
 
 namespace {
 
@@ -430,7 +430,7 @@ void build_cells(polar_handle *h) {
   // the order inside a cell follows the atomics of k_cell_fill: put it into atom order -- always, not only for `deterministic
   // yes` (reproducible sums): the device colouring breaks its ties by position in the cell, and a colouring that changed from
   // run to run would make unconverged (`fixed_iteration`) results differ at 1e-6 instead of the 1e-9 of the in-place race
-  k_cell_sort<<<nblk(ncell, 128), 128, 0, s>>>(ncell, h->d_cell_first.p, (h->pol_first || h->sweep_kernel == 4) ? h->d_cell_fill.p : nullptr, h->d_perm.p, h->d_inv.p);
+  k_cell_sort<<<nblk(ncell, 4), 256, 0, s>>>(ncell, h->d_cell_first.p, (h->pol_first || h->sweep_kernel == 4) ? h->d_cell_fill.p : nullptr, h->d_perm.p, h->d_inv.p);
   h->sorted = true;
   if (sharded(h)) {
     h->d_ownrows.ensure(own_n(h) + 1);
@@ -877,6 +877,16 @@ inline void build_colors(polar_handle *, const std::vector<double> &) { throw st
 void build_colors_device(polar_handle *h, bool ranked) {
   const int n = h->nlocal;
   hipStream_t s = h->stream;
+  const bool dbg = getenv("POLAR_DEBUG") != nullptr;
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {   // POLAR_DEBUG: wall time since the last lap, the device drained first
+    if (!dbg) return;
+    HIPCHECK(hipStreamSynchronize(s));
+    const auto tn = std::chrono::steady_clock::now();
+    fprintf(stderr, "[polar] colouring: %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(tn - tprev).count());
+    tprev = tn;
+  };
+  lap("(work queued before)");
   const long long ncell = h->ncell;
   if (!h->h_cflags) {
     HIPCHECK(hipHostMalloc((void **)&h->h_cflags, 96 * sizeof(int)));
@@ -901,6 +911,7 @@ void build_colors_device(polar_handle *h, bool ranked) {
     h->cadj_pitch = (h->h_cflags[0] + 4 + 7) / 8 * 8;
   }
   const int ap_ = h->cadj_pitch;
+  lap("conflict lists");
   // sequential DSATUR cell by cell (k_color_cells): one launch per parity class of the cell grid -- per dimension the even
   // cells, the odd cells and, when a periodic dimension has an odd count, its last cell on its own.  Safe while two cells of
   // a class (a whole cell apart) cannot hold neighbours: colour distance below the shortest cell edge.
@@ -947,6 +958,7 @@ void build_colors_device(polar_handle *h, bool ranked) {
     coloured = h->h_cflags[1] == 0;
   }
   if (!coloured) throw std::runtime_error("colouring: Jones-Plassmann did not finish");
+  lap("cell pass + rounds");
   if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] device colouring: %d rounds\n", rounds);
   auto stats = [&]() {  // rows and rank sums per colour -> number of colours in use
     HIPCHECK(hipMemsetAsync(h->d_cstat.p, 0, 128 * sizeof(double), s));
@@ -967,13 +979,14 @@ void build_colors_device(polar_handle *h, bool ranked) {
     }
   };
   fold();
+  lap("fold");
   // local repair of a small top class (k_color_ball): the cell-by-cell pass leaves about one row per unit cell in a fifth
   // class on the MOF boxes; first balls of one conflict step, then of two, then of three
   const int kcap = 8192;
-  // (only a SMALL top class is worth it -- at most 2 % of the rows: where atoms overlap, e.g. sorbates flying through the
+  // (only a SMALL top class of at most six is worth it -- at most 2 % of the rows: where atoms overlap, e.g. sorbates flying through the
   //  framework in bench.py's ballistic leg, the extra classes are needed and no local search removes them)
   const double krows = std::min((double)kcap, 0.02 * (double)own_n(h));
-  for (int hops = 1; hops <= 3 && ncolors > 2 && h->h_cstat[2 * (ncolors - 1)] <= krows; hops++) {
+  for (int hops = 1; hops <= 3 && ncolors > 2 && ncolors <= 6 && h->h_cstat[2 * (ncolors - 1)] <= (hops < 3 ? krows : 128.0); hops++) {   // (the last, long search only for a handful of rows)
     h->d_klist.ensure(4 * (size_t)kcap + 8);
     int *raw = h->d_klist.p, *list = raw + kcap, *st0 = raw + 2 * kcap, *st1 = raw + 3 * kcap, *cnt = raw + 4 * kcap;
     HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int), s));
@@ -981,7 +994,7 @@ void build_colors_device(polar_handle *h, bool ranked) {
     k_sort_small<<<8, 256, 0, s>>>(cnt, kcap, raw, list, st0, st1);
     const int waves = (int)h->h_cstat[2 * (ncolors - 1)];
     const double reach = (2 * hops + 1) * h->color_dist;
-    const int budget = hops == 1 ? 768 : hops == 2 ? 2048 : 16384;   // search steps per ball: the later stages see few rows
+    const int budget = hops == 1 ? 768 : hops == 2 ? 2048 : 8192;   // search steps per ball: the later stages see few rows
     for (int round = 0; round < 2 + 2 * hops; round++)
       k_color_ball<<<waves, 64, 0, s>>>(cnt, kcap, list, (round & 1) ? st1 : st0, (round & 1) ? st0 : st1, h->d_pos4.p, h->box, reach * reach,
                                         ncolors - 1, hops, budget, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p);
@@ -990,6 +1003,7 @@ void build_colors_device(polar_handle *h, bool ranked) {
     if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] colour repair (%d-step balls): %d rows in the top class, %d classes -> %d\n", hops, waves, before, ncolors);
     if (ncolors < before) break;
   }
+  lap("repair");
   // iterated greedy (Culberson) for what is still above four classes -- overlapping atoms, or the Jones-Plassmann fallback,
   // whose parallel rounds decide on stale saturation counts: regrouping by old classes in another order never adds a class
   // and sometimes removes one
@@ -1009,6 +1023,7 @@ void build_colors_device(polar_handle *h, bool ranked) {
     fold();
     stale = ncolors < before ? 0 : stale + 1;
   }
+  lap("iterated greedy");
   if (ncolors > 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
   // phase order: "ranked" flavour = colours by descending mean rank metric (PS.cpp:192-227 ranks the dipoles most likely to
   // change first); otherwise by descending size
@@ -1033,6 +1048,7 @@ void build_colors_device(polar_handle *h, bool ranked) {
   h->d_rows_orig.ensure((size_t)tot + 1); h->d_rows.ensure((size_t)tot + 1);
   k_color_fill<<<nblk(ncell, 128), 128, 0, s>>>(ncell, ncolors, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_perm.p, h->d_coff.p,
                                                h->d_rows_orig.p);
+  lap("phase order + rows");
   h->h_color.assign((size_t)n, 0);  // (its size says "a colouring for n atoms exists": the colours themselves live on the device)
   h->color_epoch++;
   h->colors_rebuilt++;

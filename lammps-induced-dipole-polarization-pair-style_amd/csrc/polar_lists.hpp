@@ -94,24 +94,36 @@ __global__ void k_cell_fill(int n, const int *__restrict__ cell_id, const long l
   perm[s] = i;
   inv[i] = s;
 }
-// `deterministic yes`: k_cell_fill places the atoms of a cell in the order its atomics happened to run; here one thread per
-// cell puts each of the two groups (polarizable atoms, the others) into ascending atom index -- insertion sort of ~20
-// entries -- so that every list, and with it every floating-point sum, has the same order run after run
-__global__ void k_cell_sort(long long ncell, const long long *__restrict__ cell_first, const int *__restrict__ npol,
-                            int *__restrict__ perm, int *__restrict__ inv) {
-  const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+// k_cell_fill places the atoms of a cell in the order its atomics happened to run; here one wave per cell puts each of the
+// two groups (polarizable atoms, the others) into ascending atom index, so that every list -- and with it every
+// floating-point sum and the device colouring's tie-breaks -- has the same order run after run.  A lane holds one atom and
+// counts the smaller indices of its group (rank sort, ~20 entries); groups of more than 64 fall to a serial insertion sort.
+__global__ __launch_bounds__(256) void k_cell_sort(long long ncell, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+                                                   int *__restrict__ perm, int *__restrict__ inv) {
+  const int lane = threadIdx.x & 63;
+  const long long c = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= ncell) return;
   const int a = (int)cell_first[c], b = (int)cell_first[c + 1], m = npol ? a + npol[c] : b;
   for (int part = 0; part < 2; part++) {
     const int lo = part ? m : a, hi = part ? b : m;
-    for (int k = lo + 1; k < hi; k++) {
-      const int v = perm[k];
-      int j = k - 1;
-      while (j >= lo && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
-      perm[j + 1] = v;
+    const int cnt = hi - lo;
+    if (cnt <= 1) continue;
+    if (cnt <= 64) {
+      const int v = lane < cnt ? perm[lo + lane] : 0x7fffffff;
+      int r = 0;
+      for (int k = 0; k < cnt; k++) r += __shfl(v, k, 64) < v;
+      __builtin_amdgcn_wave_barrier();   // all reads of the group above, all writes below
+      if (lane < cnt) { perm[lo + r] = v; inv[v] = lo + r; }  // (atom indices are distinct: the ranks are a permutation)
+    } else if (lane == 0) {
+      for (int k = lo + 1; k < hi; k++) {
+        const int v = perm[k];
+        int j = k - 1;
+        while (j >= lo && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
+        perm[j + 1] = v;
+      }
+      for (int k = lo; k < hi; k++) inv[perm[k]] = k;
     }
   }
-  for (int k = a; k < b; k++) inv[perm[k]] = k;
 }
 __global__ void k_map_rows(int n, const int *__restrict__ inv, const int *__restrict__ in, int *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -342,9 +354,6 @@ __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count
                                                    int *__restrict__ state, const double4 *__restrict__ pos4, Box box, double reachsq, int top, int hops,
                                                    int budget, int apitch, const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s) {
   __shared__ int ball[64];
-  __shared__ unsigned long long inball[64], allowed[64];
-  __shared__ int col[64];
-  __shared__ int found;
   const int m_all = *count;
   const int w = blockIdx.x, lane = threadIdx.x;
   if (m_all > cap || w >= m_all) return;
@@ -380,10 +389,11 @@ __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count
     }
     level0 = level1;
   }
-  // per ball row: the colours its neighbours outside the ball hold, and its neighbours inside
+  // per ball row (lane = position in the ball): the colours its neighbours outside the ball hold, and its neighbours inside
+  unsigned long long in = 0ull, allow = 0ull;
   if (lane < m) {
     const int node = ball[lane];
-    unsigned long long used = 0ull, in = 0ull;
+    unsigned long long used = 0ull;
     const int d = deg[node];
     for (int k = 0; k < d; k++) {
       const int j = adj[(size_t)node * apitch + k];
@@ -392,26 +402,32 @@ __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count
       if (at >= 0) in |= 1ull << at;
       else used |= 1ull << color_s[j];
     }
-    inball[lane] = in;
-    allowed[lane] = ~used & ((1ull << top) - 1ull);
-    col[lane] = -1;
+    allow = ~used & ((1ull << top) - 1ull);
   }
-  if (lane == 0) found = 0;
-  __syncthreads();
-  if (lane == 0) {   // depth-first search, rows in ball order (the centre first, then by distance)
-    int k = 0;
-    for (int step = 0; step < budget && k >= 0 && k < m; step++) {   // (a ball that has a colouring is usually found in a few hundred steps)
-      unsigned long long ok = allowed[k];
-      const unsigned long long earlier = inball[k] & ((1ull << k) - 1ull);
-      for (int q = 0; q < k; q++) if ((earlier >> q) & 1ull) ok &= ~(1ull << col[q]);
-      ok &= col[k] >= 0 ? ~((2ull << col[k]) - 1ull) : ~0ull;   // colours above the one tried last
-      if (ok) { col[k] = __ffsll((long long)ok) - 1; k++; if (k < m) col[k] = -1; }
-      else { col[k] = -1; k--; }
+  // Depth-first search, rows in ball order (the centre first, then by distance), the whole wave in step: lane q keeps the
+  // colour of ball row q in a register, the colours the earlier in-ball neighbours of row k hold are collected with one
+  // ballot per colour -- no memory in the loop (a one-lane version walking LDS arrays took about a microsecond per step).
+  int mycol = -1;
+  int k = 0;
+  for (int step = 0; step < budget && k >= 0 && k < m; step++) {
+    const unsigned long long ek = __shfl(in, k, 64) & ((1ull << k) - 1ull);   // earlier in-ball neighbours of row k (k < 64)
+    const bool nb = (ek >> lane) & 1ull;
+    unsigned long long ok = __shfl(allow, k, 64);
+    for (int c = 0; c < top; c++)
+      if (((ok >> c) & 1ull) && __ballot(nb && mycol == c)) ok &= ~(1ull << c);
+    const int cur = __shfl(mycol, k, 64);
+    if (cur >= 0) ok &= ~((2ull << cur) - 1ull);   // colours above the one tried last
+    if (ok) {
+      const int c = __ffsll((long long)ok) - 1;
+      if (lane == k) mycol = c;
+      k++;
+      if (lane == k) mycol = -1;
+    } else {
+      if (lane == k) mycol = -1;
+      k--;
     }
-    found = k >= m ? 1 : 0;
   }
-  __syncthreads();
-  if (found && lane < m) color_s[ball[lane]] = col[lane];
+  if (k >= m && lane < m) color_s[ball[lane]] = mycol;   // found: every row of the ball has a colour below `top`
 }
 // iterated greedy (Culberson): recolour greedily in an order that keeps every old class together -- never more colours than
 // before, often fewer.  This kernel sets the stage: priorities = (rank of the atom's old class in the new order, hash, index),

@@ -12,6 +12,7 @@ these systems, the properties need none:
 
 configs[1]  3x3x3 =  36,423 atoms, fixed_iteration 30, uploaded half list
 configs[2]  5x5x4 = 134,900 atoms, polar_gs_ranked, precision 1e-11 (the bench headline), uploaded half list
+configs[3]  6x6x6 = 291,384 atoms on ONE GPU (the box the 2- and 4-GPU runs split), precision 1e-11, device-built list
 configs[4]  7x7x8 = 528,808 atoms on ONE GPU (the strong-scaling denominator), precision 1e-11, device-built list
 """
 import os
@@ -29,8 +30,11 @@ PREC = ["fixed_iteration", "no", "precision", "1e-11", "max_iterations", "100"]
 CASES = {
     "config1_36k": dict(reps=(3, 3, 3), solver=FIXED, device_neigh=False, peratom=True),
     "config2_135k": dict(reps=(5, 5, 4), solver=PREC, device_neigh=False, peratom=True),
+    "config3_291k_one_gpu": dict(reps=(6, 6, 6), solver=PREC, device_neigh=True, peratom=False),
     "config4_529k_one_gpu": dict(reps=(7, 7, 8), solver=PREC, device_neigh=True, peratom=False),
 }
+PER_CELL = {}   # case -> (E_pol, E_vdwl) per replica cell, filled as the cases run (E_coul is the real-space part of an
+                # Ewald sum whose splitting parameter follows the box: not a property of the cell)
 
 
 @pytest.fixture(scope="module", params=list(CASES), ids=list(CASES))
@@ -42,6 +46,7 @@ def full(request, wl, pkg):
     p = pkg.pair_from_system(s, device_neigh=c["device_neigh"])
     out = p.compute(eflag=3, vflag=5) if c["peratom"] else p.compute(eflag=1, vflag=2)
     p.close()
+    PER_CELL[request.param] = np.array([out["eng_pol"], out["eng_vdwl"]]) / np.prod(c["reps"])
     return s, out, c
 
 
@@ -97,3 +102,12 @@ def test_peratom_tallies_add_up(full):
     np.add.at(ea, s.owner, out["eatom"])
     cell = ea.reshape(nimg, n0).sum(axis=1)
     assert np.max(np.abs(cell - cell[0])) < 1e-8 * abs(cell[0])
+
+
+def test_energy_per_cell_is_the_same_in_every_box(full):
+    """Every box is whole copies of one cell and wider than two cutoffs: the energies per cell are properties of the cell.
+    (Compared between the precision-mode boxes: configs[2], [3], [4]; the 30 fixed sweeps of configs[1] stop at 1e-11 too.)"""
+    s, out, c = full
+    mine = np.array([out["eng_pol"], out["eng_vdwl"]]) / np.prod(c["reps"])
+    for name, other in PER_CELL.items():
+        assert np.max(np.abs(mine - other) / np.abs(other)) < 1e-8, (name, mine, other)

@@ -27,7 +27,7 @@ par = importlib.import_module(bench.PKG + ".parallel")
 reps = tuple(int(v) for v in os.environ.get("LAB_REPS", "2x2x8").split("x"))
 world = int(os.environ.get("LAB_WORLD", "8"))
 ws = os.environ.get("LAB_W", "0,0.3,0.5,adaptive").split(",")
-PREC = ["fixed_iteration", "no", "precision", "1e-11", "max_iterations", "200"]
+PREC = ["fixed_iteration", "no", "precision", "1e-11", "max_iterations", "200"] + os.environ.get("LAB_EXTRA", "").split()   # e.g. LAB_EXTRA="polar_sor 1.15"
 
 sg = bench.build_workload(wl, reps, [], build_list=False, solver=PREC)
 n_total = sg.nlocal
