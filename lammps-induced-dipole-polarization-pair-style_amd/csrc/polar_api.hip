@@ -212,6 +212,13 @@ struct polar_handle {
   int quad_block = POLAR_BLOCK;  // workgroup size of k_field_quad / k_field_lp (POLAR_QUAD_BLOCK)
   int lp_tiles = 2;              // LDS tiles per wave of k_field_lp (POLAR_LP_TILES: 1 or 2)
   int lp_rows = 1;               // launch rows per wave (k_field_lpr when > 1; POLAR_LP_ROWS)
+  int lp_pairs = 0;              // lab (POLAR_LP_PAIRS=1): paired rows, k_field_lp2 over union lists
+  DBuf<int> d_ulead, d_udd_j;    // paired rows: leader flags per launch row, union lists
+  DBuf<long long> d_upos;        // ... unit number of every leader (scan)
+  DBuf<int2> d_unit;             // ... {row atom A, row atom B or -1} per unit
+  DBuf<int4> d_udesc;            // ... {A, B, trips | wrap << 30, entries}
+  std::vector<int> unit_off;     // ... first unit of every phase
+  long long upitch = 0;
   int lp_depth = 0;              // >= 2: k_field_lpa with the gathers that many trips ahead (POLAR_LP_DEPTH: 0, 2, 3)
   int cache_r2 = -1;      // sweep stream (POLAR_CACHE_R2): 0 cached (s3,s5), 20 B/pair; 1 cached r^2, 12 B/pair; 2 nothing,
                           // 4 B/pair (r^2 rebuilt from the gathered positions); -1: 1 or 2 by size, see build_lists
@@ -1322,6 +1329,67 @@ template <int EP> inline void launch_field_tile(polar_handle *, const TileLaunch
 #endif  // POLAR_LAB
 
 // one sweep over the rows this handle owns (Jacobi, or the colour phases)
+#ifdef POLAR_LAB
+// paired rows (lab): this step's units and their union lists; needs the colour rows in s space (map_color_rows) and the cells
+void build_units(polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  hipStream_t s = h->stream;
+  const bool gs = st.polar_gs || st.polar_gs_ranked;
+  PhaseOff P;
+  if (gs) {
+    P.n = (int)h->color_off.size() - 1;
+    if (P.n > 64) throw InputError("paired rows: more than 64 colour phases");
+    for (int q = 0; q <= P.n; q++) P.off[q] = h->color_off[q];
+  } else { P.n = 1; P.off[0] = 0; P.off[1] = own_n(h); }
+  const int tot = P.off[P.n];
+  h->unit_off.assign((size_t)P.n + 1, 0);
+  if (tot <= 0) return;
+  const int *rows = gs ? h->d_rows.p : own_rows(h);
+  h->d_ulead.ensure((size_t)tot + 1); h->d_upos.ensure((size_t)tot + 2); h->d_unit.ensure((size_t)tot + 1); h->d_udesc.ensure((size_t)tot + 1);
+  k_unit_flag<<<nblk(tot, 256), 256, 0, s>>>(tot, rows, h->d_perm.p, h->d_cell_id.p, P, h->d_ulead.p);
+  k_exclusive_scan<int><<<1, 1024, 0, s>>>((long long)tot, h->d_ulead.p, h->d_upos.p);
+  k_unit_fill<<<nblk(tot, 256), 256, 0, s>>>(tot, rows, h->d_perm.p, h->d_cell_id.p, P, h->d_ulead.p, h->d_upos.p, h->d_unit.p);
+  std::vector<long long> first((size_t)P.n + 1);
+  for (int q = 0; q <= P.n; q++)
+    HIPCHECK(hipMemcpyAsync(&first[q], h->d_upos.p + P.off[q], sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  for (int q = 0; q <= P.n; q++) h->unit_off[q] = (int)first[q];
+  const int nunits = h->unit_off[P.n];
+  if (h->upitch == 0) h->upitch = ((h->dd_pitch * 3 / 2 + 255) / 256) * 256;
+  for (int attempt = 0;; attempt++) {
+    h->d_udd_j.ensure((size_t)nunits * h->upitch + 1024);
+    zero_many(s, {{h->d_overflow.p + 4, 4 * sizeof(int)}, {h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long)}});
+    if (h->box.triclinic)
+      k_dd_units<true><<<nblk(nunits, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(nunits, h->d_unit.p, h->d_pos4.p, h->box, h->grid, h->d_cell_first.p, st.dd_cutoff * st.dd_cutoff,
+                                                                                 h->upitch, h->d_udd_j.p, h->d_udesc.p, h->lp_quad_major ? 1 : 0, h->nlocal, h->d_overflow.p + 4, h->d_ddtot.p);
+    else
+      k_dd_units<false><<<nblk(nunits, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(nunits, h->d_unit.p, h->d_pos4.p, h->box, h->grid, h->d_cell_first.p, st.dd_cutoff * st.dd_cutoff,
+                                                                                  h->upitch, h->d_udd_j.p, h->d_udesc.p, h->lp_quad_major ? 1 : 0, h->nlocal, h->d_overflow.p + 4, h->d_ddtot.p);
+    int over = 0;
+    HIPCHECK(hipMemcpyAsync(&over, h->d_overflow.p + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (over <= h->upitch) break;
+    if (attempt > 2) throw std::runtime_error("paired rows: union list pitch overflow persists");
+    h->upitch = (((long long)over * 9 / 8 + 255) / 256) * 256;
+  }
+  if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] paired rows: %d units for %d rows, union pitch %lld\n", nunits, tot, h->upitch);
+}
+template <int EP>
+void launch_field_lp2(polar_handle *h, int q) {
+  const int nunits = h->unit_off[q + 1] - h->unit_off[q];
+  if (nunits <= 0) return;
+  const polar_settings &st = h->ph.st;
+  const size_t lds = (size_t)4 * 2 * POLAR_LP_TILE;
+  const double omega = EP == EP_INPLACE ? st.polar_sor : 1.0;
+  if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
+    k_field_lp2<EP, 0><<<nblk_xcd(nunits, 4), 256, lds, h->stream>>>(nunits, (long long)h->unit_off[q], h->d_udesc.p, h->d_rec0.p, h->d_rec1.p, h->box, h->upitch,
+                                                                     h->d_udd_j.p, st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, omega);
+  else
+    k_field_lp2<EP, 1><<<nblk_xcd(nunits, 4), 256, lds, h->stream>>>(nunits, (long long)h->unit_off[q], h->d_udesc.p, h->d_rec0.p, h->d_rec1.p, h->box, h->upitch,
+                                                                     h->d_udd_j.p, st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, omega);
+}
+#endif
+
 void sweep_once(polar_handle *h, bool ap) {
   const polar_settings &st = h->ph.st;
   const bool gs = st.polar_gs || st.polar_gs_ranked;
@@ -1340,6 +1408,13 @@ void sweep_once(polar_handle *h, bool ap) {
     }
     return;
   }
+#ifdef POLAR_LAB
+  if (!ap && h->sweep_kernel == 2 && h->lp_pairs && !deterministic(h) && h->part_n <= 1) {
+    if (!gs) { launch_field_lp2<EP_JACOBI>(h, 0); return; }
+    for (int c = 0; c + 1 < (int)h->unit_off.size(); c++) launch_field_lp2<EP_INPLACE>(h, c);
+    return;
+  }
+#endif
   if (!ap && h->sweep_kernel == 2) {
     if (!gs) { launch_field_lp<EP_JACOBI>(h, own_n(h), h->d_lpdesc.p); return; }
     const int ncol = (int)h->color_off.size() - 1;
@@ -1483,6 +1558,9 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     if (!ap && gs && h->sweep_kernel == 2 && !slots_current(h)) { compute_slots(h); build_lists(h); }  // rows into launch order
     if (gs) out->ncolors = tile ? (int)h->tile_launches.size() : (int)h->color_off.size() - 1;
     if (!ap && h->sweep_kernel == 2) prepare_lp(h);
+#ifdef POLAR_LAB
+    if (!ap && h->sweep_kernel == 2 && h->lp_pairs && !deterministic(h)) build_units(h);
+#endif
     // fixed-iteration GS takes no decision between sweeps: its end-of-sweep logic is applied in two
     // launches (all sweeps but the last, then the last one, whose sum |dmu|^2 is the one reported)
     const bool lazy = st.fixed_iteration && gs;
@@ -1884,6 +1962,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_LP_QM")) h->lp_quad_major = atoi(e) != 0;
   if (const char *e = getenv("POLAR_LP_TILES")) h->lp_tiles = atoi(e) == 1 ? 1 : 2;
   if (const char *e = getenv("POLAR_LP_ROWS")) h->lp_rows = std::max(1, std::min(64, atoi(e)));
+  if (const char *e = getenv("POLAR_LP_PAIRS")) h->lp_pairs = atoi(e) != 0;
   if (const char *e = getenv("POLAR_CLUSTER_DIST")) h->cluster_dist = atof(e);
   if (const char *e = getenv("POLAR_CLUSTER_MAX")) h->cluster_max = std::max(1, std::min(4, atoi(e)));
   if (const char *e = getenv("POLAR_LP_DEPTH")) { int v = atoi(e); h->lp_depth = (v == 2 || v == 3) ? v : 0; }
@@ -1942,7 +2021,7 @@ int polar_destroy(polar_handle *h) {
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_slot.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_trace.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
-    h->d_cadj.release(); h->d_cdeg.release(); h->d_ccnt.release(); h->d_cflags.release(); h->d_crelabel.release(); h->d_klist.release(); h->d_cprio.release(); h->d_cstat.release(); h->d_coff.release(); h->d_lp_pend.release(); h->d_lp_part.release();
+    h->d_cadj.release(); h->d_cdeg.release(); h->d_ccnt.release(); h->d_cflags.release(); h->d_crelabel.release(); h->d_klist.release(); h->d_ulead.release(); h->d_udd_j.release(); h->d_upos.release(); h->d_unit.release(); h->d_udesc.release(); h->d_cprio.release(); h->d_cstat.release(); h->d_coff.release(); h->d_lp_pend.release(); h->d_lp_part.release();
     if (h->h_cflags) (void)hipHostFree(h->h_cflags);
     if (h->h_cstat) (void)hipHostFree(h->h_cstat);
     if (h->h_coff) (void)hipHostFree(h->h_coff);

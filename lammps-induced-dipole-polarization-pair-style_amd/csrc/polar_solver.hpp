@@ -725,6 +725,144 @@ __global__ __launch_bounds__(256) void k_field_lpr(int nrows, long long row0, co
 }
 
 // ------------------------------------------------------------------------------------------
+// k_field_lp2 (lab): PAIRED ROWS -- one wave sweeps two rows of one colour phase that share a cell over the union of their
+// neighbours (polar_lists.hpp, k_dd_units).  Same trip structure as k_field_lp; a gathered record is used for both rows, an
+// entry's two low bits say which of the rows it belongs to (the other one's tensor scalars are multiplied by zero).
+// LAB ONLY -- no gain: 49.9 us per launch against 50.4 with 0.64 x the gathers and half the waves, and the per-step union
+// build (0.5 ms) on top (profiles/r03_lab_paired_rows.txt).  Forcing five waves per SIMD (95 registers, 4 spilled) changes nothing.
+template <int WRAP, int DAMP>
+__device__ __forceinline__ void lp2_trip(const char *rd0, const char *rd1, const char *rd2, int cur, int nxt, bool more, const char *srcc,
+                                         int jcur, int jnext, unsigned g0, unsigned g1, unsigned g2, unsigned g3, char *tile0,
+                                         double ax_, double ay_, double az_, double bx_, double by_, double bz_, bool twoB,
+                                         double px, double py, double pz, const Box &box, double pd, const ExpCoef &K,
+                                         double &aax, double &aay, double &aaz, double &bax, double &bay, double &baz) {
+  const double2 A = *reinterpret_cast<const double2 *>(rd0 + cur);
+  const double2 B = *reinterpret_cast<const double2 *>(rd1 + cur);
+  const double2 C = *reinterpret_cast<const double2 *>(rd2 + cur);
+  if (more) {  // wave-uniform
+    char *nt = tile0 + nxt;
+    const int jg = jnext & ~63;
+    lp_gather<0>(srcc, jg, g0, nt); lp_gather<1>(srcc, jg, g1, nt);
+    lp_gather<2>(srcc, jg, g2, nt); lp_gather<3>(srcc, jg, g3, nt);
+  }
+  const double mA = (double)(jcur & 1), mB = (double)((jcur >> 1) & 1);
+  {
+    double dx = ax_ - A.x, dy = ay_ - B.x, dz = az_ - C.x;
+    if (WRAP == 1) {
+      dx = fma(-px, rint(dx * box.inv[0]), dx); dy = fma(-py, rint(dy * box.inv[1]), dy); dz = fma(-pz, rint(dz * box.inv[2]), dz);
+    } else if (WRAP == 2) {
+      const double nz = pz != 0.0 ? rint(dz * box.inv[2]) : 0.0;
+      dz = fma(-pz, nz, dz); dy = fma(-box.yz, nz, dy); dx = fma(-box.xz, nz, dx);
+      const double ny = py != 0.0 ? rint(dy * box.inv[1]) : 0.0;
+      dy = fma(-py, ny, dy); dx = fma(-box.xy, ny, dx);
+      dx = fma(-px, rint(dx * box.inv[0]), dx);
+    }
+    const double r2 = fmax(fma(dx, dx, fma(dy, dy, dz * dz)), 1e-12);
+    double s3, s5;
+    tensor_scalars_lp<DAMP>(r2, pd, K, s3, s5);
+    s3 *= mA; s5 *= mA;
+    const double dot = fma(A.y, dx, fma(B.y, dy, C.y * dz));
+    const double cc = s5 * dot;
+    aax = fma(cc, dx, fma(-s3, A.y, aax)); aay = fma(cc, dy, fma(-s3, B.y, aay)); aaz = fma(cc, dz, fma(-s3, C.y, aaz));
+  }
+  if (twoB) {  // wave-uniform: units with one row skip the second half
+    double dx = bx_ - A.x, dy = by_ - B.x, dz = bz_ - C.x;
+    if (WRAP == 1) {
+      dx = fma(-px, rint(dx * box.inv[0]), dx); dy = fma(-py, rint(dy * box.inv[1]), dy); dz = fma(-pz, rint(dz * box.inv[2]), dz);
+    } else if (WRAP == 2) {
+      const double nz = pz != 0.0 ? rint(dz * box.inv[2]) : 0.0;
+      dz = fma(-pz, nz, dz); dy = fma(-box.yz, nz, dy); dx = fma(-box.xz, nz, dx);
+      const double ny = py != 0.0 ? rint(dy * box.inv[1]) : 0.0;
+      dy = fma(-py, ny, dy); dx = fma(-box.xy, ny, dx);
+      dx = fma(-px, rint(dx * box.inv[0]), dx);
+    }
+    const double r2 = fmax(fma(dx, dx, fma(dy, dy, dz * dz)), 1e-12);
+    double s3, s5;
+    tensor_scalars_lp<DAMP>(r2, pd, K, s3, s5);
+    s3 *= mB; s5 *= mB;
+    const double dot = fma(A.y, dx, fma(B.y, dy, C.y * dz));
+    const double cc = s5 * dot;
+    bax = fma(cc, dx, fma(-s3, A.y, bax)); bay = fma(cc, dy, fma(-s3, B.y, bay)); baz = fma(cc, dz, fma(-s3, C.y, baz));
+  }
+}
+template <int WRAP, int DAMP>
+__device__ __forceinline__ void lp2_row(int T, const int4 *pc, const int4 &Ja0, const int4 &Jb0, const char *srcc, char *tile0, int lane,
+                                        double ax_, double ay_, double az_, double bx_, double by_, double bz_, bool twoB,
+                                        const Box &box, double pd, const ExpCoef &K,
+                                        double &aax, double &aay, double &aaz, double &bax, double &bay, double &baz) {
+  const double px = box.periodic[0] ? box.prd[0] : 0.0, py = box.periodic[1] ? box.prd[1] : 0.0,
+               pz = box.periodic[2] ? box.prd[2] : 0.0;
+  const int k = lane & 3, q = lane >> 2;
+  const unsigned g0 = (unsigned)(k * 16), g1 = (unsigned)((k ^ 1) * 16), g2 = (unsigned)((k ^ 2) * 16), g3 = (unsigned)((k ^ 3) * 16);
+  const char *rd0 = tile0 + k * 1024 + (4 * q + k) * 16;
+  const char *rd1 = tile0 + k * 1024 + (4 * q + (k ^ 1)) * 16;
+  const char *rd2 = tile0 + k * 1024 + (4 * q + (k ^ 2)) * 16;
+  if (T <= 0) return;
+  const int C = (T + 3) >> 2;
+  int4 Ja = Ja0, Jb = Jb0, Jc = Jb0;
+#define POLAR_LP2_TRIP(CUR, NXT, TT, JCUR, JNEXT)                                                                         \
+  lp2_trip<WRAP, DAMP>(rd0, rd1, rd2, CUR, NXT, t0 + (TT) + 1 < T, srcc, JCUR, JNEXT, g0, g1, g2, g3, tile0, ax_, ay_, az_, \
+                       bx_, by_, bz_, twoB, px, py, pz, box, pd, K, aax, aay, aaz, bax, bay, baz)
+  for (int c = 0; c < C; c++) {
+    const int t0 = 4 * c;
+    if (c + 2 < C) Jc = pc[64 * (c + 2)];
+    POLAR_LP2_TRIP(0, POLAR_LP_TILE, 0, Ja.x, Ja.y);
+    if (t0 + 1 >= T) break;
+    POLAR_LP2_TRIP(POLAR_LP_TILE, 0, 1, Ja.y, Ja.z);
+    if (t0 + 2 >= T) break;
+    POLAR_LP2_TRIP(0, POLAR_LP_TILE, 2, Ja.z, Ja.w);
+    if (t0 + 3 >= T) break;
+    POLAR_LP2_TRIP(POLAR_LP_TILE, 0, 3, Ja.w, Jb.x);
+    Ja = Jb; Jb = Jc;
+  }
+#undef POLAR_LP2_TRIP
+}
+template <int EP, int DAMP>
+__global__ __launch_bounds__(256) void k_field_lp2(int nunits, long long unit0, const int4 *__restrict__ udesc, AtomRec *recA, AtomRec *recB,
+                                                   Box box, long long upitch, const int *__restrict__ udd_j, double pd, ExpCoef K,
+                                                   const double *__restrict__ ef, const Scal *scal, double *__restrict__ slots, double omega) {
+  extern __shared__ __attribute__((aligned(16))) char lp_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rpb = blockDim.x >> 6;
+  const int lb = xcd_block(blockIdx.x, (nunits + rpb - 1) / rpb);
+  if (lb < 0) return;
+  const int u = lb * rpb + wv;
+  if (u >= nunits) return;
+  const int4 *pc = reinterpret_cast<const int4 *>(udd_j + (size_t)(unit0 + u) * upitch) + lane;
+  const int4 de = udesc[unit0 + u];
+  const int4 Ja0 = pc[0], Jb0 = pc[64];
+  const int done = scal->done, curv = scal->cur;
+  if (done) return;
+  const int iA = __builtin_amdgcn_readfirstlane(de.x), iB = __builtin_amdgcn_readfirstlane(de.y);
+  const int T = __builtin_amdgcn_readfirstlane(de.z & 0xFFFF);
+  const int wrapped = __builtin_amdgcn_readfirstlane(de.z >> 30);
+  const int cur = __builtin_amdgcn_readfirstlane(curv);
+  const AtomRec *src = (EP == EP_JACOBI && cur) ? recB : recA;
+  AtomRec *dst = (EP == EP_JACOBI) ? (cur ? recA : recB) : recA;
+  const char *srcc = reinterpret_cast<const char *>(src);
+  char *tile0 = lp_lds + (size_t)wv * (2 * POLAR_LP_TILE);
+  if (T > 0) lp_first_gather(srcc, Ja0.x & ~63, lane, tile0);
+  const bool twoB = iB >= 0;
+  const int iBs = twoB ? iB : iA;
+  double ax_, ay_, az_, bx_, by_, bz_;
+  {
+    const double *r = reinterpret_cast<const double *>(src + iA);
+    ax_ = wave_uniform(r[0]); ay_ = wave_uniform(r[2]); az_ = wave_uniform(r[4]);
+    const double *rb = reinterpret_cast<const double *>(src + iBs);
+    bx_ = wave_uniform(rb[0]); by_ = wave_uniform(rb[2]); bz_ = wave_uniform(rb[4]);
+  }
+  const LpSelf selfA = lp_self(lane, src + iA, ef + 3 * (size_t)iA);
+  const LpSelf selfB = lp_self(lane, src + iBs, ef + 3 * (size_t)iBs);
+  double aax = 0.0, aay = 0.0, aaz = 0.0, bax = 0.0, bay = 0.0, baz = 0.0;
+  if (!wrapped) lp2_row<0, DAMP>(T, pc, Ja0, Jb0, srcc, tile0, lane, ax_, ay_, az_, bx_, by_, bz_, twoB, box, pd, K, aax, aay, aaz, bax, bay, baz);
+  else if (!box.triclinic) lp2_row<1, DAMP>(T, pc, Ja0, Jb0, srcc, tile0, lane, ax_, ay_, az_, bx_, by_, bz_, twoB, box, pd, K, aax, aay, aaz, bax, bay, baz);
+  else lp2_row<2, DAMP>(T, pc, Ja0, Jb0, srcc, tile0, lane, ax_, ay_, az_, bx_, by_, bz_, twoB, box, pd, K, aax, aay, aaz, bax, bay, baz);
+  lp_finish<false>(aax, aay, aaz, lane, selfA, dst + iA, slots, omega, nullptr);
+  if (twoB) lp_finish<false>(bax, bay, baz, lane, selfB, dst + iB, slots, omega, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
 // Cluster sweep: one wave = one CLUSTER of up to four rows (polar_lists.hpp, k_cl_build) against the union of
 // their neighbours.  Per 64-neighbour trip the gather, the index stream and the LDS reads are paid once and the
 // pair arithmetic M times (a pair outside the dd cutoff of a member is switched off through its r^2), so the bytes
