@@ -335,7 +335,8 @@ def test_row_sharded_handles_tally_per_atom(wl, pkg, oracle):
                                   "POLAR_SWEEP_KERNEL=2;POLAR_LP_DEPTH=3", "POLAR_SWEEP_KERNEL=4",
                                   "POLAR_SWEEP_KERNEL=4;POLAR_DETERMINISTIC=1", "POLAR_SWEEP_KERNEL=4;POLAR_TILE_WAVES=8",
                                   "POLAR_SWEEP_KERNEL=4;POLAR_TILE_WIDE=1;POLAR_TILE_WAVES=8", "POLAR_SWEEP_KERNEL=2",
-                                  "POLAR_SWEEP_KERNEL=2;POLAR_DETERMINISTIC=1", "POLAR_SWEEP_KERNEL=3",
+                                  "POLAR_SWEEP_KERNEL=2;POLAR_DETERMINISTIC=1", "POLAR_SWEEP_KERNEL=2;POLAR_LP_ROWS=3",
+                                  "POLAR_SWEEP_KERNEL=2;POLAR_LP_PAIRS=1", "POLAR_SWEEP_KERNEL=2;POLAR_COLOR_JP=1", "POLAR_SWEEP_KERNEL=3",
                                   "POLAR_SWEEP_KERNEL=3;POLAR_CLUSTER_MAX=2"])
 def test_alternative_sweep_kernels_agree(knob, wl, pkg, oracle, monkeypatch):
     """LAB BUILD (libpolar_mi355x_lab.so, -DPOLAR_LAB): the sweep kernels that were built, measured and not kept as the
@@ -385,7 +386,8 @@ def test_product_library_ignores_lab_switches(wl, pkg, monkeypatch):
     assert np.max(np.abs(out["mu"] - base["mu"])) / np.max(np.abs(base["mu"])) < 1e-8    # (in-place phases: not bit for bit)
     assert rel(out["eng_pol"], base["eng_pol"]) < 1e-9
     blob = open(pkg.LIB_PATH, "rb").read()
-    for name in (b"k_field_quad", b"k_field_cl", b"k_field_tile", b"k_field_lpa", b"k_dd_scalars", b"POLAR_ABLATE", b"POLAR_SWEEP_KERNEL"):
+    for name in (b"k_field_quad", b"k_field_cl", b"k_field_tile", b"k_field_lpa", b"k_field_lpr", b"k_field_lp2", b"k_dd_scalars", b"POLAR_ABLATE",
+                 b"POLAR_SWEEP_KERNEL", b"POLAR_LP_PAIRS"):
         assert name not in blob, name
     assert b"k_field_lp" in blob
     lab = open(pkg.LIB_PATH_LAB, "rb").read()
