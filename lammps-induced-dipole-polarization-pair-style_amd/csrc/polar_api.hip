@@ -254,6 +254,11 @@ struct polar_handle {
   // force and tally accumulators with them): fork after the accumulators are zeroed, join before they are read
   hipStream_t lj_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_lj0 = nullptr, ev_lj1 = nullptr, ev_dl0 = nullptr, ev_dl1 = nullptr;
+  // polar_compute: the dipoles and the static field are final before the force kernel starts; they travel to the host on
+  // their own stream while it runs (early_mu / early_ef: where in the pinned staging area; null = not asked for)
+  hipStream_t dl_stream = nullptr;
+  hipEvent_t ev_mu_ready = nullptr;
+  double *early_mu = nullptr, *early_ef = nullptr;
   bool overlap_lj = true;  // POLAR_NO_OVERLAP=1 keeps a3 on the main stream
   bool lj_forked = false;
   std::vector<double> h_tmp;
@@ -289,7 +294,11 @@ int guarded(polar_handle *h, F &&fn) {
 // pinned host staging area of at least `count` doubles (grown geometrically, freed with the handle)
 double *staging(polar_handle *h, size_t count) {
   if (count > h->h_stage_cap) {
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_stage) {  // (an upload or an early download may still be using the old area)
+      if (h->stream) (void)hipStreamSynchronize(h->stream);
+      if (h->dl_stream) (void)hipStreamSynchronize(h->dl_stream);
+      (void)hipHostFree(h->h_stage);
+    }
     h->h_stage = nullptr; h->h_stage_cap = 0;
     const size_t want = count + count / 4 + 1024;
     HIPCHECK(hipHostMalloc((void **)&h->h_stage, want * sizeof(double)));
@@ -1807,6 +1816,16 @@ int phase_finish(polar_handle *h, polar_result *out) {
 #endif
   k_fallback<<<nblk(n, 256), 256, 0, s>>>(n, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p);
   HIPCHECK(hipEventRecord(h->ev[5], s));
+  // the dipoles and the static field are final: back into the caller's atom order now, so that polar_compute can send them
+  // to the host while the force kernel runs (nothing below writes the records)
+  k_unpack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p, h->d_mu.p, h->d_ef.p);
+  if (h->early_mu && n > 0) {
+    HIPCHECK(hipEventRecord(h->ev_mu_ready, s));
+    HIPCHECK(hipStreamWaitEvent(h->dl_stream, h->ev_mu_ready, 0));
+    HIPCHECK(hipMemcpyAsync(h->early_mu, h->d_mu.p, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->dl_stream));
+    if (h->early_ef) HIPCHECK(hipMemcpyAsync(h->early_ef, h->d_ef.p, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->dl_stream));
+    HIPCHECK(hipEventRecord(h->ev_dl1, h->dl_stream));
+  }
   double *vatom = (h->step_vflag / 4) ? h->d_vatom.p : nullptr;
   // join a3: before the force kernel when both write the (non-atomic) per-atom virial rows,
   // otherwise only before the accumulators are read
@@ -1828,7 +1847,6 @@ int phase_finish(polar_handle *h, polar_result *out) {
     k_virial_fdotr<<<std::min(1024, nblk(n, 256)), 256, 0, s>>>(n, h->d_x.p, h->d_fpol.p, h->d_slots.p);
     k_add_into<<<nblk(3 * (long long)n, 256), 256, 0, s>>>(3 * (long long)n, h->d_fpol.p, h->d_f.p);
   } else if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_slots.p);  // a10
-  k_unpack<<<nblk(n, 256), 256, 0, s>>>(n, h->sorted ? h->d_perm.p : nullptr, h->d_scal.p, h->d_rec0.p, h->d_rec1.p, h->d_ef_s.p, h->d_mu.p, h->d_ef.p);
   k_fold_scal<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, 0);
   HIPCHECK(hipEventRecord(h->ev[6], s));
   read_scal(h);
@@ -1987,6 +2005,8 @@ int polar_create(int device, polar_handle **out) {
     HIPCHECK(hipEventCreate(&h->ev_fork)); HIPCHECK(hipEventCreate(&h->ev_join));
     HIPCHECK(hipEventCreate(&h->ev_lj0)); HIPCHECK(hipEventCreate(&h->ev_lj1));
     HIPCHECK(hipEventCreateWithFlags(&h->ev_dl0, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&h->ev_dl1, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_mu_ready, hipEventDisableTiming));
+    HIPCHECK(hipStreamCreateWithFlags(&h->dl_stream, hipStreamNonBlocking));
     if (getenv("POLAR_NO_OVERLAP")) h->overlap_lj = false;
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
     HIPCHECK(hipHostMalloc((void **)&h->h_flags, 16 * sizeof(int)));
@@ -2005,7 +2025,8 @@ int polar_destroy(polar_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->lj_stream) { (void)hipStreamSynchronize(h->lj_stream); (void)hipStreamDestroy(h->lj_stream); }
-    for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1, h->ev_dl0, h->ev_dl1}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1, h->ev_dl0, h->ev_dl1, h->ev_mu_ready}) if (e) (void)hipEventDestroy(e);
+    if (h->dl_stream) (void)hipStreamDestroy(h->dl_stream);
     h->d_ljpos.release(); h->d_ljaux.release(); h->d_tag.release(); h->d_nspecial.release(); h->d_special.release();
     h->d_ljcell_id.release(); h->d_ljcell_cnt.release(); h->d_ljcell_fill.release(); h->d_ljcell_first.release(); h->d_cutneighsq.release();
     h->d_xchg.release(); h->d_xidx.release();
@@ -2414,17 +2435,22 @@ int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, 
     if (eflag / 2 || vflag / 4) throw InputError("per-atom tallies (eflag & 2, vflag & 4) are returned by polar_compute_peratom");
     need_device(h);
     HIPCHECK(hipSetDevice(h->device));
-    int rc = do_compute(h, eflag, vflag, mu, out);
-    if (rc < 0) return rc;
     const size_t n = h->nlocal, nall = (size_t)h->nlocal + h->nghost;
     // results come back through one pinned staging area (pageable destinations cost ~3x the PCIe time):
-    // [f nall*3 | mu n*3 | ef n*3], three asynchronous copies; the host adds the forces in while mu and ef still travel
+    // [f nall*3 | mu n*3 | ef n*3]; mu and ef leave as soon as the solve is over (phase_finish, their own stream, beside the
+    // force kernel), f after the force kernel; the host adds the forces in while whatever is left still travels
     double *st = staging(h, 3 * nall + 6 * n);
+    struct Early {  // (cleared on every way out: the stepwise interface shares phase_finish)
+      polar_handle *h;
+      ~Early() { h->early_mu = h->early_ef = nullptr; }
+    } early{h};
+    h->early_mu = st + 3 * nall;
+    h->early_ef = ef_static ? st + 3 * nall + 3 * n : nullptr;
+    int rc = do_compute(h, eflag, vflag, mu, out);
+    if (rc < 0) return rc;
     HIPCHECK(hipMemcpyAsync(st, h->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipEventRecord(h->ev_dl0, h->stream));
-    HIPCHECK(hipMemcpyAsync(st + 3 * nall, h->d_mu.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (ef_static) HIPCHECK(hipMemcpyAsync(st + 3 * nall + 3 * n, h->d_ef.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipEventRecord(h->ev_dl1, h->stream));
+    if (n == 0) HIPCHECK(hipEventRecord(h->ev_dl1, h->stream));
     HIPCHECK(hipEventSynchronize(h->ev_dl0));
     host_chunks(3 * nall, [&](size_t a, size_t b) { for (size_t k = a; k < b; k++) f[k] += st[k]; });
     HIPCHECK(hipEventSynchronize(h->ev_dl1));
