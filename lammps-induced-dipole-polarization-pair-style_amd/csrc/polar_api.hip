@@ -16,6 +16,11 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <unistd.h>
 #include <vector>
 
 #include "pair_host.hpp"
@@ -258,7 +263,8 @@ struct polar_handle {
   // their own stream while it runs (early_mu / early_ef: where in the pinned staging area; null = not asked for)
   hipStream_t dl_stream = nullptr;
   hipEvent_t ev_mu_ready = nullptr;
-  double *early_mu = nullptr, *early_ef = nullptr;
+  double *early_mu = nullptr, *early_ef = nullptr, *user_mu = nullptr, *user_ef = nullptr;  // staging slots; the caller's arrays
+  hipEvent_t ev_fchunk[4] = {nullptr, nullptr, nullptr, nullptr};
   bool overlap_lj = true;  // POLAR_NO_OVERLAP=1 keeps a3 on the main stream
   bool lj_forked = false;
   std::vector<double> h_tmp;
@@ -314,16 +320,74 @@ void need_device(polar_handle *h) {
 // host-side array work of a compute call (adding 4 MB of forces into the caller's array, copying dipoles and fields out of
 // the staging area): one thread moves ~10 GB/s, the PCIe link brings the data three times faster -- a few short-lived
 // threads, each on its own contiguous quarter
+// Three helper threads that live as long as the library (a std::thread per call cost 30-50 us each: 0.3 ms per MD step over
+// the three copies of a step).  run(fn, parts): fn(k) for k = 1 .. parts-1 on the helpers, fn(0) on the caller; returns when
+// all are done.  One job at a time (the library's host copies are serial per process anyway).
+class HostPool {
+ public:
+  static HostPool &get() { static HostPool p; return p; }
+  int width() const { return (int)th_.size() + 1; }
+  void run(const std::function<void(int)> &fn, int parts) {
+    if (parts <= 1 || th_.empty() || getpid() != pid_) { for (int k = 0; k < parts; k++) fn(k); return; }   // (a forked child has no helpers)
+    std::unique_lock<std::mutex> job(job_m_);   // one job at a time
+    {
+      std::lock_guard<std::mutex> g(m_);
+      fn_ = &fn; parts_ = parts; pending_ = std::min(parts - 1, (int)th_.size()); gen_++;
+    }
+    cv_.notify_all();
+    fn(0);
+    for (int k = (int)th_.size() + 1; k < parts; k++) fn(k);   // (more parts than threads: the caller takes the rest)
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  HostPool() {
+    pid_ = getpid();
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n = hw >= 4 ? 3 : (hw >= 2 ? (int)hw - 1 : 0);
+    for (int t = 0; t < n; t++) th_.emplace_back([this, t]() { loop(t); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  void loop(int t) {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(int)> *fn = nullptr;
+      int part = -1;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        if (t + 1 < parts_) { fn = fn_; part = t + 1; }
+      }
+      if (fn) {
+        (*fn)(part);
+        std::lock_guard<std::mutex> g(m_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_, job_m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)> *fn_ = nullptr;
+  int parts_ = 0, pending_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+  pid_t pid_ = 0;
+};
 template <typename F>
 void host_chunks(size_t total, F &&fn) {
-  const unsigned hw = std::thread::hardware_concurrency();
-  const size_t nt = total < (1u << 16) ? 1 : std::min<size_t>(4, hw ? hw : 1);
+  HostPool &pool = HostPool::get();
+  const size_t nt = total < (1u << 16) ? 1 : (size_t)pool.width();
   if (nt <= 1) { fn((size_t)0, total); return; }
-  std::vector<std::thread> th;
   const size_t per = (total + nt - 1) / nt;
-  for (size_t t = 1; t < nt; t++) th.emplace_back([&, t]() { fn(std::min(total, t * per), std::min(total, (t + 1) * per)); });
-  fn((size_t)0, std::min(total, per));
-  for (auto &t : th) t.join();
+  pool.run([&](int k) { fn(std::min(total, (size_t)k * per), std::min(total, ((size_t)k + 1) * per)); }, (int)nt);
 }
 
 // upload LJ tables + Coulomb tables from the host mirror (or raw setters) into P, repacked so that
@@ -1849,6 +1913,15 @@ int phase_finish(polar_handle *h, polar_result *out) {
   } else if (vmode == 2) k_virial_fdotr<<<std::min(1024, nblk(nall, 256)), 256, 0, s>>>(nall, h->d_x.p, h->d_f.p, h->d_slots.p);  // a10
   k_fold_scal<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, 0);
   HIPCHECK(hipEventRecord(h->ev[6], s));
+  if (h->early_mu && h->user_mu && n > 0) {  // the force kernel is still running: the dipoles and the field, on the host by now, go into the caller's arrays meanwhile
+    HIPCHECK(hipEventSynchronize(h->ev_dl1));
+    const double *sm = h->early_mu, *se = h->early_ef;
+    double *um = h->user_mu, *ue = h->user_ef;
+    host_chunks(3 * (size_t)n, [&](size_t a, size_t b) {
+      memcpy(um + a, sm + a, (b - a) * sizeof(double));
+      if (ue && se) memcpy(ue + a, se + a, (b - a) * sizeof(double));
+    });
+  }
   read_scal(h);
   h->mu_resident = true;
 
@@ -2006,6 +2079,7 @@ int polar_create(int device, polar_handle **out) {
     HIPCHECK(hipEventCreate(&h->ev_lj0)); HIPCHECK(hipEventCreate(&h->ev_lj1));
     HIPCHECK(hipEventCreateWithFlags(&h->ev_dl0, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&h->ev_dl1, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&h->ev_mu_ready, hipEventDisableTiming));
+    for (auto &e : h->ev_fchunk) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHECK(hipStreamCreateWithFlags(&h->dl_stream, hipStreamNonBlocking));
     if (getenv("POLAR_NO_OVERLAP")) h->overlap_lj = false;
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
@@ -2027,6 +2101,7 @@ int polar_destroy(polar_handle *h) {
     if (h->lj_stream) { (void)hipStreamSynchronize(h->lj_stream); (void)hipStreamDestroy(h->lj_stream); }
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1, h->ev_dl0, h->ev_dl1, h->ev_mu_ready}) if (e) (void)hipEventDestroy(e);
     if (h->dl_stream) (void)hipStreamDestroy(h->dl_stream);
+    for (hipEvent_t e : h->ev_fchunk) if (e) (void)hipEventDestroy(e);
     h->d_ljpos.release(); h->d_ljaux.release(); h->d_tag.release(); h->d_nspecial.release(); h->d_special.release();
     h->d_ljcell_id.release(); h->d_ljcell_cnt.release(); h->d_ljcell_fill.release(); h->d_ljcell_first.release(); h->d_cutneighsq.release();
     h->d_xchg.release(); h->d_xidx.release();
@@ -2442,22 +2517,35 @@ int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, 
     double *st = staging(h, 3 * nall + 6 * n);
     struct Early {  // (cleared on every way out: the stepwise interface shares phase_finish)
       polar_handle *h;
-      ~Early() { h->early_mu = h->early_ef = nullptr; }
+      ~Early() { h->early_mu = h->early_ef = h->user_mu = h->user_ef = nullptr; }
     } early{h};
     h->early_mu = st + 3 * nall;
     h->early_ef = ef_static ? st + 3 * nall + 3 * n : nullptr;
+    h->user_mu = mu; h->user_ef = ef_static;
+    const bool dbg = getenv("POLAR_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!dbg) return;
+      const auto t1 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[polar] compute: %-22s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+      t0 = t1;
+    };
     int rc = do_compute(h, eflag, vflag, mu, out);
     if (rc < 0) return rc;
-    HIPCHECK(hipMemcpyAsync(st, h->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipEventRecord(h->ev_dl0, h->stream));
-    if (n == 0) HIPCHECK(hipEventRecord(h->ev_dl1, h->stream));
-    HIPCHECK(hipEventSynchronize(h->ev_dl0));
-    host_chunks(3 * nall, [&](size_t a, size_t b) { for (size_t k = a; k < b; k++) f[k] += st[k]; });
-    HIPCHECK(hipEventSynchronize(h->ev_dl1));
-    host_chunks(3 * n, [&](size_t a, size_t b) {
-      memcpy(mu + a, st + 3 * nall + a, (b - a) * sizeof(double));
-      if (ef_static) memcpy(ef_static + a, st + 3 * nall + 3 * n + a, (b - a) * sizeof(double));
-    });
+    lap("device step + sync");
+    // the forces: four pieces, each added into the caller's array while the next one travels
+    const size_t tot = 3 * nall, piece = (tot + 3) / 4;
+    for (int k = 0; k < 4; k++) {
+      const size_t a = std::min(tot, k * piece), b = std::min(tot, (k + 1) * piece);
+      if (b > a) HIPCHECK(hipMemcpyAsync(st + a, h->d_f.p + a, (b - a) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipEventRecord(h->ev_fchunk[k], h->stream));
+    }
+    for (int k = 0; k < 4; k++) {
+      const size_t a = std::min(tot, k * piece), b = std::min(tot, (k + 1) * piece);
+      HIPCHECK(hipEventSynchronize(h->ev_fchunk[k]));
+      host_chunks(b - a, [&](size_t lo, size_t hi) { for (size_t i = a + lo; i < a + hi; i++) f[i] += st[i]; });
+    }
+    lap("f arrived and added");
     h->mu_host_in_sync = true;
     return rc;
   });
