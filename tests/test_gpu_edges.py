@@ -269,3 +269,19 @@ def test_random_systems_against_the_oracle(seed, solver, wl, pkg, oracle):
         out, ref = _check(pkg, oracle, s)
         if mode == "exact" and solver in ("ranked", "gs", "jacobi5"):
             assert out["iterations"] == ref["iterations"]
+
+
+def test_results_come_back_the_same_with_and_without_the_static_field(wl, pkg):
+    """polar_compute with ef_static == NULL (the caller does not want E_static): forces and dipoles are those of the full call;
+    two calls in a row give the same numbers (the dipoles and the field travel on their own stream beside the force kernel,
+    the forces in four pieces: nothing of one call may leak into the next)."""
+    s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"), extra_args=["use_previous", "no", "dd_cutoff", "9.0", "deterministic", "yes"])
+    p = pkg.pair_from_system(s)
+    a = p.compute(eflag=1, vflag=2)
+    b = p.compute(eflag=1, vflag=2, want_ef=False)
+    c = p.compute(eflag=1, vflag=2)
+    for o in (b, c):
+        assert np.array_equal(o["f"], a["f"]) and np.array_equal(o["mu"], a["mu"])
+    assert np.array_equal(c["ef_static"], a["ef_static"]) and not np.any(b["ef_static"])
+    assert np.any(a["ef_static"])
+    p.close()
