@@ -121,8 +121,9 @@ def roofline(s, out, ms_solve, launches, steps, pkg):
             "fp64_tflops": tflops, "fp64_frac": tflops / FP64_PEAK_TFLOPS,
             "valu_busy": valu_busy, "issue_busy": issue_busy, "waves_per_simd": waves,
             "note": "valu_busy / issue_busy / waves_per_simd: SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_ANY, SQ_WAVE_CYCLES over the chip's quad-cycles, from the "
-                    "committed PMC passes of this kernel version (null when profiles/traffic_pmc.json is of another build): the sweep is bound by "
-                    "instruction issue (FP64 at 4 cycles per wave instruction), not by HBM bytes"}
+                    "committed PMC passes of this kernel version (null when profiles/traffic_pmc.json is of another build).  The sweep is not bound by "
+                    "HBM bytes: it gathers 64-byte records at ~62 GB/s per CU (the L2-served gather rate of a CU) with the FP64 arithmetic "
+                    "overlapped underneath, in launches of a quarter sweep whose ramp and drain nothing can fill (DESIGN.md section 4)"}
 
 
 def sub_config(torch, pkg, wl, k, steps, warmup, device_neigh=False, extra=()):
