@@ -2870,6 +2870,12 @@ RcclApi &rccl() {
   static RcclApi api;
   if (api.lib) return api;
   // the copy already in the process first (PyTorch ships its own librccl.so and two copies would not see each other's state)
+  // POLAR_RCCL_LIB=<path>: open this library instead (a site's own RCCL build; tests/dist_mock: an in-process stand-in that
+  // lets several ranks of ONE process drive this code on one GPU)
+  if (const char *e = getenv("POLAR_RCCL_LIB")) {
+    api.lib = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    if (!api.lib) throw std::runtime_error(std::string("polar_dist: cannot open POLAR_RCCL_LIB: ") + e);
+  }
   const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
   for (int pass = 0; pass < 2 && !api.lib; pass++)
     for (const char *nm : names) {
