@@ -735,13 +735,14 @@ def test_in_library_rccl_driver_with_one_rank(mode, wl, pkg, oracle):
     p.close()
 
 
-@pytest.mark.parametrize("world,solver,reduce_every", [(2, "precision", 1), (3, "precision", 2), (4, "fixed", 1), (3, "jacobi", 1)])
-def test_in_library_driver_with_several_ranks_on_a_mock_transport(world, solver, reduce_every, pkg, tmp_path):
+@pytest.mark.parametrize("world,solver,reduce_every,pitch", [(2, "precision", 1, 0), (3, "precision", 2, 0), (4, "fixed", 1, 0), (3, "jacobi", 1, 0),
+                                                            (3, "precision", 1, 64)])
+def test_in_library_driver_with_several_ranks_on_a_mock_transport(world, solver, reduce_every, pitch, pkg, tmp_path):
     """polar_dist_step with 2, 3 and 4 RANKS on the one GPU: every rank is a thread with its own compact shard and its own
     driver, the RCCL entry points are an in-process stand-in (tests/dist_mock/fake_rccl.cpp through POLAR_RCCL_LIB: a send /
     receive pair is a device-to-device copy).  What is exercised is the driver's own logic with several peers -- pack /
     grouped exchange / unpack in plan order, the all-reduced stop rule and its cadence, the summed results, every rank
-    stopping at the same sweep -- against the unsharded handle.  (RCCL itself with more than one rank needs more than one GPU.)"""
+    stopping at the same sweep, the agreed repeat of a step whose rows outgrew their pitch -- against the unsharded handle.  (RCCL itself with more than one rank needs more than one GPU.)"""
     import json
     import shutil
     import subprocess
@@ -753,6 +754,8 @@ def test_in_library_driver_with_several_ranks_on_a_mock_transport(world, solver,
     so = str(tmp_path / "libfake_rccl.so")
     subprocess.check_call([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(here, "dist_mock", "fake_rccl.cpp")])
     env = dict(os.environ, POLAR_RCCL_LIB=so)
+    if pitch:   # rows outgrow this pitch on the first step: every rank must agree to repeat it (max-reduced POLAR_RETRY_STEP)
+        env["POLAR_INIT_PITCH"] = str(pitch)
     r = subprocess.run([sys.executable, os.path.join(here, "dist_mock", "run_mock_dist.py"), str(world), solver, str(reduce_every)],
                        env=env, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
