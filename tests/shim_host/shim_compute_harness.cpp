@@ -34,6 +34,14 @@ struct Rec {
   polar_settings st;
   int rc_compute;
   std::string modify;
+  /* one-MPI-rank-per-GPU path (compute_sharded): what the stepwise entry points were given */
+  bool sharded = false;
+  int row_lo = -1, row_hi = -1, sweeps = 0; long long global = -1;
+  double last_change = 0.0;
+  std::vector<double> xcopy, put_val;
+  std::vector<int> csr_ilist, csr_nn, csr_flat, put_idx;
+  std::vector<long long> csr_first;
+  long long get_lo = -1, get_n = -1;
 } R;
 polar_handle g_handle;
 double g_tab[3][64];
@@ -95,6 +103,7 @@ int polar_set_atoms(polar_handle *, int nlocal, int nghost, const double *x, con
                     const int *mol) {
   R.calls.push_back("set_atoms");
   R.nlocal = nlocal; R.nghost = nghost; R.x = x; R.q = q; R.alpha = alpha; R.type = type; R.mol = mol;
+  if (R.sharded) R.xcopy.assign(x, x + 3 * (size_t)(nlocal + nghost));   /* (a temporary in library order: keep the numbers) */
   return POLAR_OK;
 }
 int polar_set_positions(polar_handle *, int nlocal, int nghost, const double *x) {
@@ -108,7 +117,16 @@ int polar_set_neighbors(polar_handle *, int inum, const int *ilist, const int *n
   R.inum = inum; R.ilist = ilist; R.numneigh = numneigh; R.firstneigh = firstneigh;
   return POLAR_OK;
 }
-int polar_set_neighbors_csr(polar_handle *, int, const int *, const int *, const long long *, const int *) { R.calls.push_back("set_neighbors_csr"); return POLAR_OK; }
+int polar_set_neighbors_csr(polar_handle *, int inum, const int *il, const int *nn, const long long *first, const int *flat) {
+  R.calls.push_back("set_neighbors_csr");
+  R.csr_ilist.assign(il, il + inum);
+  const int n = R.nlocal;
+  R.csr_nn.assign(nn, nn + n); R.csr_first.assign(first, first + n);
+  long long tot = 0;
+  for (int i = 0; i < inum; i++) tot = std::max(tot, first[il[i]] + nn[il[i]]);
+  R.csr_flat.assign(flat, flat + tot);
+  return POLAR_OK;
+}
 int polar_build_neighbors(polar_handle *, const double *cn, const int *tag, const int *nsp, const int *sp, int maxsp, const int sf[4], int excl) {
   R.calls.push_back("build_neighbors");
   R.cutneighsq = cn; R.tag = tag; R.nspecial = nsp; R.special = sp; R.maxspecial = maxsp; R.special_flag = sf; R.excl = excl;
@@ -136,21 +154,37 @@ int polar_compute_peratom(polar_handle *, int eflag, int vflag, double *f, doubl
 }
 int polar_compute_resident(polar_handle *, int, int, polar_result *) { return POLAR_ERR_STATE; }
 void *polar_dev_ptr(polar_handle *, const char *) { return NULL; }
-int polar_download(polar_handle *, const char *, double *, long long) { return POLAR_ERR_STATE; }
-int polar_upload_mu(polar_handle *, const double *, long long) { return POLAR_ERR_STATE; }
+int polar_download(polar_handle *, const char *name, double *dst, long long n) {
+  if (!R.sharded) return POLAR_ERR_STATE;
+  R.calls.push_back(std::string("download:") + name);
+  const double base = !strcmp(name, "f") ? 0.0 : !strcmp(name, "mu") ? 300.0 : !strcmp(name, "ef_static") ? 400.0 : !strcmp(name, "eatom") ? 0.5 : 0.25;
+  for (long long k = 0; k < n; k++) dst[k] = !strcmp(name, "f") ? 0.001 * (k + 1) : base + k;   /* library order */
+  return POLAR_OK;
+}
+int polar_upload_mu(polar_handle *, const double *, long long) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("upload_mu"); return POLAR_OK; }
 int polar_get_debug_trace(polar_handle *, double *, int) { return 0; }
 int polar_set_stream(polar_handle *, void *) { return POLAR_OK; }
-int polar_set_row_range(polar_handle *, int, int) { return POLAR_OK; }
-int polar_set_global_count(polar_handle *, long long) { return POLAR_OK; }
-int polar_step_begin(polar_handle *, int, int) { return POLAR_ERR_STATE; }
-int polar_step_sweep(polar_handle *) { return POLAR_ERR_STATE; }
-int polar_step_sweep_end(polar_handle *, const double *) { return POLAR_ERR_STATE; }
-int polar_step_sweep_end_host(polar_handle *, double) { return POLAR_ERR_STATE; }
-int polar_step_state(polar_handle *, int *, int *, int *) { return POLAR_ERR_STATE; }
-int polar_step_finish(polar_handle *, polar_result *) { return POLAR_ERR_STATE; }
-int polar_step_mu_get(polar_handle *, long long, long long, double *) { return POLAR_ERR_STATE; }
-int polar_step_mu_put_idx(polar_handle *, long long, const int *, const double *) { return POLAR_ERR_STATE; }
-int polar_step_change_get(polar_handle *, double *) { return POLAR_ERR_STATE; }
+int polar_set_row_range(polar_handle *, int lo, int hi) { R.calls.push_back("set_row_range"); R.row_lo = lo; R.row_hi = hi; return POLAR_OK; }
+int polar_set_global_count(polar_handle *, long long n) { R.global = n; return POLAR_OK; }
+int polar_step_begin(polar_handle *, int ef, int vf) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("step_begin"); R.eflag = ef; R.vflag = vf; R.sweeps = 0; return POLAR_OK; }
+int polar_step_sweep(polar_handle *) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("sweep"); R.sweeps++; return POLAR_OK; }
+int polar_step_sweep_end(polar_handle *, const double *) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("sweep_end"); return POLAR_OK; }
+int polar_step_sweep_end_host(polar_handle *, double v) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("sweep_end_host"); R.last_change = v; return POLAR_OK; }
+int polar_step_state(polar_handle *, int *done, int *it, int *st) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("state"); *done = R.sweeps >= 3; *it = R.sweeps; *st = 0; return POLAR_OK; }
+int polar_step_finish(polar_handle *, polar_result *out) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("finish"); canned(out); return R.rc_compute; }
+int polar_step_mu_get(polar_handle *, long long lo, long long n, double *dst) {
+  if (!R.sharded) return POLAR_ERR_STATE;
+  R.calls.push_back("mu_get"); R.get_lo = lo; R.get_n = n;
+  for (long long k = 0; k < 3 * n; k++) dst[k] = 100.0 + 10.0 * R.sweeps + k;   /* the own dipoles after sweep R.sweeps */
+  return POLAR_OK;
+}
+int polar_step_mu_put_idx(polar_handle *, long long n, const int *idx, const double *src) {
+  if (!R.sharded) return POLAR_ERR_STATE;
+  R.calls.push_back("mu_put");
+  R.put_idx.assign(idx, idx + n); R.put_val.assign(src, src + 3 * n);
+  return POLAR_OK;
+}
+int polar_step_change_get(polar_handle *, double *c) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("change_get"); *c = 1.0 / R.sweeps; return POLAR_OK; }
 // the multi-rank driver is not reached by a one-rank compute(): present so that the shim links
 int polar_dist_unique_id(void *) { return POLAR_ERR_STATE; }
 int polar_dist_create(const void *, int, int, int, polar_dist **) { return POLAR_ERR_STATE; }
@@ -168,12 +202,13 @@ struct Fail { std::string msg; };
   } while (0)
 }  // namespace
 
-extern "C" {
-/* runs every combination; returns 0, or -1 with the first mismatch in msg.  *ncombos = combinations executed */
-int shimcompute_check(int *ncombos, char *msg, int nmsg) {
-  g_last_error.clear();
-  *ncombos = 0;
-  const int nlocal = 5, nghost = 3, nall = nlocal + nghost, ntypes = 2;
+/* the LAMMPS objects the shim reads in compute(): five local atoms, three ghosts, a paged half list */
+struct World {
+  LAMMPS *lmp; Force *force; Domain *dom; Atom *atom; Neighbor *nb; NeighList *list; Memory *mem;
+  int *ilist, *numneigh; int **first;
+};
+static World make_world(int nlocal, int nghost, int ntypes) {
+  const int nall = nlocal + nghost;
   LAMMPS *lmp = blank<LAMMPS>();
   lmp->screen = NULL;
   lmp->error = blank<Error>(); lmp->atom = blank<Atom>(); lmp->force = blank<Force>(); lmp->domain = blank<Domain>();
@@ -224,6 +259,20 @@ int shimcompute_check(int *ncombos, char *msg, int nmsg) {
   static int *first[5] = {r0, r1, r2, NULL, r4};
   list->inum = 5; list->ilist = ilist; list->numneigh = numneigh; list->firstneigh = first;
 
+  World W{lmp, force, dom, atom, nb, list, mem, ilist, numneigh, first};
+  return W;
+}
+
+extern "C" {
+/* runs every combination; returns 0, or -1 with the first mismatch in msg.  *ncombos = combinations executed */
+int shimcompute_check(int *ncombos, char *msg, int nmsg) {
+  g_last_error.clear();
+  *ncombos = 0;
+  const int nlocal = 5, nghost = 3, nall = nlocal + nghost, ntypes = 2;
+  World W = make_world(nlocal, nghost, ntypes);
+  LAMMPS *lmp = W.lmp; Force *force = W.force; Atom *atom = W.atom; Neighbor *nb = W.nb; NeighList *list = W.list;
+  int *ilist = W.ilist, *numneigh = W.numneigh; int **first = W.first;
+  (void)nall;
   int rc = 0;
   try {
     for (int dn = 0; dn < 2; dn++) {
@@ -342,6 +391,155 @@ int shimcompute_check(int *ncombos, char *msg, int nmsg) {
     snprintf(msg, nmsg, "error->all: %s", e.msg.c_str());
     rc = -1;
   }
+  return rc;
+}
+
+/* ---- one MPI rank per GPU: compute() with comm->nprocs > 1 goes through compute_sharded() ------------------------------
+ * Serial MPI (the reference's STUBS), comm->nprocs set to 2: the path a rank of a multi-rank run takes, with this rank's
+ * own contribution as "the sum over ranks".  Comm::forward_comm_pair is emulated through the shim's own pack / unpack:
+ * images of own atoms get their owner's dipole, atoms owned elsewhere the numbers "the other rank" sent.
+ * Checked: library order [own | halo | other ghosts], row range and global count, the re-indexed CSR list, the per-sweep
+ * sequence (sweep, sum, MPI_Allreduce, end of sweep, dipoles out, forward communication, halo dipoles in, state), the stop
+ * at the sweep the library reports, results scattered back in LAMMPS order. */
+}  /* extern "C" */
+namespace {
+LAMMPS_NS::Atom *g_atom = NULL;
+int g_nlocal = 0, g_nall = 0, g_fwd = 0;
+void seam_forward_comm(void *, void *pair_) {
+  PairLJCutCoulLongPolarizationMI355X *pair = (PairLJCutCoulLongPolarizationMI355X *)pair_;
+  g_fwd++;
+  for (int g = g_nlocal; g < g_nall; g++) {
+    double buf[3];
+    const int owner = g_atom->map(g_atom->tag[g]);
+    if (owner >= 0 && owner < g_nlocal) { int one = owner; pair->pack_forward_comm(1, &one, buf, 0, NULL); }
+    else { buf[0] = 900.0 + 10 * g + g_fwd; buf[1] = buf[0] + 1.0; buf[2] = buf[0] + 2.0; }   /* what its owner's rank sent */
+    pair->unpack_forward_comm(1, g, buf);
+  }
+}
+}  // namespace
+extern "C" {
+int shimsharded_check(int *ncombos, char *msg, int nmsg) {
+  g_last_error.clear();
+  *ncombos = 0;
+  const int nlocal = 5, nghost = 3, nall = nlocal + nghost, ntypes = 2;
+  World W = make_world(nlocal, nghost, ntypes);
+  LAMMPS *lmp = W.lmp; Force *force = W.force; Atom *atom = W.atom; Neighbor *nb = W.nb; NeighList *list = W.list;
+  /* two ranks: ghost 5 and ghost 7 belong to the other one (tags 101, 102), ghost 6 is an image of own atom 1 (tag 2) */
+  lmp->comm->nprocs = 2;
+  lmp->comm->cutghost[0] = lmp->comm->cutghost[1] = lmp->comm->cutghost[2] = 20.0;
+  static void *vtab2[64];
+  for (int k = 0; k < 64; k++) vtab2[k] = (void *)&seam_forward_comm;
+  *(void ***)lmp->comm = vtab2;
+  atom->natoms = 12;
+  atom->tag[5] = 101; atom->tag[6] = 2; atom->tag[7] = 102;
+  static int map_array[128];
+  for (int k = 0; k < 128; k++) map_array[k] = -1;
+  for (int i = nall - 1; i >= 0; i--) map_array[atom->tag[i]] = i;     /* owned atoms win over their images, like Atom::map_set */
+  atom->map_style = 1; atom->map_array = map_array; atom->map_tag_max = 127;
+  g_atom = atom; g_nlocal = nlocal; g_nall = nall;
+  R.sharded = true;
+  int rc = 0;
+  try {
+    for (int dn = 0; dn < 2; dn++)
+    for (int fixed = 0; fixed < 2; fixed++)
+    for (int eflag = 0; eflag <= 3; eflag += 3)
+    for (int vflag = 0; vflag <= 6; vflag += 2) {
+      std::ostringstream t; t << "sharded: device_neigh " << dn << " fixed_iteration " << fixed << " eflag " << eflag << " vflag " << vflag;
+      const std::string tag = t.str();
+      memset(&R.st, 0, sizeof(R.st));
+      R.st.cut_lj_global = 9.0; R.st.cut_coul = 9.0; R.st.dd_cutoff = 9.0; R.st.iterations_max = 4; R.st.device_neigh = dn; R.st.fixed_iteration = fixed;
+      R.rc_compute = POLAR_OK;
+      PairLJCutCoulLongPolarizationMI355X *shim = new PairLJCutCoulLongPolarizationMI355X(lmp);
+      force->pair = shim;
+      shim->ncoultablebits = 0;
+      char a0[] = "9.0", a1[] = "9.0"; char *sa[2] = {a0, a1};
+      shim->settings(2, sa);
+      char c0[] = "*", c1[] = "*", c2[] = "0.1", c3[] = "3.0"; char *ca[4] = {c0, c1, c2, c3};
+      shim->coeff(4, ca);
+      shim->init_style();
+      shim->init_list(0, list);
+      nb->ago = 0;
+      g_fwd = 0;
+      std::vector<double> f0(3 * nall);
+      for (int k = 0; k < 3 * nall; k++) { f0[k] = 7.0 + 0.5 * k; atom->f[0][k] = f0[k]; atom->mu_induced[0][k] = -1.0; atom->ef_static[0][k] = -2.0; }
+      R.calls.clear();
+      shim->compute(eflag, vflag);
+      (*ncombos)++;
+      /* library order: own atoms keep their places, then ONE ghost per foreign tag, then the images of own atoms */
+      EXPECT(R.nlocal == nlocal + 2 && R.nghost == 1, "set_atoms: " << R.nlocal << " + " << R.nghost << " (own + halo, other ghosts)");
+      const int lib_of[8] = {0, 1, 2, 3, 4, 5, 7, 6};
+      for (int a = 0; a < nall; a++)
+        for (int c = 0; c < 3; c++) EXPECT(R.xcopy[3 * lib_of[a] + c] == atom->x[a][c], "positions in library order, atom " << a);
+      EXPECT(R.row_lo == 0 && R.row_hi == nlocal, "row range = the own atoms");
+      EXPECT(R.global == 12, "global atom count for the stop rule");
+      EXPECT(R.newton == 1, "newton_pair");
+      if (!dn) {
+        const int flat_want[5] = {1, 5, 2, 7, 6};     /* rows 0: {1, 5}, 1: {2}, 2: {6 -> 7}, 4: {7 -> 6} */
+        EXPECT(R.csr_ilist.size() == 5 && R.csr_flat.size() == 5, "CSR list sizes");
+        for (int k = 0; k < 5; k++) EXPECT(R.csr_flat[k] == flat_want[k], "neighbor " << k << " re-indexed into library order: " << R.csr_flat[k]);
+        EXPECT(R.csr_nn[3] == 0 && R.csr_nn[0] == 2, "row lengths");
+      } else {
+        EXPECT(R.tag[5] == 101 && R.tag[6] == 102 && R.tag[7] == 2, "tags in library order for the device list");
+      }
+      /* the call sequence */
+      std::string want = "set_box set_atoms set_row_range set_newton ";
+      want += dn ? "build_neighbors " : "set_neighbors_csr ";
+      want += "step_begin mu_get mu_put ";
+      const int nsweeps = fixed ? R.st.iterations_max + 1 : 3;       /* fixed: every sweep; otherwise until the library says done */
+      for (int sw = 0; sw < nsweeps; sw++) want += fixed ? "sweep sweep_end mu_get mu_put " : "sweep change_get sweep_end_host mu_get mu_put state ";
+      want += "finish download:f download:mu download:ef_static ";
+      if (eflag / 2) want += "download:eatom ";
+      if (vflag / 4) want += "download:vatom ";
+      std::string got;
+      for (auto &c : R.calls) got += c + " ";
+      EXPECT(got == want, "call sequence: got '" << got << "' expected '" << want << "'");
+      if (!fixed) EXPECT(R.last_change == 1.0 / 3.0, "the all-reduced sum goes back in (serial MPI: this rank's own)");
+      EXPECT(R.get_lo == 0 && R.get_n == nlocal, "own dipoles fetched for the forward communication");
+      /* halo dipoles: slot k of the halo = ghost halo_ghost[k], as the last forward communication left it */
+      EXPECT(R.put_idx.size() == 2 && R.put_idx[0] == nlocal && R.put_idx[1] == nlocal + 1, "halo rows");
+      EXPECT(R.put_val[0] == 900.0 + 50 + g_fwd && R.put_val[3] == 900.0 + 70 + g_fwd, "halo dipoles of ghosts 5 and 7: " << R.put_val[0] << " " << R.put_val[3]);
+      EXPECT(g_fwd == nsweeps + 1, "one forward communication after the initial guess and one per sweep: " << g_fwd);
+      /* images of own atoms carry their owner's dipole after the forward communication (pack / unpack of the shim) */
+      /* results in LAMMPS order */
+      for (int a = 0; a < nall; a++)
+        for (int c = 0; c < 3; c++)
+          EXPECT(fabs(atom->f[a][c] - (f0[3 * a + c] + 0.001 * (3 * lib_of[a] + c + 1))) < 1e-12, "forces added in LAMMPS order, atom " << a);
+      EXPECT(atom->mu_induced[0][4] == 304.0 && atom->ef_static[0][4] == 404.0, "dipoles / static field of the own atoms");
+      const int eg = eflag % 2;
+      if (eg) EXPECT(shim->eng_vdwl == 1.25 && shim->eng_coul == -2.5, "energies of this rank's rows");
+      EXPECT(force->pair->eng_pol == -0.75, "eng_pol");
+      if (eflag / 2) EXPECT(shim->eatom[6] == 0.5 + 7 && shim->eatom[7] == 0.5 + 6, "per-atom energies back in LAMMPS order");
+      if (vflag / 4) EXPECT(shim->vatom[6][0] == 0.25 + 6 * 7, "per-atom virial back in LAMMPS order");
+    }
+    /* the checks compute_sharded makes before anything moves */
+    {
+      std::string tag = "sharded: exact mode refused";
+      memset(&R.st, 0, sizeof(R.st));
+      R.st.cut_lj_global = 9.0; R.st.cut_coul = 9.0; R.st.dd_cutoff = 0.0; R.st.iterations_max = 4;
+      PairLJCutCoulLongPolarizationMI355X *shim = new PairLJCutCoulLongPolarizationMI355X(lmp);
+      force->pair = shim; shim->ncoultablebits = 0;
+      char a0[] = "9.0", a1[] = "9.0"; char *sa[2] = {a0, a1};
+      shim->settings(2, sa);
+      char c0[] = "*", c1[] = "*", c2[] = "0.1", c3[] = "3.0"; char *ca[4] = {c0, c1, c2, c3};
+      shim->coeff(4, ca); shim->init_style(); shim->init_list(0, list);
+      bool thrown = false;
+      try { shim->compute(1, 2); } catch (SeamError &e) { thrown = e.msg.find("dd_cutoff") != std::string::npos; }
+      EXPECT(thrown, "several ranks without dd_cutoff must stop with the dd_cutoff message");
+      R.st.dd_cutoff = 9.0;
+      lmp->comm->cutghost[1] = 5.0;
+      thrown = false;
+      try { shim->compute(1, 2); } catch (SeamError &e) { thrown = e.msg.find("ghost cutoff") != std::string::npos; }
+      EXPECT(thrown, "a ghost shell shorter than the list reach must stop the run");
+      lmp->comm->cutghost[1] = 20.0;
+    }
+  } catch (Fail &f) {
+    snprintf(msg, nmsg, "%s", f.msg.c_str());
+    rc = -1;
+  } catch (SeamError &e) {
+    snprintf(msg, nmsg, "error->all: %s", e.msg.c_str());
+    rc = -1;
+  }
+  R.sharded = false;
   return rc;
 }
 }

@@ -157,3 +157,11 @@ def test_shim_compute_marshalling_against_a_recording_stub(tmp_path):
     rc = L.shimcompute_check(C.byref(n), msg, 1024)
     assert rc == 0, msg.value.decode()
     assert n.value == 2 * 2 * 2 * 4 * 6
+    # one MPI rank per GPU (comm->nprocs > 1 -> compute_sharded): library order [own | halo | other ghosts], row range, the
+    # re-indexed list, the per-sweep sequence around MPI_Allreduce and Comm::forward_comm_pair (emulated through the shim's own
+    # pack_forward_comm / unpack_forward_comm), the stop at the sweep the library reports, results back in LAMMPS order;
+    # device_neigh {no, yes} x fixed_iteration {no, yes} x eflag {0, 3} x vflag {0, 2, 4, 6}, and the two refusals
+    n2 = C.c_int(0)
+    rc = L.shimsharded_check(C.byref(n2), msg, 1024)
+    assert rc == 0, msg.value.decode()
+    assert n2.value == 2 * 2 * 2 * 4
