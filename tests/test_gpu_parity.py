@@ -276,11 +276,14 @@ def test_row_sharded_handles_match_single_handle(mode, wl, pkg, oracle):
     assert np.max(np.abs(vir - ref["virial"])) < max(tol, 1e-9) * np.max(np.abs(ref["virial"]))
 
 
-def test_sweep_in_parts_equals_the_whole_sweep(wl, pkg, oracle):
-    """polar_step_sweep_part: a sweep run as two (or four) windows of its colour phases is the same sweep."""
+@pytest.mark.parametrize("det", ["no", "yes"])
+def test_sweep_in_parts_equals_the_whole_sweep(det, wl, pkg, oracle):
+    """polar_step_sweep_part: a sweep run as two (or four) windows of its colour phases is the same sweep -- bit for bit with
+    `deterministic yes`; otherwise up to the in-place race of the rows of one phase, which after 13 unconverged sweeps of this
+    small box is worth up to a few 1e-7 of the largest dipole (1e-9 at convergence)."""
     import importlib
     par = importlib.import_module(pkg.__name__ + ".parallel")
-    extra = ["use_previous", "no", "dd_cutoff", "9.0", "fixed_iteration", "yes", "max_iterations", "12"]
+    extra = ["use_previous", "no", "dd_cutoff", "9.0", "fixed_iteration", "yes", "max_iterations", "12", "deterministic", det]
     s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"), extra_args=extra)
     whole = None   # (the iterates of 13 colour-phase sweeps are not the oracle's: compare with the undivided sweep)
     for nparts in (1, 2, 4):
@@ -296,7 +299,10 @@ def test_sweep_in_parts_equals_the_whole_sweep(wl, pkg, oracle):
         assert out["sweeps"] == 13 and out["status"] == 0
         if whole is None:
             whole = mu
-        assert np.max(np.abs(mu - whole)) / np.max(np.abs(whole)) < 1e-8     # rows of one phase race by design
+        if det == "yes":
+            assert np.array_equal(mu, whole)
+        else:
+            assert np.max(np.abs(mu - whole)) / np.max(np.abs(whole)) < 2e-6     # rows of one phase race by design
         p.close()
     with pytest.raises(pkg.PolarError, match="bad part"):
         p2 = pkg.pair_from_system(s)
