@@ -160,6 +160,23 @@ def test_triclinic_box_exact_mode(wl, pkg, oracle):
         s2.settings = wl.parse_pair_style_args(["8.0", "7.5", "damp_type", "exponential", "dd_cutoff", "7.5"] + extra)
         out, ref = _check(pkg, oracle, s2)
         assert out["dd_pairs"] > 0
+    # the colour phases of the list-mode GS in the tilted cell (Jones-Plassmann path: the cell pass needs cells twice the
+    # colour distance wide there): no two atoms of a phase within 2.4 A of each other, over all 27 images
+    s2_gs = copy.copy(s2)
+    s2_gs.settings = wl.parse_pair_style_args(["8.0", "7.5", "damp_type", "exponential", "dd_cutoff", "7.5", "precision", "1e-13", "max_iterations", "200"])
+    p = pkg.pair_from_system(s2_gs)
+    p.compute()
+    nc, col = p.colors(n)
+    p.close()
+    assert nc >= 1 and np.all(col[s2.alpha[:n] != 0] >= 0)
+    a, b, c = np.array([L, 0, 0]), np.array([xy, L, 0]), np.array([xz, yz, L])
+    shifts = np.array([i * a + j * b + k * c for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1)])
+    for q in range(nc):
+        xq = s2.x[col == q]
+        d = xq[:, None, None, :] - xq[None, :, None, :] + shifts[None, None, :, :]
+        r2 = np.einsum("ijkl,ijkl->ijk", d, d).min(axis=2)
+        r2[np.arange(len(xq)), np.arange(len(xq))] = np.inf
+        assert r2.min() > 2.4 ** 2, (q, np.sqrt(r2.min()))
     # a box too thin for the cutoff between two opposite faces is refused (widths, not edge lengths, count)
     s3 = copy.copy(s2)
     s3.tilt = (7.9, 0.0, 0.0)
