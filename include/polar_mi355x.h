@@ -62,7 +62,8 @@ typedef struct {
   /* polar_sor <omega> (extension keyword, list mode with polar_gs / polar_gs_ranked): successive over-relaxation of the
    * Gauss-Seidel update, mu <- mu + omega (alpha (E_static + E_ind) - mu).  1 (default) is the reference's update
    * (PS.cpp:1170-1180); 1.1 - 1.2 reaches the same fixed point under the same stop rule in about 30 % fewer sweeps on the MOF
-   * boxes (profiles/r03_lab_sor.txt).  0 < omega < 2. */
+   * boxes (profiles/r03_lab_det_sor.txt).  0 < omega < 2.  Single-handle runs only: across ranks (block-Jacobi) over-relaxation
+   * slows the iteration down (60 instead of 38 sweeps on 8 slabs at 1.15). */
   double polar_sor;
   /* rccl_halo yes|no (extension keyword, one MPI rank per GPU on one node): the LAMMPS shim hands the per-sweep exchange of
    * the halo dipoles and the all-reduced stop rule to the library's own RCCL driver (polar_dist_step) instead of staging
