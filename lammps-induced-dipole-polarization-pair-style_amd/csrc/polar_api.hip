@@ -1129,6 +1129,20 @@ void build_colors_device(polar_handle *h, bool ranked) {
   k_color_fill<<<nblk(ncell, 128), 128, 0, s>>>(ncell, ncolors, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_perm.p, h->d_coff.p,
                                                h->d_rows_orig.p);
   lap("phase order + rows");
+#ifdef POLAR_LAB
+  if (getenv("POLAR_LP_SORT_T") && tot > 0) {   // lab: inside a phase the rows with the most trips first (stable: cell order inside a trip count)
+    std::vector<int> rows((size_t)tot), cnt((size_t)n), inv((size_t)n);
+    HIPCHECK(hipMemcpyAsync(rows.data(), h->d_rows_orig.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(cnt.data(), h->d_dd_cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(inv.data(), h->d_inv.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    for (int c = 0; c < ncolors; c++)
+      std::stable_sort(rows.begin() + h->color_off[c], rows.begin() + h->color_off[c + 1],
+                       [&](int a, int b) { return (cnt[inv[a]] + 63) / 64 > (cnt[inv[b]] + 63) / 64; });
+    HIPCHECK(hipMemcpyAsync(h->d_rows_orig.p, rows.data(), (size_t)tot * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipStreamSynchronize(s));
+  }
+#endif
   h->h_color.assign((size_t)n, 0);  // (its size says "a colouring for n atoms exists": the colours themselves live on the device)
   h->color_epoch++;
   h->colors_rebuilt++;
