@@ -212,6 +212,11 @@ int polar_compute_peratom(polar_handle *h, int eflag, int vflag, double *f, doub
  * returns how many sweeps were recorded (0 unless the debug keyword is on), < 0 on error. */
 int polar_get_debug_trace(polar_handle *h, double *u_polar, int max);
 
+/* `debug yes`, the two force lines of PS.cpp:637-638: out6 = {polarization force on the caller's atom 0 (PS.cpp:612-626),
+ * its dipole-dipole part (PS.cpp:542-556, 583-597)} of the last compute, in the units of `f`.  Returns 1 when the numbers
+ * are there, 0 (and zeros) without the debug keyword or when atom 0 is not a row of this handle, < 0 on error. */
+int polar_get_debug_forces(polar_handle *h, double *out6);
+
 /* Diagnostics (no reference counterpart: the reference's sweep is serial, PS.cpp:1158-1180): the colour phase of every
  * local atom in the list-mode Gauss-Seidel of the last compute, in the caller's atom order; -1 for atoms that are not rows
  * (not polarizable, or outside the handle's row range).  Atoms of one colour are relaxed by one launch and must lie farther

@@ -122,6 +122,7 @@ EXPORTS = {
     "polar_set_list_style": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_set_newton": (C.c_int, [C.c_void_p, C.c_int]),
     "polar_get_debug_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "polar_get_debug_forces": (C.c_int, [C.c_void_p, _dp]),
     "polar_get_colors": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "polar_restart_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "polar_restart_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -430,6 +431,12 @@ class PolarPair:
         a = np.zeros(nmax)
         n = self._ck(self.L.polar_get_debug_trace(self.h, _dptr(a), nmax))
         return a[:n].copy()
+
+    def debug_forces(self):
+        """(polarization force on atom 0, its dipole-dipole part) of the last compute (`debug yes`, reference PS.cpp:637-638)."""
+        a = np.zeros(6)
+        self._ck(self.L.polar_get_debug_forces(self.h, _dptr(a)))
+        return a[:3].copy(), a[3:].copy()
 
     def colors(self, n):
         """(ncolors, colour of every local atom in the caller's order; -1: not a row) of the last list-mode GS compute."""

@@ -172,6 +172,7 @@ struct polar_handle {
   int inum = 0;
   long long nneigh = 0;
   bool mu_resident = false;
+  DBuf<double> d_dbgf;           // `debug yes`: {force on atom 0, its dipole-dipole part} of the last compute
   bool mu_host_in_sync = false;  // the caller's mu array still holds what the last polar_compute returned (no polar_set_atoms since)
   // colour phases (cutoff-mode Gauss-Seidel)
   std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
@@ -1535,10 +1536,17 @@ void launch_force(polar_handle *h, int eflag, int vglobal, double *vatom, double
   const polar_settings &st = h->ph.st;
   dim3 grid(nblk(own_n(h), POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
   const double ccs = st.cut_coul * st.cut_coul, dds = st.dd_cutoff * st.dd_cutoff, e2s = std::sqrt(h->P.qqrd2e);
+  double *dbg6 = nullptr;   // `debug yes`: polarization force on the caller's atom 0 and its dipole-dipole part (PS.cpp:637-638)
+  if (st.debug) {
+    h->d_dbgf.ensure(8);
+    HIPCHECK(hipMemsetAsync(h->d_dbgf.p, 0, 8 * sizeof(double), h->stream));
+    dbg6 = h->d_dbgf.p;
+  }
 #define LF(E, V)                                                                                                    \
   k_polar_force<AP, DAMP, E, V><<<grid, block, 0, h->stream>>>(own_rows(h), own_n(h), h->sorted ? h->d_perm.p : nullptr, h->nlocal, h->d_scal.p, h->d_rec0.p, h->d_rec1.p,  \
                                                                h->d_mol_s.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch}, h->d_nl_j.p,  \
-                                                               ccs, dds, st.polar_damp, e2s, fdst, h->d_slots.p, vatom, vglobal, make_expcoef())
+                                                               ccs, dds, st.polar_damp, e2s, fdst, h->d_slots.p, vatom, vglobal, make_expcoef(),  \
+                                                               dbg6)
   if (eflag) { if (vpair) LF(true, true); else LF(true, false); }
   else       { if (vpair) LF(false, true); else LF(false, false); }
 #undef LF
@@ -2131,7 +2139,7 @@ int polar_destroy(polar_handle *h) {
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_slot.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_trace.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();
     h->d_cell_first.release(); h->d_nl_first.release(); h->d_dd_first.release(); h->d_dd_s.release(); h->d_xq.release(); h->d_pos4.release();
     h->d_overflow.release(); h->d_ddtot.release();
-    h->d_cadj.release(); h->d_cdeg.release(); h->d_ccnt.release(); h->d_cflags.release(); h->d_crelabel.release(); h->d_klist.release(); h->d_ulead.release(); h->d_udd_j.release(); h->d_upos.release(); h->d_unit.release(); h->d_udesc.release(); h->d_cprio.release(); h->d_cstat.release(); h->d_coff.release(); h->d_lp_pend.release(); h->d_lp_part.release();
+    h->d_cadj.release(); h->d_cdeg.release(); h->d_ccnt.release(); h->d_cflags.release(); h->d_crelabel.release(); h->d_klist.release(); h->d_dbgf.release(); h->d_ulead.release(); h->d_udd_j.release(); h->d_upos.release(); h->d_unit.release(); h->d_udesc.release(); h->d_cprio.release(); h->d_cstat.release(); h->d_coff.release(); h->d_lp_pend.release(); h->d_lp_part.release();
     if (h->h_cflags) (void)hipHostFree(h->h_cflags);
     if (h->h_cstat) (void)hipHostFree(h->h_cstat);
     if (h->h_coff) (void)hipHostFree(h->h_coff);
@@ -2677,6 +2685,16 @@ int polar_get_colors(polar_handle *h, int *color, int n) {
     return (int)POLAR_OK;
   });
   return rc < 0 ? rc : nc;
+}
+int polar_get_debug_forces(polar_handle *h, double *out6) {
+  return guarded(h, [&]() {
+    need_device(h);
+    if (!out6) throw InputError("polar_get_debug_forces: null pointer");
+    for (int k = 0; k < 6; k++) out6[k] = 0.0;
+    if (!h->ph.st.debug || !h->d_dbgf.p) return 0;
+    HIPCHECK(hipMemcpy(out6, h->d_dbgf.p, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    return 1;
+  });
 }
 int polar_set_newton(polar_handle *h, int newton_pair) {
   if (!h) return POLAR_ERR_STATE;

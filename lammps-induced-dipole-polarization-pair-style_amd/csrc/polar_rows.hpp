@@ -407,7 +407,8 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
                                                              const int *__restrict__ nl_j, double cut_coulsq,
                                                              double ddcutsq, double pd, double e2s,
                                                              double *__restrict__ f, double *__restrict__ slots,
-                                                             double *__restrict__ vatom, int vglobal, ExpCoef K) {
+                                                             double *__restrict__ vatom, int vglobal, ExpCoef K,
+                                                             double *__restrict__ dbg6) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -418,6 +419,9 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
   const double f_shift = -1.0 / cut_coulsq;
   double fx = 0, fy = 0, fz = 0, uef = 0, udd = 0;
   double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  // `debug yes` (PS.cpp:542-556, 612-626, 637-638): the row of the caller's atom 0 also keeps the dipole-dipole part of its force
+  const bool isdbg = dbg6 && (perm ? perm[i] : i) == 0;   // wave-uniform
+  double ddx = 0, ddy = 0, ddz = 0;
   long long beg = 0, end = nlocal;
   if (!ALLPAIRS) row_range(nl, i, beg, end);
   // (the cooperative record fetch of k_static_field was tried here too: this kernel is bound by its FP64
@@ -486,9 +490,10 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
         pre3 = 3.0 * r5inv * pidotr;
         if (EFLAG) udd += r3inv * pdotp - 3.0 * r5inv * pidotr * pjdotr;
       }
-      px += pre_r * dx + pre2 * ri.mx + pre3 * rj.mx;
-      py += pre_r * dy + pre2 * ri.my + pre3 * rj.my;
-      pz += pre_r * dz + pre2 * ri.mz + pre3 * rj.mz;
+      const double qx = pre_r * dx + pre2 * ri.mx + pre3 * rj.mx, qy = pre_r * dy + pre2 * ri.my + pre3 * rj.my,
+                   qz = pre_r * dz + pre2 * ri.mz + pre3 * rj.mz;
+      px += qx; py += qy; pz += qz;
+      if (isdbg) { ddx += qx; ddy += qy; ddz += qz; }
     }
     fx += px; fy += py; fz += pz;
     if (VPAIR) {  // ev_tally_xyz, src/pair.cpp:1001-1075 (each pair seen from both rows -> 0.5)
@@ -500,6 +505,10 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
   if (lane == 0) {
     const int o = perm ? perm[i] : i;  // forces leave in LAMMPS' order
     atomicAdd(&f[3 * o], fx); atomicAdd(&f[3 * o + 1], fy); atomicAdd(&f[3 * o + 2], fz);
+  }
+  if (isdbg) {
+    ddx = wave_sum(ddx); ddy = wave_sum(ddy); ddz = wave_sum(ddz);
+    if (lane == 0) { dbg6[0] = fx; dbg6[1] = fy; dbg6[2] = fz; dbg6[3] = ddx; dbg6[4] = ddy; dbg6[5] = ddz; }
   }
   if (EFLAG) {
     uef = wave_sum(uef); udd = wave_sum(udd);

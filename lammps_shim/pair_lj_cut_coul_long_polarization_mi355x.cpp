@@ -103,6 +103,10 @@ void PairLJCutCoulLongPolarizationMI355X::debug_prints(const polar_result &res)
   printf("u_polar: %.18f\n",u_polar);                                                  // PS.cpp:403
   printf("self: %.18f\nef: %.18f\ndd: %.18f\n",res.u_self,res.u_ef,res.u_dd);        // PS.cpp:635
   printf("u_polar calc: %.18f\n",res.eng_pol);
+  double f0[6] = {0.0,0.0,0.0,0.0,0.0,0.0};
+  polar_get_debug_forces(h,f0);                                                        // PS.cpp:637-638
+  printf("polar force on atom 0: %.18f,%.18f,%.18f\n",f0[0],f0[1],f0[2]);
+  printf("polar dipole force on atom 0: %.18f,%.18f,%.18f\n",f0[3],f0[4],f0[5]);
   if (atom->nlocal > 0) printf("pos of atom 0: %.5f,%.5f,%.5f\n",atom->x[0][0],atom->x[0][1],atom->x[0][2]);
 }
 

@@ -50,6 +50,7 @@ class OrcResult(C.Structure):
         ("t_rank", C.c_double), ("t_ljcoul", C.c_double), ("t_static", C.c_double),
         ("t_matrix", C.c_double), ("t_solve", C.c_double), ("t_force", C.c_double),
         ("sweeps", C.c_int),
+        ("force_atom0", C.c_double * 3), ("dipole_force_atom0", C.c_double * 3),
     ]
 
 
@@ -146,7 +147,7 @@ def compute(sys, eflag=1, vflag=2, mu0=None, settings=None, trace=False):
     out = dict(f=f, mu=mu, ef_static=ef, status=rc, utrace=ut, eatom=eatom, vatom=vatom)
     for name, _ in OrcResult._fields_:
         v = getattr(res, name)
-        out[name] = np.array(list(v)) if name == "virial" else v
+        out[name] = np.array(list(v)) if name in ("virial", "force_atom0", "dipole_force_atom0") else v
     return out
 
 

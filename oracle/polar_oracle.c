@@ -743,7 +743,7 @@ done:
  * Returns the force on i (to be subtracted from j).                         */
 static void polar_pair(const orc_system *s, int eflag, int i, int j, double delx, double dely,
                        double delz, const double *mu, double cut_coulsq, double f_shift, double e2s,
-                       double ddcutsq, double *fout, double *u_ef, double *u_dd) {
+                       double ddcutsq, double *fout, double *u_ef, double *u_dd, double *fdd /* dipole-dipole part of fout */) {
   const double *q = s->q, *alpha = s->alpha;
   const int *mol = s->molecule;
   const double pd = s->polar_damp;
@@ -755,6 +755,7 @@ static void polar_pair(const orc_system *s, int eflag, int i, int j, double delx
   double r = 1.0 / rinv;
   double r3inv = r2inv * rinv;
   double fx = 0.0, fy = 0.0, fz = 0.0;
+  fdd[0] = fdd[1] = fdd[2] = 0.0;
   const double *mi = mu + 3 * (size_t)i, *mj = mu + 3 * (size_t)j;
 
   if (rsq < cut_coulsq) {
@@ -813,18 +814,20 @@ static void polar_pair(const orc_system *s, int eflag, int i, int j, double delx
       double pre4 = -pdotp * r3inv * (-term_1 * (pd * rinv + pd * pd) + term_1 * pd * term_2 * rinv);
       double pre5 = 3.0 * pidotr * pjdotr * r5inv *
                     (-term_1 * (pd * rinv + pd * pd + 0.5 * r * pd * pd * pd) + term_1 * pd * term_3 * rinv);
-      fx += pre1 * delx + pre2 * mi[0] + pre3 * mj[0] + pre4 * delx + pre5 * delx;
-      fy += pre1 * dely + pre2 * mi[1] + pre3 * mj[1] + pre4 * dely + pre5 * dely;
-      fz += pre1 * delz + pre2 * mi[2] + pre3 * mj[2] + pre4 * delz + pre5 * delz;
+      fdd[0] = pre1 * delx + pre2 * mi[0] + pre3 * mj[0] + pre4 * delx + pre5 * delx;   /* PS.cpp:544-550 */
+      fdd[1] = pre1 * dely + pre2 * mi[1] + pre3 * mj[1] + pre4 * dely + pre5 * dely;
+      fdd[2] = pre1 * delz + pre2 * mi[2] + pre3 * mj[2] + pre4 * delz + pre5 * delz;
+      fx += fdd[0]; fy += fdd[1]; fz += fdd[2];
       if (eflag)
         *u_dd += r3inv * pdotp * (1.0 - term_1 * term_2) - 3.0 * r5inv * pidotr * pjdotr * (1.0 - term_1 * term_3);
     } else {
       double pre1 = 3.0 * r5inv * pdotp - 15.0 * r7inv * pidotr * pjdotr;
       double pre2 = 3.0 * r5inv * pjdotr;
       double pre3 = 3.0 * r5inv * pidotr;
-      fx += pre1 * delx + pre2 * mi[0] + pre3 * mj[0];
-      fy += pre1 * dely + pre2 * mi[1] + pre3 * mj[1];
-      fz += pre1 * delz + pre2 * mi[2] + pre3 * mj[2];
+      fdd[0] = pre1 * delx + pre2 * mi[0] + pre3 * mj[0];   /* PS.cpp:585-591 */
+      fdd[1] = pre1 * dely + pre2 * mi[1] + pre3 * mj[1];
+      fdd[2] = pre1 * delz + pre2 * mi[2] + pre3 * mj[2];
+      fx += fdd[0]; fy += fdd[1]; fz += fdd[2];
       if (eflag) *u_dd += r3inv * pdotp - 3.0 * r5inv * pidotr * pjdotr;
     }
   }
@@ -856,10 +859,12 @@ void orc_polar_forces(const orc_system *s, int eflag, int vflag_pairwise, const 
       for (long long p = L.first[i]; p < L.first[i + 1]; p++) {
         int j = L.j[p];
         if (j < i) continue; /* i<j, same orientation as the reference */
-        double fo[3];
+        double fo[3], fdd[3];
         polar_pair(s, eflag, i, j, L.d[3 * p], L.d[3 * p + 1], L.d[3 * p + 2], mu, cut_coulsq, f_shift, e2s,
-                   ddsq, fo, &u_ef, &u_dd);
+                   ddsq, fo, &u_ef, &u_dd, fdd);
         for (int k = 0; k < 3; k++) { f[3 * i + k] += fo[k]; f[3 * j + k] -= fo[k]; }
+        if (i == 0) for (int k = 0; k < 3; k++) { res->force_atom0[k] += fo[k]; res->dipole_force_atom0[k] += fdd[k]; }   /* PS.cpp:546-550, 616-620 */
+        if (j == 0) for (int k = 0; k < 3; k++) { res->force_atom0[k] -= fo[k]; res->dipole_force_atom0[k] -= fdd[k]; }   /* PS.cpp:552-556, 622-626 */
         if (vflag_pairwise) {
           const double *d = &L.d[3 * p];
           res->virial[0] += d[0] * fo[0]; res->virial[1] += d[1] * fo[1]; res->virial[2] += d[2] * fo[2];
@@ -875,11 +880,13 @@ void orc_polar_forces(const orc_system *s, int eflag, int vflag_pairwise, const 
       if (eflag && alpha[i] != 0.0)
         u_self += 0.5 * (mu[3 * i] * mu[3 * i] + mu[3 * i + 1] * mu[3 * i + 1] + mu[3 * i + 2] * mu[3 * i + 2]) / alpha[i];
       for (int j = i + 1; j < nlocal; j++) {
-        double xjimage[3], fo[3];
+        double xjimage[3], fo[3], fdd[3];
         orc_closest_image(s, &x[3 * i], &x[3 * j], xjimage);
         double delx = xtmp - xjimage[0], dely = ytmp - xjimage[1], delz = ztmp - xjimage[2];
-        polar_pair(s, eflag, i, j, delx, dely, delz, mu, cut_coulsq, f_shift, e2s, -1.0, fo, &u_ef, &u_dd);
+        polar_pair(s, eflag, i, j, delx, dely, delz, mu, cut_coulsq, f_shift, e2s, -1.0, fo, &u_ef, &u_dd, fdd);
         for (int k = 0; k < 3; k++) { f[3 * i + k] += fo[k]; f[3 * j + k] -= fo[k]; }
+        if (i == 0) for (int k = 0; k < 3; k++) { res->force_atom0[k] += fo[k]; res->dipole_force_atom0[k] += fdd[k]; }
+        if (j == 0) for (int k = 0; k < 3; k++) { res->force_atom0[k] -= fo[k]; res->dipole_force_atom0[k] -= fdd[k]; }
         if (vflag_pairwise) { /* ev_tally_xyz pair.cpp:1001-1075, newton or both local */
           res->virial[0] += delx * fo[0]; res->virial[1] += dely * fo[1]; res->virial[2] += delz * fo[2];
           res->virial[3] += delx * fo[1]; res->virial[4] += delx * fo[2]; res->virial[5] += dely * fo[2];

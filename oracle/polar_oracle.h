@@ -77,6 +77,9 @@ typedef struct {
   double rms_dmu;   /* sqrt(change/(3N)) of the last sweep */
   double t_rank, t_ljcoul, t_static, t_matrix, t_solve, t_force; /* seconds */
   int sweeps;       /* number of sweeps actually executed */
+  /* the reference's `debug yes` lines PS.cpp:637-638: polarization force on atom 0 (PS.cpp:617-626) and its dipole-dipole
+   * part (PS.cpp:548-556, 589-597), accumulated with + for i == 0 and - for j == 0 */
+  double force_atom0[3], dipole_force_atom0[3];
 } orc_result;
 
 /* a9: Domain::closest_image, domain.cpp:1220-1312 */

@@ -163,6 +163,7 @@ int polar_download(polar_handle *, const char *name, double *dst, long long n) {
 }
 int polar_upload_mu(polar_handle *, const double *, long long) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("upload_mu"); return POLAR_OK; }
 int polar_get_debug_trace(polar_handle *, double *, int) { return 0; }
+int polar_get_debug_forces(polar_handle *, double *o) { for (int k = 0; k < 6; k++) o[k] = 0.0; return 0; }
 int polar_set_stream(polar_handle *, void *) { return POLAR_OK; }
 int polar_set_row_range(polar_handle *, int lo, int hi) { R.calls.push_back("set_row_range"); R.row_lo = lo; R.row_hi = hi; return POLAR_OK; }
 int polar_set_global_count(polar_handle *, long long n) { R.global = n; return POLAR_OK; }

@@ -487,7 +487,27 @@ def test_debug_trace_matches_the_oracle(wl, pkg, oracle):
     p = pkg.pair_from_system(s)
     p.compute()
     assert len(p.debug_trace()) == 0
+    assert not np.any(np.concatenate(p.debug_forces()))
     p.close()
+
+
+@pytest.mark.parametrize("case,extra", [("bulk_h2", []), ("mof5_h2", []), ("mof5_h2", ["dd_cutoff", "9.0"]), ("mof5_h2", ["damp_type", "none", "max_iterations", "30"]),
+                                        ("sifsix_co2", ["dd_cutoff", "8.0"])])
+def test_debug_force_lines_match_the_oracle(case, extra, wl, pkg, oracle):
+    """`debug yes`, the reference's "polar force on atom 0" and "polar dipole force on atom 0" (PS.cpp:542-556, 612-626,
+    637-638): the total polarization force on the caller's atom 0 and its dipole-dipole part, exact and list mode, damped and
+    undamped, against the oracle's restatement of the same accumulations."""
+    s, _ = wl.load_fixture(os.path.join(GOLD, f"{case}.npz"), extra_args=["use_previous", "no", "debug", "yes"] + extra)
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    p = pkg.pair_from_system(s)
+    out = p.compute()
+    tot, dd = p.debug_forces()
+    p.close()
+    assert out["status"] == ref["status"]
+    scale = np.max(np.linalg.norm(ref["f"][:s.nlocal], axis=1))
+    assert np.max(np.abs(tot - ref["force_atom0"])) < TOL * scale, (tot, ref["force_atom0"])
+    assert np.max(np.abs(dd - ref["dipole_force_atom0"])) < TOL * scale, (dd, ref["dipole_force_atom0"])
+    assert np.any(ref["force_atom0"] != 0.0)
 
 
 @pytest.mark.parametrize("comm", ["device", "host"])
