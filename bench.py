@@ -231,6 +231,58 @@ def md_leg(pkg, s, steps=20, every=10, seed=7, device_neigh=False, use_previous=
             "color_share_of_run": ms_rebuilds / max(float(np.sum(t_plain) + np.sum(t_relist)), 1e-9)}
 
 
+def visible_gpus():
+    """GPUs a fresh child process sees through the library (the launcher itself never initialises HIP)."""
+    import subprocess
+
+    code = (f"import sys, importlib; sys.path.insert(0, {ROOT!r}); "
+            f"print('POLAR_GPUS', importlib.import_module({PKG!r}).device_count())")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("POLAR_GPUS"):
+                return int(ln.split()[1])
+    except (OSError, subprocess.SubprocessError, ValueError):
+        pass
+    return 0
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) of this same file under
+    torch.distributed.run as CHILD processes, relay rank 0's one JSON line, return the launcher's exit code.  Never prints an
+    N = 1 line for a --gpus N request: if N ranks cannot be had the exit code is non-zero and stderr says why in one line.
+    POLAR_DIST_BACKEND=gloo (rehearsal): the ranks share whatever GPUs exist, exchanges staged through the host."""
+    import socket
+    import subprocess
+
+    backend = os.environ.get("POLAR_DIST_BACKEND", "nccl")
+    have = visible_gpus()
+    if have < 1:
+        print("bench.py: no MI355X visible: the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
+    if backend == "nccl" and have < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs, this node shows {have} (RCCL takes one rank per device; "
+              "POLAR_DIST_BACKEND=gloo rehearses the ranks on shared devices)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in r.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or not lines:
+        print(f"bench.py: the {n}-rank run failed (exit code {r.returncode}" + ("" if lines else ", no result line") + ")", file=sys.stderr)
+        return r.returncode or 3
+    print(lines[-1])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,10 +295,19 @@ def main():
     ap.add_argument("--synth", type=int, default=0, help="use the SURVEY 8(d) synthetic generator with this many atoms instead of the replicated cell")
     ap.add_argument("--extra", nargs="*", default=[], help="extra pair_style keywords (experiments)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("POLAR_FORCE_LAUNCH")):
+        # `python bench.py --gpus N` by itself: become the launcher of N ranks.  Nothing here has touched the GPU (no torch,
+        # no HIP call): the ranks are fresh children, never a re-exec of an initialised process.
+        raise SystemExit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not os.environ.get("POLAR_FORCE_DIST"):
+        # a line that says n_gpus = world for a --gpus N request would be a wrong record: refuse
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}`, which starts the ranks itself)")
     import torch
 
     pkg = importlib.import_module(PKG)

@@ -44,19 +44,40 @@ def _sources():
         os.path.join(os.path.dirname(_HERE), "include", "polar_mi355x.h")]
 
 
+TRANSLATION_UNITS = ("polar_api.hip", "polar_step.hip", "polar_color.hip", "polar_dist.hip")
+
+
 def build(force=False, verbose=False, lab=True):
     """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU): the product library and, with
-    ``lab``, the lab build of the same sources."""
-    src = os.path.join(_CSRC, "polar_api.hip")
-    for path, extra in ((LIB_PATH, []), (LIB_PATH_LAB, ["-DPOLAR_LAB"])):
+    ``lab``, the lab build of the same sources.  The translation units are compiled side by side, then linked."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    jobs, links = [], []
+    for path, extra, tag in ((LIB_PATH, [], "product"), (LIB_PATH_LAB, ["-DPOLAR_LAB"], "lab")):
         if path == LIB_PATH_LAB and not lab:
             continue
         stale = (not os.path.exists(path)) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in _sources())
-        if force or stale:
-            cmd = [HIPCC] + HIP_FLAGS + extra + ["-o", path, src]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+        if not (force or stale):
+            continue
+        odir = os.path.join(_CSRC, "build", tag)
+        os.makedirs(odir, exist_ok=True)
+        objs = []
+        for tu in TRANSLATION_UNITS:
+            obj = os.path.join(odir, tu.replace(".hip", ".o"))
+            objs.append(obj)
+            jobs.append([HIPCC] + [f for f in HIP_FLAGS if f != "-shared"] + extra + ["-Wno-unused-function", "-c", "-o", obj, os.path.join(_CSRC, tu)])
+        links.append([HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", path] + objs)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2)))) as ex:
+            list(ex.map(run, jobs))
+        for cmd in links:
+            run(cmd)
     return LIB_PATH
 
 

@@ -1,0 +1,560 @@
+// polar_color.hip -- colour phases of the list-mode Gauss-Seidel: atoms of one colour are relaxed by one launch and must lie
+// farther apart than the colour distance.  Built on the device (sequential DSATUR cell by cell + local repair), re-validated
+// on reneighbor steps.  No reference counterpart: the reference's sweep is serial (PS.cpp:1158-1180).
+#include "polar_handle.hpp"
+
+#ifdef POLAR_LAB
+// ---- clusters of rows for k_field_cl and their colouring ------------------------------------------
+// Clusters: greedy, in cell order -- a seed atom takes its nearest unassigned polarizable neighbours while every
+// member stays within cluster_dist of every other (adjacency lists hold the atoms within color_dist, so
+// cluster_dist <= color_dist).  Two clusters conflict when any two of their members are closer than color_dist;
+// DSATUR colours the cluster graph, phases are ordered by the mean rank metric, members by descending rank metric
+// (the in-cluster update is sequential: PS.cpp:1130-1143's "most coupled first", restricted to the cluster).
+void build_cluster_colors(polar_handle *h, const std::vector<double> &rank, const std::vector<std::vector<int>> &cells,
+                          const std::vector<std::vector<int>> &adj) {
+  const int n = h->nlocal;
+  const polar_settings &st = h->ph.st;
+  const bool gs = st.polar_gs || st.polar_gs_ranked;
+  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
+  const double dcl = std::min(h->cluster_dist, h->color_dist), dcl2 = dcl * dcl;
+  auto dist2 = [&](int i, int j) { return min_image_dist2(h->box, &h->hx[3 * (size_t)i], &h->hx[3 * (size_t)j]); };
+  auto row_atom = [&](int i) { return i >= lo && i < hi && h->halpha[i] != 0.0; };
+  std::vector<int> cl_of((size_t)n, -1);
+  std::vector<int> mem;  // 4 per cluster
+  for (const auto &cell : cells)
+    for (int i : cell) {
+      if (!row_atom(i) || cl_of[i] >= 0) continue;
+      const int c = (int)(mem.size() / 4);
+      int m[4] = {i, -1, -1, -1}, cnt = 1;
+      cl_of[i] = c;
+      if (h->cluster_max > 1) {
+        std::vector<std::pair<double, int>> cand;
+        for (int j : adj[i])
+          if (row_atom(j) && cl_of[j] < 0) { const double d2 = dist2(i, j); if (d2 <= dcl2) cand.push_back({d2, j}); }
+        std::sort(cand.begin(), cand.end());
+        for (const auto &cj : cand) {
+          if (cnt >= h->cluster_max) break;
+          bool ok = true;
+          for (int k = 1; k < cnt; k++) ok = ok && dist2(m[k], cj.second) <= dcl2;
+          if (!ok) continue;
+          m[cnt++] = cj.second;
+          cl_of[cj.second] = c;
+        }
+      }
+      if (!rank.empty()) std::stable_sort(m, m + cnt, [&](int a, int b) { return rank[a] > rank[b]; });
+      mem.insert(mem.end(), m, m + 4);
+    }
+  const int ncl = (int)(mem.size() / 4);
+  // cluster graph
+  std::vector<std::vector<int>> cadj((size_t)ncl);
+  if (gs)
+    for (int c = 0; c < ncl; c++) {
+      for (int k = 0; k < 4; k++) {
+        const int a = mem[4 * (size_t)c + k];
+        if (a < 0) continue;
+        for (int b : adj[a]) { const int o = cl_of[b]; if (o >= 0 && o != c) cadj[c].push_back(o); }
+      }
+      std::sort(cadj[c].begin(), cadj[c].end());
+      cadj[c].erase(std::unique(cadj[c].begin(), cadj[c].end()), cadj[c].end());
+    }
+  std::vector<int> color((size_t)ncl, gs ? -1 : 0), satur((size_t)ncl, 0);
+  int ncolors = gs ? 0 : (ncl > 0 ? 1 : 0);
+  if (gs) {
+    std::vector<unsigned long long> seenmask((size_t)ncl, 0ull);
+    struct Key { int sat, deg, idx; };
+    auto lessk = [](const Key &a, const Key &b) {
+      if (a.sat != b.sat) return a.sat < b.sat;
+      if (a.deg != b.deg) return a.deg < b.deg;
+      return a.idx > b.idx;
+    };
+    std::vector<Key> heap;
+    heap.reserve((size_t)ncl * 2);
+    for (int c = 0; c < ncl; c++) heap.push_back(Key{0, (int)cadj[c].size(), c});
+    std::make_heap(heap.begin(), heap.end(), lessk);
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), lessk);
+      const Key kx = heap.back();
+      heap.pop_back();
+      const int c = kx.idx;
+      if (color[c] >= 0 || kx.sat != satur[c]) continue;
+      int col = 0;
+      while (col < 64 && ((seenmask[c] >> col) & 1ull)) col++;
+      if (col >= 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
+      color[c] = col;
+      ncolors = std::max(ncolors, col + 1);
+      for (int o : cadj[c]) {
+        if (color[o] >= 0) continue;
+        if (!((seenmask[o] >> col) & 1ull)) {
+          seenmask[o] |= 1ull << col;
+          satur[o]++;
+          heap.push_back(Key{satur[o], (int)cadj[o].size(), o});
+          std::push_heap(heap.begin(), heap.end(), lessk);
+        }
+      }
+    }
+    // balance the phases: DSATUR leaves classes as uneven as 3k / 9k / 6k / 25k clusters, and a phase with few
+    // clusters cannot fill the GPU.  A cluster of the heaviest class moves to the lightest class none of its
+    // neighbours uses, while that narrows the spread (weights = rows per cluster).
+    if (getenv("POLAR_COLOR_BALANCE")) {  // measured: no gain (135k atoms: 246 vs 232 us per sweep), off by default
+      std::vector<long long> wsum((size_t)ncolors, 0);
+      std::vector<int> wcl((size_t)ncl, 0);
+      for (int c = 0; c < ncl; c++) {
+        for (int k = 0; k < 4; k++) wcl[c] += mem[4 * (size_t)c + k] >= 0;
+        wsum[color[c]] += wcl[c];
+      }
+      for (int pass = 0; pass < 8; pass++) {
+        long long moved = 0;
+        for (int c = 0; c < ncl; c++) {
+          const int from = color[c];
+          unsigned long long used = 0ull;
+          for (int o : cadj[c]) used |= 1ull << color[o];
+          int best = -1;
+          for (int k = 0; k < ncolors; k++)
+            if (k != from && !((used >> k) & 1ull) && wsum[k] + wcl[c] < wsum[from] && (best < 0 || wsum[k] < wsum[best])) best = k;
+          if (best >= 0) { wsum[from] -= wcl[c]; wsum[best] += wcl[c]; color[c] = best; moved++; }
+        }
+        if (!moved) break;
+      }
+    }
+    // phase order: colours by descending mean rank metric (ranked flavour) or by descending size
+    std::vector<double> key((size_t)ncolors, 0.0);
+    std::vector<int> cnt((size_t)ncolors, 0), ord((size_t)ncolors), relabel((size_t)ncolors);
+    for (int c = 0; c < ncl; c++)
+      for (int k = 0; k < 4; k++) {
+        const int a = mem[4 * (size_t)c + k];
+        if (a < 0) continue;
+        cnt[color[c]]++;
+        key[color[c]] += rank.empty() ? 1.0 : rank[a];
+      }
+    if (!rank.empty())
+      for (int c = 0; c < ncolors; c++) key[c] /= std::max(cnt[c], 1);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] > key[b]; });
+    for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
+    for (int c = 0; c < ncl; c++) color[c] = relabel[color[c]];
+  }
+  // clusters sorted by colour (cell order inside a colour, i.e. the order they were formed in)
+  h->color_off.assign((size_t)ncolors + 1, 0);
+  for (int c = 0; c < ncl; c++) h->color_off[color[c] + 1]++;
+  for (int c = 0; c < ncolors; c++) h->color_off[c + 1] += h->color_off[c];
+  std::vector<int> fill(h->color_off.begin(), h->color_off.end() - 1);
+  h->h_cl.assign((size_t)ncl * 4, -1);
+  long long natoms = 0;
+  for (int c = 0; c < ncl; c++) {
+    const int slot = fill[color[c]]++;
+    for (int k = 0; k < 4; k++) { h->h_cl[4 * (size_t)slot + k] = mem[4 * (size_t)c + k]; natoms += mem[4 * (size_t)c + k] >= 0; }
+  }
+  h->ncl = ncl;
+  h->d_cl_orig.ensure((size_t)ncl * 4 + 4);
+  h->d_cl_s.ensure((size_t)ncl + 1);
+  if (ncl > 0) HIPCHECK(hipMemcpy(h->d_cl_orig.p, h->h_cl.data(), (size_t)ncl * 4 * sizeof(int), hipMemcpyHostToDevice));
+  if (getenv("POLAR_DEBUG")) {
+    fprintf(stderr, "[polar] %d clusters of %lld rows (%.2f per cluster, dist %.2f), %d colour phases:", ncl, natoms,
+            ncl ? (double)natoms / ncl : 0.0, dcl, ncolors);
+    for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
+    fprintf(stderr, "\n");
+  }
+  h->color_epoch++;
+  h->colors_valid = true;
+}
+
+#else
+inline void build_cluster_colors(polar_handle *, const std::vector<double> &, const std::vector<std::vector<int>> &, const std::vector<std::vector<int>> &) { throw std::logic_error("lab build only"); }
+#endif  // POLAR_LAB
+
+#ifdef POLAR_LAB
+// ---- host-side greedy distance colouring for the colour-phase Gauss-Seidel (cutoff mode) ----
+// Atoms of one colour are >= color_dist apart, so the couplings treated Jacobi-style inside a
+// phase are weak and the splitting M = D + L_colour stays convergent for the SPD dipole system
+// (DESIGN.md "colour-phase Gauss-Seidel").  Visit order = ranked order when polar_gs_ranked.
+void build_colors(polar_handle *h, const std::vector<double> &rank) {
+  const int n = h->nlocal;
+  const double dc = h->color_dist, dcsq = dc * dc;
+  int nc[3];
+  long long ncell = 1;
+  double width[3];
+  box_widths(h->box, width);
+  for (int k = 0; k < 3; k++) { nc[k] = std::max(1, (int)std::floor(width[k] / dc)); nc[k] = std::min(nc[k], 512); ncell *= nc[k]; }
+  auto cellof = [&](int i, int c[3]) {
+    double fr3[3];
+    frac_coords(h->box, h->boxlo, h->hx[3 * (size_t)i], h->hx[3 * (size_t)i + 1], h->hx[3 * (size_t)i + 2], fr3);
+    for (int k = 0; k < 3; k++) {
+      double fr = fr3[k];
+      fr -= std::floor(fr);
+      c[k] = std::min(nc[k] - 1, (int)(fr * nc[k]));
+    }
+  };
+  // 1. conflict graph: polarizable atoms closer than color_dist (cell grid of edge >= color_dist)
+  std::vector<std::vector<int>> cells((size_t)ncell);
+  for (int i = 0; i < n; i++) {
+    if (h->halpha[i] == 0.0) continue;  // never updated: needs no phase
+    int c[3];
+    cellof(i, c);
+    cells[((size_t)c[2] * nc[1] + c[1]) * nc[0] + c[0]].push_back(i);
+  }
+  std::vector<std::vector<int>> adj((size_t)n);
+  for (int i = 0; i < n; i++) {
+    if (h->halpha[i] == 0.0) continue;
+    int c[3];
+    cellof(i, c);
+    int seen[27], nseen = 0;
+    for (int dz = -1; dz <= 1; dz++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          int b[3] = {c[0] + dx, c[1] + dy, c[2] + dz};
+          bool ok = true;
+          for (int k = 0; k < 3; k++) {
+            if (h->box.periodic[k]) b[k] = (b[k] + nc[k]) % nc[k];
+            else if (b[k] < 0 || b[k] >= nc[k]) ok = false;
+          }
+          if (!ok) continue;
+          const int cj = (int)(((size_t)b[2] * nc[1] + b[1]) * nc[0] + b[0]);
+          bool dup = false;
+          for (int t = 0; t < nseen; t++) dup |= seen[t] == cj;
+          if (dup) continue;  // tiny grids: a cell reached through two offsets
+          seen[nseen++] = cj;
+          for (int j : cells[cj]) {
+            if (j == i) continue;
+            const double rsq = min_image_dist2(h->box, &h->hx[3 * (size_t)i], &h->hx[3 * (size_t)j]);
+            if (rsq < dcsq) adj[i].push_back(j);
+          }
+        }
+  }
+  if (h->sweep_kernel == 3) { build_cluster_colors(h, rank, cells, adj); return; }
+  // 2. DSATUR (Brelaz): always colour the vertex that sees the most distinct colours; ties by degree,
+  //    then by index (deterministic: every rank of a multi-GPU run derives the same colouring).
+  //    One colour fewer, and better balanced, than first-fit on the MOF test systems -> one launch
+  //    fewer per sweep.  Lazy max-heap: stale entries are skipped when popped.
+  std::vector<int> color((size_t)n, -1), satur((size_t)n, 0);
+  std::vector<unsigned long long> seenmask((size_t)n, 0ull);  // colours 0..63 seen by the neighbours
+  struct Key { int sat, deg, idx; };
+  auto lessk = [](const Key &a, const Key &b) {
+    if (a.sat != b.sat) return a.sat < b.sat;
+    if (a.deg != b.deg) return a.deg < b.deg;
+    return a.idx > b.idx;
+  };
+  std::vector<Key> heap;
+  heap.reserve((size_t)n * 2);
+  for (int i = 0; i < n; i++)
+    if (h->halpha[i] != 0.0) heap.push_back(Key{0, (int)adj[i].size(), i});
+  std::make_heap(heap.begin(), heap.end(), lessk);
+  int ncolors = 0;
+  while (!heap.empty()) {
+    std::pop_heap(heap.begin(), heap.end(), lessk);
+    const Key kx = heap.back();
+    heap.pop_back();
+    const int i = kx.idx;
+    if (color[i] >= 0 || kx.sat != satur[i]) continue;  // already coloured, or a stale entry
+    int col = 0;
+    while (col < 64 && ((seenmask[i] >> col) & 1ull)) col++;
+    if (col >= 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
+    color[i] = col;
+    ncolors = std::max(ncolors, col + 1);
+    for (int j : adj[i]) {
+      if (color[j] >= 0) continue;
+      if (!((seenmask[j] >> col) & 1ull)) {
+        seenmask[j] |= 1ull << col;
+        satur[j]++;
+        heap.push_back(Key{satur[j], (int)adj[j].size(), j});
+        std::push_heap(heap.begin(), heap.end(), lessk);
+      }
+    }
+  }
+  // 3. phase order: "ranked" flavour = colours by descending mean rank metric (PS.cpp:192-227 ranks the
+  //    dipoles most likely to change first); otherwise by descending size.  Relabel accordingly.
+  {
+    std::vector<double> key((size_t)ncolors, 0.0);
+    std::vector<int> cnt((size_t)ncolors, 0), ord((size_t)ncolors), relabel((size_t)ncolors);
+    for (int i = 0; i < n; i++)
+      if (color[i] >= 0) { cnt[color[i]]++; key[color[i]] += rank.empty() ? 1.0 : rank[i]; }
+    if (!rank.empty())
+      for (int c = 0; c < ncolors; c++) key[c] /= std::max(cnt[c], 1);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] > key[b]; });
+    for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
+    for (int i = 0; i < n; i++)
+      if (color[i] >= 0) color[i] = relabel[color[i]];
+  }
+  std::vector<int> rows;
+  rows.reserve(n);
+  h->color_off.assign((size_t)ncolors + 1, 0);
+  // the colouring is global (every rank computes the same one); a sharded handle keeps only its rows
+  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
+  auto mine = [&](int i) { return color[i] >= 0 && i >= lo && i < hi; };
+  for (int i = 0; i < n; i++)
+    if (mine(i)) h->color_off[color[i] + 1]++;
+  for (int c = 0; c < ncolors; c++) h->color_off[c + 1] += h->color_off[c];
+  rows.resize((size_t)h->color_off[ncolors]);
+  std::vector<int> fill(h->color_off.begin(), h->color_off.end() - 1);
+  // inside a colour, keep the rows in cell order of the colouring grid: neighbouring waves of a
+  // phase then work on neighbouring atoms (shared records in L1/L2)
+  for (auto &cell : cells)
+    for (int i : cell)
+      if (mine(i)) rows[fill[color[i]]++] = i;
+  h->h_rows = rows;
+  h->color_epoch++;  // the launch order changed: dd rows laid out for an earlier colouring are stale (slots_current)
+  h->h_color.assign(color.begin(), color.end());
+  h->d_color_orig.ensure((size_t)n + 1);
+  if (n > 0) HIPCHECK(hipMemcpy(h->d_color_orig.p, h->h_color.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  h->colors_rebuilt++;
+  h->d_rows_orig.ensure(rows.size() + 1);
+  h->d_rows.ensure(rows.size() + 1);
+  if (!rows.empty()) HIPCHECK(hipMemcpy(h->d_rows_orig.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (getenv("POLAR_DEBUG")) {
+    fprintf(stderr, "[polar] %d colour phases (dist %.2f):", ncolors, h->color_dist);
+    for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
+    fprintf(stderr, "\n");
+  }
+  h->colors_valid = true;
+}
+
+#else
+inline void build_colors(polar_handle *, const std::vector<double> &) { throw std::logic_error("host-side colouring: lab build only"); }
+#endif  // POLAR_LAB
+
+// ---- the colour phases on the device (polar_lists.hpp, k_color_*): sequential DSATUR cell by cell (parity classes of the
+//      cell grid), the small top class repaired by local exhaustive search, Jones-Plassmann rounds as the fallback; phase
+//      order and the rows of every phase in cell order.
+//      Needs this step's cell order (phase_begin has run) and, for the ranked flavour, the rank metric in d_rank (s space).
+void build_colors_device(polar_handle *h, bool ranked) {
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  const bool dbg = getenv("POLAR_DEBUG") != nullptr;
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {   // POLAR_DEBUG: wall time since the last lap, the device drained first
+    if (!dbg) return;
+    HIPCHECK(hipStreamSynchronize(s));
+    const auto tn = std::chrono::steady_clock::now();
+    fprintf(stderr, "[polar] colouring: %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(tn - tprev).count());
+    tprev = tn;
+  };
+  lap("(work queued before)");
+  const long long ncell = h->ncell;
+  if (!h->h_cflags) {
+    HIPCHECK(hipHostMalloc((void **)&h->h_cflags, 96 * sizeof(int)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_cstat, 128 * sizeof(double)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_coff, 72 * sizeof(long long)));
+  }
+  h->d_cdeg.ensure(n + 1); h->d_cprio.ensure(n + 1);
+  h->d_color_s.ensure(n + 1); h->d_color_orig.ensure(n + 1); h->d_cflags.ensure(96); h->d_cstat.ensure(128); h->d_crelabel.ensure(64);
+  int *flags = h->d_cflags.p;  // [0] conflict-list overflow, [1] atoms deferred in the last round, [2] a row that saw 64 colours, [65..] atoms that could not leave a folded class
+  HIPCHECK(hipMemsetAsync(h->d_color_orig.p, 0xFF, (size_t)(n + 1) * sizeof(int), s));
+  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
+  const double dc2 = h->color_dist * h->color_dist;
+  for (int attempt = 0;; attempt++) {  // conflict lists; an atom with more neighbours than the lists hold makes them wider
+    h->d_cadj.ensure((size_t)n * h->cadj_pitch + 16);
+    HIPCHECK(hipMemsetAsync(flags, 0, 96 * sizeof(int), s));
+    k_color_adj<<<nblk(n, 128), 128, 0, s>>>(n, h->d_pos4.p, h->d_perm.p, lo, hi, h->box, h->grid, h->d_cell_first.p, h->d_cell_fill.p, dc2,
+                                             h->cadj_pitch, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags);
+    HIPCHECK(hipMemcpyAsync(h->h_cflags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (h->h_cflags[0] <= h->cadj_pitch) break;
+    if (h->h_cflags[0] > 62 || attempt > 3) throw std::runtime_error("colouring: more than 62 polarizable atoms within the colour distance of one atom (64 colours at most): reduce POLAR_COLOR_DIST");
+    h->cadj_pitch = (h->h_cflags[0] + 4 + 7) / 8 * 8;
+  }
+  const int ap_ = h->cadj_pitch;
+  lap("conflict lists");
+  // sequential DSATUR cell by cell (k_color_cells): one launch per parity class of the cell grid -- per dimension the even
+  // cells, the odd cells and, when a periodic dimension has an odd count, its last cell on its own.  Safe while two cells of
+  // a class (a whole cell apart) cannot hold neighbours: colour distance below the shortest cell edge.
+  const double min_edge = std::min({h->box.prd[0] / h->grid.nc[0], h->box.prd[1] / h->grid.nc[1], h->box.prd[2] / h->grid.nc[2]});
+  // (tilted box: a cell's perpendicular width is below its edge along the lattice vector -- by at most 1/sqrt(1.5) at LAMMPS'
+  //  tilt limit of half a box length)
+  bool cell_pass = h->color_dist < (h->box.triclinic ? 0.5 : 1.0) * min_edge;
+#ifdef POLAR_LAB
+  if (getenv("POLAR_COLOR_JP")) cell_pass = false;  // lab: Jones-Plassmann alone (the round-3 first version: 5 classes)
+#endif
+  if (cell_pass) {
+    struct Cls { int start, stride, count; };
+    std::vector<Cls> cls[3];
+    for (int k = 0; k < 3; k++) {
+      const int nc = h->grid.nc[k];
+      const bool seam = h->box.periodic[k] && (nc & 1) && nc > 1;
+      const int lim = seam ? nc - 1 : nc;
+      if ((lim + 1) / 2 > 0) cls[k].push_back(Cls{0, 2, (lim + 1) / 2});
+      if (lim / 2 > 0) cls[k].push_back(Cls{1, 2, lim / 2});
+      if (seam) cls[k].push_back(Cls{nc - 1, 1, 1});
+    }
+    for (const Cls &cz : cls[2]) for (const Cls &cy : cls[1]) for (const Cls &cx : cls[0])
+      k_color_cells<<<cx.count * cy.count * cz.count, 64, 0, s>>>(cx.start, cy.start, cz.start, cx.stride, cy.stride, cz.stride, cx.count, cy.count,
+                                                                  cz.count, h->grid.nc[0], h->grid.nc[1], h->d_cell_first.p, h->d_cell_fill.p, ap_,
+                                                                  h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p, flags + 2);
+  }
+  // Jones-Plassmann rounds for whatever is still uncoloured (nothing after the cell pass; everything without it): an uncoloured
+  // row whose priority beats every uncoloured neighbour's takes the lowest free colour.  First look after one round.
+  bool coloured = false;
+  int rounds = 0;
+  const int max_rounds = 4096, look_every = 32;
+  while (!coloured && rounds < max_rounds) {   // rounds (priorities, then decisions), then a look at how many atoms the last one deferred
+    const int hashed = rounds >= 1024 ? 1 : 0;  // index-ordered ties while the chains stay short (see k_color_prio)
+    const int batch = rounds == 0 ? 1 : look_every;
+    for (int k = 0; k < batch; k++) {
+      k_color_prio<<<nblk(n, 256), 256, 0, s>>>(n, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p, h->d_perm.p, h->d_cprio.p, hashed);
+      if (k == batch - 1) HIPCHECK(hipMemsetAsync(flags + 1, 0, sizeof(int), s));
+      k_color_round<<<nblk(n, 256), 256, 0, s>>>(n, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags + 1);
+    }
+    rounds += batch;
+    HIPCHECK(hipMemcpyAsync(h->h_cflags, flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (h->h_cflags[2] >= 1000) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
+    coloured = h->h_cflags[1] == 0;
+  }
+  if (!coloured) throw std::runtime_error("colouring: Jones-Plassmann did not finish");
+  lap("cell pass + rounds");
+  if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] device colouring: %d rounds\n", rounds);
+  auto stats = [&]() {  // rows and rank sums per colour -> number of colours in use
+    HIPCHECK(hipMemsetAsync(h->d_cstat.p, 0, 128 * sizeof(double), s));
+    k_color_stats<<<nblk(n, 256), 256, 0, s>>>(n, h->d_color_s.p, ranked ? h->d_rank.p : nullptr, h->d_cstat.p);
+    HIPCHECK(hipMemcpyAsync(h->h_cstat, h->d_cstat.p, 128 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    int nc = 0;
+    for (int c = 0; c < 64; c++) if (h->h_cstat[2 * c] > 0.0) nc = c + 1;
+    return nc;
+  };
+  int ncolors = stats();
+  auto fold = [&]() {  // dissolve the highest class while that works
+    for (int pass = 0; pass < 6 && ncolors > 1; pass++) {
+      k_color_fold<<<nblk(n, 256), 256, 0, s>>>(n, ap_, ncolors - 1, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p, flags + 65 + pass);
+      const int before = ncolors;
+      ncolors = stats();
+      if (ncolors == before) break;
+    }
+  };
+  fold();
+  lap("fold");
+  // local repair of a small top class (k_color_ball): the cell-by-cell pass leaves about one row per unit cell in a fifth
+  // class on the MOF boxes; first balls of one conflict step, then of two, then of three
+  const int kcap = 8192;
+  // (only a SMALL top class of at most six is worth it -- at most 2 % of the rows: where atoms overlap, e.g. sorbates flying through the
+  //  framework in bench.py's ballistic leg, the extra classes are needed and no local search removes them)
+  const double krows = std::min((double)kcap, 0.02 * (double)own_n(h));
+  for (int hops = 1; hops <= 3 && ncolors > 2 && ncolors <= 6 && h->h_cstat[2 * (ncolors - 1)] <= (hops < 3 ? krows : 128.0); hops++) {   // (the last, long search only for a handful of rows)
+    h->d_klist.ensure(4 * (size_t)kcap + 8);
+    int *raw = h->d_klist.p, *list = raw + kcap, *st0 = raw + 2 * kcap, *st1 = raw + 3 * kcap, *cnt = raw + 4 * kcap;
+    HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int), s));
+    k_color_collect<<<nblk(n, 256), 256, 0, s>>>(n, ncolors - 1, h->d_color_s.p, kcap, raw, cnt);
+    k_sort_small<<<8, 256, 0, s>>>(cnt, kcap, raw, list, st0, st1);
+    const int waves = (int)h->h_cstat[2 * (ncolors - 1)];
+    const double reach = (2 * hops + 1) * h->color_dist;
+    const int budget = hops == 1 ? 768 : hops == 2 ? 2048 : 8192;   // search steps per ball: the later stages see few rows
+    for (int round = 0; round < 2 + 2 * hops; round++)
+      k_color_ball<<<waves, 64, 0, s>>>(cnt, kcap, list, (round & 1) ? st1 : st0, (round & 1) ? st0 : st1, h->d_pos4.p, h->box, reach * reach,
+                                        ncolors - 1, hops, budget, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_color_s.p);
+    const int before = ncolors;
+    ncolors = stats();
+    if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] colour repair (%d-step balls): %d rows in the top class, %d classes -> %d\n", hops, waves, before, ncolors);
+    if (ncolors < before) break;
+  }
+  lap("repair");
+  // iterated greedy (Culberson) for what is still above four classes -- overlapping atoms, or the Jones-Plassmann fallback,
+  // whose parallel rounds decide on stale saturation counts: regrouping by old classes in another order never adds a class
+  // and sometimes removes one
+  for (int ig = 0, stale = 0; ig < 2 && stale < 2 && ncolors > 4; ig++) {
+    std::vector<int> ord((size_t)ncolors), rank(64, 0);
+    std::iota(ord.begin(), ord.end(), 0);
+    if (ig % 2 == 0) std::reverse(ord.begin(), ord.end());                                    // highest class first
+    else std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {                         // smallest / largest class first
+      return (ig % 4 == 1) ? h->h_cstat[2 * a] < h->h_cstat[2 * b] : h->h_cstat[2 * a] > h->h_cstat[2 * b]; });
+    for (int c = 0; c < ncolors; c++) rank[ord[c]] = c;
+    HIPCHECK(hipMemcpyAsync(h->d_crelabel.p, rank.data(), 64 * sizeof(int), hipMemcpyHostToDevice, s));
+    k_color_regroup<<<nblk(n, 256), 256, 0, s>>>(n, h->d_cdeg.p, h->d_crelabel.p, h->d_perm.p, h->d_color_s.p, h->d_cprio.p);
+    for (int k = 0; k < ncolors + 1; k++)
+      k_color_round<<<nblk(n, 256), 256, 0, s>>>(n, ap_, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags + 80);
+    const int before = ncolors;
+    ncolors = stats();   // (synchronises: `rank` may go)
+    fold();
+    stale = ncolors < before ? 0 : stale + 1;
+  }
+  lap("iterated greedy");
+  if (ncolors > 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
+  // phase order: "ranked" flavour = colours by descending mean rank metric (PS.cpp:192-227 ranks the dipoles most likely to
+  // change first); otherwise by descending size
+  std::vector<int> ord((size_t)ncolors), relabel(64, 0);
+  std::iota(ord.begin(), ord.end(), 0);
+  auto key = [&](int c) { return ranked ? h->h_cstat[2 * c + 1] / std::max(h->h_cstat[2 * c], 1.0) : h->h_cstat[2 * c]; };
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key(a) > key(b); });
+  for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
+  HIPCHECK(hipMemcpyAsync(h->d_crelabel.p, relabel.data(), 64 * sizeof(int), hipMemcpyHostToDevice, s));
+  k_color_relabel<<<nblk(n, 256), 256, 0, s>>>(n, h->d_crelabel.p, h->d_perm.p, h->d_color_s.p, h->d_color_orig.p);
+  // rows of every phase in cell order
+  const size_t ncc = (size_t)ncolors * ncell;
+  h->d_ccnt.ensure(ncc + 1); h->d_coff.ensure(ncc + 2);
+  k_color_cellcount<<<nblk(ncell, 128), 128, 0, s>>>(ncell, ncolors, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_ccnt.p);
+  k_exclusive_scan<int><<<1, 1024, 0, s>>>((long long)ncc, h->d_ccnt.p, h->d_coff.p);
+  for (int c = 0; c <= ncolors; c++)
+    HIPCHECK(hipMemcpyAsync(h->h_coff + c, h->d_coff.p + (size_t)c * ncell, sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));  // (also: `relabel` is a stack vector)
+  h->color_off.assign((size_t)ncolors + 1, 0);
+  for (int c = 0; c <= ncolors; c++) h->color_off[c] = (int)h->h_coff[c];
+  const int tot = h->color_off[ncolors];
+  h->d_rows_orig.ensure((size_t)tot + 1); h->d_rows.ensure((size_t)tot + 1);
+  k_color_fill<<<nblk(ncell, 128), 128, 0, s>>>(ncell, ncolors, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_perm.p, h->d_coff.p,
+                                               h->d_rows_orig.p);
+  lap("phase order + rows");
+#ifdef POLAR_LAB
+  if (getenv("POLAR_LP_SORT_T") && tot > 0) {   // lab: inside a phase the rows with the most trips first (stable: cell order inside a trip count)
+    std::vector<int> rows((size_t)tot), cnt((size_t)n), inv((size_t)n);
+    HIPCHECK(hipMemcpyAsync(rows.data(), h->d_rows_orig.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(cnt.data(), h->d_dd_cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(inv.data(), h->d_inv.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    for (int c = 0; c < ncolors; c++)
+      std::stable_sort(rows.begin() + h->color_off[c], rows.begin() + h->color_off[c + 1],
+                       [&](int a, int b) { return (cnt[inv[a]] + 63) / 64 > (cnt[inv[b]] + 63) / 64; });
+    HIPCHECK(hipMemcpyAsync(h->d_rows_orig.p, rows.data(), (size_t)tot * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipStreamSynchronize(s));
+  }
+#endif
+  h->h_color.assign((size_t)n, 0);  // (its size says "a colouring for n atoms exists": the colours themselves live on the device)
+  h->color_epoch++;
+  h->colors_rebuilt++;
+  if (getenv("POLAR_DEBUG")) {
+    fprintf(stderr, "[polar] %d colour phases (device, dist %.2f):", ncolors, h->color_dist);
+    for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
+    fprintf(stderr, "\n");
+  }
+  h->colors_valid = true;
+}
+// ---- the solve: a6+a7 (PS.cpp:1113-1238) -----------------------------------------------------
+void ensure_colors(polar_handle *h) {
+  if (h->colors_valid) return;
+  const polar_settings &st = h->ph.st;
+  const int n = h->nlocal;
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool on_device = h->sorted && st.dd_cutoff > 0.0 && h->sweep_kernel == 2 && !h->host_colors && h->pol_first;
+  if (on_device) {
+    build_colors_device(h, st.polar_gs_ranked != 0);
+  } else {  // lab paths (cluster rows, POLAR_HOST_COLORS): the host-side conflict graph + DSATUR of rounds 1-2
+    std::vector<double> rk;
+    if (st.polar_gs_ranked && !sharded(h)) {  // a sharded handle only knows its own rows' metric
+      std::vector<double> rs(n);
+      std::vector<int> perm(n);
+      rk.assign(n, 0.0);
+      HIPCHECK(hipMemcpyAsync(rs.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipMemcpyAsync(perm.data(), h->d_perm.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      for (int k = 0; k < n; k++) rk[perm[k]] = rs[k];  // rank metric was computed in s space
+    }
+    build_colors(h, rk);
+  }
+  // (wall time of the rebuild, host work and the waits for the device included)
+  h->ms_color_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+// per step: the colour rows (orig ids) -> s space of this step's cell order
+void map_color_rows(polar_handle *h) {
+  const int tot = h->color_off.empty() ? 0 : h->color_off.back();
+  if (tot > 0) k_map_rows<<<nblk(tot, 256), 256, 0, h->stream>>>(tot, h->d_inv.p, h->d_rows_orig.p, h->d_rows.p);
+}
+
+// reneighbor steps: k_nl_build has checked the colouring in use against the new positions; rebuild only on a clash
+void resolve_colors(polar_handle *h) {
+  if (!h->colors_recheck) return;
+  h->colors_recheck = false;
+  if (!h->colors_valid) return;
+  int clash = 0;
+  HIPCHECK(hipMemcpyAsync(&clash, h->d_overflow.p + 8, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  if (!clash) { h->colors_reused++; return; }
+  h->colors_valid = false;
+  if (h->ph.st.polar_gs_ranked) { launch_rank_pass(h, false, 1); launch_rank_pass(h, false, 2); }  // a2 for the phase order
+}

@@ -29,7 +29,7 @@ __device__ __forceinline__ int cell_of(const CellGrid &g, const Box &b, double x
   return (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
 }
 
-__global__ void k_cell_count(int n, const double *__restrict__ x, CellGrid g, Box b, int *__restrict__ cell_id,
+static __global__ void k_cell_count(int n, const double *__restrict__ x, CellGrid g, Box b, int *__restrict__ cell_id,
                              int *__restrict__ cell_cnt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -40,7 +40,7 @@ __global__ void k_cell_count(int n, const double *__restrict__ x, CellGrid g, Bo
 
 // single-workgroup exclusive scan (n up to a few million; run once per list build)
 template <typename T>
-__global__ __launch_bounds__(1024) void k_exclusive_scan(long long n, const T *__restrict__ in,
+static __global__ __launch_bounds__(1024) void k_exclusive_scan(long long n, const T *__restrict__ in,
                                                          long long *__restrict__ out) {
   __shared__ long long part[1024];
   const int t = threadIdx.x;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(long long n, const T *_
 // Inside a cell the polarizable atoms come first (filled from the front), the others last (from the back): the dipole lists
 // then hold long runs of CONSECUTIVE records -- gathers of neighbouring records merge into whole 128-byte lines and run
 // 20 % faster than scattered ones (tools/calib_gather48.hip: 246 against 203 G records/s from an L2-resident table).
-__global__ void k_cell_fill(int n, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
+static __global__ void k_cell_fill(int n, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
                             int *__restrict__ fill, int *__restrict__ fill_back, const double *__restrict__ alpha,
                             int *__restrict__ perm, int *__restrict__ inv) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,7 +98,7 @@ __global__ void k_cell_fill(int n, const int *__restrict__ cell_id, const long l
 // two groups (polarizable atoms, the others) into ascending atom index, so that every list -- and with it every
 // floating-point sum and the device colouring's tie-breaks -- has the same order run after run.  A lane holds one atom and
 // counts the smaller indices of its group (rank sort, ~20 entries); groups of more than 64 fall to a serial insertion sort.
-__global__ __launch_bounds__(256) void k_cell_sort(long long ncell, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+static __global__ __launch_bounds__(256) void k_cell_sort(long long ncell, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                                                    int *__restrict__ perm, int *__restrict__ inv) {
   const int lane = threadIdx.x & 63;
   const long long c = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -125,25 +125,25 @@ __global__ __launch_bounds__(256) void k_cell_sort(long long ncell, const long l
     }
   }
 }
-__global__ void k_map_rows(int n, const int *__restrict__ inv, const int *__restrict__ in, int *__restrict__ out) {
+static __global__ void k_map_rows(int n, const int *__restrict__ inv, const int *__restrict__ in, int *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = inv[in[i]];
 }
-__global__ void k_map_rows_pad(int n, const int *__restrict__ inv, const int *__restrict__ in, int *__restrict__ out) {
+static __global__ void k_map_rows_pad(int n, const int *__restrict__ inv, const int *__restrict__ in, int *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] >= 0 ? inv[in[i]] : -1;  // -1: padding of a cluster's member table
 }
 // dd_slot[rows[r]] = r: where k_nl_build stores the dd row of an atom (launch order of the lp sweep)
-__global__ void k_slot_from_rows(int n, const int *__restrict__ rows, int *__restrict__ slot) {
+static __global__ void k_slot_from_rows(int n, const int *__restrict__ rows, int *__restrict__ slot) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) slot[rows ? rows[r] : r] = r;
 }
 // colours of the atoms in this step's s order (colour re-validation): -1 = no colour
-__global__ void k_color_map(int n, const int *__restrict__ perm, const int *__restrict__ color_orig, int *__restrict__ color_s) {
+static __global__ void k_color_map(int n, const int *__restrict__ perm, const int *__restrict__ color_orig, int *__restrict__ color_s) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) color_s[i] = color_orig[perm[i]];
 }
-__global__ void k_map_range(int lo, int n, const int *__restrict__ inv, int *__restrict__ out) {
+static __global__ void k_map_range(int lo, int n, const int *__restrict__ inv, int *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = inv[lo + i];
 }
@@ -164,7 +164,7 @@ __device__ __forceinline__ unsigned color_hash(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-__global__ void k_color_adj(int n, const double4 *__restrict__ pos4, const int *__restrict__ perm, int own_lo, int own_hi,
+static __global__ void k_color_adj(int n, const double4 *__restrict__ pos4, const int *__restrict__ perm, int own_lo, int own_hi,
                             Box box, CellGrid g, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                             double colordistsq, int apitch, int *__restrict__ adj, int *__restrict__ deg,
                             unsigned long long *__restrict__ prio, int *__restrict__ color_s, int *__restrict__ flags) {
@@ -228,7 +228,7 @@ __global__ void k_color_adj(int n, const double4 *__restrict__ pos4, const int *
 // distance), so no two waves of a launch ever colour neighbours: 8 launches walk the whole box.  The parallel rounds of
 // Jones-Plassmann decide many neighbours-of-neighbours on stale saturation counts and end with 5 classes on the MOF boxes;
 // this order finds the 4 the host-side DSATUR of rounds 1-2 found.  cells: c_k = start_k + stride_k * i_k, i_k < count_k.
-__global__ __launch_bounds__(64) void k_color_cells(int s0, int s1, int s2, int t0, int t1, int t2, int m0, int m1, int m2, int n0, int n1,
+static __global__ __launch_bounds__(64) void k_color_cells(int s0, int s1, int s2, int t0, int t1, int t2, int m0, int m1, int m2, int n0, int n1,
                                                     const long long *__restrict__ cell_first, const int *__restrict__ npol, int apitch,
                                                     const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s,
                                                     int *__restrict__ flags) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) void k_color_cells(int s0, int s1, int s2, int 
 // priorities of the uncoloured atoms for the next round: (colours already seen among the neighbours, degree, hash, index) --
 // the saturation-first order of DSATUR, evaluated on a snapshot (its own launch) so that two neighbours never both think
 // they go first
-__global__ void k_color_prio(int n, int apitch, const int *__restrict__ adj, const int *__restrict__ deg, const int *__restrict__ color_s,
+static __global__ void k_color_prio(int n, int apitch, const int *__restrict__ adj, const int *__restrict__ deg, const int *__restrict__ color_s,
                              const int *__restrict__ perm, unsigned long long *__restrict__ prio, int hashed) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -299,7 +299,7 @@ __global__ void k_color_prio(int n, int apitch, const int *__restrict__ adj, con
   const unsigned long long tie = hashed ? ((unsigned long long)(color_hash(o) >> 16) << 32) | o : (unsigned long long)o;
   prio[i] = ((unsigned long long)__popcll(used) << 56) | ((unsigned long long)(d < 255 ? d : 255) << 48) | tie;
 }
-__global__ void k_color_round(int n, int apitch, const int *__restrict__ adj, const int *__restrict__ deg,
+static __global__ void k_color_round(int n, int apitch, const int *__restrict__ adj, const int *__restrict__ deg,
                               const unsigned long long *__restrict__ prio, int *__restrict__ color_s, int *__restrict__ left) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -315,7 +315,7 @@ __global__ void k_color_round(int n, int apitch, const int *__restrict__ adj, co
   }
   color_s[i] = __ffsll((long long)~used) - 1;
 }
-__global__ void k_color_fold(int n, int apitch, int top, const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s,
+static __global__ void k_color_fold(int n, int apitch, int top, const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s,
                              int *__restrict__ stay) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || deg[i] < 0 || color_s[i] != top) return;
@@ -332,13 +332,13 @@ __global__ void k_color_fold(int n, int apitch, int top, const int *__restrict__
 // gives one wave to each; a wave waits while an earlier, still untried row of the list lies within `reach` (the balls write up
 // to `hops` steps from their centres and read one step further), so the result does not depend on the order the waves run in.
 // `state` 0 = untried, 1 = tried; `prev` = the states before this launch.
-__global__ void k_color_collect(int n, int top, const int *__restrict__ color_s, int cap, int *__restrict__ list, int *__restrict__ count) {
+static __global__ void k_color_collect(int n, int top, const int *__restrict__ color_s, int cap, int *__restrict__ list, int *__restrict__ count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || color_s[i] != top) return;
   const int k = atomicAdd(count, 1);
   if (k < cap) list[k] = i;
 }
-__global__ __launch_bounds__(256) void k_sort_small(const int *__restrict__ count, int cap, const int *__restrict__ in, int *__restrict__ out,
+static __global__ __launch_bounds__(256) void k_sort_small(const int *__restrict__ count, int cap, const int *__restrict__ in, int *__restrict__ out,
                                                     int *__restrict__ state_a, int *__restrict__ state_b) {
   const int m = *count;
   if (m > cap) return;   // (the host skips the repair as well)
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_sort_small(const int *__restrict__ coun
     state_a[k] = 0; state_b[k] = 0;
   }
 }
-__global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count, int cap, const int *__restrict__ list, const int *__restrict__ prev,
+static __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count, int cap, const int *__restrict__ list, const int *__restrict__ prev,
                                                    int *__restrict__ state, const double4 *__restrict__ pos4, Box box, double reachsq, int top, int hops,
                                                    int budget, int apitch, const int *__restrict__ adj, const int *__restrict__ deg, int *__restrict__ color_s) {
   __shared__ int ball[64];
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict__ count
 // iterated greedy (Culberson): recolour greedily in an order that keeps every old class together -- never more colours than
 // before, often fewer.  This kernel sets the stage: priorities = (rank of the atom's old class in the new order, hash, index),
 // colours cleared; k_color_round then needs one round per old class (a class is an independent set: it decides at once).
-__global__ void k_color_regroup(int n, const int *__restrict__ deg, const int *__restrict__ class_rank, const int *__restrict__ perm,
+static __global__ void k_color_regroup(int n, const int *__restrict__ deg, const int *__restrict__ class_rank, const int *__restrict__ perm,
                                 int *__restrict__ color_s, unsigned long long *__restrict__ prio) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || deg[i] < 0) return;
@@ -441,7 +441,7 @@ __global__ void k_color_regroup(int n, const int *__restrict__ deg, const int *_
   color_s[i] = -1;
 }
 // per colour: rows and the sum of their rank metric (phase order of the ranked flavour)
-__global__ __launch_bounds__(256) void k_color_stats(int n, const int *__restrict__ color_s, const double *__restrict__ rank,
+static __global__ __launch_bounds__(256) void k_color_stats(int n, const int *__restrict__ color_s, const double *__restrict__ rank,
                                                      double *__restrict__ sums) {
   // (summed per workgroup in LDS first: a hundred thousand FP64 atomics on five addresses took 2 ms)
   __shared__ double part[128];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void k_color_stats(int n, const int *__restric
   __syncthreads();
   if (threadIdx.x < 128 && part[threadIdx.x] != 0.0) atomicAdd(sums + threadIdx.x, part[threadIdx.x]);
 }
-__global__ void k_color_relabel(int n, const int *__restrict__ relabel, const int *__restrict__ perm, int *__restrict__ color_s,
+static __global__ void k_color_relabel(int n, const int *__restrict__ relabel, const int *__restrict__ perm, int *__restrict__ color_s,
                                 int *__restrict__ color_orig) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -465,7 +465,7 @@ __global__ void k_color_relabel(int n, const int *__restrict__ relabel, const in
   color_orig[perm[i]] = c;
 }
 // rows of every phase, cells in order, atoms of a cell in order: counts per (colour, cell), one scan, fill
-__global__ void k_color_cellcount(long long ncell, int ncolors, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+static __global__ void k_color_cellcount(long long ncell, int ncolors, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                                   const int *__restrict__ color_s, int *__restrict__ cnt) {
   const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (c >= ncell) return;
@@ -476,7 +476,7 @@ __global__ void k_color_cellcount(long long ncell, int ncolors, const long long 
     cnt[(size_t)q * ncell + c] = k;
   }
 }
-__global__ void k_color_fill(long long ncell, int ncolors, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+static __global__ void k_color_fill(long long ncell, int ncolors, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                              const int *__restrict__ color_s, const int *__restrict__ perm, const long long *__restrict__ off,
                              int *__restrict__ rows_orig) {
   const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -494,7 +494,7 @@ __global__ void k_color_fill(long long ncell, int ncolors, const long long *__re
 //   dd : alpha_i != 0, alpha_j != 0 and rsq < ddcutsq      (the dipole sweep stream)
 // cnt[] receives the TRUE counts; writes stop at the pitch and *overflow is raised.
 template <bool TRI, bool RECHECK>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict__ rows, int nrows,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_nl_build(const int *__restrict__ rows, int nrows,
                                                           const double4 *__restrict__ pos4, Box box, CellGrid g,
                                                           const long long *__restrict__ cell_first, double cutallsq,
                                                           double ddcutsq, long long nl_pitch, long long dd_pitch,
@@ -661,7 +661,7 @@ __device__ __forceinline__ int phase_of(const PhaseOff &P, int r) {
   while (q + 1 < P.n && r >= P.off[q + 1]) q++;
   return q;
 }
-__global__ void k_unit_flag(int ntot, const int *__restrict__ rows, const int *__restrict__ perm, const int *__restrict__ cell_id,
+static __global__ void k_unit_flag(int ntot, const int *__restrict__ rows, const int *__restrict__ perm, const int *__restrict__ cell_id,
                             PhaseOff P, int *__restrict__ lead) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ntot) return;
@@ -672,7 +672,7 @@ __global__ void k_unit_flag(int ntot, const int *__restrict__ rows, const int *_
   for (int b = r - 1; b >= lo && cell_id[perm[rows ? rows[b] : b]] == c; b--) k++;
   lead[r] = (k & 1) ? 0 : 1;
 }
-__global__ void k_unit_fill(int ntot, const int *__restrict__ rows, const int *__restrict__ perm, const int *__restrict__ cell_id,
+static __global__ void k_unit_fill(int ntot, const int *__restrict__ rows, const int *__restrict__ perm, const int *__restrict__ cell_id,
                             PhaseOff P, const int *__restrict__ lead, const long long *__restrict__ upos, int2 *__restrict__ unit) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ntot || !lead[r]) return;
@@ -687,7 +687,7 @@ __global__ void k_unit_fill(int ntot, const int *__restrict__ rows, const int *_
   unit[upos[r]] = make_int2(iA, iB);
 }
 template <bool TRI>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_dd_units(int nunits, const int2 *__restrict__ unit, const double4 *__restrict__ pos4,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_units(int nunits, const int2 *__restrict__ unit, const double4 *__restrict__ pos4,
                                                           Box box, CellGrid g, const long long *__restrict__ cell_first, double ddcutsq,
                                                           long long upitch, int *__restrict__ udd_j, int4 *__restrict__ udesc, int qm,
                                                           int dummy, int *__restrict__ overflow, unsigned long long *__restrict__ dd_total) {
@@ -796,7 +796,7 @@ struct ClusterRows {
   const int4 *members;  // [ncl] s-space indices, -1 padded; member 0 always valid
   int ncl;
 };
-__global__ __launch_bounds__(POLAR_BLOCK) void k_cl_build(ClusterRows cl, const double4 *__restrict__ pos4, Box box,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_cl_build(ClusterRows cl, const double4 *__restrict__ pos4, Box box,
                                                           CellGrid g, const long long *__restrict__ cell_first,
                                                           double ddcutsq, long long pitch, int *__restrict__ cnt,
                                                           int *__restrict__ dd_j, int pad_index,
@@ -950,7 +950,7 @@ __device__ __forceinline__ int lj_cell_of(const LJGrid &g, double x, double y, d
   }
   return (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
 }
-__global__ void k_lj_cell_count(int nall, const double *__restrict__ x, LJGrid g, int *__restrict__ cell_id,
+static __global__ void k_lj_cell_count(int nall, const double *__restrict__ x, LJGrid g, int *__restrict__ cell_id,
                                 int *__restrict__ cell_cnt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nall) return;
@@ -959,7 +959,7 @@ __global__ void k_lj_cell_count(int nall, const double *__restrict__ x, LJGrid g
   atomicAdd(&cell_cnt[c], 1);
 }
 // s order = cell order: pos[s] = {x, y, z, (type, molecule)}, aux[s] = {atom index, tag}
-__global__ void k_lj_cell_fill(int nall, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
+static __global__ void k_lj_cell_fill(int nall, const int *__restrict__ cell_id, const long long *__restrict__ cell_first,
                                int *__restrict__ fill, const double *__restrict__ x, const int *__restrict__ type,
                                const int *__restrict__ mol, const int *__restrict__ tag, double4 *__restrict__ pos,
                                int2 *__restrict__ aux) {
@@ -979,7 +979,7 @@ __global__ void k_lj_cell_fill(int nall, const int *__restrict__ cell_id, const 
 //            (0: drop the pair, 1: keep plain, 2: keep with `which` in bits 30-31), except that a
 //            pair farther apart than half a periodic box length is an image and kept plain
 //            (Domain::minimum_image_check).
-__global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int row_lo, int nrows, int ntypes, const double *__restrict__ x,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int row_lo, int nrows, int ntypes, const double *__restrict__ x,
                                                              const int *__restrict__ type, const int *__restrict__ mol,
                                                              const double4 *__restrict__ pos, const int2 *__restrict__ aux,
                                                              LJGrid g, const long long *__restrict__ cell_first,
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_lj_nl_build(int row_lo, int nro
     atomicAdd(total + (blockIdx.x & 63) * 16, (unsigned long long)count);
   }
 }
-__global__ void k_lj_rows(int row_lo, int nrows, long long pitch, int *__restrict__ ilist, long long *__restrict__ first) {
+static __global__ void k_lj_rows(int row_lo, int nrows, long long pitch, int *__restrict__ ilist, long long *__restrict__ first) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   ilist[r] = row_lo + r;
@@ -1073,14 +1073,14 @@ struct MuView {
 __device__ __forceinline__ double *mu_of(const MuView &v, const Scal *scal, long long s) {
   return reinterpret_cast<double *>((scal->cur ? v.b : v.a) + s * v.stride);
 }
-__global__ void k_mu_gather(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal, MuView v,
+static __global__ void k_mu_gather(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal, MuView v,
                             double *__restrict__ dst) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
   const double *r = mu_of(v, scal, inv ? inv[i] : i);
   dst[3 * (i - lo)] = r[1]; dst[3 * (i - lo) + 1] = r[3]; dst[3 * (i - lo) + 2] = r[5];
 }
-__global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal, MuView v,
+static __global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__ inv, const Scal *scal, MuView v,
                              const double *__restrict__ src) {
   long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= hi) return;
@@ -1089,7 +1089,7 @@ __global__ void k_mu_scatter(long long lo, long long hi, const int *__restrict__
 }
 
 // halo exchange by index list (orig ids; negative entries are padding and skipped)
-__global__ void k_mu_gather_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
+static __global__ void k_mu_gather_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
                                 MuView v, double *__restrict__ dst) {
   long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -1098,7 +1098,7 @@ __global__ void k_mu_gather_idx(long long n, const int *__restrict__ idx, const 
   const double *r = mu_of(v, scal, inv ? inv[o] : o);
   dst[3 * t] = r[1]; dst[3 * t + 1] = r[3]; dst[3 * t + 2] = r[5];
 }
-__global__ void k_mu_scatter_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
+static __global__ void k_mu_scatter_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
                                  MuView v, const double *__restrict__ src, int own_lo, int own_hi) {
   long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -1115,19 +1115,19 @@ struct ZeroJobs {
   unsigned long long nwords[6];  // 4-byte words
   int n;
 };
-__global__ void k_zero_many(ZeroJobs jobs) {
+static __global__ void k_zero_many(ZeroJobs jobs) {
   const unsigned long long gid = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
   const unsigned long long stride = gridDim.x * (unsigned long long)blockDim.x;
   for (int j = 0; j < jobs.n; j++)
     for (unsigned long long w = gid; w < jobs.nwords[j]; w += stride) jobs.p[j][w] = 0u;
 }
-__global__ void k_zero_scal(Scal *s, int keep_solver) {
+static __global__ void k_zero_scal(Scal *s, int keep_solver) {
   s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;
   for (int k = 0; k < 6; k++) s->virial[k] = 0.0;
   s->change = 0.0; s->last_change = 0.0; s->pad = 0; s->det_change = 0.0;
   s->rmin_bits = (unsigned long long)__double_as_longlong(1000.0);
   if (!keep_solver) { s->iterations = 0; s->done = 0; s->status = 0; s->cur = 0; s->sweeps = 0; }
 }
-__global__ void k_set_done(Scal *s, int done) { s->done = done; }
+static __global__ void k_set_done(Scal *s, int done) { s->done = done; }
 
 }  // namespace polar

@@ -9,7 +9,7 @@ namespace polar {
 
 // ------------------------------------------------------------------------------------------
 // pack: x/q/alpha (+ initial mu) -> 64-byte records (both Jacobi buffers)
-__global__ void k_pack(int n, const int *__restrict__ perm, const double *__restrict__ x, const double *__restrict__ q,
+static __global__ void k_pack(int n, const int *__restrict__ perm, const double *__restrict__ x, const double *__restrict__ q,
                        const double *__restrict__ alpha, const int *__restrict__ mol, const double *__restrict__ mu0,
                        AtomRec *__restrict__ r0, AtomRec *__restrict__ r1, int *__restrict__ mol_s,
                        double4 *__restrict__ pos4, double4 *__restrict__ xq_s, int wrap, Box box, double lo0, double lo1,
@@ -51,7 +51,7 @@ __global__ void k_pack(int n, const int *__restrict__ perm, const double *__rest
 // ALLPAIRS: raw (non-minimum-image) distances to locals AND ghosts, exactly as the reference.
 // list mode (extension): minimum-image distances over the library's full list.
 template <bool ALLPAIRS, int PASS>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, const double *__restrict__ x,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int ntotal, const double *__restrict__ x,
                                                       const double *__restrict__ alpha, const int *__restrict__ mol,
                                                       Box box, RowList nl,
                                                       const int *__restrict__ nl_j,
@@ -134,7 +134,7 @@ struct LJCoulParams {
 };
 
 // per-atom pack for the half-list loop: 32-byte {x,y,z,q} + type, locals AND ghosts, orig order
-__global__ void k_pack_lj(int nall, const double *__restrict__ x, const double *__restrict__ q, double4 *__restrict__ xq) {
+static __global__ void k_pack_lj(int nall, const double *__restrict__ x, const double *__restrict__ q, double4 *__restrict__ xq) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nall) xq[i] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], q[i]);
 }
@@ -143,7 +143,7 @@ __global__ void k_pack_lj(int nall, const double *__restrict__ x, const double *
 // (i,j) of the half list appears in the row of i AND in the row of j (ghost atoms get rows too), so
 // the force loop needs no atomics on j -- the three scattered FP64 atomics per pair were 85 % of
 // the kernel.  Each row then accumulates the full force on its atom; pair tallies count 1/2 per row.
-__global__ __launch_bounds__(POLAR_BLOCK) void k_sym_count(int inum, const int *__restrict__ ilist,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_sym_count(int inum, const int *__restrict__ ilist,
                                                            const int *__restrict__ numneigh,
                                                            const long long *__restrict__ first,
                                                            const int *__restrict__ neigh, int *__restrict__ cnt) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_sym_count(int inum, const int *
   for (int jj = lane; jj < jn; jj += 64) atomicAdd(&cnt[jl[jj] & 0x3FFFFFFF], 1);
   if (lane == 0) atomicAdd(&cnt[i], jn);
 }
-__global__ __launch_bounds__(POLAR_BLOCK) void k_sym_fill(int inum, const int *__restrict__ ilist,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_sym_fill(int inum, const int *__restrict__ ilist,
                                                           const int *__restrict__ numneigh,
                                                           const long long *__restrict__ first,
                                                           const int *__restrict__ neigh,
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_sym_fill(int inum, const int *_
 // 64-byte line -- the loop is bound by L1 transactions and by the three FP64 atomics that deposit
 // -F on j (LAMMPS' newton-on contract: ghosts are folded back by reverse_comm).
 template <bool EFLAG, bool VPAIR>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum, const int *__restrict__ ilist,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum, const int *__restrict__ ilist,
                                                         const int *__restrict__ numneigh,
                                                         const long long *__restrict__ first,
                                                         const int *__restrict__ neigh,
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum
 // (PS.cpp:363-386).  Full-row evaluation: E_i = sum_j ef_temp * q_j * del_ij, which is the
 // reference's i<j scatter seen from row i (del is antisymmetric under the image rule).
 template <bool ALLPAIRS>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restrict__ rows, int nrows, int nlocal,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restrict__ rows, int nrows, int nlocal,
                                                               const AtomRec *__restrict__ rec,
                                                               const int *__restrict__ mol, Box box,
                                                               RowList nl,
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_static_field(const int *__restr
 // The pair force is antisymmetric, so summing rows reproduces the reference's i<j scatter;
 // pair energies are counted from both rows and halved.
 template <bool ALLPAIRS, int DAMP, bool EFLAG, bool VPAIR>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restrict__ rows, int nrows, const int *__restrict__ perm,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restrict__ rows, int nrows, const int *__restrict__ perm,
                                                              int nlocal, const Scal *scal_in,
                                                              const AtomRec *__restrict__ recA,
                                                              const AtomRec *__restrict__ recB,
@@ -533,13 +533,13 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_polar_force(const int *__restri
   }
 }
 
-__global__ void k_add_into(long long n, const double *__restrict__ src, double *__restrict__ dst) {
+static __global__ void k_add_into(long long n, const double *__restrict__ src, double *__restrict__ dst) {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i < n) dst[i] += src[i];
 }
 
 // a10  virial_fdotr_compute, src/pair.cpp:1495-1540: sum over locals AND ghosts of f_i x_i
-__global__ __launch_bounds__(POLAR_BLOCK) void k_virial_fdotr(int nall, const double *__restrict__ x,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_virial_fdotr(int nall, const double *__restrict__ x,
                                                               const double *__restrict__ f, double *__restrict__ slots) {
   double v[6] = {0, 0, 0, 0, 0, 0};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nall; i += gridDim.x * blockDim.x) {

@@ -19,7 +19,7 @@ namespace polar {
 enum { EP_JACOBI = 0, EP_INPLACE = 1, EP_FIELD = 2 };
 
 template <bool ALLPAIRS, int DAMP, int EP>
-__global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict__ rows, int nlocal,
+static __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict__ rows, int nlocal,
                                                        AtomRec *__restrict__ recA, AtomRec *__restrict__ recB, Box box,
                                                        RowList ddl,
                                                        const int *__restrict__ dd_j,
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void k_field(int nrows, const int *__restrict
 // SMODE 0: stream the cached (s3,s5) (20 B/pair); 1 / 2: stream the cached r^2 (12 B/pair) and
 // rebuild (s3,s5) with exponential / no damping -- lane L for ITS pair, before the quad hand-round.
 template <int EP, int SMODE>
-__global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__restrict__ rows,
+static __global__ __launch_bounds__(1024) void k_field_quad(int nrows, const int *__restrict__ rows,
                                                             AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
                                                             Box box, RowList ddl, const int *__restrict__ dd_j,
                                                             const double2 *__restrict__ dd_s,
@@ -389,7 +389,7 @@ __device__ __forceinline__ void lp_finish(double ax, double ay, double az, int l
 // DET: fold a launch's pending dipoles into the record table; every workgroup leaves the sum of its 256 rows' (dmu)^2 --
 // wave butterflies, then the four waves in order: the same association every run -- in its own slot of `part`, which the
 // end-of-sweep kernel adds up in slot order
-__global__ __launch_bounds__(256) void k_lp_commit(int nrows, long long row0, const int2 *__restrict__ desc,
+static __global__ __launch_bounds__(256) void k_lp_commit(int nrows, long long row0, const int2 *__restrict__ desc,
                                                    const double *__restrict__ pend, AtomRec *recA, AtomRec *recB, int jacobi,
                                                    const Scal *scal, double *__restrict__ part) {
   if (scal->done) return;
@@ -499,7 +499,7 @@ __device__ __forceinline__ void lp_row(int T, const int4 *pc, const int4 &Ja0, c
 }
 // row descriptors of a step: {row atom (s index), trips | wrap flag << 30}; one coalesced 8-byte load tells a wave
 // everything it needs to start its index stream, its record fetch and its field fetch at once
-__global__ void k_lp_desc(int nrows, const int *__restrict__ rows, RowList ddl, const int *__restrict__ dd_wrap,
+static __global__ void k_lp_desc(int nrows, const int *__restrict__ rows, RowList ddl, const int *__restrict__ dd_wrap,
                           int2 *__restrict__ desc) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
@@ -509,7 +509,7 @@ __global__ void k_lp_desc(int nrows, const int *__restrict__ rows, RowList ddl, 
   desc[r] = make_int2(i, (int)((c + 63) >> 6) | (dd_wrap[i] ? 0x40000000 : 0));
 }
 template <int EP, int DAMP, int NT, bool DET>
-__global__ __launch_bounds__(1024) void k_field_lp(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA,
+static __global__ __launch_bounds__(1024) void k_field_lp(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA,
                                                    AtomRec *recB, Box box, long long pitch,
                                                    const int *__restrict__ dd_j, double pd, ExpCoef K,
                                                    const double *__restrict__ ef, const Scal *scal,
@@ -650,7 +650,7 @@ __device__ __forceinline__ void lpr_row(int T, const int4 *pc, const int4 &Ja0, 
 #undef POLAR_LPR_TRIP
 }
 template <int EP, int DAMP, bool DET>
-__global__ __launch_bounds__(256) void k_field_lpr(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA,
+static __global__ __launch_bounds__(256) void k_field_lpr(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA,
                                                    AtomRec *recB, Box box, long long pitch, const int *__restrict__ dd_j, double pd,
                                                    ExpCoef K, const double *__restrict__ ef, const Scal *scal,
                                                    double *__restrict__ slots, double omega, double *pend, int R) {
@@ -818,7 +818,7 @@ __device__ __forceinline__ void lp2_row(int T, const int4 *pc, const int4 &Ja0, 
 #undef POLAR_LP2_TRIP
 }
 template <int EP, int DAMP>
-__global__ __launch_bounds__(256) void k_field_lp2(int nunits, long long unit0, const int4 *__restrict__ udesc, AtomRec *recA, AtomRec *recB,
+static __global__ __launch_bounds__(256) void k_field_lp2(int nunits, long long unit0, const int4 *__restrict__ udesc, AtomRec *recA, AtomRec *recB,
                                                    Box box, long long upitch, const int *__restrict__ udd_j, double pd, ExpCoef K,
                                                    const double *__restrict__ ef, const Scal *scal, double *__restrict__ slots, double omega) {
   extern __shared__ __attribute__((aligned(16))) char lp_lds[];
@@ -962,7 +962,7 @@ __device__ __forceinline__ void cl_rows(int T, int M, const int4 *pc, const char
 #undef POLAR_CL_TRIP
 }
 // descriptors of a step: members (s-space) come from the cluster table; {trips | wrap << 30}
-__global__ void k_cl_desc(int ncl, const int *__restrict__ cnt, long long pitch, const int *__restrict__ wrapf,
+static __global__ void k_cl_desc(int ncl, const int *__restrict__ cnt, long long pitch, const int *__restrict__ wrapf,
                           int *__restrict__ tw) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncl) return;
@@ -971,7 +971,7 @@ __global__ void k_cl_desc(int ncl, const int *__restrict__ cnt, long long pitch,
   tw[c] = (int)((n + 63) >> 6) | (wrapf[c] ? 0x40000000 : 0);
 }
 template <int EP, int DAMP, int NT>
-__global__ __launch_bounds__(256) void k_field_cl(int ncl, int first, const int4 *__restrict__ members,
+static __global__ __launch_bounds__(256) void k_field_cl(int ncl, int first, const int4 *__restrict__ members,
                                                   const int *__restrict__ tw, AtomRec *recA, AtomRec *recB, Box box,
                                                   long long pitch, const int *__restrict__ dd_j, double ddcutsq,
                                                   double pd, ExpCoef K, const double *__restrict__ ef, const Scal *scal,
@@ -1189,7 +1189,7 @@ __device__ __forceinline__ void lpa_row(int T, const int4 *pc, const char *srcc,
 #undef POLAR_LPA_TRIP
 }
 template <int EP, int DAMP, int D>
-__global__ __launch_bounds__(256) void k_field_lpa(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA, AtomRec *recB,
+static __global__ __launch_bounds__(256) void k_field_lpa(int nrows, long long row0, const int2 *__restrict__ desc, AtomRec *recA, AtomRec *recB,
                                                    Box box, long long pitch, const int *__restrict__ dd_j, double pd,
                                                    ExpCoef K, const double *__restrict__ ef, const Scal *scal,
                                                    double *__restrict__ slots, int ablate) {
@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_field_lpa(int nrows, long long row0, co
 // a6 for the list path: the damped tensor scalars of every listed pair, once per step
 // (the sparse, matrix-free-storage analog of build_dipole_field_matrix, PS.cpp:1273-1306).
 template <int DAMP>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restrict__ rows, int nrows, const AtomRec *__restrict__ rec,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restrict__ rows, int nrows, const AtomRec *__restrict__ rec,
                                                             Box box,
                                                             RowList ddl,
                                                             int *__restrict__ dd_j, double pd,
@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__restric
 // so atoms later in the order see the new dipoles, atoms earlier keep a current field for the
 // next sweep.  Arithmetic differs from the reference only in summation order.
 template <int DAMP>
-__global__ __launch_bounds__(64) void k_gs_block_seq(int nlocal, int b0, const int *__restrict__ order,
+static __global__ __launch_bounds__(64) void k_gs_block_seq(int nlocal, int b0, const int *__restrict__ order,
                                                      AtomRec *__restrict__ rec, Box box, double pd,
                                                      const double *__restrict__ ef, double *__restrict__ F,
                                                      double *__restrict__ dmu_blk, const Scal *scal,
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(64) void k_gs_block_seq(int nlocal, int b0, const i
 }
 
 template <int DAMP>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_gs_block_push(int nlocal, int b0, const int *__restrict__ order,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_gs_block_push(int nlocal, int b0, const int *__restrict__ order,
                                                                const int *__restrict__ pos_in_order,
                                                                const AtomRec *__restrict__ rec, Box box, double pd,
                                                                const double *__restrict__ dmu_blk,
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_gs_block_push(int nlocal, int b
 // then has no exp / rsqrt / minimum image in it, only 9 FMAs per step.  Atoms are in RANKED order
 // here (s space = sweep order), so a block of 64 consecutive steps reads contiguous tensor rows.
 template <int DAMP>
-__global__ __launch_bounds__(POLAR_BLOCK) void k_build_T6(int n, const AtomRec *__restrict__ rec, Box box, double pd,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_build_T6(int n, const AtomRec *__restrict__ rec, Box box, double pd,
                                                           double *__restrict__ T6) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_build_T6(int n, const AtomRec *
 }
 
 // F_i = - sum_j T_ij mu_j  (dense mat-vec; initial running field of the Gauss-Seidel)
-__global__ __launch_bounds__(POLAR_BLOCK) void k_dense_field(int n, const double *__restrict__ T6,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_dense_field(int n, const double *__restrict__ T6,
                                                              const AtomRec *__restrict__ rec, double *__restrict__ F) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -1415,7 +1415,7 @@ __device__ __forceinline__ double readlane_d(double v, int k) {  // k wave-unifo
 // ONE wave: the sequential recurrence over the 64 atoms b0..b0+63 of the sweep order
 // (PS.cpp:1158-1180).  Lane l owns atom b0+l; step k: mu_k <- alpha_k (E_k + F_k), and every lane
 // folds T_{l,k} dmu_k into its running field.  Tensor rows are prefetched four steps ahead.
-__global__ __launch_bounds__(64) void k_gs_seq_T6(int n, int b0, const double *__restrict__ T6,
+static __global__ __launch_bounds__(64) void k_gs_seq_T6(int n, int b0, const double *__restrict__ T6,
                                                   AtomRec *__restrict__ rec, const double *__restrict__ ef,
                                                   double *__restrict__ F, double *__restrict__ dmu_blk,
                                                   const Scal *scal, double *__restrict__ slots) {
@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(64) void k_gs_seq_T6(int n, int b0, const double *_
 }
 
 // rows outside the block receive the block's dipole changes: F_j -= sum_k T_{j,b0+k} dmu_k
-__global__ __launch_bounds__(POLAR_BLOCK) void k_gs_push_T6(int n, int b0, const double *__restrict__ T6,
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_gs_push_T6(int n, int b0, const double *__restrict__ T6,
                                                             const AtomRec *__restrict__ rec,
                                                             const double *__restrict__ dmu_blk, double *__restrict__ F,
                                                             const Scal *scal) {
@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(POLAR_BLOCK) void k_gs_push_T6(int n, int b0, const
 // ------------------------------------------------------------------------------------------
 // a7 loop control, one thread: the reference's end-of-sweep logic (PS.cpp:1193-1236) kept on the
 // device so the host never has to look at ||dmu||^2 between sweeps.
-__global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double *__restrict__ slots, int nlocal,
+static __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double *__restrict__ slots, int nlocal,
                                                            int fixed_iteration, int iterations_max, double precision,
                                                            int jacobi, const double *__restrict__ global_change,
                                                            int count, const double *__restrict__ part, int npart) {
@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, double 
 }
 
 // fold the change slots into scal->change without touching the loop state (multi-GPU export)
-__global__ __launch_bounds__(POLAR_NSLOT) void k_fold_change(Scal *scal, double *__restrict__ slots, double *dst,
+static __global__ __launch_bounds__(POLAR_NSLOT) void k_fold_change(Scal *scal, double *__restrict__ slots, double *dst,
                                                            const double *__restrict__ part, int npart) {
   __shared__ double red[POLAR_NSLOT / 64];
   double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(POLAR_NSLOT) void k_fold_change(Scal *scal, double 
 }
 
 // fold energies / virial / rmin slots into the Scal block (run before the host reads it)
-__global__ __launch_bounds__(POLAR_NSLOT) void k_fold_scal(Scal *scal, double *__restrict__ slots, int rmin_only) {
+static __global__ __launch_bounds__(POLAR_NSLOT) void k_fold_scal(Scal *scal, double *__restrict__ slots, int rmin_only) {
   // one wave per accumulator field (wave 0: rmin; waves 1..11: energies and virial), all at once
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   if (w == 0) {
@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(POLAR_NSLOT) void k_fold_scal(Scal *scal, double *_
   }
 }
 // start-of-step reset of the slot accumulators and (thread 0) of the Scal block: one launch
-__global__ void k_zero_slots(double *__restrict__ slots, Scal *s) {
+static __global__ void k_zero_slots(double *__restrict__ slots, Scal *s) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0 && s) {
     s->eng_vdwl = s->eng_coul = s->u_self = s->u_ef = s->u_dd = 0.0;
@@ -1596,7 +1596,7 @@ __global__ void k_zero_slots(double *__restrict__ slots, Scal *s) {
 
 // `debug yes`: u_polar = -1/2 sum_i E_static,i . mu_i after a sweep (PS.cpp:1182-1191 prints it per iteration).
 // The dipoles are read where the sweep keeps them: component k of record i = double 2k + 1 at base + i * stride.
-__global__ __launch_bounds__(1024) void k_debug_upolar(int n, const Scal *scal, const char *recA, const char *recB, int stride,
+static __global__ __launch_bounds__(1024) void k_debug_upolar(int n, const Scal *scal, const char *recA, const char *recB, int stride,
                                                        const double *__restrict__ ef, double *__restrict__ trace, int slot,
                                                        int jacobi_next) {
   if (scal->done) return;  // a launch past the end of a finished solve (the host looks at the state every 4 sweeps)
@@ -1619,7 +1619,7 @@ __global__ __launch_bounds__(1024) void k_debug_upolar(int n, const Scal *scal, 
 }
 
 // divergence fallback mu = alpha * E (no gamma), PS.cpp:1227-1235
-__global__ void k_fallback(int n, const Scal *scal, AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
+static __global__ void k_fallback(int n, const Scal *scal, AtomRec *__restrict__ recA, AtomRec *__restrict__ recB,
                            const double *__restrict__ ef) {
   if (!scal->status) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1630,7 +1630,7 @@ __global__ void k_fallback(int n, const Scal *scal, AtomRec *__restrict__ recA, 
 }
 
 // copy the final dipoles and the static field out (records are in s order, outputs in orig order)
-__global__ void k_unpack(int n, const int *__restrict__ perm, const Scal *scal, const AtomRec *__restrict__ recA,
+static __global__ void k_unpack(int n, const int *__restrict__ perm, const Scal *scal, const AtomRec *__restrict__ recA,
                          const AtomRec *__restrict__ recB, const double *__restrict__ ef_s, double *__restrict__ mu,
                          double *__restrict__ ef) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

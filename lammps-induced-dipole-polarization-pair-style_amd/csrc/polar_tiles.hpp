@@ -75,7 +75,7 @@ __device__ __forceinline__ void tile_shift(const Box &b, int code, double &sx, d
 
 #ifdef POLAR_LAB  // the kernels below exist in the lab build only (the types and layout constants above are shared with the host code)
 // AtomRec (both buffers hold the same initial dipoles) -> sweep records, and the solved dipoles back
-__global__ void k_srec_pack(int n, const AtomRec *__restrict__ r, SRec *__restrict__ s0, SRec *__restrict__ s1) {
+static __global__ void k_srec_pack(int n, const AtomRec *__restrict__ r, SRec *__restrict__ s0, SRec *__restrict__ s1) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const AtomRec a = r[i];
@@ -84,7 +84,7 @@ __global__ void k_srec_pack(int n, const AtomRec *__restrict__ r, SRec *__restri
   s0[i] = s;
   if (s1) s1[i] = s;
 }
-__global__ void k_srec_unpack(int n, const Scal *scal, const SRec *__restrict__ s0, const SRec *__restrict__ s1,
+static __global__ void k_srec_unpack(int n, const Scal *scal, const SRec *__restrict__ s0, const SRec *__restrict__ s1,
                               AtomRec *__restrict__ r0, AtomRec *__restrict__ r1) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -100,7 +100,7 @@ __global__ void k_srec_unpack(int n, const Scal *scal, const SRec *__restrict__ 
 // list, pass 3 colours the rows of the tile, pass 4 writes the row table in sub-phase order.
 //   flags[5] union entries needed (+1 for the dummy) when un_pitch is too small     flags[6] the same for a row list
 //   flags[7] a tile the builder cannot describe (more than MAXROWS atoms or MAXSUB sub-phases)   flags[9] largest U
-__global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const double4 *__restrict__ pos4,
+static __global__ __launch_bounds__(256) void k_tile_build(CellGrid g, Box box, const double4 *__restrict__ pos4,
                                                     const long long *__restrict__ cell_first,
                                                     const int *__restrict__ npol, const int *__restrict__ perm,
                                                     int own_lo, int own_hi, double ddcutsq, double colordistsq, int subcap,
@@ -517,7 +517,7 @@ __device__ __forceinline__ void tile_row_pairs1(const TileRow &R, const char *re
 
 // NW = waves of the workgroup (4: two workgroups per CU leave a SIMD two waves; 8: four)
 template <int EP, int DAMP, bool DET, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_field_tile(TileLaunch L, const TileHdr *__restrict__ hdr, const TileRowEnt *__restrict__ trow,
+static __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_field_tile(TileLaunch L, const TileHdr *__restrict__ hdr, const TileRowEnt *__restrict__ trow,
                                                     const int *__restrict__ un_j, int un_pitch,
                                                     const unsigned short *__restrict__ dd16, long long pitch16, SRec *s0,
                                                     SRec *s1, double *pend, const double *__restrict__ ef, Box box, double pd,
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_field_tile(TileLau
 }
 
 // DET: fold the pending dipoles of a launch's rows into the record table (the launch itself only read the table)
-__global__ void k_tile_commit(TileLaunch L, const TileHdr *__restrict__ hdr, const TileRowEnt *__restrict__ trow,
+static __global__ void k_tile_commit(TileLaunch L, const TileHdr *__restrict__ hdr, const TileRowEnt *__restrict__ trow,
                               const double *__restrict__ pend, SRec *s0, const Scal *scal) {
   if (scal->done) return;
   const int ntile = L.count[0] * L.count[1] * L.count[2];
