@@ -70,7 +70,14 @@ typedef struct {
    * them through atom->mu_induced and Comm::forward_comm_pair -- the capability PS.h:51-52 / PS.cpp:1320-1362
    * (pack_comm / unpack_comm, never called) was meant to provide.  Off by default. */
   int rccl_halo;
+  /* polar_accel <m> (extension keyword, list mode with polar_gs / polar_gs_ranked; 0 = off, the default): Anderson mixing of
+   * depth m (1 .. POLAR_ACCEL_MAX) on the sweep map.  With G(mu) = one Gauss-Seidel sweep (PS.cpp:1158-1180) and residual
+   * r_k = G(mu_k) - mu_k, the next iterate is G(mu_k) minus the combination of the last m differences of G that minimises
+   * |r_k - sum gamma_j (r_{k-j+1} - r_{k-j})|: the same fixed point, the same stop rule on |G(mu_k) - mu_k| (PS.cpp:1194-1210),
+   * fewer sweeps.  Per sweep it adds m dot products over 3N doubles; across ranks they ride the stop rule's all-reduce. */
+  int polar_accel;
 } polar_settings;
+#define POLAR_ACCEL_MAX 8
 
 typedef struct {
   double eng_vdwl, eng_coul, eng_pol; /* Pair::eng_vdwl/eng_coul/eng_pol (src/pair.h:36) */
@@ -158,6 +165,9 @@ int polar_set_atoms(polar_handle *h, int nlocal, int nghost, const double *x, co
  * steps, so q, static_polarizability, type and molecule on the device still hold (what PS.cpp:125-188 re-reads through atom->
  * every step is, on these steps, only x).  Same nlocal / nghost as the last polar_set_atoms, or POLAR_ERR_INPUT. */
 int polar_set_positions(polar_handle *h, int nlocal, int nghost, const double *x);
+/* positions of the atoms [lo, hi) only (x = [hi-lo][3]): a rank of a multi-GPU run uploads its own atoms and lets
+ * polar_dist_positions fetch the rest from their owners */
+int polar_set_positions_range(polar_handle *h, int lo, int hi, const double *x);
 /* NeighList inum/ilist/numneigh/firstneigh (src/neigh_list.h:46-50); call when neighbor->ago == 0 */
 int polar_set_neighbors(polar_handle *h, int inum, const int *ilist, const int *numneigh,
                         int *const *firstneigh);
@@ -223,6 +233,13 @@ int polar_get_debug_forces(polar_handle *h, double *out6);
  * apart than the colour distance (tests check exactly that).  Returns the number of colours, < 0 on error. */
 int polar_get_colors(polar_handle *h, int *color, int n);
 
+/* The colour phases handed in by the caller instead of built by the library (no reference counterpart): color[nlocal] in the
+ * caller's atom order, 0 .. 63 for polarizable atoms, -1 for the others; phases run in the order of the colour numbers.  Atoms
+ * of one colour must lie farther apart than the colour distance.  On a sharded handle the halo rows carry the colours their
+ * owners gave them: all ranks then sweep ONE colouring (polar_dist_set_schedule).  If atoms of one colour later come closer than
+ * the library tolerates, its own colouring takes over.  n = 0 withdraws the colours. */
+int polar_set_colors(polar_handle *h, const int *color, int n);
+
 /* ---- device-resident variant (bench, multi-GPU driver): no host<->device traffic ---------- */
 /* Runs compute() on the atoms/lists already resident from polar_set_*; results stay on the
  * device (polar_dev_ptr) and only the scalars in polar_result come back. */
@@ -254,6 +271,10 @@ int polar_set_list_style(polar_handle *h, int full);
  * handle's rows tallied: the shards' arrays add up to the unsharded ones. */
 int polar_step_begin(polar_handle *h, int eflag, int vflag);
 int polar_step_sweep(polar_handle *h); /* one sweep over the owned rows */
+/* one colour phase of the list-mode Gauss-Seidel sweep: part 0 = all rows of colour `color`, 1 = its boundary rows (the rows a
+ * peer receives, polar_dist_set_halo; all rows on a handle without boundary flags), 2 = its interior rows.  Phases 0 .. ncolors-1
+ * in order, parts 1 then 2 (or 0), equal polar_step_sweep. */
+int polar_step_sweep_phase(polar_handle *h, int color, int part);
 /* one sweep in `nparts` pieces: piece `part` runs its share of the colour phases (colour-phase Gauss-Seidel of list mode only),
  * so that a driver can exchange halo dipoles INSIDE a sweep -- neighbours then see the phases already done one piece, not one
  * sweep, late.  Calling all pieces 0 .. nparts-1 in order equals polar_step_sweep. */
@@ -298,25 +319,51 @@ int polar_step_sweep_end_host(polar_handle *h, double global_change);
  * dependency on it, and a process that already holds a copy (PyTorch's) shares it.
  *   polar_dist_unique_id   rank 0: the 128-byte ncclUniqueId, to be broadcast by the caller (MPI_Bcast, a file, a store)
  *   polar_dist_create      ncclCommInitRank on `device` (collective over the ranks)
- *   polar_dist_set_halo    this rank's exchange plan: for peer k (a rank; the rank itself is allowed) the handle-local
- *                          indices of the atoms whose dipoles it sends, and of the atoms it receives dipoles for, in the
- *                          order the peer sends them (concatenated over the peers)
+ *   polar_dist_set_halo    this rank's exchange plan for handle h: for peer k (a rank; the rank itself is allowed) the
+ *                          handle-local indices of the atoms whose dipoles it sends, and of the atoms it receives dipoles for,
+ *                          in the order the peer sends them (concatenated over the peers).  The rows it sends become the
+ *                          handle's BOUNDARY rows: they are swept first in their colour phase.
  *   polar_dist_set_cadence sweeps per all-reduce of the stop rule (1 = the reference's rule after every sweep) and
  *                          sweeps per look at the loop state
+ *   polar_dist_set_schedule  how the Gauss-Seidel solve exchanges.  nclasses > 0: the ranks build ONE colouring together -- they
+ *                          take turns by class (my_class in 0 .. nclasses-1; no two peers may share a class), a rank colours its
+ *                          rows against the colours its peers' rows already hold -- so that the colour phases of all ranks
+ *                          together are the single-GPU iteration; after phase c only colour c's boundary rows travel, on a
+ *                          second stream, and a phase waits for the exchange issued lag + 1 phases earlier: lag 0 = the
+ *                          single-GPU iterates exactly (the exchange hides behind the interior rows of its own phase only),
+ *                          lag 1 (default) = a halo dipole may be one phase old, every exchange has a whole phase to hide
+ *                          behind; lag -1 or nclasses 0 = one exchange of all halo dipoles per sweep, every rank colouring for
+ *                          itself (block-Jacobi across the ranks: more sweeps).  A colouring handed in with polar_set_colors
+ *                          (own AND halo rows) counts as shared.
+ *   polar_dist_set_ghosts  the periodic images the handle holds behind its local atoms: owner (handle-local index) and shift
+ *                          of every ghost, for polar_dist_positions
+ *   polar_dist_positions   per step, before polar_dist_step: the positions of the halo atoms from their owners (the same plan
+ *                          as the dipoles, 24 B per halo atom) and of the ghost images from theirs -- "ghost x over RCCL";
+ *                          the caller has uploaded its OWN atoms' new positions (polar_set_positions_range)
  *   polar_dist_step        one Pair::compute across the ranks (collective); forces, dipoles and per-atom arrays stay on the
- *                          device (polar_download / polar_dev_ptr)
- *   polar_dist_exchange    one dipole exchange by itself (tests) */
+ *                          device (polar_download / polar_dev_ptr).  out = energies, virial and pair count SUMMED over the
+ *                          ranks; polar_dist_local_result = this rank's own share of the same step (what a host that sums
+ *                          per-rank accumulators itself -- LAMMPS: compute pe, thermo, pressure -- must add).
+ *                          A rank that fails before the first exchange (bad input, allocation) makes EVERY rank return an
+ *                          error: the begin status is max-reduced first.
+ *   polar_dist_exchange    one dipole exchange by itself (tests)
+ *   polar_dist_comm_count  ncclCommCount of the communicator (the number of ranks RCCL itself sees) */
 #define POLAR_DIST_ID_BYTES 128
 typedef struct polar_dist polar_dist;
 int polar_dist_unique_id(void *id128);
 int polar_dist_create(const void *id128, int rank, int nranks, int device, polar_dist **out);
 int polar_dist_destroy(polar_dist *d);
 const char *polar_dist_last_error(const polar_dist *d);
+int polar_dist_comm_count(const polar_dist *d);
 int polar_dist_set_cadence(polar_dist *d, int reduce_every, int check_every);
-int polar_dist_set_halo(polar_dist *d, int npeers, const int *peers, const int *send_count, const int *send_idx,
+int polar_dist_set_schedule(polar_dist *d, int lag, int my_class, int nclasses);
+int polar_dist_set_halo(polar_dist *d, polar_handle *h, int npeers, const int *peers, const int *send_count, const int *send_idx,
                         const int *recv_count, const int *recv_idx);
+int polar_dist_set_ghosts(polar_dist *d, polar_handle *h, int nghost, const int *owner, const double *shift);
+int polar_dist_positions(polar_dist *d, polar_handle *h);
 int polar_dist_exchange(polar_dist *d, polar_handle *h);
 int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_result *out);
+int polar_dist_local_result(const polar_dist *d, polar_result *out);
 int polar_dist_counters(const polar_dist *d, int *exchanges, int *allreduces);
 
 #ifdef __cplusplus

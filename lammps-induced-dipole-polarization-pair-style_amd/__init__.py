@@ -86,7 +86,7 @@ class Settings(C.Structure):
                 ("polar_damp", C.c_double), ("polar_gamma", C.c_double), ("iterations_max", C.c_int),
                 ("damping_type", C.c_int), ("zodid", C.c_int), ("fixed_iteration", C.c_int), ("polar_gs", C.c_int),
                 ("polar_gs_ranked", C.c_int), ("use_previous", C.c_int), ("debug", C.c_int), ("dd_cutoff", C.c_double),
-                ("device_neigh", C.c_int), ("restart_polar", C.c_int), ("deterministic", C.c_int), ("polar_sor", C.c_double), ("rccl_halo", C.c_int)]
+                ("device_neigh", C.c_int), ("restart_polar", C.c_int), ("deterministic", C.c_int), ("polar_sor", C.c_double), ("rccl_halo", C.c_int), ("polar_accel", C.c_int)]
 
 
 class Result(C.Structure):
@@ -163,7 +163,15 @@ EXPORTS = {
     "polar_dist_destroy": (C.c_int, [C.c_void_p]),
     "polar_dist_last_error": (C.c_char_p, [C.c_void_p]),
     "polar_dist_set_cadence": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "polar_dist_set_halo": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _ip]),
+    "polar_dist_set_halo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _ip]),
+    "polar_dist_set_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "polar_dist_set_ghosts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _ip, _dp]),
+    "polar_dist_positions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "polar_dist_local_result": (C.c_int, [C.c_void_p, C.POINTER(Result)]),
+    "polar_dist_comm_count": (C.c_int, [C.c_void_p]),
+    "polar_step_sweep_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "polar_set_colors": (C.c_int, [C.c_void_p, _ip, C.c_int]),
+    "polar_set_positions_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp]),
     "polar_dist_exchange": (C.c_int, [C.c_void_p, C.c_void_p]),
     "polar_dist_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Result)]),
     "polar_dist_counters": (C.c_int, [C.c_void_p, _ip, _ip]),
@@ -332,6 +340,19 @@ class PolarPair:
         self._ck(self.L.polar_set_atoms(self.h, nlocal, nghost, _dptr(x), _dptr(q), _dptr(alpha), _iptr(typ), _iptr(mol)))
         self.nlocal, self.nghost = nlocal, nghost
 
+    def set_colors(self, color):
+        """Impose the colour phases (one int per local atom, -1 = none); ``None`` withdraws them."""
+        if color is None:
+            self._ck(self.L.polar_set_colors(self.h, None, 0))
+            return
+        c = np.ascontiguousarray(color, dtype=np.int32)
+        self._ck(self.L.polar_set_colors(self.h, c.ctypes.data_as(_ip), len(c)))
+
+    def set_positions_range(self, lo, hi, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (hi - lo, 3)
+        self._ck(self.L.polar_set_positions_range(self.h, lo, hi, _dptr(x)))
+
     def set_positions(self, x):
         """Positions only (steps between two neighbor-list builds)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
@@ -380,6 +401,8 @@ class PolarPair:
             args += ["deterministic", "yes"]
         if getattr(st, "polar_sor", 1.0) != 1.0:
             args += ["polar_sor", repr(float(st.polar_sor))]
+        if getattr(st, "polar_accel", 0):
+            args += ["polar_accel", str(int(st.polar_accel))]
         self.settings(args)
         if modify_args:
             self.modify(list(modify_args))
@@ -499,15 +522,36 @@ class PolarDist:
     def set_cadence(self, reduce_every=1, check_every=4):
         self._ck(self.L.polar_dist_set_cadence(self.d, reduce_every, check_every))
 
-    def set_halo(self, peers, send_lists, recv_lists):
-        """peers[k] = rank; send_lists[k] / recv_lists[k] = handle-local atom indices (int arrays)."""
+    def set_halo(self, pair, peers, send_lists, recv_lists):
+        """peers[k] = rank; send_lists[k] / recv_lists[k] = handle-local atom indices (int arrays) of ``pair``'s handle."""
         peers = np.ascontiguousarray(peers, dtype=np.int32)
         sc = np.array([len(a) for a in send_lists], dtype=np.int32)
         rc_ = np.array([len(a) for a in recv_lists], dtype=np.int32)
         si = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32) for a in send_lists]) if len(send_lists) else np.zeros(0, np.int32))
         ri = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32) for a in recv_lists]) if len(recv_lists) else np.zeros(0, np.int32))
-        self._ck(self.L.polar_dist_set_halo(self.d, len(peers), _iptr(peers), _iptr(sc), _iptr(si) if len(si) else None,
+        self._ck(self.L.polar_dist_set_halo(self.d, pair.h, len(peers), _iptr(peers), _iptr(sc), _iptr(si) if len(si) else None,
                                             _iptr(rc_), _iptr(ri) if len(ri) else None))
+
+    def set_schedule(self, lag=1, my_class=0, nclasses=0):
+        """``nclasses`` > 0: one colouring shared by the ranks (this rank colours in turn ``my_class``), per-phase exchanges
+        ``lag`` phases late at most; ``nclasses`` 0 or ``lag`` -1: one exchange per sweep (block-Jacobi across ranks)."""
+        self._ck(self.L.polar_dist_set_schedule(self.d, lag, my_class, nclasses))
+
+    def set_ghosts(self, pair, owner, shift):
+        owner = np.ascontiguousarray(owner, dtype=np.int32)
+        shift = np.ascontiguousarray(shift, dtype=np.float64)
+        self._ck(self.L.polar_dist_set_ghosts(self.d, pair.h, len(owner), _iptr(owner) if len(owner) else None, _dptr(shift) if len(owner) else None))
+
+    def positions(self, pair):
+        self._ck(self.L.polar_dist_positions(self.d, pair.h))
+
+    def local_result(self):
+        res = Result()
+        self._ck(self.L.polar_dist_local_result(self.d, C.byref(res)))
+        return _result_dict(res)
+
+    def comm_count(self):
+        return self._ck(self.L.polar_dist_comm_count(self.d))
 
     def exchange(self, pair):
         self._ck(self.L.polar_dist_exchange(self.d, pair.h))

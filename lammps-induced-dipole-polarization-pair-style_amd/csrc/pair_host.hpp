@@ -47,6 +47,7 @@ inline void settings_defaults(polar_settings &s) {  // PS.cpp:65-78
   s.deterministic = 0;
   s.polar_sor = 1.0;
   s.rccl_halo = 0;
+  s.polar_accel = 0;
 }
 
 // Force::numeric / Force::inumeric behaviour: whole token must parse.
@@ -151,6 +152,10 @@ class PairHost {
       else if (strcmp("restart_polar", k) == 0) st.restart_polar = yesno(v);  // extension keyword
       else if (strcmp("deterministic", k) == 0) st.deterministic = yesno(v);  // extension keyword
       else if (strcmp("rccl_halo", k) == 0) st.rccl_halo = yesno(v);          // extension keyword
+      else if (strcmp("polar_accel", k) == 0) {                               // extension keyword
+        st.polar_accel = inumeric(v);
+        if (st.polar_accel < 0 || st.polar_accel > POLAR_ACCEL_MAX) throw InputError("Illegal pair_style command");
+      }
       else if (strcmp("polar_sor", k) == 0) {                                 // extension keyword
         st.polar_sor = numeric(v);
         if (!(st.polar_sor > 0.0 && st.polar_sor < 2.0)) throw InputError("Illegal pair_style command");

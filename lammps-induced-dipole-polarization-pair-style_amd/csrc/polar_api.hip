@@ -131,7 +131,7 @@ int polar_destroy(polar_handle *h) {
     h->d_xchg.release(); h->d_xidx.release();
     h->d_eatom.release(); h->d_vatom.release(); h->d_dd_r2.release(); h->d_fpol.release();
     h->d_x.release(); h->d_q.release(); h->d_alpha.release(); h->d_f.release(); h->d_ef.release(); h->d_F.release();
-    h->d_mu.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
+    h->d_mu.release(); h->d_mu0.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
     h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();
     h->d_numneigh.release(); h->d_neigh.release(); h->d_rows.release(); h->d_first.release();
     h->d_sym_first.release(); h->d_sym_cnt.release(); h->d_sym_fill.release(); h->d_sym_j.release();
@@ -223,8 +223,9 @@ int polar_get_settings(const polar_handle *h, polar_settings *out) {
 }
 namespace {
 const int kRestartMagic = 0x524C4F50;  // 'POLR' (little endian)
-const int kRestartVersion = 1;
-const int kRestartPayload = 4 * (int)sizeof(double) + 10 * (int)sizeof(int);
+const int kRestartVersion = 2;         // 2: + deterministic, rccl_halo, polar_accel (int32) and polar_sor (double) behind the version-1 payload
+const int kRestartPayloadV1 = 4 * (int)sizeof(double) + 10 * (int)sizeof(int);
+const int kRestartPayload = kRestartPayloadV1 + 4 * (int)sizeof(int) + (int)sizeof(double);
 }
 int polar_restart_pack(const polar_handle *h, void *buf, int max_bytes) {
   if (!h) return POLAR_ERR_STATE;
@@ -239,7 +240,10 @@ int polar_restart_pack(const polar_handle *h, void *buf, int max_bytes) {
   memcpy(p, d, sizeof(d)); p += sizeof(d);
   const int iv[10] = {st.iterations_max, st.damping_type, st.zodid, st.fixed_iteration, st.polar_gs, st.polar_gs_ranked,
                       st.use_previous, st.debug, st.device_neigh, st.restart_polar};
-  memcpy(p, iv, sizeof(iv));
+  memcpy(p, iv, sizeof(iv)); p += sizeof(iv);
+  const int iv2[4] = {st.deterministic, st.rccl_halo, st.polar_accel, 0};
+  memcpy(p, iv2, sizeof(iv2)); p += sizeof(iv2);
+  memcpy(p, &st.polar_sor, sizeof(double));
   return total;
 }
 int polar_restart_unpack(polar_handle *h, const void *buf, int nbytes) {
@@ -249,15 +253,23 @@ int polar_restart_unpack(polar_handle *h, const void *buf, int nbytes) {
     int head[3];
     memcpy(head, p, sizeof(head)); p += sizeof(head);
     if (head[0] != kRestartMagic) throw InputError("not a polarization restart record");
-    if (head[1] != kRestartVersion || head[2] != kRestartPayload || nbytes < POLAR_RESTART_HEADER_BYTES + head[2])
+    const bool v1 = head[1] == 1 && head[2] == kRestartPayloadV1, v2 = head[1] == kRestartVersion && head[2] == kRestartPayload;
+    if (!(v1 || v2) || nbytes < POLAR_RESTART_HEADER_BYTES + head[2])
       throw InputError("polarization restart record of an unknown version or length");
     double d[4]; int iv[10];
     memcpy(d, p, sizeof(d)); p += sizeof(d);
-    memcpy(iv, p, sizeof(iv));
+    memcpy(iv, p, sizeof(iv)); p += sizeof(iv);
     polar_settings s = h->ph.st;  // the cutoffs stay as the stock record set them
     s.polar_precision = d[0]; s.polar_damp = d[1]; s.polar_gamma = d[2]; s.dd_cutoff = d[3];
     s.iterations_max = iv[0]; s.damping_type = iv[1]; s.zodid = iv[2]; s.fixed_iteration = iv[3]; s.polar_gs = iv[4];
     s.polar_gs_ranked = iv[5]; s.use_previous = iv[6]; s.debug = iv[7]; s.device_neigh = iv[8]; s.restart_polar = iv[9];
+    if (v2) {  // (a version-1 record leaves these at the defaults in force)
+      int iv2[4]; double sor;
+      memcpy(iv2, p, sizeof(iv2)); p += sizeof(iv2);
+      memcpy(&sor, p, sizeof(double));
+      s.deterministic = iv2[0]; s.rccl_halo = iv2[1]; s.polar_accel = iv2[2]; s.polar_sor = sor;
+      if (!(s.polar_sor > 0.0 && s.polar_sor < 2.0) || s.polar_accel < 0 || s.polar_accel > POLAR_ACCEL_MAX) throw InputError("polarization restart record holds an illegal polar_sor / polar_accel");
+    }
     if (s.zodid && (s.polar_gs || s.polar_gs_ranked)) throw InputError("Zodid doesn't work with polar_gs or polar_gs_ranked");
     if (s.polar_gs && s.polar_gs_ranked) throw InputError("polar_gs and polar_gs_ranked are mutually exclusive");
     h->ph.st = s;
@@ -269,7 +281,11 @@ int polar_set_settings(polar_handle *h, const polar_settings *s) {
   return guarded(h, [&]() {
     if (s->zodid && (s->polar_gs || s->polar_gs_ranked)) throw InputError("Zodid doesn't work with polar_gs or polar_gs_ranked");
     if (s->polar_gs && s->polar_gs_ranked) throw InputError("polar_gs and polar_gs_ranked are mutually exclusive");
-    h->ph.st = *s;
+    polar_settings v = *s;
+    if (v.polar_sor == 0.0) v.polar_sor = 1.0;   // a zero-initialised struct means "the reference's update", not "freeze the dipoles"
+    if (!(v.polar_sor > 0.0 && v.polar_sor < 2.0)) throw InputError("polar_sor must lie in (0, 2)");
+    if (v.polar_accel < 0 || v.polar_accel > POLAR_ACCEL_MAX) throw InputError("polar_accel must lie in 0 .. 8");
+    h->ph.st = v;
     h->colors_valid = false;
     return POLAR_OK;
   });
@@ -381,7 +397,32 @@ int polar_set_positions(polar_handle *h, int nlocal, int nghost, const double *x
     //  returns the same address with other pages behind it -- LAMMPS re-creates its per-atom arrays between runs -- and the
     //  next DMA would then land in the stale pages.  A copy by four threads costs 0.1 ms at 260k atoms.)
     double *st = staging(h, 3 * nall + 6 * (size_t)nlocal);
-    host_chunks(3 * nall, [&](size_t a, size_t b) { memcpy(st + a, x + a, (b - a) * sizeof(double)); });
+    // one pass: the copy, the check polar_set_atoms makes (non-finite coordinates must not reach the cell build) and the
+    // bounding box polar_build_neighbors lays its grid over -- so that polar_set_positions -> polar_build_neighbors is as
+    // good as polar_set_atoms -> polar_build_neighbors
+    struct Ext { double lo[3], hi[3]; int bad; char pad[64]; };
+    const int nparts = nall < (1u << 14) ? 1 : std::min(8, HostPool::get().width());
+    Ext ext[8];
+    for (auto &e : ext) { for (int k = 0; k < 3; k++) { e.lo[k] = 1e300; e.hi[k] = -1e300; } e.bad = 0; }
+    const size_t per = (nall + nparts - 1) / nparts;
+    HostPool::get().run([&](int part) {
+      Ext &e = ext[part];
+      const size_t a0 = std::min(nall, (size_t)part * per), a1 = std::min(nall, ((size_t)part + 1) * per);
+      for (size_t a = a0; a < a1; a++)
+        for (int k = 0; k < 3; k++) {
+          const double v = x[3 * a + k];
+          st[3 * a + k] = v;
+          if (!(v - v == 0.0)) e.bad = 1;
+          e.lo[k] = v < e.lo[k] ? v : e.lo[k];
+          e.hi[k] = v > e.hi[k] ? v : e.hi[k];
+        }
+    }, nparts);
+    for (int k = 0; k < 3; k++) { h->bbox_lo[k] = 1e300; h->bbox_hi[k] = -1e300; }
+    for (const auto &e : ext) {
+      if (e.bad) throw InputError("non-finite atom coordinate");
+      for (int k = 0; k < 3; k++) { h->bbox_lo[k] = std::min(h->bbox_lo[k], e.lo[k]); h->bbox_hi[k] = std::max(h->bbox_hi[k], e.hi[k]); }
+    }
+    if (h->hx.size() == 3 * (size_t)nlocal) memcpy(h->hx.data(), st, 3 * (size_t)nlocal * sizeof(double));
     HIPCHECK(hipMemcpyAsync(h->d_x.p, st, 3 * nall * sizeof(double), hipMemcpyHostToDevice, h->stream));
     // (no synchronisation: the staging area is next written by the downloads of the compute call, which wait for the stream)
     return POLAR_OK;
@@ -711,21 +752,52 @@ int polar_set_list_style(polar_handle *h, int full) {
 }
 int polar_step_begin(polar_handle *h, int eflag, int vflag) {
   return guarded(h, [&]() {
-    HIPCHECK(hipSetDevice(h->device));
-    clear_flags(h);
-    try {
-      phase_begin(h, eflag, vflag, nullptr);
-    } catch (const TileUnavailable &) {
-      tile_fallback(h);
-      phase_begin(h, eflag, vflag, nullptr);
-    }
+    step_begin_lists(h, eflag, vflag);
+    step_begin_finish(h);
+    return POLAR_OK;
+  });
+}
+int polar_step_sweep_phase(polar_handle *h, int color, int part) {
+  return guarded(h, [&]() {
+    if (!h->in_step) throw std::runtime_error("polar_step_sweep_phase outside polar_step_begin/finish");
     const polar_settings &st = h->ph.st;
-    const bool clm = st.dd_cutoff > 0.0 && h->sweep_kernel == 3, tile = tile_mode(h);
-    if (st.dd_cutoff > 0.0 && !tile) resolve_colors(h);
-    if (!tile && !st.zodid && (st.polar_gs || st.polar_gs_ranked || clm) && !h->colors_valid) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
-    if (!st.zodid && st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && h->sweep_kernel == 2 && !slots_current(h)) { compute_slots(h); build_lists(h); }
-    if (!st.zodid && st.dd_cutoff > 0.0 && h->sweep_kernel == 2) prepare_lp(h);
-    h->in_step = true;
+    if (!(st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && h->sweep_kernel == 2)) throw InputError("polar_step_sweep_phase: colour phases exist for the Gauss-Seidel sweep of list mode only");
+    if (color < 0 || color >= (int)h->color_off.size() - 1 || part < 0 || part > 2) throw InputError("polar_step_sweep_phase: bad colour or part");
+    sweep_phase(h, color, part);
+    return POLAR_OK;
+  });
+}
+int polar_set_colors(polar_handle *h, const int *color, int n) {
+  return guarded(h, [&]() {
+    if (!color && n != 0) throw InputError("polar_set_colors: null pointer");
+    if (n == 0) { h->user_colors.clear(); h->user_colors_clashed = false; h->colors_valid = false; return POLAR_OK; }
+    if (!h->atoms_set || n != h->nlocal) throw InputError("polar_set_colors: one colour per local atom of the last polar_set_atoms");
+    for (int k = 0; k < n; k++) {
+      if (color[k] < -1 || color[k] > 63) throw InputError("polar_set_colors: colours are -1 (none) or 0 .. 63");
+      if ((color[k] >= 0) != (h->halpha[k] != 0.0)) throw InputError("polar_set_colors: exactly the polarizable atoms carry a colour");
+    }
+    h->user_colors.assign(color, color + n);
+    h->user_colors_clashed = false;
+    h->colors_valid = false;
+    return POLAR_OK;
+  });
+}
+int polar_set_positions_range(polar_handle *h, int lo, int hi, const double *x) {
+  return guarded(h, [&]() {
+    need_device(h);
+    HIPCHECK(hipSetDevice(h->device));
+    if (!h->atoms_set || lo < 0 || hi < lo || hi > h->nlocal + h->nghost) throw InputError("polar_set_positions_range: range outside the atoms of the last polar_set_atoms");
+    if (hi > lo && !x) throw InputError("polar_set_positions_range: null pointer");
+    const size_t cnt = 3 * (size_t)(hi - lo);
+    for (size_t k = 0; k < cnt; k++) if (!(x[k] - x[k] == 0.0)) throw InputError("non-finite atom coordinate");
+    double *st = staging(h, 3 * ((size_t)h->nlocal + h->nghost) + 6 * (size_t)h->nlocal);
+    if (cnt) {
+      memcpy(st, x, cnt * sizeof(double));
+      HIPCHECK(hipMemcpyAsync(h->d_x.p + 3 * (size_t)lo, st, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      for (int a = lo; a < std::min(hi, h->nlocal); a++) for (int k = 0; k < 3; k++) h->hx[3 * (size_t)a + k] = x[3 * (size_t)(a - lo) + k];
+      for (int a = lo; a < hi; a++) for (int k = 0; k < 3; k++) { const double v = x[3 * (size_t)(a - lo) + k]; h->bbox_lo[k] = std::min(h->bbox_lo[k], v); h->bbox_hi[k] = std::max(h->bbox_hi[k], v); }
+      HIPCHECK(hipStreamSynchronize(h->stream));   // (the staging area is the caller's to reuse)
+    }
     return POLAR_OK;
   });
 }

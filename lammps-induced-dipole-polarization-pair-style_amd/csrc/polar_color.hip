@@ -316,20 +316,36 @@ inline void build_colors(polar_handle *, const std::vector<double> &) { throw st
 //      cell grid), the small top class repaired by local exhaustive search, Jones-Plassmann rounds as the fallback; phase
 //      order and the rows of every phase in cell order.
 //      Needs this step's cell order (phase_begin has run) and, for the ranked flavour, the rank metric in d_rank (s space).
-void build_colors_device(polar_handle *h, bool ranked) {
-  const int n = h->nlocal;
-  hipStream_t s = h->stream;
-  const bool dbg = getenv("POLAR_DEBUG") != nullptr;
-  auto tprev = std::chrono::steady_clock::now();
-  auto lap = [&](const char *what) {   // POLAR_DEBUG: wall time since the last lap, the device drained first
-    if (!dbg) return;
+namespace {
+struct Lap {   // POLAR_DEBUG: wall time since the last lap, the device drained first
+  hipStream_t s; bool on; std::chrono::steady_clock::time_point t;
+  explicit Lap(hipStream_t st) : s(st), on(getenv("POLAR_DEBUG") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void operator()(const char *what) {
+    if (!on) return;
     HIPCHECK(hipStreamSynchronize(s));
     const auto tn = std::chrono::steady_clock::now();
-    fprintf(stderr, "[polar] colouring: %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(tn - tprev).count());
-    tprev = tn;
-  };
+    fprintf(stderr, "[polar] colouring: %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(tn - t).count());
+    t = tn;
+  }
+};
+// rows and rank sums per colour of the OWN rows -> h_cstat (pinned), number of colours in use on this handle
+int color_stats(polar_handle *h, bool ranked) {
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  HIPCHECK(hipMemsetAsync(h->d_cstat.p, 0, 128 * sizeof(double), s));
+  k_color_stats<<<nblk(n, 256), 256, 0, s>>>(n, h->d_color_s.p, ranked ? h->d_rank.p : nullptr, h->d_cstat.p, h->d_perm.p, own_lo(h), own_lo(h) + own_n(h));
+  HIPCHECK(hipMemcpyAsync(h->h_cstat, h->d_cstat.p, 128 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  int nc = 0;
+  for (int c = 0; c < 64; c++) if (h->h_cstat[2 * c] > 0.0) nc = c + 1;
+  return nc;
+}
+// stage 1: buffers and the conflict lists.  color_s = -1 everywhere afterwards.
+void color_adjacency(polar_handle *h, bool with_halo) {
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  Lap lap(s);
   lap("(work queued before)");
-  const long long ncell = h->ncell;
   if (!h->h_cflags) {
     HIPCHECK(hipHostMalloc((void **)&h->h_cflags, 96 * sizeof(int)));
     HIPCHECK(hipHostMalloc((void **)&h->h_cstat, 128 * sizeof(double)));
@@ -341,19 +357,33 @@ void build_colors_device(polar_handle *h, bool ranked) {
   HIPCHECK(hipMemsetAsync(h->d_color_orig.p, 0xFF, (size_t)(n + 1) * sizeof(int), s));
   const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
   const double dc2 = h->color_dist * h->color_dist;
+  {  // k_color_adj looks at the 3 x 3 x 3 cells around an atom: the colour distance must fit inside one cell
+    double wdt[3];
+    box_widths(h->box, wdt);
+    const double wmin = std::min({wdt[0] / h->grid.nc[0], wdt[1] / h->grid.nc[1], wdt[2] / h->grid.nc[2]});
+    if (h->color_dist > wmin) throw InputError("colour distance (POLAR_COLOR_DIST) beyond a cell width of the list grid (half the list cutoff): the conflict lists would miss pairs");
+  }
   for (int attempt = 0;; attempt++) {  // conflict lists; an atom with more neighbours than the lists hold makes them wider
     h->d_cadj.ensure((size_t)n * h->cadj_pitch + 16);
     HIPCHECK(hipMemsetAsync(flags, 0, 96 * sizeof(int), s));
     k_color_adj<<<nblk(n, 128), 128, 0, s>>>(n, h->d_pos4.p, h->d_perm.p, lo, hi, h->box, h->grid, h->d_cell_first.p, h->d_cell_fill.p, dc2,
-                                             h->cadj_pitch, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags);
+                                             h->cadj_pitch, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags, with_halo ? 1 : 0);
     HIPCHECK(hipMemcpyAsync(h->h_cflags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     if (h->h_cflags[0] <= h->cadj_pitch) break;
     if (h->h_cflags[0] > 62 || attempt > 3) throw std::runtime_error("colouring: more than 62 polarizable atoms within the colour distance of one atom (64 colours at most): reduce POLAR_COLOR_DIST");
     h->cadj_pitch = (h->h_cflags[0] + 4 + 7) / 8 * 8;
   }
-  const int ap_ = h->cadj_pitch;
   lap("conflict lists");
+}
+// stage 2: colour the own rows (colours of other ranks' rows, where known, are fixed constraints).  Returns the number of
+// colours in use among the own rows.
+int color_assign(polar_handle *h, bool ranked) {
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  Lap lap(s);
+  int *flags = h->d_cflags.p;
+  const int ap_ = h->cadj_pitch;
   // sequential DSATUR cell by cell (k_color_cells): one launch per parity class of the cell grid -- per dimension the even
   // cells, the odd cells and, when a periodic dimension has an odd count, its last cell on its own.  Safe while two cells of
   // a class (a whole cell apart) cannot hold neighbours: colour distance below the shortest cell edge.
@@ -402,15 +432,7 @@ void build_colors_device(polar_handle *h, bool ranked) {
   if (!coloured) throw std::runtime_error("colouring: Jones-Plassmann did not finish");
   lap("cell pass + rounds");
   if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] device colouring: %d rounds\n", rounds);
-  auto stats = [&]() {  // rows and rank sums per colour -> number of colours in use
-    HIPCHECK(hipMemsetAsync(h->d_cstat.p, 0, 128 * sizeof(double), s));
-    k_color_stats<<<nblk(n, 256), 256, 0, s>>>(n, h->d_color_s.p, ranked ? h->d_rank.p : nullptr, h->d_cstat.p);
-    HIPCHECK(hipMemcpyAsync(h->h_cstat, h->d_cstat.p, 128 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    int nc = 0;
-    for (int c = 0; c < 64; c++) if (h->h_cstat[2 * c] > 0.0) nc = c + 1;
-    return nc;
-  };
+  auto stats = [&]() { return color_stats(h, ranked); };
   int ncolors = stats();
   auto fold = [&]() {  // dissolve the highest class while that works
     for (int pass = 0; pass < 6 && ncolors > 1; pass++) {
@@ -466,6 +488,15 @@ void build_colors_device(polar_handle *h, bool ranked) {
     stale = ncolors < before ? 0 : stale + 1;
   }
   lap("iterated greedy");
+  return ncolors;
+}
+// stage 3: phase order from h_cstat (rows and rank sums per colour -- of this handle, or summed over the ranks by the
+// caller), relabel, and the rows of every phase in cell order (boundary rows first when the handle has boundary flags)
+void color_finish(polar_handle *h, bool ranked, int ncolors) {
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  Lap lap(s);
+  const long long ncell = h->ncell;
   if (ncolors > 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
   // phase order: "ranked" flavour = colours by descending mean rank metric (PS.cpp:192-227 ranks the dipoles most likely to
   // change first); otherwise by descending size
@@ -476,20 +507,26 @@ void build_colors_device(polar_handle *h, bool ranked) {
   for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
   HIPCHECK(hipMemcpyAsync(h->d_crelabel.p, relabel.data(), 64 * sizeof(int), hipMemcpyHostToDevice, s));
   k_color_relabel<<<nblk(n, 256), 256, 0, s>>>(n, h->d_crelabel.p, h->d_perm.p, h->d_color_s.p, h->d_color_orig.p);
-  // rows of every phase in cell order
-  const size_t ncc = (size_t)ncolors * ncell;
+  // rows of every phase in cell order; with boundary flags (multi-GPU) every phase lists its boundary rows first
+  const int *bflag = (h->bflag_n == n && sharded(h) && !deterministic(h)) ? h->d_bflag.p : nullptr;
+  const int nclass = bflag ? 2 * ncolors : ncolors;
+  if (nclass > 71) throw std::runtime_error("colouring: too many phase classes");
+  const size_t ncc = (size_t)nclass * ncell;
+  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
   h->d_ccnt.ensure(ncc + 1); h->d_coff.ensure(ncc + 2);
-  k_color_cellcount<<<nblk(ncell, 128), 128, 0, s>>>(ncell, ncolors, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_ccnt.p);
+  k_color_cellcount<<<nblk(ncell, 128), 128, 0, s>>>(ncell, nclass, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_ccnt.p, h->d_perm.p, lo, hi, bflag);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>((long long)ncc, h->d_ccnt.p, h->d_coff.p);
-  for (int c = 0; c <= ncolors; c++)
+  for (int c = 0; c <= nclass; c++)
     HIPCHECK(hipMemcpyAsync(h->h_coff + c, h->d_coff.p + (size_t)c * ncell, sizeof(long long), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));  // (also: `relabel` is a stack vector)
   h->color_off.assign((size_t)ncolors + 1, 0);
-  for (int c = 0; c <= ncolors; c++) h->color_off[c] = (int)h->h_coff[c];
+  h->color_mid.assign((size_t)ncolors, 0);
+  for (int c = 0; c <= ncolors; c++) h->color_off[c] = (int)h->h_coff[bflag ? 2 * c : c];
+  for (int c = 0; c < ncolors; c++) h->color_mid[c] = bflag ? (int)h->h_coff[2 * c + 1] : h->color_off[c + 1];   // (no flags: every row counts as a boundary row)
   const int tot = h->color_off[ncolors];
   h->d_rows_orig.ensure((size_t)tot + 1); h->d_rows.ensure((size_t)tot + 1);
-  k_color_fill<<<nblk(ncell, 128), 128, 0, s>>>(ncell, ncolors, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_perm.p, h->d_coff.p,
-                                               h->d_rows_orig.p);
+  k_color_fill<<<nblk(ncell, 128), 128, 0, s>>>(ncell, nclass, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_perm.p, h->d_coff.p,
+                                               h->d_rows_orig.p, lo, hi, bflag);
   lap("phase order + rows");
 #ifdef POLAR_LAB
   if (getenv("POLAR_LP_SORT_T") && tot > 0) {   // lab: inside a phase the rows with the most trips first (stable: cell order inside a trip count)
@@ -515,6 +552,59 @@ void build_colors_device(polar_handle *h, bool ranked) {
   }
   h->colors_valid = true;
 }
+}  // namespace
+
+void build_colors_device(polar_handle *h, bool ranked) {
+  color_adjacency(h, false);
+  const int ncolors = color_assign(h, ranked);
+  color_finish(h, ranked, ncolors);
+  h->colors_global = false;
+}
+
+// ONE colouring consistent across the ranks of a multi-GPU run (polar_dist): no two rows of one colour closer than the colour
+// distance, whichever ranks own them -- so that the colour phases of all ranks together are the single-GPU iteration and a
+// per-phase exchange of boundary dipoles loses nothing.  Ranks take turns by class (no two peers share a class, polar_dist
+// derives the classes from the peer graph): a rank colours its rows with the sequential DSATUR above against the colours its
+// already-coloured neighbours' rows hold in its halo; after every turn the colours of the halo rows travel (cc.exchange).
+// Phase order and labels come from the all-reduced rows / rank sums per colour, identical on every rank.
+void build_colors_distributed(polar_handle *h, bool ranked, ColorComm &cc) {
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!(h->sorted && h->ph.st.dd_cutoff > 0.0 && h->sweep_kernel == 2 && h->pol_first)) throw std::logic_error("distributed colouring: needs the row sweep of list mode");
+  if (ranked) { launch_rank_pass(h, false, 1); launch_rank_pass(h, false, 2); }   // a2 of the own rows for the phase order
+  color_adjacency(h, true);
+  for (int cls = 0; cls < cc.nclasses; cls++) {
+    if (cls == cc.my_class) (void)color_assign(h, ranked);
+    cc.exchange(h->d_color_s.p);     // halo rows take their owners' colours (collective: every rank, every turn)
+  }
+  (void)color_stats(h, ranked);      // own rows -> h_cstat
+  cc.allreduce(h->h_cstat, 128);     // -> rows and rank sums per colour over all ranks
+  int ncolors = 0;
+  for (int c = 0; c < 64; c++) if (h->h_cstat[2 * c] > 0.0) ncolors = c + 1;
+  color_finish(h, ranked, ncolors);
+  h->colors_global = true;
+  h->ms_color_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// polar_set_colors: a colouring handed in by the caller (own rows and, on a sharded handle, the halo rows): phases in the
+// order of the colour numbers, rows of a phase in cell order.  Needs this step's cell order.
+void apply_imposed_colors(polar_handle *h) {
+  const int n = h->nlocal;
+  hipStream_t s = h->stream;
+  if ((int)h->user_colors.size() != n) throw std::logic_error("imposed colours: atom count changed");
+  if (!h->h_cflags) {
+    HIPCHECK(hipHostMalloc((void **)&h->h_cflags, 96 * sizeof(int)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_cstat, 128 * sizeof(double)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_coff, 72 * sizeof(long long)));
+  }
+  h->d_color_s.ensure(n + 1); h->d_color_orig.ensure(n + 1); h->d_cstat.ensure(128); h->d_crelabel.ensure(64);
+  HIPCHECK(hipMemcpyAsync(h->d_color_orig.p, h->user_colors.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+  k_color_map<<<nblk(n, 256), 256, 0, s>>>(n, h->d_perm.p, h->d_color_orig.p, h->d_color_s.p);
+  int ncolors = 0;
+  for (int c : h->user_colors) ncolors = std::max(ncolors, c + 1);
+  for (int c = 0; c < 64; c++) { h->h_cstat[2 * c] = (double)(64 - c); h->h_cstat[2 * c + 1] = (double)(64 - c); }   // identity relabel: keep the caller's order
+  color_finish(h, false, ncolors);
+  h->colors_global = true;
+}
 // ---- the solve: a6+a7 (PS.cpp:1113-1238) -----------------------------------------------------
 void ensure_colors(polar_handle *h) {
   if (h->colors_valid) return;
@@ -522,7 +612,9 @@ void ensure_colors(polar_handle *h) {
   const int n = h->nlocal;
   const auto t0 = std::chrono::steady_clock::now();
   const bool on_device = h->sorted && st.dd_cutoff > 0.0 && h->sweep_kernel == 2 && !h->host_colors && h->pol_first;
-  if (on_device) {
+  if (on_device && !h->user_colors.empty() && (int)h->user_colors.size() == n && !h->user_colors_clashed) {
+    apply_imposed_colors(h);
+  } else if (on_device) {
     build_colors_device(h, st.polar_gs_ranked != 0);
   } else {  // lab paths (cluster rows, POLAR_HOST_COLORS): the host-side conflict graph + DSATUR of rounds 1-2
     std::vector<double> rk;
@@ -556,5 +648,7 @@ void resolve_colors(polar_handle *h) {
   HIPCHECK(hipStreamSynchronize(h->stream));
   if (!clash) { h->colors_reused++; return; }
   h->colors_valid = false;
+  if (!h->user_colors.empty()) h->user_colors_clashed = true;   // the caller's colouring no longer separates its classes: the library's own takes over
   if (h->ph.st.polar_gs_ranked) { launch_rank_pass(h, false, 1); launch_rank_pass(h, false, 2); }  // a2 for the phase order
 }
+

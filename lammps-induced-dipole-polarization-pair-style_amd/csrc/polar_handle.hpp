@@ -175,9 +175,17 @@ struct polar_handle {
   long long nneigh = 0;
   bool mu_resident = false;
   DBuf<double> d_dbgf;           // `debug yes`: {force on atom 0, its dipole-dipole part} of the last compute
+  DBuf<double> d_mu0;            // use_previous: the initial guess of the running step (a retry after a pitch overflow starts from it again)
+  bool mu0_saved = false;
+  int attempt = 0;               // which attempt of the running step (do_compute)
   bool mu_host_in_sync = false;  // the caller's mu array still holds what the last polar_compute returned (no polar_set_atoms since)
   // colour phases (cutoff-mode Gauss-Seidel)
   std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
+  std::vector<int> color_mid;  // [ncolors] end of a phase's BOUNDARY rows (multi-GPU: rows whose dipoles a peer receives come first)
+  DBuf<int> d_bflag; int bflag_n = 0;   // boundary flags by original index (polar_dist_set_halo), 0 = none
+  bool colors_global = false;  // the colouring in force is consistent across the ranks of a multi-GPU run (halo rows carry their owners' colours)
+  std::vector<int> user_colors;  // polar_set_colors: a colouring imposed by the caller (original order, -1 = none)
+  bool user_colors_clashed = false;
   std::vector<int> h_rows;     // rows sorted by colour (host copy)
   bool colors_valid = false;
   double color_keep = 2.0;      // A (POLAR_COLOR_KEEP): a colouring built at color_dist stays in use on later lists while
@@ -432,9 +440,16 @@ void tile_fallback(polar_handle *h);
 bool grow_pitches(polar_handle *h);
 int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, polar_result *out);
 void step_begin_lists(polar_handle *h, int eflag, int vflag);   // polar_step_begin up to the point where the colour phases are needed
+bool step_needs_colors(const polar_handle *h);
 void step_begin_finish(polar_handle *h);                        // ... and from there on (rows into launch order, descriptors)
 void build_cluster_lists(polar_handle *h);
 // ---- polar_color.hip --------------------------------------------------------------------------------------------------
 void ensure_colors(polar_handle *h);
+struct ColorComm {   // what a distributed colouring needs from the transport (polar_dist.hip)
+  int my_class = 0, nclasses = 1;
+  std::function<void(int *color_s_dev)> exchange;           // halo rows <- their owners' colours (s space, device)
+  std::function<void(double *host, int count)> allreduce;   // sum over the ranks, in place (pinned host memory)
+};
+void build_colors_distributed(polar_handle *h, bool ranked, ColorComm &cc);
 void map_color_rows(polar_handle *h);
 void resolve_colors(polar_handle *h);

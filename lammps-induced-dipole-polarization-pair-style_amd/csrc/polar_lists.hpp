@@ -167,7 +167,11 @@ __device__ __forceinline__ unsigned color_hash(unsigned x) {
 static __global__ void k_color_adj(int n, const double4 *__restrict__ pos4, const int *__restrict__ perm, int own_lo, int own_hi,
                             Box box, CellGrid g, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                             double colordistsq, int apitch, int *__restrict__ adj, int *__restrict__ deg,
-                            unsigned long long *__restrict__ prio, int *__restrict__ color_s, int *__restrict__ flags) {
+                            unsigned long long *__restrict__ prio, int *__restrict__ color_s, int *__restrict__ flags,
+                            int with_halo) {
+  // `with_halo` (multi-GPU, one colouring consistent across the ranks): the polarizable atoms this handle holds for other
+  // ranks' rows count as neighbours too.  They are never coloured here (deg = -1): their colour arrives from their owner
+  // (-1 until then: an uncoloured neighbour constrains nothing, its owner will respect OUR colours when its turn comes).
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double4 ri = pos4[i];
@@ -210,7 +214,7 @@ static __global__ void k_color_adj(int n, const double4 *__restrict__ pos4, cons
           min_image_rint(box, ri.x, ri.y, ri.z, rj.x, rj.y, rj.z, ex, ey, ez);
           if (ex * ex + ey * ey + ez * ez < colordistsq) {
             const int oj = perm[j];
-            if (oj < own_lo || oj >= own_hi) continue;
+            if (!with_halo && (oj < own_lo || oj >= own_hi)) continue;
             if (d < apitch) adj[(size_t)i * apitch + d] = j;
             d++;
           }
@@ -320,7 +324,7 @@ static __global__ void k_color_fold(int n, int apitch, int top, const int *__res
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || deg[i] < 0 || color_s[i] != top) return;
   unsigned long long used = 0ull;
-  for (int k = 0; k < deg[i]; k++) used |= 1ull << color_s[adj[(size_t)i * apitch + k]];  // (no neighbour has colour `top`)
+  for (int k = 0; k < deg[i]; k++) { const int cj = color_s[adj[(size_t)i * apitch + k]]; if (cj >= 0) used |= 1ull << cj; }  // (no neighbour has colour `top`; -1: a halo atom its owner has not coloured yet)
   const int c = __ffsll((long long)~used) - 1;
   if (c < top) color_s[i] = c;
   else atomicAdd(stay, 1);
@@ -380,6 +384,7 @@ static __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict_
       const int node = ball[q];
       const int d = deg[node];
       int j = lane < d ? adj[(size_t)node * apitch + lane] : -1;
+      if (j >= 0 && deg[j] < 0) j = -1;   // another rank's row: its colour is fixed
       if (j >= 0) for (int k = 0; k < m; k++) if (ball[k] == j) { j = -1; break; }
       const unsigned long long fresh = __ballot(j >= 0);
       const int at = m + __popcll(fresh & ((1ull << lane) - 1ull));
@@ -400,7 +405,7 @@ static __global__ __launch_bounds__(64) void k_color_ball(const int *__restrict_
       int at = -1;
       for (int q = 0; q < m; q++) if (ball[q] == j) { at = q; break; }
       if (at >= 0) in |= 1ull << at;
-      else used |= 1ull << color_s[j];
+      else { const int cj = color_s[j]; if (cj >= 0) used |= 1ull << cj; }
     }
     allow = ~used & ((1ull << top) - 1ull);
   }
@@ -442,13 +447,14 @@ static __global__ void k_color_regroup(int n, const int *__restrict__ deg, const
 }
 // per colour: rows and the sum of their rank metric (phase order of the ranked flavour)
 static __global__ __launch_bounds__(256) void k_color_stats(int n, const int *__restrict__ color_s, const double *__restrict__ rank,
-                                                     double *__restrict__ sums) {
+                                                     double *__restrict__ sums, const int *__restrict__ perm, int own_lo, int own_hi) {
   // (summed per workgroup in LDS first: a hundred thousand FP64 atomics on five addresses took 2 ms)
   __shared__ double part[128];
   if (threadIdx.x < 128) part[threadIdx.x] = 0.0;
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = i < n ? color_s[i] : -1;
+  int c = i < n ? color_s[i] : -1;
+  if (c >= 0) { const int o = perm[i]; if (o < own_lo || o >= own_hi) c = -1; }   // (a halo atom carries its owner's colour: not a row here)
   if (c >= 0) {
     atomicAdd(&part[2 * c], 1.0);
     atomicAdd(&part[2 * c + 1], rank ? rank[i] : 1.0);
@@ -464,27 +470,39 @@ static __global__ void k_color_relabel(int n, const int *__restrict__ relabel, c
   color_s[i] = c;
   color_orig[perm[i]] = c;
 }
-// rows of every phase, cells in order, atoms of a cell in order: counts per (colour, cell), one scan, fill
-static __global__ void k_color_cellcount(long long ncell, int ncolors, const long long *__restrict__ cell_first, const int *__restrict__ npol,
-                                  const int *__restrict__ color_s, int *__restrict__ cnt) {
+// rows of every phase, cells in order, atoms of a cell in order: counts per (class, cell), one scan, fill.  Rows = the
+// polarizable atoms this handle owns (halo atoms carry their owners' colours and are skipped).  Without `bflag` a class is a
+// colour; with it (multi-GPU: bflag[orig] = "a peer receives this row's dipole") class 2c holds colour c's boundary rows and
+// class 2c + 1 its interior rows, so that a phase can send its boundary rows off while the interior rows are still swept.
+__device__ __forceinline__ int color_class(int j, const int *__restrict__ color_s, const int *__restrict__ perm, int own_lo, int own_hi,
+                                           const int *__restrict__ bflag) {
+  const int c = color_s[j];
+  if (c < 0) return -1;
+  const int o = perm[j];
+  if (o < own_lo || o >= own_hi) return -1;
+  return bflag ? 2 * c + (bflag[o] ? 0 : 1) : c;
+}
+static __global__ void k_color_cellcount(long long ncell, int nclass, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+                                  const int *__restrict__ color_s, int *__restrict__ cnt, const int *__restrict__ perm, int own_lo, int own_hi,
+                                  const int *__restrict__ bflag) {
   const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (c >= ncell) return;
   const int a = (int)cell_first[c], e = a + npol[c];
-  for (int q = 0; q < ncolors; q++) {
+  for (int q = 0; q < nclass; q++) {
     int k = 0;
-    for (int j = a; j < e; j++) k += color_s[j] == q;
+    for (int j = a; j < e; j++) k += color_class(j, color_s, perm, own_lo, own_hi, bflag) == q;
     cnt[(size_t)q * ncell + c] = k;
   }
 }
-static __global__ void k_color_fill(long long ncell, int ncolors, const long long *__restrict__ cell_first, const int *__restrict__ npol,
+static __global__ void k_color_fill(long long ncell, int nclass, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                              const int *__restrict__ color_s, const int *__restrict__ perm, const long long *__restrict__ off,
-                             int *__restrict__ rows_orig) {
+                             int *__restrict__ rows_orig, int own_lo, int own_hi, const int *__restrict__ bflag) {
   const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (c >= ncell) return;
   const int a = (int)cell_first[c], e = a + npol[c];
-  for (int q = 0; q < ncolors; q++) {
+  for (int q = 0; q < nclass; q++) {
     long long w = off[(size_t)q * ncell + c];
-    for (int j = a; j < e; j++) if (color_s[j] == q) rows_orig[w++] = perm[j];
+    for (int j = a; j < e; j++) if (color_class(j, color_s, perm, own_lo, own_hi, bflag) == q) rows_orig[w++] = perm[j];
   }
 }
 
@@ -1106,6 +1124,42 @@ static __global__ void k_mu_scatter_idx(long long n, const int *__restrict__ idx
   if (o < 0 || (o >= own_lo && o < own_hi)) return;  // padding, or a row this handle owns itself
   double *r = mu_of(v, scal, inv ? inv[o] : o);
   r[1] = src[3 * t]; r[3] = src[3 * t + 1]; r[5] = src[3 * t + 2];
+}
+
+// the same plumbing for the colours of a distributed colouring (int per atom, s space: color_s) and for positions
+// (orig space: x[nall][3]); idx = handle-local atom indices
+// (colours travel as doubles: one data type on the wire)
+static __global__ void k_color_gather_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const int *__restrict__ color_s,
+                                          double *__restrict__ dst) {
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  dst[t] = (double)color_s[inv ? inv[idx[t]] : idx[t]];
+}
+static __global__ void k_color_scatter_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, int *__restrict__ color_s,
+                                           const double *__restrict__ src) {
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  color_s[inv ? inv[idx[t]] : idx[t]] = (int)src[t];
+}
+static __global__ void k_vec3_gather_idx(long long n, const int *__restrict__ idx, const double *__restrict__ x, double *__restrict__ dst) {
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const size_t o = (size_t)idx[t];
+  dst[3 * t] = x[3 * o]; dst[3 * t + 1] = x[3 * o + 1]; dst[3 * t + 2] = x[3 * o + 2];
+}
+static __global__ void k_vec3_scatter_idx(long long n, const int *__restrict__ idx, double *__restrict__ x, const double *__restrict__ src) {
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const size_t o = (size_t)idx[t];
+  x[3 * o] = src[3 * t]; x[3 * o + 1] = src[3 * t + 1]; x[3 * o + 2] = src[3 * t + 2];
+}
+// periodic images: atom first + g sits at its owner's position plus a whole number of box vectors
+static __global__ void k_ghost_images(long long n, long long first, const int *__restrict__ owner, const double *__restrict__ shift,
+                                      double *__restrict__ x) {
+  long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const size_t o = (size_t)owner[g], a = (size_t)(first + g);
+  x[3 * a] = x[3 * o] + shift[3 * g]; x[3 * a + 1] = x[3 * o + 1] + shift[3 * g + 1]; x[3 * a + 2] = x[3 * o + 2] + shift[3 * g + 2];
 }
 
 // small utilities

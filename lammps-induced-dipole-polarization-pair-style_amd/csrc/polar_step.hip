@@ -569,6 +569,18 @@ void sweep_once(polar_handle *h, bool ap) {
   }
 }
 
+// one colour phase of the list-mode Gauss-Seidel (row sweep): part 0 = all its rows, 1 = its boundary rows (rows whose
+// dipoles a peer of a multi-GPU run receives: they come first in the phase), 2 = its interior rows.  `deterministic yes`
+// keeps a phase in one launch (its partial sums are laid out per launch): part 1 = everything, part 2 = nothing.
+void sweep_phase(polar_handle *h, int c, int part) {
+  const int ncol = (int)h->color_off.size() - 1;
+  if (c < 0 || c >= ncol) throw std::logic_error("sweep_phase: no such colour");
+  const int a = h->color_off[c], b = h->color_off[c + 1];
+  const int m = ((int)h->color_mid.size() == ncol && !deterministic(h)) ? h->color_mid[c] : b;
+  const int lo = part == 2 ? m : a, hi = part == 1 ? m : b;
+  launch_field_lp<EP_INPLACE>(h, hi - lo, h->d_lpdesc.p + lo);
+}
+
 template <bool AP, int DAMP>
 void launch_force(polar_handle *h, int eflag, int vglobal, double *vatom, double *fdst) {
   const bool vpair = vglobal || vatom;
@@ -814,10 +826,18 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     // the caller's mu_induced (PS.cpp:376-386 reads atom->mu_induced).  Between two polar_set_atoms calls the atoms keep
     // their places and the caller's array is what the last compute call wrote into it: the resident copy is the same
     // numbers (a caller that edits mu_induced in between goes through polar_upload_mu or polar_set_atoms)
-    if (mu_host && !(h->mu_resident && h->mu_host_in_sync)) {
-      HIPCHECK(hipMemcpyAsync(h->d_mu.p, mu_host, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
-      mu0 = h->d_mu.p;
-    } else if (h->mu_resident) mu0 = h->d_mu.p;
+    if (h->attempt > 0) {
+      // a retry after an outgrown pitch starts from the SAME guess as the first attempt: the failed attempt has overwritten
+      // d_mu (k_unpack) and, through the early download, the caller's array
+      if (h->mu0_saved) { HIPCHECK(hipMemcpyAsync(h->d_mu.p, h->d_mu0.p, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s)); mu0 = h->d_mu.p; }
+    } else {
+      if (mu_host && !(h->mu_resident && h->mu_host_in_sync)) {
+        HIPCHECK(hipMemcpyAsync(h->d_mu.p, mu_host, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        mu0 = h->d_mu.p;
+      } else if (h->mu_resident) mu0 = h->d_mu.p;
+      h->mu0_saved = mu0 != nullptr;
+      if (mu0) { h->d_mu0.ensure(3 * (size_t)n + 3); HIPCHECK(hipMemcpyAsync(h->d_mu0.p, h->d_mu.p, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s)); }
+    }
   }
   h->sorted = false;
   h->dense_gs = false;
@@ -939,6 +959,7 @@ int phase_finish(polar_handle *h, polar_result *out) {
   }
   read_scal(h);
   h->mu_resident = true;
+  h->mu_host_in_sync = false;  // d_mu has new numbers; polar_compute / polar_compute_peratom set this again once the caller's array holds them
 
   const Scal &sc = *h->h_scal;
   out->eng_vdwl = sc.eng_vdwl; out->eng_coul = sc.eng_coul;
@@ -1013,8 +1034,10 @@ int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, pol
   const bool ap = !(h->ph.st.dd_cutoff > 0.0);
   int rc = 0;
   bool done = false;
+  struct Attempt { polar_handle *h; ~Attempt() { h->attempt = 0; } } guard{h};
   for (int attempt = 0; attempt < 5; attempt++) {
     clear_flags(h);
+    h->attempt = attempt;
     try {
       phase_begin(h, eflag, vflag, mu_host);
     } catch (const TileUnavailable &) {  // density beyond what a workgroup can stage: the row sweep takes over
@@ -1030,4 +1053,33 @@ int do_compute(polar_handle *h, int eflag, int vflag, const double *mu_host, pol
   }
   if (!done) throw std::runtime_error("neighbor list pitch overflow persists");
   return rc;
+}
+
+// polar_step_begin in two halves, so that a multi-GPU driver can agree on failures and on a common colouring in between:
+// step_begin_lists = everything up to the point where the colour phases are needed (PS.cpp:125-386: lists, a3 forked, static
+// field, initial guess; on reneighbor steps the verdict on the colouring in use); step_begin_finish = the colouring if it is
+// still missing (this handle's own), rows into launch order, descriptors.
+void step_begin_lists(polar_handle *h, int eflag, int vflag) {
+  HIPCHECK(hipSetDevice(h->device));
+  clear_flags(h);
+  try {
+    phase_begin(h, eflag, vflag, nullptr);
+  } catch (const TileUnavailable &) {
+    tile_fallback(h);
+    phase_begin(h, eflag, vflag, nullptr);
+  }
+  if (h->ph.st.dd_cutoff > 0.0 && !tile_mode(h)) resolve_colors(h);
+}
+bool step_needs_colors(const polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  const bool clm = st.dd_cutoff > 0.0 && h->sweep_kernel == 3;
+  return st.dd_cutoff > 0.0 && !tile_mode(h) && !st.zodid && (st.polar_gs || st.polar_gs_ranked || clm) && !h->colors_valid;
+}
+void step_begin_finish(polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  const bool clm = st.dd_cutoff > 0.0 && h->sweep_kernel == 3;
+  if (step_needs_colors(h)) { ensure_colors(h); if (clm) build_cluster_lists(h); else map_color_rows(h); }
+  if (!st.zodid && st.dd_cutoff > 0.0 && (st.polar_gs || st.polar_gs_ranked) && h->sweep_kernel == 2 && !slots_current(h)) { compute_slots(h); build_lists(h); }
+  if (!st.zodid && st.dd_cutoff > 0.0 && h->sweep_kernel == 2) prepare_lp(h);
+  h->in_step = true;
 }

@@ -195,6 +195,35 @@ class P2PHaloPlan:
         return np.concatenate([self.send[r][rank] for r in peers]) if peers else np.zeros(0, dtype=np.int32)
 
 
+def rank_classes(peer_lists):
+    """Turns of a colouring shared by the ranks (polar_dist_set_schedule): greedy colouring of the peer graph in rank order,
+    so that no two peers share a class.  ``peer_lists[r]`` = the peers of rank r.  Returns (class of every rank, classes).
+    A ring of an even number of slabs gets 2 classes, three mutually adjacent ranks 3."""
+    cls = []
+    for r, peers in enumerate(peer_lists):
+        used = {cls[q] for q in peers if q < r}
+        c = 0
+        while c in used:
+            c += 1
+        cls.append(c)
+    return cls, (max(cls) + 1 if cls else 0)
+
+
+def ghost_map(shard):
+    """(owner, shift) of the periodic images a compact shard holds behind its local atoms (polar_dist_set_ghosts): the local
+    index of the atom a ghost is an image of, and the whole box vectors between them."""
+    n, ng = shard.nlocal, shard.nghost
+    gid = np.asarray(shard.owner)
+    order = np.argsort(gid[:n], kind="stable")
+    pos = np.searchsorted(gid[:n][order], gid[n:])
+    pos = np.minimum(pos, max(n - 1, 0))
+    owner = order[pos] if n else np.zeros(0, dtype=np.int64)
+    if ng and not np.array_equal(gid[:n][owner], gid[n:]):
+        raise ValueError("a ghost image whose owner the shard does not hold")
+    shift = shard.x[n:] - shard.x[owner] if ng else np.zeros((0, 3))
+    return owner.astype(np.int32), np.ascontiguousarray(shift)
+
+
 def p2p_buffers(backend, plan, rank, compact_lo=None):
     """Device index lists and packed buffers of one rank: segments ordered by peer.
     ``compact_lo``: the handle holds only [own | halo | ghosts] (workload.compact_shard) -- own atom g
@@ -516,6 +545,8 @@ def bench_distributed(args, rank, world, local_rank):
         REDUCE_EVERY = 2   # bench cadence: at most one sweep past the stop rule for half of the all-reduce latencies
     backend_name = os.environ.get("POLAR_DIST_BACKEND", "nccl")
     if backend_name == "nccl":
+        if torch.cuda.device_count() <= local_rank:   # never an N = 1 line for a --gpus N request
+            raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({torch.cuda.device_count()} visible, RCCL takes one rank per device)")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -603,6 +634,7 @@ def bench_distributed(args, rank, world, local_rank):
     # for the all-gather variant.
     driver = None
     driver_fallback = None
+    lag, ncls = -1, 0
     if backend_name == "nccl" and isinstance(plan, P2PHaloPlan) and os.environ.get("POLAR_DIST_DRIVER", "cpp") == "cpp":
         ids = [pkg.PolarDist.unique_id() if rank == 0 else None]
         if world > 1:
@@ -618,8 +650,14 @@ def bench_distributed(args, rank, world, local_rank):
                 m = len(plan.send[r][rank])
                 recv_lists.append(np.arange(at, at + m, dtype=np.int32))
                 at += m
-            driver.set_halo(peers, send_lists, recv_lists)
+            driver.set_halo(p, peers, send_lists, recv_lists)
             driver.set_cadence(REDUCE_EVERY, 4)
+            # one colouring shared by the ranks + per-phase exchanges on a second stream (POLAR_DIST_LAG=-1: the round-3
+            # schedule, every rank colouring for itself and one exchange per sweep)
+            lag = int(os.environ.get("POLAR_DIST_LAG", "1"))
+            cls, ncls = rank_classes([plan.peers(r) for r in range(world)])
+            driver.set_schedule(lag, cls[rank], ncls if lag >= 0 else 0)
+            driver.set_ghosts(p, *ghost_map(s))
         except Exception as e:  # noqa: BLE001 -- the communicator could not be made on this rank: all ranks must take the same loop
             driver_error = repr(e)
         ok = torch.tensor([0.0 if driver_error else 1.0], dtype=torch.float64, device=be.dev)
@@ -674,8 +712,12 @@ def bench_distributed(args, rank, world, local_rank):
                        "atoms_held_rank0": n_held, "halo_rows_per_rank": plan.counts, "rows_per_rank": counts,
                        "peers_rank0": len(plan.peers(0)) if hasattr(plan, "peers") else None,
                        "stop_rule_allreduce_every_sweeps": REDUCE_EVERY,
-                       "sweep_loop": ("in-library C++ driver (polar_dist_step): pack kernel, ncclGroupStart/Send/Recv/End, unpack kernel and the "
-                                      "all-reduced stop rule enqueued on the compute stream, state read every 4 sweeps") if driver is not None
+                       "rccl_ranks": driver.comm_count() if driver is not None else None,
+                       "schedule": (f"one colouring shared by the ranks ({ncls} turns), colour c's boundary dipoles exchanged after phase c on a second stream, "
+                                    f"a phase waits for the exchange issued {lag + 1} phase(s) earlier" if driver is not None and lag >= 0
+                                    else "every rank colours for itself, one exchange of all halo dipoles per sweep (block-Jacobi across ranks)"),
+                       "sweep_loop": ("in-library C++ driver (polar_dist_step): pack kernel, ncclGroupStart/Send/Recv/End, unpack kernel on the "
+                                      "communication stream, the all-reduced stop rule on the compute stream, state read every 4 sweeps") if driver is not None
                                      else "Python loop over the stepwise C-ABI (torch.distributed collectives)" + (f" -- C++ driver unavailable: {driver_fallback}" if driver_fallback else ""),
                        "exchanges_last_step": out.get("exchanges"), "allreduces_last_step": out.get("allreduces"),
                        "kernel_version": pkg.kernel_version()},

@@ -349,6 +349,7 @@ class PolarSettings:
     deterministic: int = 0  # extension: sweeps commit their updates between launches (bit-reproducible runs)
     polar_sor: float = 1.0  # extension: over-relaxation factor of the list-mode Gauss-Seidel update (1 = reference)
     rccl_halo: int = 0      # extension: the LAMMPS shim's multi-rank sweeps run through the library's RCCL driver
+    polar_accel: int = 0    # extension: Anderson mixing of this depth on the list-mode Gauss-Seidel sweep map (0 = off)
 
 
 @dataclass
@@ -761,6 +762,10 @@ def parse_pair_style_args(args, base=None):
             st.deterministic = yn[v]
         elif k == "rccl_halo":  # extension keyword (not in the reference)
             st.rccl_halo = yn[v]
+        elif k == "polar_accel":  # extension keyword (not in the reference)
+            st.polar_accel = int(v)
+            if not 0 <= st.polar_accel <= 8:
+                raise ValueError("Illegal pair_style command")
         elif k == "polar_sor":  # extension keyword (not in the reference)
             st.polar_sor = float(v)
             if not 0.0 < st.polar_sor < 2.0:

@@ -128,10 +128,17 @@ void PairLJCutCoulLongPolarizationMI355X::compute(int eflag, int vflag)
   int periodic[3] = {domain->xperiodic,domain->yperiodic,domain->zperiodic};
   check(polar_set_box(h,domain->boxlo,domain->prd,tilt,periodic,domain->triclinic));
   // atoms are reordered, exchanged and re-ghosted only when the lists are rebuilt: in between only their positions move
-  if (neighbor->ago == 0 || !atoms_sent || atom->nlocal != sent_nlocal || atom->nghost != sent_nghost) {
+  // (the reference re-reads atom->q every step, PS.cpp:125-188: a fix that changes charges between two list builds --
+  //  fix qeq/*, fix adapt charge -- is noticed by comparing with the charges last sent, 8 B per atom, and answered with a
+  //  full upload.  static_polarizability, type and molecule only change through commands that force a new list.)
+  const int nall_now = atom->nlocal + atom->nghost;
+  const bool q_changed = atoms_sent && (int) q_sent.size() == nall_now && nall_now > 0 &&
+                         memcmp(q_sent.data(),atom->q,(size_t) nall_now*sizeof(double)) != 0;
+  if (neighbor->ago == 0 || !atoms_sent || atom->nlocal != sent_nlocal || atom->nghost != sent_nghost || q_changed) {
     check(polar_set_atoms(h,atom->nlocal,atom->nghost,&atom->x[0][0],atom->q,atom->static_polarizability,
                           atom->type,(const int *) atom->molecule));
     atoms_sent = 1; sent_nlocal = atom->nlocal; sent_nghost = atom->nghost;
+    q_sent.assign(atom->q,atom->q + nall_now);
   } else check(polar_set_positions(h,atom->nlocal,atom->nghost,&atom->x[0][0]));
   if (neighbor->ago == 0) {
     check(polar_set_newton(h,force->newton_pair));       // PS.cpp:293 and the ev_tally weights read force->newton_pair
@@ -285,8 +292,26 @@ void PairLJCutCoulLongPolarizationMI355X::build_rccl_plan()
     for (int k = rdisp[r]; k < rdisp[r + 1]; k++) rflat.push_back(nlocal + rslot[k]);
   }
   sflat.push_back(0); rflat.push_back(0); peers.push_back(0); sc.push_back(0); rc_.push_back(0);   // (never empty pointers)
-  if (polar_dist_set_halo(dist,(int) peers.size() - 1,peers.data(),sc.data(),sflat.data(),rc_.data(),rflat.data()) < 0)
+  if (polar_dist_set_halo(dist,h,(int) peers.size() - 1,peers.data(),sc.data(),sflat.data(),rc_.data(),rflat.data()) < 0)
     error->one(FLERR,polar_dist_last_error(dist));
+  // ONE colouring shared by the ranks: they colour in turns, and no two peers may share a turn -- greedy colouring of the peer
+  // graph in rank order, computed identically by every rank from the gathered peer lists.  Boundary dipoles then travel after
+  // every colour phase on the library's communication stream, at most one phase late (polar_dist_set_schedule, lag 1).
+  std::vector<int> ispeer(np,0), allpeer((size_t) np*np,0), cls(np,0);
+  for (size_t k = 0; k + 1 < peers.size(); k++) if (peers[k] != me) ispeer[peers[k]] = 1;
+  MPI_Allgather(ispeer.data(),np,MPI_INT,allpeer.data(),np,MPI_INT,world);
+  int ncls = 0;
+  for (int r = 0; r < np; r++) {
+    int c = 0;
+    for (bool again = true; again; ) {
+      again = false;
+      for (int q2 = 0; q2 < r; q2++)
+        if ((allpeer[(size_t) r*np + q2] || allpeer[(size_t) q2*np + r]) && cls[q2] == c) { c++; again = true; break; }
+    }
+    cls[r] = c;
+    if (c + 1 > ncls) ncls = c + 1;
+  }
+  if (polar_dist_set_schedule(dist,1,cls[me],ncls) < 0) error->one(FLERR,polar_dist_last_error(dist));
 }
 
 void PairLJCutCoulLongPolarizationMI355X::exchange_dipoles()
@@ -373,6 +398,13 @@ void PairLJCutCoulLongPolarizationMI355X::compute_sharded(int eflag, int vflag)
     int rc = polar_dist_step(dist,h,ef,vf,&res);
     if (rc < 0) error->one(FLERR,polar_dist_last_error(dist));
     check(rc);
+    // polar_dist_step returns energies and virial SUMMED over the ranks; LAMMPS sums the per-rank accumulators itself
+    // (compute_pe.cpp:80, thermo.cpp:2227, compute pressure): this rank contributes its own share only
+    polar_result mine;
+    if (polar_dist_local_result(dist,&mine) < 0) error->one(FLERR,polar_dist_last_error(dist));
+    res.eng_vdwl = mine.eng_vdwl; res.eng_coul = mine.eng_coul; res.eng_pol = mine.eng_pol;
+    res.u_self = mine.u_self; res.u_ef = mine.u_ef; res.u_dd = mine.u_dd;
+    for (int k = 0; k < 6; k++) res.virial[k] = mine.virial[k];
   } else
   for (int attempt = 0;; attempt++) {
     check(polar_step_begin(h,ef,vf));

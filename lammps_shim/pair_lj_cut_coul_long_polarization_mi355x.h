@@ -54,6 +54,7 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   int device_neigh;                      // extension keyword: list built by polar_build_neighbors
   int debug_flag;                        // keyword `debug yes`: the reference's prints (debug_prints)
   int atoms_sent, sent_nlocal, sent_nghost;   // what the last polar_set_atoms handed over (positions alone travel in between)
+  std::vector<double> q_sent;                 // ... and the charges it carried (a fix may change atom->q between two list builds)
   // one MPI rank per GPU: library order = [own | halo (one ghost per foreign tag) | other ghosts]
   int nhalo, sh_n;
   std::vector<int> lib_of_lammps, lammps_of_lib, halo_ghost, sh_nn, sh_flat, sh_idx, sh_t, sh_t2, sh_m;
@@ -62,7 +63,7 @@ class PairLJCutCoulLongPolarizationMI355X : public Pair {
   // `rccl_halo yes`: the sweeps of a multi-rank step run inside the library (polar_dist_step, RCCL over xGMI)
   polar_dist *dist;
   int device_index;
-  void build_rccl_plan();
+  virtual void build_rccl_plan();   // (virtual: the host-path tests replace the MPI plan exchange)
   void compute_sharded(int, int);
   void build_halo_map();
   void exchange_dipoles();

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE -- an in-process stand-in for the nine RCCL entry points the library's multi-GPU driver uses
-// (polar_dist_*, csrc/polar_api.hip).  The "ranks" are THREADS of one process that share one GPU: a send / receive pair
+// (polar_dist_*, csrc/polar_dist.hip).  The "ranks" are THREADS of one process that share one GPU: a send / receive pair
 // is a device-to-device copy, an all-reduce goes through the host.  Loaded through POLAR_RCCL_LIB; it exists so that the
 // driver's own logic -- halo plans with several peers, the all-reduced stop rule and its cadence, the agreed retry, the
 // summed results -- runs with more than one rank on the one-GPU test box.  It says nothing about RCCL itself.
@@ -73,7 +73,10 @@ ncclResult_t run_ops(fakeComm *c) {
       p = w->box[key].front();
     }
     if (p.count != o.count) return ncclInvalidArgument;   // the two ranks' plans disagree
-    if (hipMemcpy(o.ptr, p.ptr, o.count * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) return ncclInternalError;
+    // on the receiver's stream, drained before the call returns: the driver's streams need not be ordered with the null
+    // stream (its communication stream is a non-blocking one), and a device-to-device hipMemcpy may return early
+    if (hipMemcpyAsync(o.ptr, p.ptr, o.count * sizeof(double), hipMemcpyDeviceToDevice, o.stream) != hipSuccess) return ncclInternalError;
+    if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclInternalError;
     {
       std::lock_guard<std::mutex> g(w->m);
       auto key = std::make_pair(o.peer, c->rank);
@@ -150,7 +153,8 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
   World *w = c->w;
   std::vector<double> mine(count);
   if (hipStreamSynchronize(s) != hipSuccess) return ncclInternalError;
-  if (hipMemcpy(mine.data(), send, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ncclInternalError;
+  if (hipMemcpyAsync(mine.data(), send, count * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return ncclInternalError;
+  if (hipStreamSynchronize(s) != hipSuccess) return ncclInternalError;
   std::vector<double> out;
   {
     std::unique_lock<std::mutex> g(w->m);
@@ -172,7 +176,8 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
     out = w->result;
   }
   if (out.size() != count) return ncclInvalidArgument;   // the ranks disagree about the collective
-  if (hipMemcpy(recv, out.data(), count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return ncclInternalError;
+  if (hipMemcpyAsync(recv, out.data(), count * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) return ncclInternalError;
+  if (hipStreamSynchronize(s) != hipSuccess) return ncclInternalError;   // (`out` is a stack vector)
   return ncclSuccess;
 }
 const char *ncclGetErrorString(ncclResult_t r) {

@@ -186,13 +186,23 @@ int polar_step_mu_put_idx(polar_handle *, long long n, const int *idx, const dou
   return POLAR_OK;
 }
 int polar_step_change_get(polar_handle *, double *c) { if (!R.sharded) return POLAR_ERR_STATE; R.calls.push_back("change_get"); *c = 1.0 / R.sweeps; return POLAR_OK; }
-// the multi-rank driver is not reached by a one-rank compute(): present so that the shim links
+// the multi-rank driver (rccl_halo yes): recorded like the rest.  polar_dist_step returns the sums over the (two) ranks,
+// polar_dist_local_result this rank's own share -- what the shim must add to LAMMPS' per-rank accumulators
 int polar_dist_unique_id(void *) { return POLAR_ERR_STATE; }
 int polar_dist_create(const void *, int, int, int, polar_dist **) { return POLAR_ERR_STATE; }
 int polar_dist_destroy(polar_dist *) { return POLAR_OK; }
 const char *polar_dist_last_error(const polar_dist *) { return "stub"; }
-int polar_dist_set_halo(polar_dist *, int, const int *, const int *, const int *, const int *, const int *) { return POLAR_ERR_STATE; }
-int polar_dist_step(polar_dist *, polar_handle *, int, int, polar_result *) { return POLAR_ERR_STATE; }
+int polar_dist_set_halo(polar_dist *, polar_handle *, int, const int *, const int *, const int *, const int *, const int *) { return POLAR_ERR_STATE; }
+int polar_dist_set_schedule(polar_dist *, int, int, int) { return POLAR_ERR_STATE; }
+int polar_dist_step(polar_dist *, polar_handle *, int ef, int vf, polar_result *out) {
+  if (!R.sharded) return POLAR_ERR_STATE;
+  R.calls.push_back("dist_step"); R.eflag = ef; R.vflag = vf;
+  canned(out);
+  out->eng_vdwl *= 2.0; out->eng_coul *= 2.0; out->eng_pol *= 2.0; out->u_self *= 2.0; out->u_ef *= 2.0; out->u_dd *= 2.0;   // two ranks with equal shares
+  for (int k = 0; k < 6; k++) out->virial[k] *= 2.0;
+  return R.rc_compute;
+}
+int polar_dist_local_result(const polar_dist *, polar_result *out) { R.calls.push_back("dist_local"); canned(out); return POLAR_OK; }
 }
 
 namespace {
@@ -511,6 +521,42 @@ int shimsharded_check(int *ncombos, char *msg, int nmsg) {
       EXPECT(force->pair->eng_pol == -0.75, "eng_pol");
       if (eflag / 2) EXPECT(shim->eatom[6] == 0.5 + 7 && shim->eatom[7] == 0.5 + 6, "per-atom energies back in LAMMPS order");
       if (vflag / 4) EXPECT(shim->vatom[6][0] == 0.25 + 6 * 7, "per-atom virial back in LAMMPS order");
+    }
+    /* rccl_halo yes: the whole solve in the library's RCCL driver; energies and virial must be THIS rank's share, not the
+       driver's sums over the ranks (LAMMPS adds the ranks up itself) */
+    {
+      struct ShimNoPlan : PairLJCutCoulLongPolarizationMI355X {
+        explicit ShimNoPlan(LAMMPS *l) : PairLJCutCoulLongPolarizationMI355X(l) {}
+        void build_rccl_plan() override {}          /* (the plan exchange needs real MPI ranks) */
+      };
+      for (int dn = 0; dn < 2; dn++) {
+        std::ostringstream t; t << "sharded rccl_halo: device_neigh " << dn;
+        const std::string tag = t.str();
+        memset(&R.st, 0, sizeof(R.st));
+        R.st.cut_lj_global = 9.0; R.st.cut_coul = 9.0; R.st.dd_cutoff = 9.0; R.st.iterations_max = 4; R.st.device_neigh = dn; R.st.rccl_halo = 1;
+        R.rc_compute = POLAR_OK;
+        ShimNoPlan *shim = new ShimNoPlan(lmp);
+        force->pair = shim; shim->ncoultablebits = 0;
+        char a0[] = "9.0", a1[] = "9.0"; char *sa[2] = {a0, a1};
+        shim->settings(2, sa);
+        char c0[] = "*", c1[] = "*", c2[] = "0.1", c3[] = "3.0"; char *ca[4] = {c0, c1, c2, c3};
+        shim->coeff(4, ca); shim->init_style(); shim->init_list(0, list);
+        nb->ago = 0;
+        for (int k = 0; k < 3 * nall; k++) { atom->f[0][k] = 0.0; atom->mu_induced[0][k] = -1.0; atom->ef_static[0][k] = -2.0; }
+        shim->eng_vdwl = shim->eng_coul = 0.0;
+        for (int k = 0; k < 6; k++) shim->virial[k] = 0.0;
+        R.calls.clear();
+        shim->compute(1, 1);
+        (*ncombos)++;
+        std::string got;
+        for (auto &c : R.calls) got += c + " ";
+        std::string want = "set_box set_atoms set_row_range set_newton ";
+        want += dn ? "build_neighbors " : "set_neighbors_csr ";
+        want += "dist_step dist_local download:f download:mu download:ef_static ";
+        EXPECT(got == want, "call sequence: got '" << got << "' expected '" << want << "'");
+        EXPECT(shim->eng_vdwl == 1.25 && shim->eng_coul == -2.5 && force->pair->eng_pol == -0.75, "energies = this rank's share: " << shim->eng_vdwl << " " << shim->eng_coul << " " << force->pair->eng_pol);
+        for (int k = 0; k < 6; k++) EXPECT(shim->virial[k] == 10.0 + k, "virial[" << k << "] = this rank's share: " << shim->virial[k]);
+      }
     }
     /* the checks compute_sharded makes before anything moves */
     {

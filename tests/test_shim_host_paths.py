@@ -164,4 +164,4 @@ def test_shim_compute_marshalling_against_a_recording_stub(tmp_path):
     n2 = C.c_int(0)
     rc = L.shimsharded_check(C.byref(n2), msg, 1024)
     assert rc == 0, msg.value.decode()
-    assert n2.value == 2 * 2 * 2 * 4
+    assert n2.value == 2 * 2 * 2 * 4 + 2   # + rccl_halo yes with device_neigh {no, yes}: this rank's share of energies / virial, not the sums over the ranks

@@ -7,7 +7,10 @@ the protocol of parallel.bench_distributed.  Used to try exchange variants befor
   LAB_WORLD "8"
   LAB_GLUE  "-1"        >= 0: geometric slabs with clusters below this distance kept on one rank (workload.slab_order)
   LAB_W     "0,0.3,0.5,adaptive"   extrapolation weights for the received halo dipoles; "parts2" / "parts4": exchange
-            inside the sweep, after every half / every colour phase (polar_step_sweep_part)
+            inside the sweep, after every half / every colour phase (polar_step_sweep_part);
+            "phase0" / "phase1" / "phase2" (round 4): the single handle's colouring handed to every shard (polar_set_colors: ONE
+            colouring across the cuts), an exchange after every colour phase, delivered 0 / 1 / 2 phases LATE -- the worst case of
+            polar_dist_step's lag (there a late exchange may also arrive early)
 """
 import importlib
 import os
@@ -34,6 +37,7 @@ n_total = sg.nlocal
 p = pkg.pair_from_system(sg, device_neigh=True)
 ref = p.compute_resident()
 mu_ref = p.download("mu", 3 * n_total).reshape(-1, 3)
+ncol_ref, col_ref = p.colors(n_total)
 p.close()
 print(f"single handle: {n_total} atoms, sweeps {ref['sweeps']}, E_pol {ref['eng_pol']:.9f}", flush=True)
 
@@ -42,21 +46,22 @@ grid = [int(v) for v in os.environ.get("LAB_GRID", "").split("x") if v]   # e.g.
 if len(grid) == 3:
     order, offs = wl.brick_order(sg, grid, glue_dist=max(glue_dist, 0.0))
     sg = wl.permute_locals(sg, order)
-    mu_ref = mu_ref[order]
+    mu_ref = mu_ref[order]; col_ref = col_ref[order]
     counts = [int(offs[r + 1] - offs[r]) for r in range(world)]
 elif glue_dist >= 0.0:
     order, key, glue = wl.slab_order(sg, axis=2, glue_dist=glue_dist)
     sg = wl.permute_locals(sg, order)
-    mu_ref = mu_ref[order]
+    mu_ref = mu_ref[order]; col_ref = col_ref[order]
     counts, offs = wl.split_sorted(key[order], world, glue)
 else:
     counts, offs = par.split_rows(n_total, world)
 reach = float(sg.extra["cutneigh"]) + 1e-6
 plan = par.P2PHaloPlan(sg.x[:sg.nlocal], sg.prd, offs, reach)
-bes, bufs = [], []
+bes, bufs, shard_ids = [], [], []
 for r in range(world):
     lo, hi = int(offs[r]), int(offs[r + 1])
     sc = wl.compact_shard_geometric(sg, np.arange(lo, hi), plan.halo_of(r), reach)
+    shard_ids.append(np.concatenate([np.arange(lo, hi), np.asarray(plan.halo_of(r), dtype=np.int64)]))
     pr = pkg.pair_from_system(sc, device_neigh=True, row_range=(0, hi - lo))
     be = par.HipShardBackend(pr, 0, hi - lo, 0, global_count=n_total)
     bes.append(be)
@@ -84,7 +89,29 @@ def exchange(w):
         be.scatter_idx(bufs[r]["idx_in"], bufs[r]["recv"])
 
 
+def snapshot():
+    """what every rank would receive if all halo dipoles travelled now"""
+    for r, be in enumerate(bes):
+        be.gather_idx(bufs[r]["idx_out"], bufs[r]["send"])
+    snap = [torch.zeros_like(b["recv"]) for b in bufs]
+    for r in range(world):
+        for k, q in enumerate(bufs[r]["peers"]):
+            kq = bufs[q]["peers"].index(r)
+            a, b = 3 * bufs[r]["seg_in"][k], 3 * bufs[r]["seg_in"][k + 1]
+            c, d = 3 * bufs[q]["seg_out"][kq], 3 * bufs[q]["seg_out"][kq + 1]
+            snap[r][a:b] = bufs[q]["send"][c:d]
+    return snap
+
+
+def deliver(snap):
+    for r, be in enumerate(bes):
+        be.scatter_idx(bufs[r]["idx_in"], snap[r])
+
+
 for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have enlarged a row pitch: POLAR_RETRY_STEP)
+    phase_lag = int(wspec[5:]) if wspec.startswith("phase") else -1
+    for r, be in enumerate(bes):
+        be.pair.set_colors(col_ref[shard_ids[r]] if phase_lag >= 0 else None)
     for be in bes:
         be.begin(1, 2)
     exchange(0.0)
@@ -92,8 +119,19 @@ for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have e
     sweeps = 0
     sweep_events = []
     nparts = int(wspec[5:]) if wspec.startswith("parts") else 1
+    pending, g = [], 0
+    ncs = [be.pair.colors(1)[0] for be in bes] if phase_lag >= 0 else []
     for sw in range(bes[0].max_it + 1):
-        if nparts > 1:
+        if phase_lag >= 0:
+            for c in range(ncol_ref):
+                while pending and pending[0][0] <= g - 1 - phase_lag:
+                    deliver(pending.pop(0)[1])
+                for r, be in enumerate(bes):
+                    if c < ncs[r]:
+                        be.pair._ck(be.pair.L.polar_step_sweep_phase(be.pair.h, c, 0))
+                pending.append((g, snapshot()))
+                g += 1
+        elif nparts > 1:
             for part in range(nparts):
                 for be in bes:
                     be.sweep_part(part, nparts)
@@ -111,6 +149,10 @@ for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have e
             be.sweep_end(tot)
         changes.append(float(tot.item()))
         sweeps += 1
+        if phase_lag >= 0:
+            if all(be.state()[0] for be in bes):
+                break
+            continue
         if nparts > 1:
             w = 0.0
         elif wspec == "adaptive":
@@ -120,6 +162,8 @@ for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have e
         exchange(w)
         if all(be.state()[0] for be in bes):
             break
+    while pending:
+        deliver(pending.pop(0)[1])
     outs = [be.finish() for be in bes]
     torch.cuda.synchronize()
     mu = np.zeros((n_total, 3))
