@@ -37,6 +37,7 @@ CUT_COUL = 12.8345
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak; the sweep has no matrix work
 FLOP_PER_PAIR = 60.0     # ~45 FP64 flop + exp + rsqrt per directed pair of a sweep
+L2_GATHER_TBS = (16.8, 18.8)  # MI355X_MICROARCH.md: chip-wide rate of L2-served 64-byte row gathers (66-73 GB/s per CU x 256)
 FIXED30 = ["fixed_iteration", "yes", "max_iterations", "30"]
 PREC11 = ["fixed_iteration", "no", "precision", "1e-11", "max_iterations", "100"]
 CONFIGS = {  # BASELINE.json configs[k] -> replication of the 1,349-atom MOF5+H2 cell, solver keywords
@@ -115,7 +116,14 @@ def roofline(s, out, ms_solve, launches, steps, pkg):
         pass
     # the other roof SURVEY 8(d) asks for: FP64 vector rate of the pair arithmetic (60 flop-equivalents per directed pair)
     tflops = FLOP_PER_PAIR * out["dd_pairs"] / ncol / (ms_launch * 1e-3) / 1e12
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    # what the sweep is closest to: every directed pair is one 64-byte record gathered through L2 (rows padded
+    # to whole 64-pair trips: + ~6 %); MI355X_MICROARCH.md gives 16.8-18.8 TB/s chip-wide for L2-served row gathers
+    gathered = 64.0 * out["dd_pairs"] / ncol
+    l2 = {"bytes_per_launch": gathered, "tb_per_s": gathered / (ms_launch * 1e-3) / 1e12, "guide_tb_per_s": L2_GATHER_TBS,
+          "frac": gathered / (ms_launch * 1e-3) / 1e12 / L2_GATHER_TBS[0],
+          "what": "64-byte neighbour records gathered per launch (one per directed pair) over the launch time, against the low end of the guide's "
+                  "L2-served gather rate: the resource the sweep sits closest to, next to the HBM 'frac' and the FP64 'fp64_frac'"}
+    return {"bound": "hbm", "l2_gather": l2, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_low": low, "traffic_source": src, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; {pkg.kernel_version()})",
             "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch, "launches_per_step": launches / max(steps, 1),
             "fp64_tflops": tflops, "fp64_frac": tflops / FP64_PEAK_TFLOPS,
@@ -135,9 +143,40 @@ def sub_config(torch, pkg, wl, k, steps, warmup, device_neigh=False, extra=()):
     p.close()
     return {"workload": describe(cfg, s.nlocal) + (", LJ/Coulomb list built on the device" if device_neigh else "") + ("; extra keywords: " + " ".join(extra) if extra else ""),
             "natoms": s.nlocal, "steps": steps, "ms_per_step": 1e3 * dt / steps, "atom_steps_per_s": s.nlocal * steps / dt,
-            "sweeps": out["sweeps"], "colors": out["ncolors"], "dd_pairs": out["dd_pairs"],
+            "sweeps": out["sweeps"], "colors": out["ncolors"], "dd_pairs": out["dd_pairs"], "eng_pol": out["eng_pol"],
             "ms_per_dipole_iteration": ms_solve / steps / max(out["sweeps"], 1), "ms_solve": ms_solve / steps,
             "rms_dmu_last_sweep": out["rms_dmu"], "roofline_frac": rf["frac"], "ms_per_sweep_launch": rf["ms_per_launch"]}
+
+
+def config0_exact(torch, pkg, wl, steps=10, warmup=2):
+    """BASELINE configs[0]: the reference's own example, polarization/examples/MOF5+H2 (1349 atoms), EXACT reference semantics
+    (all minimum-image pairs, exact-order ranked Gauss-Seidel, max_iterations 30: the knife edge of SURVEY 8(c)), resident."""
+    s, _ = wl.load_fixture(os.path.join(ROOT, "tests", "golden", "mof5_h2.npz"),
+                           extra_args=["use_previous", "no", "polar_gs_ranked", "yes", "precision", "1e-11", "max_iterations", "30"])
+    p = pkg.pair_from_system(s)
+    out, dt, ms_solve, _ = timed_steps(torch, p, steps, warmup)
+    p.close()
+    return {"workload": "BASELINE configs[0]: polarization/examples/MOF5+H2, 1349 atoms, exact all-pairs mode (reference semantics), ranked GS, "
+                        "precision 1e-11, max_iterations 30", "natoms": s.nlocal, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "atom_steps_per_s": s.nlocal * steps / dt, "iterations": out["iterations"], "status": out["status"],
+            "us_per_iteration": 1e3 * ms_solve / steps / max(out["sweeps"], 1), "ms_solve": ms_solve / steps, "eng_pol": out["eng_pol"],
+            "reference_cpu_s_per_step": 0.85}
+
+
+def synth_config(torch, pkg, wl, natoms, steps, warmup):
+    """SURVEY 8(d)'s PRIMARY generator synth(N, seed 1) at configs[2]'s size and settings (a load generator: sorbates are placed
+    without regard to the framework, so its sweep count says nothing about the solver; density, list lengths and memory pattern
+    are the MOF's).  Lists built on the device."""
+    s = wl.synth_system(natoms, seed=1, extra_args=PREC11 + ["dd_cutoff", repr(CUT_COUL)], build_list=False)
+    p = pkg.pair_from_system(s, device_neigh=True)
+    out, dt, ms_solve, launches = timed_steps(torch, p, steps, warmup)
+    rf = roofline(s, out, ms_solve, launches, steps, pkg)
+    p.close()
+    return {"workload": f"SURVEY 8(d) primary generator synth({s.nlocal}, seed 1), exponential damping, ranked GS, precision 1e-11, dd_cutoff=cut_coul={CUT_COUL}, "
+                        "LJ/Coulomb list built on the device", "natoms": s.nlocal, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "atom_steps_per_s": s.nlocal * steps / dt, "sweeps": out["sweeps"], "colors": out["ncolors"], "dd_pairs": out["dd_pairs"], "status": out["status"],
+            "ms_per_dipole_iteration": ms_solve / steps / max(out["sweeps"], 1), "ms_solve": ms_solve / steps, "roofline_frac": rf["frac"],
+            "l2_gather_frac": rf["l2_gather"]["frac"], "ms_per_sweep_launch": rf["ms_per_launch"]}
 
 
 def md_leg(pkg, s, steps=20, every=10, seed=7, device_neigh=False, use_previous=False, motion="jitter", temperature=300.0):
@@ -367,10 +406,13 @@ def main():
         config["md_leg_device_neigh"] = md_leg(pkg, s, device_neigh=True)
         config["md_leg_use_previous"] = md_leg(pkg, s, device_neigh=True, use_previous=True)
         config["md_leg_ballistic"] = md_leg(pkg, s, steps=200, device_neigh=True, motion="ballistic", temperature=300.0)
+        config["config0_1349_exact"] = config0_exact(torch, pkg, wl)
+        config["config2_synth_131k"] = synth_config(torch, pkg, wl, 131072, steps=min(args.steps, 5), warmup=1)
         config["config1_36k"] = sub_config(torch, pkg, wl, 1, steps=max(args.steps, 10), warmup=args.warmup)
         config["config4_529k_one_gpu"] = sub_config(torch, pkg, wl, 4, steps=min(args.steps, 5), warmup=1, device_neigh=True)
         # opt-in extension keywords on the headline box (NOT the headline: the reference has neither)
         config["config2_polar_sor_1p15"] = sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("polar_sor", "1.15"))
+        config["config2_polar_accel_4"] = sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("polar_accel", "4"))
         config["config2_deterministic"] = sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("deterministic", "yes"))
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(wl, cfg["solver"])

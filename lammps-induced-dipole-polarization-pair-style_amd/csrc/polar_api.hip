@@ -131,7 +131,7 @@ int polar_destroy(polar_handle *h) {
     h->d_xchg.release(); h->d_xidx.release();
     h->d_eatom.release(); h->d_vatom.release(); h->d_dd_r2.release(); h->d_fpol.release();
     h->d_x.release(); h->d_q.release(); h->d_alpha.release(); h->d_f.release(); h->d_ef.release(); h->d_F.release();
-    h->d_mu.release(); h->d_mu0.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
+    h->d_mu.release(); h->d_mu0.release(); h->d_acc_x.release(); h->d_acc_f.release(); h->d_acc_g.release(); h->d_acc_dF.release(); h->d_acc_dG.release(); h->d_acc_part.release(); h->d_acc_state.release(); h->d_bflag.release(); h->d_rank.release(); h->d_dmu.release(); h->d_tab.release(); h->d_lj.release();
     h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();
     h->d_numneigh.release(); h->d_neigh.release(); h->d_rows.release(); h->d_first.release();
     h->d_sym_first.release(); h->d_sym_cnt.release(); h->d_sym_fill.release(); h->d_sym_j.release();

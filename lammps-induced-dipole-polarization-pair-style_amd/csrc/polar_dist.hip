@@ -273,8 +273,8 @@ int polar_dist_create(const void *id128, int rank, int nranks, int device, polar
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     RCCLCHECK(rccl().CommInitRank(&d->comm, nranks, id, rank));
-    d->d_red.ensure(64);
-    HIPCHECK(hipHostMalloc((void **)&d->h_red, 64 * sizeof(double)));
+    d->d_red.ensure(128);
+    HIPCHECK(hipHostMalloc((void **)&d->h_red, 128 * sizeof(double)));
     const double inf = INFINITY;
     HIPCHECK(hipMemcpy(d->d_red.p + 1, &inf, sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(hipStreamCreateWithFlags(&d->xs, hipStreamNonBlocking));
@@ -446,6 +446,11 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
       if (!st.zodid && phased) {
         const int nc = d->plan_nc, lag = deterministic(h) ? 0 : d->lag;
         const bool lazy = st.fixed_iteration != 0;
+        // `polar_accel m` across the ranks: every rank mixes with the SAME coefficients -- the dot products ride the stop
+        // rule's all-reduce (1 + 16 doubles, every sweep) -- and the mixed boundary dipoles travel in one exchange of all
+        // halo rows after the mix (every row changed, not one colour)
+        const bool accel = accel_begin(h, false);
+        double *ared = d->d_red.p + 64;   // [0] sum (dmu)^2, [1 .. 16] the dot products
         // boundary rows first, the exchange behind the interior rows -- where there are interior rows worth a launch of their
         // own (8 slabs two cutoffs thick have none: every row is some peer's halo)
         long long interior = 0, rows = h->color_off.empty() ? 0 : h->color_off.back();
@@ -464,7 +469,16 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
             dist_exchange_color(d, h, c, d->xs);
             HIPCHECK(hipEventRecord(d->ev_xdone[g % kRing], d->xs));
           }
-          if (!st.fixed_iteration) {
+          if (accel && (!lazy || sw < max_sweeps - 1)) {
+            if (g > 0) HIPCHECK(hipStreamWaitEvent(s, d->ev_xdone[(g - 1) % kRing], 0));   // no late unpack may land on the mixed dipoles
+            accel_export(h, ared + 1);
+            if (!lazy) k_fold_change<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, ared, nullptr, 0);
+            RCCLCHECK(R.AllReduce(ared, ared, 1 + 2 * POLAR_ACCEL_MAXM, ncclDouble, ncclSum, d->comm, s));
+            d->allreduces++;
+            if (!lazy) k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), 0, st.iterations_max, st.polar_precision, 0, ared, 1, nullptr, 0);
+            accel_step(h, ared + 1);
+            dist_exchange(d, h);
+          } else if (!st.fixed_iteration) {
             const double *gc = d->d_red.p + 1;   // +inf: "not converged yet"
             if ((sw % d->reduce_every) == d->reduce_every - 1 || sw >= st.iterations_max) {
               k_fold_change<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, d->d_red.p, det_part(h), det_npart(h));
@@ -474,7 +488,8 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
             }
             k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
                                                   0, gc, 1, gc == d->d_red.p ? nullptr : det_part(h), gc == d->d_red.p ? 0 : det_npart(h));
-          } else if (lazy) {
+          }
+          if (lazy) {
             if (sw == max_sweeps - 2 || sw == max_sweeps - 1 || max_sweeps == 1)
               k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
                                                     0, nullptr, (sw == max_sweeps - 2) ? max_sweeps - 1 : 1, det_part(h), det_npart(h));
@@ -487,6 +502,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
         if (g > 0) HIPCHECK(hipStreamWaitEvent(s, d->ev_xdone[(g - 1) % kRing], 0));   // every halo dipole is its owner's final one
       } else if (!st.zodid) {
         const bool lazy = st.fixed_iteration && gs;
+        if (st.polar_accel > 0) throw InputError("polar_accel across ranks needs the shared colouring (polar_dist_set_schedule with classes and lag >= 0)");
         for (int sw = 0; sw < max_sweeps; sw++) {
           sweep_once(h, false);
           if (!st.fixed_iteration) {

@@ -175,6 +175,9 @@ struct polar_handle {
   long long nneigh = 0;
   bool mu_resident = false;
   DBuf<double> d_dbgf;           // `debug yes`: {force on atom 0, its dipole-dipole part} of the last compute
+  DBuf<double> d_acc_x, d_acc_f, d_acc_g, d_acc_dF, d_acc_dG, d_acc_part;   // `polar_accel`: iterate, last residual, last G(x), difference histories, partial dots
+  DBuf<AccelState> d_acc_state;
+  long long acc_pitch = 0; int acc_rows = 0;
   DBuf<double> d_mu0;            // use_previous: the initial guess of the running step (a retry after a pitch overflow starts from it again)
   bool mu0_saved = false;
   int attempt = 0;               // which attempt of the running step (do_compute)
@@ -432,6 +435,9 @@ void sweep_once(polar_handle *h, bool ap);
 void sweep_phase(polar_handle *h, int color, int part);   // one colour phase of the list-mode Gauss-Seidel: part 0 = all its rows, 1 = boundary rows, 2 = interior rows
 void read_scal(polar_handle *h);
 void debug_trace(polar_handle *h, int sw, bool jacobi);
+bool accel_begin(polar_handle *h, bool ap);
+void accel_export(polar_handle *h, double *dev_local_dots);
+void accel_step(polar_handle *h, const double *global_dots);
 void solve(polar_handle *h, bool ap, polar_result *out);
 void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host);
 int phase_finish(polar_handle *h, polar_result *out);

@@ -641,6 +641,48 @@ void debug_trace(polar_handle *h, int sw, bool /*jacobi*/) {
   h->ntrace = sw + 1;
 }
 
+// `polar_accel m` (extension keyword): Anderson mixing of depth m on the sweep map of the list-mode Gauss-Seidel
+// (kernels and formulas: polar_solver.hpp, k_accel_*).  accel_begin: buffers, x_0 = the initial guess of the own rows; returns
+// whether the keyword applies to this solve.  accel_step: after a sweep (and its end-of-sweep decision) -- differences and
+// their dot products, the m x m solve, the mixed iterate into the records.  `global_dots`: multi-GPU, the all-reduced dot
+// products in device memory ([2 * POLAR_ACCEL_MAXM] doubles); the local ones are then exported first (accel_export).
+bool accel_begin(polar_handle *h, bool ap) {
+  const polar_settings &st = h->ph.st;
+  const bool gs = st.polar_gs || st.polar_gs_ranked;
+  if (st.polar_accel <= 0) return false;
+  if (ap || !gs || h->sweep_kernel != 2) throw InputError("polar_accel needs the Gauss-Seidel sweep of list mode (dd_cutoff > 0 with polar_gs or polar_gs_ranked)");
+  if (deterministic(h)) throw InputError("polar_accel and `deterministic yes` exclude each other");
+  const int tot = h->color_off.empty() ? 0 : h->color_off.back();
+  const long long pitch = ((long long)tot + 255) / 256 * 256;
+  const int M = POLAR_ACCEL_MAXM;
+  h->acc_pitch = pitch; h->acc_rows = tot;
+  const bool fresh = h->d_acc_dF.cap < (size_t)M * 3 * pitch + 1;
+  h->d_acc_x.ensure(3 * pitch + 1); h->d_acc_f.ensure(3 * pitch + 1); h->d_acc_g.ensure(3 * pitch + 1);
+  h->d_acc_dF.ensure((size_t)M * 3 * pitch + 1); h->d_acc_dG.ensure((size_t)M * 3 * pitch + 1);
+  h->d_acc_part.ensure((size_t)2 * M * nblk(tot, 256) + 2 * M); h->d_acc_state.ensure(1);
+  if (fresh) {  // (slots outside the window are multiplied by zero, never skipped: no NaN may sit there)
+    HIPCHECK(hipMemsetAsync(h->d_acc_dF.p, 0, h->d_acc_dF.cap * sizeof(double), h->stream));
+    HIPCHECK(hipMemsetAsync(h->d_acc_dG.p, 0, h->d_acc_dG.cap * sizeof(double), h->stream));
+  }
+  k_accel_init<<<nblk(tot, 256), 256, 0, h->stream>>>(tot, pitch, h->d_lpdesc.p, h->d_rec0.p, h->d_acc_x.p, h->d_acc_state.p);
+  return true;
+}
+void accel_export(polar_handle *h, double *dev_local_dots) {
+  const int tot = h->acc_rows, nb = nblk(tot, 256), ring = std::min(h->ph.st.polar_accel, POLAR_ACCEL_MAXM);
+  k_accel_diff<POLAR_ACCEL_MAXM><<<nb, 256, 0, h->stream>>>(tot, h->acc_pitch, h->d_lpdesc.p, h->d_rec0.p, h->d_scal.p, h->d_acc_state.p, h->d_acc_x.p,
+                                                           h->d_acc_f.p, h->d_acc_g.p, h->d_acc_dF.p, h->d_acc_dG.p, h->d_acc_part.p, ring);
+  k_accel_solve<POLAR_ACCEL_MAXM><<<1, 256, 0, h->stream>>>(nb, h->d_acc_part.p, h->d_scal.p, h->d_acc_state.p, dev_local_dots, nullptr, ring);
+}
+void accel_step(polar_handle *h, const double *global_dots) {
+  const int tot = h->acc_rows, nb = nblk(tot, 256), ring = std::min(h->ph.st.polar_accel, POLAR_ACCEL_MAXM);
+  if (!global_dots)
+    k_accel_diff<POLAR_ACCEL_MAXM><<<nb, 256, 0, h->stream>>>(tot, h->acc_pitch, h->d_lpdesc.p, h->d_rec0.p, h->d_scal.p, h->d_acc_state.p, h->d_acc_x.p,
+                                                             h->d_acc_f.p, h->d_acc_g.p, h->d_acc_dF.p, h->d_acc_dG.p, h->d_acc_part.p, ring);
+  k_accel_solve<POLAR_ACCEL_MAXM><<<1, 256, 0, h->stream>>>(nb, h->d_acc_part.p, h->d_scal.p, h->d_acc_state.p, nullptr, global_dots, ring);
+  k_accel_mix<POLAR_ACCEL_MAXM><<<nb, 256, 0, h->stream>>>(tot, h->acc_pitch, h->d_lpdesc.p, h->d_rec0.p, h->d_scal.p, h->d_acc_state.p, h->d_acc_x.p,
+                                                          h->d_acc_g.p, h->d_acc_dG.p);
+}
+
 void solve(polar_handle *h, bool ap, polar_result *out) {
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
@@ -650,6 +692,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
   const int max_sweeps = st.iterations_max + 1;
   const int check_every = 4;
   out->ncolors = 0;
+  if (st.polar_accel > 0 && (ap || !gs)) throw InputError("polar_accel needs the Gauss-Seidel sweep of list mode (dd_cutoff > 0 with polar_gs or polar_gs_ranked)");
 
   if (!gs || !ap) {  // Jacobi (reference "polar_gs no") or colour-phase Gauss-Seidel over the dd list
     const bool clm = !ap && h->sweep_kernel == 3, tile = !ap && h->sweep_kernel == 4;  // tile sweep: no host-side colours at all
@@ -664,12 +707,15 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     // fixed-iteration GS takes no decision between sweeps: its end-of-sweep logic is applied in two
     // launches (all sweeps but the last, then the last one, whose sum |dmu|^2 is the one reported)
     const bool lazy = st.fixed_iteration && gs;
+    const bool accel = accel_begin(h, ap);   // `polar_accel m`: Anderson mixing between the sweeps
     for (int sw = 0; sw < max_sweeps; sw++) {
       sweep_once(h, ap);
       debug_trace(h, sw, !gs);
+      if (accel && lazy && sw < max_sweeps - 1) accel_step(h, nullptr);   // (no decision to wait for; nothing after the last sweep)
       if (lazy && sw < max_sweeps - 2) continue;
       const int count = (lazy && sw == max_sweeps - 2) ? max_sweeps - 1 : 1;
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count, det_part(h), det_npart(h));
+      if (accel && !lazy) accel_step(h, nullptr);   // (a no-op on the device once the stop rule has fired: the result is G(x_k) of the last sweep)
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;

@@ -687,6 +687,35 @@ def bench_distributed(args, rank, world, local_rank):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    # MD-shaped leg (driver only): every rank moves ITS OWN atoms each step (thermal-size jitter, inside the skin), uploads them
+    # (polar_set_positions_range: PCIe), fetches the halo atoms' positions from their owners over RCCL and rebuilds the ghost
+    # images (polar_dist_positions) -- north_star "ghost x ... over xGMI" --; every 10th step the device list is rebuilt.
+    md = None
+    if driver is not None and not args.no_extras:
+        rng = np.random.default_rng(1000 + rank)
+        n_own = hi - lo
+        x_own0 = np.ascontiguousarray(s.x[:n_own])
+        disp = np.zeros_like(x_own0)
+        md_steps, every = 10, 10
+        t_steps, sw = [], []
+        one_step()
+        for k in range(md_steps):
+            disp += rng.normal(scale=0.01, size=disp.shape)
+            dist.barrier()
+            t1 = time.perf_counter()
+            p.set_positions_range(0, n_own, x_own0 + disp)
+            driver.positions(p)
+            if k % every == every - 1:
+                p.build_neighbors_from_system(s)
+            o2 = driver.step(p, 1, 2)
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=be.dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_steps.append(1e3 * float(tt.item())); sw.append(o2["sweeps"])
+        md = {"what": f"{md_steps} steps; per step every rank uploads its own atoms' new positions (jitter 0.01 A per step), halo positions and ghost images "
+                      "through polar_dist_positions (RCCL), polar_dist_step; the device list rebuilt on the last step; wall clock, max over ranks",
+              "ms_per_step_md": float(np.mean(t_steps[:-1])), "ms_reneighbor_step": t_steps[-1], "sweeps_per_step": float(np.mean(sw)),
+              "atom_steps_per_s_md": n_total / (float(np.mean(t_steps[:-1])) * 1e-3)}
     # roofline of the dominant kernel on this rank (same accounting as the single-GPU line, bench.py)
     launches = max(len(timer.pairs), 1) * max(out["ncolors"], 1)
     ms_launch = timer.total_ms() / launches
@@ -719,7 +748,7 @@ def bench_distributed(args, rank, world, local_rank):
                        "sweep_loop": ("in-library C++ driver (polar_dist_step): pack kernel, ncclGroupStart/Send/Recv/End, unpack kernel on the "
                                       "communication stream, the all-reduced stop rule on the compute stream, state read every 4 sweeps") if driver is not None
                                      else "Python loop over the stepwise C-ABI (torch.distributed collectives)" + (f" -- C++ driver unavailable: {driver_fallback}" if driver_fallback else ""),
-                       "exchanges_last_step": out.get("exchanges"), "allreduces_last_step": out.get("allreduces"),
+                       "exchanges_last_step": out.get("exchanges"), "allreduces_last_step": out.get("allreduces"), "md_leg": md,
                        "kernel_version": pkg.kernel_version()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; rank 0; {pkg.kernel_version()})",

@@ -792,7 +792,7 @@ def load_fixture(path, extra_args=(), g_ewald=None, ncoultablebits=12, newton=Tr
     return sysm, meta
 
 
-def synth_system(N, seed=1, extra_args=(), cut_lj=2.5, cut_coul=12.8345, skin=2.0):
+def synth_system(N, seed=1, extra_args=(), cut_lj=2.5, cut_coul=12.8345, skin=2.0, build_list=True):
     """PolarSystem of the synthetic generator (SURVEY.md 8(d) "primary" configs 1-4): synth(N, seed)
     with the MOF5+H2 deck's pair_style line (exponential damping a = 2.1304, ranked GS) plus ``extra_args``.
 
@@ -806,7 +806,7 @@ def synth_system(N, seed=1, extra_args=(), cut_lj=2.5, cut_coul=12.8345, skin=2.
     st = parse_pair_style_args(args)
     g = ewald_g(1.0e-4, d["q"], st.cut_coul, d["prd"])
     return make_system(d["x"], d["q"], d["alpha"], d["type"], d["molecule"], d["boxlo"], d["prd"], d["ntypes"],
-                       synth_coeff_rows(), st, g, bonds=None, exclude_intra=True, skin=skin, name=f"synth{N}_s{seed}")
+                       synth_coeff_rows(), st, g, bonds=None, exclude_intra=True, skin=skin, name=f"synth{N}_s{seed}", build_list=build_list)
 
 
 def replicate_fixture(path, nx, ny, nz, extra_args=(), g_ewald=None, skin=2.0, rows=None, full=False, build_list=True):

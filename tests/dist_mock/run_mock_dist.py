@@ -15,6 +15,7 @@ usage: run_mock_dist.py <world> <solver: precision|fixed|jacobi> [reduce_every] 
             imposed0/1 the same schedule with the single handle's own colouring handed to the shards (polar_set_colors):
                        with lag 0 the ranks together run the single-GPU iteration
             badinput   rank 1 is given a setting the driver refuses: every rank must come back with an error, none may hang
+            accel1     lag1 with `polar_accel 4` on every rank (Anderson mixing with all-reduced dot products)
             md0/md1    five steps with every atom moved between them: own positions uploaded per rank
                        (polar_set_positions_range), halo positions and ghost images through polar_dist_positions"""
 import importlib
@@ -92,6 +93,9 @@ def rank_main(r):
         lo, hi = int(offs[r]), int(offs[r + 1])
         halo = plan.halo_of(r)
         sc = wl.compact_shard_geometric(sg, np.arange(lo, hi), halo, reach)
+        if schedule.startswith("accel"):
+            import dataclasses
+            sc.settings = dataclasses.replace(sc.settings, polar_accel=4)
         if schedule == "badinput" and r == 1:
             import dataclasses
             sc.settings = dataclasses.replace(sc.settings, dd_cutoff=0.0)     # exact mode: polar_dist_step refuses it

@@ -831,7 +831,8 @@ def test_in_library_driver_with_several_ranks_on_a_mock_transport(world, solver,
 
 @pytest.mark.parametrize("world,solver,reduce_every,schedule,pitch", [
     (2, "precision", 1, "lag0", 0), (3, "precision", 2, "lag1", 0), (4, "precision", 1, "lag1", 0), (4, "fixed", 1, "lag0", 0),
-    (3, "precision", 1, "lag1", 64), (4, "precision", 1, "imposed0", 0), (3, "precision", 1, "imposed1", 0), (2, "jacobi", 1, "lag1", 0)])
+    (3, "precision", 1, "lag1", 64), (4, "precision", 1, "imposed0", 0), (3, "precision", 1, "imposed1", 0), (2, "jacobi", 1, "lag1", 0),
+    (3, "precision", 1, "accel1", 0)])
 def test_in_library_driver_with_one_colouring_shared_by_the_ranks(world, solver, reduce_every, schedule, pitch, pkg, tmp_path):
     """the ranks build ONE colouring together (turns by class; a rank colours against the colours its
     peers' rows hold in its halo), rows of a phase boundary-first, colour c's boundary dipoles exchanged after phase c on a
@@ -851,14 +852,17 @@ def test_in_library_driver_with_one_colouring_shared_by_the_ranks(world, solver,
         return
     assert res["color_clashes"] == 0 and res["polarizable_uncoloured"] == 0
     nc = max(k["ncolors"] for k in ranks)
-    for k in ranks:             # one exchange per colour phase (+ the initial one; sweeps past the end still exchange)
-        assert k["sweeps"] * nc + 1 <= k["exchanges"] <= (k["sweeps"] + 4) * nc + 1
+    for k in ranks:             # one exchange per colour phase (+ the initial one; sweeps past the end still exchange; accel: + one of all halo rows per sweep)
+        assert k["sweeps"] * nc + 1 <= k["exchanges"] <= (k["sweeps"] + 4) * (nc + (1 if schedule == "accel1" else 0)) + 1
     if solver == "fixed":
         assert ranks[0]["sweeps"] == ref["sweeps"] and res["mu_err"] < 1e-3
     else:
         assert res["mu_err"] < TOL and rel(ranks[0]["eng_pol"], ref["eng_pol"]) < 1e-9
-        extra = {"imposed0": 1, "lag0": 3, "imposed1": 3, "lag1": 4}[schedule] + (reduce_every - 1)
-        assert ref["sweeps"] - 1 <= ranks[0]["sweeps"] <= ref["sweeps"] + extra, (ranks[0]["sweeps"], ref["sweeps"])
+        if schedule == "accel1":   # `polar_accel 4` on every rank: the same coefficients everywhere (all-reduced dot products), fewer sweeps than the plain single handle
+            assert ranks[0]["sweeps"] <= 0.8 * ref["sweeps"], (ranks[0]["sweeps"], ref["sweeps"])
+        else:
+            extra = {"imposed0": 1, "lag0": 3, "imposed1": 3, "lag1": 4}[schedule] + (reduce_every - 1)
+            assert ref["sweeps"] - 1 <= ranks[0]["sweeps"] <= ref["sweeps"] + extra, (ranks[0]["sweeps"], ref["sweeps"])
     for k in ("eng_pol", "eng_vdwl", "eng_coul"):
         assert rel(res["local_sum"][k], ranks[0][k], 1e-9) < 1e-12
 
@@ -935,3 +939,40 @@ def test_set_positions_between_two_list_builds_matches_the_oracle(mode, useprev,
     with pytest.raises(pkg.PolarError, match="non-finite"):
         p.set_positions(bad)
     p.close()
+
+
+@pytest.mark.parametrize("m", [1, 3, 5, 8])
+def test_polar_accel_reaches_the_same_fixed_point_in_fewer_sweeps(m, wl, pkg, oracle):
+    """`polar_accel m` (extension keyword): Anderson mixing of depth m on the sweep map.  Same fixed point as
+    the oracle's sequential Gauss-Seidel in the same truncated model, same stop rule (the residual it measures is G(mu) - mu, what
+    the reference's rule measures, PS.cpp:1194-1210), at least a quarter fewer sweeps than the plain colour-phase iteration; and
+    the combinations the keyword does not support are refused."""
+    base = ["use_previous", "no", "dd_cutoff", "9.0", "precision", "1e-11", "max_iterations", "100"]
+    s = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 2, 2, 2, extra_args=base)
+    ref = oracle.compute(s, eflag=1, vflag=2)
+    p0 = pkg.pair_from_system(s)
+    plain = p0.compute(eflag=1, vflag=2)
+    p0.close()
+    sa = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 2, 2, 2, extra_args=base + ["polar_accel", str(m)])
+    p = pkg.pair_from_system(sa)
+    out = p.compute(eflag=1, vflag=2)
+    out2 = p.compute(eflag=1, vflag=2)      # (a second step: buffers and history start afresh)
+    p.close()
+    assert out["status"] == 0 and out2["status"] == 0 and out2["sweeps"] == out["sweeps"]
+    assert out["sweeps"] <= 0.75 * plain["sweeps"], (out["sweeps"], plain["sweeps"])
+    for o in (out, out2):
+        assert np.max(np.abs(o["mu"] - ref["mu"])) / np.max(np.abs(ref["mu"])) < TOL
+        assert force_rel_err(oracle.fold_ghost_forces(o["f"], s.owner, s.nlocal), oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)) < TOL
+        assert rel(o["eng_pol"], ref["eng_pol"], 1e-9) < TOL
+    if m == 3:
+        for bad in (["deterministic", "yes"], ["polar_gs_ranked", "no"]):
+            sb = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 2, 2, 2, extra_args=base + ["polar_accel", "3"] + bad)
+            pb = pkg.pair_from_system(sb)
+            with pytest.raises(pkg.PolarError, match="polar_accel"):
+                pb.compute(eflag=1, vflag=2)
+            pb.close()
+        sx, _ = wl.load_fixture(os.path.join(GOLD, "bulk_h2.npz"), extra_args=["use_previous", "no", "polar_accel", "3"])   # exact mode
+        px = pkg.pair_from_system(sx)
+        with pytest.raises(pkg.PolarError, match="polar_accel"):
+            px.compute(eflag=1, vflag=2)
+        px.close()
