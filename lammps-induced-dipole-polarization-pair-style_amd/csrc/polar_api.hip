@@ -44,6 +44,83 @@ void upload_coul(polar_handle *h, double g_ewald, double qqrd2e, const double *s
 }  // namespace
 
 // =============================================================================================
+namespace {
+// The half list of a reneighbor step on its way to the device (PS.cpp:232-247 reads list->firstneigh): rows are packed in
+// ilist order into two pinned 32 MB buffers by the helper threads -- each thread checking its entries on the way -- and a
+// buffer travels (hipMemcpyAsync from pinned memory: the full PCIe rate) while the next one is packed.  270 MB at 135k atoms:
+// a single-threaded flatten + check + four copies out of pageable memory took 20 ms; this takes what the link takes.
+// `row(i)` = where atom i's numneigh[i] entries lie on the host (LAMMPS' pages, or a caller's flat array).
+template <typename RowFn>
+void upload_neighbor_rows(polar_handle *h, int inum, const int *ilist, const int *numneigh, RowFn row) {
+  const int n = h->nlocal, nall = h->nlocal + h->nghost;
+  std::vector<long long> first((size_t)std::max(n, 1), 0);
+  std::vector<int> nn((size_t)std::max(n, 1), 0);
+  std::vector<long long> at((size_t)inum + 1, 0);
+  long long total = 0;
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = ilist[ii];
+    if (i < 0 || i >= n) throw InputError("neighbor list row index out of range");
+    if (numneigh[i] < 0) throw InputError("negative neighbor count/offset");
+    first[i] = total; nn[i] = numneigh[i]; at[ii] = total;
+    total += numneigh[i];
+  }
+  at[inum] = total;
+  h->inum = inum; h->nneigh = total;
+  h->d_ilist.ensure(inum + 1); h->d_numneigh.ensure(n + 1); h->d_first.ensure(n + 1); h->d_neigh.ensure((size_t)total + 1);
+  hipStream_t s = h->stream;
+  HIPCHECK(hipMemcpyAsync(h->d_ilist.p, ilist, inum * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(h->d_numneigh.p, nn.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(h->d_first.p, first.data(), n * sizeof(long long), hipMemcpyHostToDevice, s));
+  const long long CH = 8ll << 20;   // entries per buffer (32 MB)
+  if (!h->h_nl_stage[0]) {
+    for (int k = 0; k < 2; k++) {
+      HIPCHECK(hipHostMalloc((void **)&h->h_nl_stage[k], (size_t)CH * sizeof(int)));
+      HIPCHECK(hipEventCreateWithFlags(&h->ev_nl[k], hipEventDisableTiming));
+    }
+  }
+  HostPool &pool = HostPool::get();
+  const int nt = pool.width();
+  std::vector<int> bad((size_t)nt * 16, 0);
+  int chunk = 0;
+  for (int ii0 = 0; ii0 < inum;) {
+    int ii1 = ii0;
+    while (ii1 < inum && at[ii1 + 1] - at[ii0] <= CH) ii1++;
+    if (ii1 == ii0) throw InputError("a neighbor row of more than 8M entries");
+    const int buf = chunk & 1;
+    if (chunk >= 2) HIPCHECK(hipEventSynchronize(h->ev_nl[buf]));   // the upload that last used this buffer is over
+    int *dst = h->h_nl_stage[buf];
+    const long long t0 = at[ii0], cnt = at[ii1] - t0;
+    pool.run([&](int part) {
+      // thread `part` packs the rows whose first entry lies in its share of the chunk's entries
+      const long long lo = t0 + cnt * part / nt, hi = t0 + cnt * (part + 1) / nt;
+      int a = (int)(std::lower_bound(at.begin() + ii0, at.begin() + ii1, lo) - at.begin());
+      const int b = (int)(std::lower_bound(at.begin() + ii0, at.begin() + ii1, hi) - at.begin());
+      int worst = 0;
+      for (; a < b; a++) {
+        const int i = ilist[a], m = numneigh[i];
+        const int *src = row(i);
+        int *d = dst + (at[a] - t0);
+        int mx = 0;
+        for (int k = 0; k < m; k++) { const int v = src[k]; d[k] = v; const int j = v & 0x3FFFFFFF; mx = j > mx ? j : mx; }
+        worst = mx > worst ? mx : worst;
+      }
+      if (worst >= nall) bad[(size_t)part * 16] = 1;
+    }, nt);
+    for (int t = 0; t < nt; t++) if (bad[(size_t)t * 16]) { HIPCHECK(hipStreamSynchronize(s)); throw InputError("neighbor index out of range"); }
+    if (cnt > 0) HIPCHECK(hipMemcpyAsync(h->d_neigh.p + t0, dst, (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipEventRecord(h->ev_nl[buf], s));
+    ii0 = ii1; chunk++;
+  }
+  HIPCHECK(hipStreamSynchronize(s));   // (first / nn are stack vectors; the caller's list may change after the call)
+  h->neigh_set = true;
+  h->sym_valid = false;
+  if (h->colors_valid) h->colors_recheck = true;  // reneighbor step: the colour phases are re-validated (k_nl_build)
+  h->device_list = false;
+  h->full_list = h->user_full_list;
+}
+}  // namespace
+
+
 extern "C" {
 
 const char *polar_kernel_version(void) { return POLAR_KERNEL_VERSION; }
@@ -105,6 +182,10 @@ int polar_create(int device, polar_handle **out) {
     HIPCHECK(hipEventCreateWithFlags(&h->ev_mu_ready, hipEventDisableTiming));
     for (auto &e : h->ev_fchunk) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHECK(hipStreamCreateWithFlags(&h->dl_stream, hipStreamNonBlocking));
+    HIPCHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    for (auto &row : h->ev_near) for (auto &e : row) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_half, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&h->ev_stepdone, hipEventDisableTiming));
+    if (const char *e = getenv("POLAR_PIPELINE")) h->pipeline = atoi(e) != 0;
     if (getenv("POLAR_NO_OVERLAP")) h->overlap_lj = false;
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
     HIPCHECK(hipHostMalloc((void **)&h->h_flags, 16 * sizeof(int)));
@@ -125,6 +206,12 @@ int polar_destroy(polar_handle *h) {
     if (h->lj_stream) { (void)hipStreamSynchronize(h->lj_stream); (void)hipStreamDestroy(h->lj_stream); }
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1, h->ev_dl0, h->ev_dl1, h->ev_mu_ready}) if (e) (void)hipEventDestroy(e);
     if (h->dl_stream) (void)hipStreamDestroy(h->dl_stream);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    for (int k = 0; k < 2; k++) { if (h->h_nl_stage[k]) (void)hipHostFree(h->h_nl_stage[k]); if (h->ev_nl[k]) (void)hipEventDestroy(h->ev_nl[k]); }
+    for (auto &row : h->ev_near) for (auto &e : row) if (e) (void)hipEventDestroy(e);
+    if (h->ev_half) (void)hipEventDestroy(h->ev_half);
+    if (h->ev_stepdone) (void)hipEventDestroy(h->ev_stepdone);
+    h->d_sub.release();
     for (hipEvent_t e : h->ev_fchunk) if (e) (void)hipEventDestroy(e);
     h->d_ljpos.release(); h->d_ljaux.release(); h->d_tag.release(); h->d_nspecial.release(); h->d_special.release();
     h->d_ljcell_id.release(); h->d_ljcell_cnt.release(); h->d_ljcell_fill.release(); h->d_ljcell_first.release(); h->d_cutneighsq.release();
@@ -404,18 +491,24 @@ int polar_set_positions(polar_handle *h, int nlocal, int nghost, const double *x
     const int nparts = nall < (1u << 14) ? 1 : std::min(8, HostPool::get().width());
     Ext ext[8];
     for (auto &e : ext) { for (int k = 0; k < 3; k++) { e.lo[k] = 1e300; e.hi[k] = -1e300; } e.bad = 0; }
-    const size_t per = (nall + nparts - 1) / nparts;
+    const size_t per = ((nall + nparts - 1) / nparts + 3) / 4 * 4;
     HostPool::get().run([&](int part) {
       Ext &e = ext[part];
       const size_t a0 = std::min(nall, (size_t)part * per), a1 = std::min(nall, ((size_t)part + 1) * per);
-      for (size_t a = a0; a < a1; a++)
-        for (int k = 0; k < 3; k++) {
-          const double v = x[3 * a + k];
-          st[3 * a + k] = v;
-          if (!(v - v == 0.0)) e.bad = 1;
-          e.lo[k] = v < e.lo[k] ? v : e.lo[k];
-          e.hi[k] = v > e.hi[k] ? v : e.hi[k];
-        }
+      memcpy(st + 3 * a0, x + 3 * a0, 3 * (a1 - a0) * sizeof(double));
+      // four atoms = twelve doubles at a time: twelve independent running minima / maxima (the compiler keeps them in vector
+      // registers; one accumulator per coordinate, fed with a stride of three, ran at a fifth of the copy's rate)
+      double lo[12], hi[12], acc = 0.0;
+      for (int j = 0; j < 12; j++) { lo[j] = 1e300; hi[j] = -1e300; }
+      size_t a = a0;
+      for (; a + 4 <= a1; a += 4) {
+        const double *p = x + 3 * a;
+        for (int j = 0; j < 12; j++) { const double v = p[j]; lo[j] = v < lo[j] ? v : lo[j]; hi[j] = v > hi[j] ? v : hi[j]; acc += v - v; }
+      }
+      for (; a < a1; a++)
+        for (int k = 0; k < 3; k++) { const double v = x[3 * a + k]; lo[k] = v < lo[k] ? v : lo[k]; hi[k] = v > hi[k] ? v : hi[k]; acc += v - v; }
+      for (int j = 0; j < 12; j++) { e.lo[j % 3] = std::min(e.lo[j % 3], lo[j]); e.hi[j % 3] = std::max(e.hi[j % 3], hi[j]); }
+      if (!(acc == 0.0)) e.bad = 1;   // (v - v is 0 for a finite v, NaN for an infinite or NaN one)
     }, nparts);
     for (int k = 0; k < 3; k++) { h->bbox_lo[k] = 1e300; h->bbox_hi[k] = -1e300; }
     for (const auto &e : ext) {
@@ -435,31 +528,13 @@ int polar_set_neighbors_csr(polar_handle *h, int inum, const int *ilist, const i
     need_device(h);
     HIPCHECK(hipSetDevice(h->device));
     if (!h->atoms_set) throw std::runtime_error("polar_set_neighbors before polar_set_atoms");
-    const int n = h->nlocal, nall = h->nlocal + h->nghost;
-    long long total = 0;
+    if (inum < 0 || (inum > 0 && (!ilist || !numneigh || !firstneigh || !neigh))) throw InputError("polar_set_neighbors_csr: null pointer");
     for (int ii = 0; ii < inum; ii++) {
       const int i = ilist[ii];
-      if (i < 0 || i >= n) throw InputError("neighbor list row index out of range");
-      if (numneigh[i] < 0 || firstneigh[i] < 0) throw InputError("negative neighbor count/offset");
-      total = std::max(total, firstneigh[i] + numneigh[i]);
-      for (int k = 0; k < numneigh[i]; k++) {
-        const int j = neigh[firstneigh[i] + k] & 0x3FFFFFFF;
-        if (j >= nall) throw InputError("neighbor index out of range");
-      }
+      if (i < 0 || i >= h->nlocal) throw InputError("neighbor list row index out of range");
+      if (firstneigh[i] < 0) throw InputError("negative neighbor count/offset");
     }
-    h->inum = inum; h->nneigh = total;
-    h->d_ilist.ensure(inum + 1); h->d_numneigh.ensure(n + 1); h->d_first.ensure(n + 1); h->d_neigh.ensure((size_t)total + 1);
-    hipStream_t s = h->stream;
-    HIPCHECK(hipMemcpyAsync(h->d_ilist.p, ilist, inum * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(h->d_numneigh.p, numneigh, n * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(h->d_first.p, firstneigh, n * sizeof(long long), hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(h->d_neigh.p, neigh, (size_t)total * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    h->neigh_set = true;
-    h->sym_valid = false;
-    if (h->colors_valid) h->colors_recheck = true;  // reneighbor step: the colour phases are re-validated (k_nl_build)
-    h->device_list = false;
-    h->full_list = h->user_full_list;
+    upload_neighbor_rows(h, inum, ilist, numneigh, [&](int i) { return neigh + firstneigh[i]; });
     return POLAR_OK;
   });
 }
@@ -549,24 +624,15 @@ int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *
 }
 
 int polar_set_neighbors(polar_handle *h, int inum, const int *ilist, const int *numneigh, int *const *firstneigh) {
-  if (!h) return POLAR_ERR_STATE;
-  // flatten LAMMPS' paged int** rows into one CSR buffer
-  std::vector<long long> first((size_t)std::max(h->nlocal, 1), 0);
-  long long total = 0;
-  for (int ii = 0; ii < inum; ii++) {
-    const int i = ilist[ii];
-    if (i < 0 || i >= h->nlocal) return fail(h, POLAR_ERR_INPUT, "neighbor list row index out of range");
-    first[i] = total;
-    total += numneigh[i];
-  }
-  std::vector<int> flat((size_t)total + 1);
-  std::vector<int> nn((size_t)std::max(h->nlocal, 1), 0);
-  for (int ii = 0; ii < inum; ii++) {
-    const int i = ilist[ii];
-    nn[i] = numneigh[i];
-    if (numneigh[i] > 0) memcpy(flat.data() + first[i], firstneigh[i], (size_t)numneigh[i] * sizeof(int));
-  }
-  return polar_set_neighbors_csr(h, inum, ilist, nn.data(), first.data(), flat.data());
+  return guarded(h, [&]() {
+    need_device(h);
+    HIPCHECK(hipSetDevice(h->device));
+    if (!h->atoms_set) throw std::runtime_error("polar_set_neighbors before polar_set_atoms");
+    if (inum < 0 || (inum > 0 && (!ilist || !numneigh || !firstneigh))) throw InputError("polar_set_neighbors: null pointer");
+    // LAMMPS' paged int** rows, packed straight into the pinned upload buffers (no flat copy in between)
+    upload_neighbor_rows(h, inum, ilist, numneigh, [&](int i) { return (const int *)firstneigh[i]; });
+    return POLAR_OK;
+  });
 }
 
 int polar_compute(polar_handle *h, int eflag, int vflag, double *f, double *mu, double *ef_static, polar_result *out) {

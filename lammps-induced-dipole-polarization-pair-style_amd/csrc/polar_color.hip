@@ -145,6 +145,7 @@ void build_cluster_colors(polar_handle *h, const std::vector<double> &rank, cons
     for (int k = 0; k < 4; k++) { h->h_cl[4 * (size_t)slot + k] = mem[4 * (size_t)c + k]; natoms += mem[4 * (size_t)c + k] >= 0; }
   }
   h->ncl = ncl;
+  h->color_nsub = 1; h->color_sub.clear();
   h->d_cl_orig.ensure((size_t)ncl * 4 + 4);
   h->d_cl_s.ensure((size_t)ncl + 1);
   if (ncl > 0) HIPCHECK(hipMemcpy(h->d_cl_orig.p, h->h_cl.data(), (size_t)ncl * 4 * sizeof(int), hipMemcpyHostToDevice));
@@ -292,6 +293,7 @@ void build_colors(polar_handle *h, const std::vector<double> &rank) {
     for (int i : cell)
       if (mine(i)) rows[fill[color[i]]++] = i;
   h->h_rows = rows;
+  h->color_nsub = 1; h->color_sub.clear();
   h->color_epoch++;  // the launch order changed: dd rows laid out for an earlier colouring are stale (slots_current)
   h->h_color.assign(color.begin(), color.end());
   h->d_color_orig.ensure((size_t)n + 1);
@@ -357,17 +359,20 @@ void color_adjacency(polar_handle *h, bool with_halo) {
   HIPCHECK(hipMemsetAsync(h->d_color_orig.p, 0xFF, (size_t)(n + 1) * sizeof(int), s));
   const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
   const double dc2 = h->color_dist * h->color_dist;
-  {  // k_color_adj looks at the 3 x 3 x 3 cells around an atom: the colour distance must fit inside one cell
+  int sw = 1;
+  {  // k_color_adj looks at the cells within `sw` of an atom's cell: the colour distance must fit (it used to look at
+     // 3 x 3 x 3 cells whatever the distance -- with the small cells of a short cutoff the lists then missed pairs)
     double wdt[3];
     box_widths(h->box, wdt);
     const double wmin = std::min({wdt[0] / h->grid.nc[0], wdt[1] / h->grid.nc[1], wdt[2] / h->grid.nc[2]});
-    if (h->color_dist > wmin) throw InputError("colour distance (POLAR_COLOR_DIST) beyond a cell width of the list grid (half the list cutoff): the conflict lists would miss pairs");
+    if (h->color_dist > wmin) sw = 2;
+    if (h->color_dist > 2.0 * wmin) throw InputError("colour distance (POLAR_COLOR_DIST) beyond two cell widths of the list grid (a cell is half the list cutoff wide): the conflict lists would miss pairs");
   }
   for (int attempt = 0;; attempt++) {  // conflict lists; an atom with more neighbours than the lists hold makes them wider
     h->d_cadj.ensure((size_t)n * h->cadj_pitch + 16);
     HIPCHECK(hipMemsetAsync(flags, 0, 96 * sizeof(int), s));
     k_color_adj<<<nblk(n, 128), 128, 0, s>>>(n, h->d_pos4.p, h->d_perm.p, lo, hi, h->box, h->grid, h->d_cell_first.p, h->d_cell_fill.p, dc2,
-                                             h->cadj_pitch, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags, with_halo ? 1 : 0);
+                                             h->cadj_pitch, h->d_cadj.p, h->d_cdeg.p, h->d_cprio.p, h->d_color_s.p, flags, with_halo ? 1 : 0, sw);
     HIPCHECK(hipMemcpyAsync(h->h_cflags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     if (h->h_cflags[0] <= h->cadj_pitch) break;
@@ -507,26 +512,42 @@ void color_finish(polar_handle *h, bool ranked, int ncolors) {
   for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
   HIPCHECK(hipMemcpyAsync(h->d_crelabel.p, relabel.data(), 64 * sizeof(int), hipMemcpyHostToDevice, s));
   k_color_relabel<<<nblk(n, 256), 256, 0, s>>>(n, h->d_crelabel.p, h->d_perm.p, h->d_color_s.p, h->d_color_orig.p);
-  // rows of every phase in cell order; with boundary flags (multi-GPU) every phase lists its boundary rows first
-  const int *bflag = (h->bflag_n == n && sharded(h) && !deterministic(h)) ? h->d_bflag.p : nullptr;
-  const int nclass = bflag ? 2 * ncolors : ncolors;
+  // rows of every phase in cell order, by sub-class inside a phase: multi-GPU: boundary rows first (polar_dist_set_halo);
+  // single GPU: the region pipeline's four classes (polar_step.hip, solve)
+  const int *sub = nullptr;
+  int nsub = 1;
+  if (h->bflag_n == n && sharded(h) && !deterministic(h)) { sub = h->d_bflag.p; nsub = 2; }
+  else if (h->pipeline && !sharded(h) && !deterministic(h) && 4 * ncolors + 1 <= 72) {
+    // cut along the longest box dimension; "near" = within the dipole cutoff of a cutting plane, plus a margin for the
+    // motion between two colourings (a far row that drifted closer only races with weakly coupled rows: > 10 A away)
+    int axis = 0;
+    for (int k = 1; k < 3; k++) if (h->box.prd[k] > h->box.prd[axis]) axis = k;
+    const double reach = h->ph.st.dd_cutoff + 1.5;
+    if (h->box.periodic[axis] && !h->box.triclinic && h->box.prd[axis] >= 4.0 * reach + 8.0) {
+      h->d_sub.ensure((size_t)n + 1);
+      k_region_sub<<<nblk(n, 256), 256, 0, s>>>(n, h->d_pos4.p, h->d_perm.p, axis, h->boxlo[axis], h->box.prd[axis], reach, h->d_sub.p);
+      sub = h->d_sub.p; nsub = 4;
+    }
+  }
+  const int nclass = nsub * ncolors;
   if (nclass > 71) throw std::runtime_error("colouring: too many phase classes");
   const size_t ncc = (size_t)nclass * ncell;
   const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
   h->d_ccnt.ensure(ncc + 1); h->d_coff.ensure(ncc + 2);
-  k_color_cellcount<<<nblk(ncell, 128), 128, 0, s>>>(ncell, nclass, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_ccnt.p, h->d_perm.p, lo, hi, bflag);
+  k_color_cellcount<<<nblk(ncell, 128), 128, 0, s>>>(ncell, nclass, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_ccnt.p, h->d_perm.p, lo, hi, sub, nsub);
   k_exclusive_scan<int><<<1, 1024, 0, s>>>((long long)ncc, h->d_ccnt.p, h->d_coff.p);
-  for (int c = 0; c <= nclass; c++)
-    HIPCHECK(hipMemcpyAsync(h->h_coff + c, h->d_coff.p + (size_t)c * ncell, sizeof(long long), hipMemcpyDeviceToHost, s));
+  for (int q = 0; q <= nclass; q++)
+    HIPCHECK(hipMemcpyAsync(h->h_coff + q, h->d_coff.p + (size_t)q * ncell, sizeof(long long), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));  // (also: `relabel` is a stack vector)
   h->color_off.assign((size_t)ncolors + 1, 0);
-  h->color_mid.assign((size_t)ncolors, 0);
-  for (int c = 0; c <= ncolors; c++) h->color_off[c] = (int)h->h_coff[bflag ? 2 * c : c];
-  for (int c = 0; c < ncolors; c++) h->color_mid[c] = bflag ? (int)h->h_coff[2 * c + 1] : h->color_off[c + 1];   // (no flags: every row counts as a boundary row)
+  h->color_sub.assign((size_t)nclass + 1, 0);
+  h->color_nsub = nsub;
+  for (int q = 0; q <= nclass; q++) h->color_sub[q] = (int)h->h_coff[q];
+  for (int q = 0; q <= ncolors; q++) h->color_off[q] = (int)h->h_coff[nsub * q];
   const int tot = h->color_off[ncolors];
   h->d_rows_orig.ensure((size_t)tot + 1); h->d_rows.ensure((size_t)tot + 1);
   k_color_fill<<<nblk(ncell, 128), 128, 0, s>>>(ncell, nclass, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_perm.p, h->d_coff.p,
-                                               h->d_rows_orig.p, lo, hi, bflag);
+                                               h->d_rows_orig.p, lo, hi, sub, nsub);
   lap("phase order + rows");
 #ifdef POLAR_LAB
   if (getenv("POLAR_LP_SORT_T") && tot > 0) {   // lab: inside a phase the rows with the most trips first (stable: cell order inside a trip count)

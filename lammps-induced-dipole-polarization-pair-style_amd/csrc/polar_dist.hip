@@ -347,8 +347,8 @@ int polar_dist_set_halo(polar_dist *d, polar_handle *h, int npeers, const int *p
     if (nr) HIPCHECK(hipMemcpy(d->d_recv_idx.p, recv_idx, nr * sizeof(int), hipMemcpyHostToDevice));
     d->plan_epoch = -1;   // the lists by colour are rebuilt before the next solve
     if (h) {  // boundary rows of the handle: the rows a peer receives (they come first in their colour phase)
-      std::vector<int> flag((size_t)h->nlocal + 1, 0);
-      for (size_t t = 0; t < ns; t++) flag[send_idx[t]] = 1;
+      std::vector<int> flag((size_t)h->nlocal + 1, 1);   // sub-class: 0 = boundary (comes first in its phase), 1 = interior
+      for (size_t t = 0; t < ns; t++) flag[send_idx[t]] = 0;
       h->d_bflag.ensure((size_t)h->nlocal + 1);
       HIPCHECK(hipMemcpy(h->d_bflag.p, flag.data(), (size_t)h->nlocal * sizeof(int), hipMemcpyHostToDevice));
       h->bflag_n = h->nlocal;
@@ -454,8 +454,8 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
         // boundary rows first, the exchange behind the interior rows -- where there are interior rows worth a launch of their
         // own (8 slabs two cutoffs thick have none: every row is some peer's halo)
         long long interior = 0, rows = h->color_off.empty() ? 0 : h->color_off.back();
-        if (h->color_mid.size() + 1 == h->color_off.size())
-          for (size_t c = 0; c < h->color_mid.size(); c++) interior += h->color_off[c + 1] - h->color_mid[c];
+        if (h->color_nsub == 2)
+          for (size_t c = 0; c + 1 < h->color_off.size(); c++) interior += h->color_sub[2 * c + 2] - h->color_sub[2 * c + 1];
         const bool split = !deterministic(h) && interior * 8 >= rows && interior > 0;
         long long g = 0;   // phases issued so far
         for (int sw = 0; sw < max_sweeps; sw++) {

@@ -184,8 +184,15 @@ struct polar_handle {
   bool mu_host_in_sync = false;  // the caller's mu array still holds what the last polar_compute returned (no polar_set_atoms since)
   // colour phases (cutoff-mode Gauss-Seidel)
   std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
-  std::vector<int> color_mid;  // [ncolors] end of a phase's BOUNDARY rows (multi-GPU: rows whose dipoles a peer receives come first)
-  DBuf<int> d_bflag; int bflag_n = 0;   // boundary flags by original index (polar_dist_set_halo), 0 = none
+  std::vector<int> color_sub;  // [ncolors * color_nsub + 1] offsets of the sub-classes inside the phases (class = colour * nsub + sub)
+  int color_nsub = 1;          // 1: none; 2 (multi-GPU): boundary rows, then interior rows; 4 (single GPU, region pipeline): half A near / far from the cut, half B near / far
+  DBuf<int> d_bflag; int bflag_n = 0;   // multi-GPU: sub-class by original index (polar_dist_set_halo: 0 = a peer receives this row's dipole, 1 = not), bflag_n = atoms it was made for
+  DBuf<int> d_sub;             // region pipeline: sub-class by original index (k_region_sub)
+  int pipeline = 1;            // single GPU, list-mode GS: the two halves of the box on two streams, a half's next phase gated by the other half's NEAR rows only (POLAR_PIPELINE=0: one launch per phase)
+  hipStream_t stream2 = nullptr; hipEvent_t ev_near[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}, ev_half = nullptr, ev_stepdone = nullptr;
+  bool pipe_active = false; long long pipe_g = 0;   // the running solve uses the pipeline; phases issued so far
+  int *h_nl_stage[2] = {nullptr, nullptr}; hipEvent_t ev_nl[2] = {nullptr, nullptr};   // pinned double buffer of the neighbor-list upload
+  hipStream_t lp_stream = nullptr;   // where launch_field_lp puts its kernels when set (else `stream`)
   bool colors_global = false;  // the colouring in force is consistent across the ranks of a multi-GPU run (halo rows carry their owners' colours)
   std::vector<int> user_colors;  // polar_set_colors: a colouring imposed by the caller (original order, -1 = none)
   bool user_colors_clashed = false;
@@ -356,7 +363,7 @@ class HostPool {
   HostPool() {
     pid_ = getpid();
     const unsigned hw = std::thread::hardware_concurrency();
-    const int n = hw >= 4 ? 3 : (hw >= 2 ? (int)hw - 1 : 0);
+    const int n = hw >= 16 ? 7 : (hw >= 4 ? 3 : (hw >= 2 ? (int)hw - 1 : 0));   // (eight-way where the cores are: packing 270 MB of list rows is the longest job)
     for (int t = 0; t < n; t++) th_.emplace_back([this, t]() { loop(t); });
   }
   ~HostPool() {

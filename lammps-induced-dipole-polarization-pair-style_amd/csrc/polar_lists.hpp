@@ -168,7 +168,7 @@ static __global__ void k_color_adj(int n, const double4 *__restrict__ pos4, cons
                             Box box, CellGrid g, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                             double colordistsq, int apitch, int *__restrict__ adj, int *__restrict__ deg,
                             unsigned long long *__restrict__ prio, int *__restrict__ color_s, int *__restrict__ flags,
-                            int with_halo) {
+                            int with_halo, int sw) {
   // `with_halo` (multi-GPU, one colouring consistent across the ranks): the polarizable atoms this handle holds for other
   // ranks' rows count as neighbours too.  They are never coloured here (deg = -1): their colour arrives from their owner
   // (-1 until then: an uncoloured neighbour constrains nothing, its owner will respect OUR colours when its turn comes).
@@ -192,16 +192,17 @@ static __global__ void k_color_adj(int n, const double4 *__restrict__ pos4, cons
     }
   }
   int d = 0;
-  for (int dz = -1; dz <= 1; dz++)
-    for (int dy = -1; dy <= 1; dy++)
-      for (int dx = -1; dx <= 1; dx++) {
+  // `sw` cells to either side (1 where the colour distance fits into a cell, 2 for the small cells of short cutoffs)
+  for (int dz = -sw; dz <= sw; dz++)
+    for (int dy = -sw; dy <= sw; dy++)
+      for (int dx = -sw; dx <= sw; dx++) {
         int b[3] = {cc[0] + dx, cc[1] + dy, cc[2] + dz};
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
           if (b[k] < 0 || b[k] >= g.nc[k]) {
-            if (!box.periodic[k] || g.nc[k] < 3) ok = false;  // (fewer than 3 cells: every cell is visited through offsets -1..1 already)
-            b[k] = (b[k] + g.nc[k]) % g.nc[k];
+            if (!box.periodic[k] || g.nc[k] < 2 * sw + 1) ok = false;  // (fewer cells than the stencil is wide: every cell is visited through the offsets inside the grid already)
+            b[k] = (b[k] + 2 * g.nc[k]) % g.nc[k];
           }
         }
         if (!ok) continue;
@@ -472,37 +473,55 @@ static __global__ void k_color_relabel(int n, const int *__restrict__ relabel, c
 }
 // rows of every phase, cells in order, atoms of a cell in order: counts per (class, cell), one scan, fill.  Rows = the
 // polarizable atoms this handle owns (halo atoms carry their owners' colours and are skipped).  Without `bflag` a class is a
-// colour; with it (multi-GPU: bflag[orig] = "a peer receives this row's dipole") class 2c holds colour c's boundary rows and
-// class 2c + 1 its interior rows, so that a phase can send its boundary rows off while the interior rows are still swept.
+// colour; with `sub` (a sub-class 0 .. nsub-1 per atom, by original index) class nsub * c + k holds colour c's rows of
+// sub-class k: multi-GPU: 0 = boundary rows ("a peer receives this row's dipole"), 1 = interior rows, so that a phase can
+// send its boundary rows off while the interior rows are still swept; single GPU: the four (half of the box, near / far
+// from the cut) classes of the region pipeline.
 __device__ __forceinline__ int color_class(int j, const int *__restrict__ color_s, const int *__restrict__ perm, int own_lo, int own_hi,
-                                           const int *__restrict__ bflag) {
+                                           const int *__restrict__ sub, int nsub) {
   const int c = color_s[j];
   if (c < 0) return -1;
   const int o = perm[j];
   if (o < own_lo || o >= own_hi) return -1;
-  return bflag ? 2 * c + (bflag[o] ? 0 : 1) : c;
+  return sub ? nsub * c + sub[o] : c;
+}
+// sub-class of every atom for the region pipeline of the single-GPU sweep (polar_step.hip, solve): the box is cut in two
+// halves along `axis` (fractional coordinate below / above one half, seen from `origin`); 2 * region + (0: within `reach`
+// of one of the two cutting planes -- a row that may see rows of the other half --, 1: farther away)
+static __global__ void k_region_sub(int n, const double4 *__restrict__ pos4, const int *__restrict__ perm, int axis, double lo, double len,
+                                    double reach, int *__restrict__ sub) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double4 p = pos4[i];
+  const double v = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
+  double fr = (v - lo) / len;
+  fr -= floor(fr);
+  const int region = fr < 0.5 ? 0 : 1;
+  const double d0 = fmin(fr, 1.0 - fr), d1 = fabs(fr - 0.5);   // to the plane at 0 (= 1) and to the plane at 1/2
+  const bool near = fmin(d0, d1) * len < reach;
+  sub[perm[i]] = 2 * region + (near ? 0 : 1);
 }
 static __global__ void k_color_cellcount(long long ncell, int nclass, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                                   const int *__restrict__ color_s, int *__restrict__ cnt, const int *__restrict__ perm, int own_lo, int own_hi,
-                                  const int *__restrict__ bflag) {
+                                  const int *__restrict__ sub, int nsub) {
   const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (c >= ncell) return;
   const int a = (int)cell_first[c], e = a + npol[c];
   for (int q = 0; q < nclass; q++) {
     int k = 0;
-    for (int j = a; j < e; j++) k += color_class(j, color_s, perm, own_lo, own_hi, bflag) == q;
+    for (int j = a; j < e; j++) k += color_class(j, color_s, perm, own_lo, own_hi, sub, nsub) == q;
     cnt[(size_t)q * ncell + c] = k;
   }
 }
 static __global__ void k_color_fill(long long ncell, int nclass, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                              const int *__restrict__ color_s, const int *__restrict__ perm, const long long *__restrict__ off,
-                             int *__restrict__ rows_orig, int own_lo, int own_hi, const int *__restrict__ bflag) {
+                             int *__restrict__ rows_orig, int own_lo, int own_hi, const int *__restrict__ sub, int nsub) {
   const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (c >= ncell) return;
   const int a = (int)cell_first[c], e = a + npol[c];
   for (int q = 0; q < nclass; q++) {
     long long w = off[(size_t)q * ncell + c];
-    for (int j = a; j < e; j++) if (color_class(j, color_s, perm, own_lo, own_hi, bflag) == q) rows_orig[w++] = perm[j];
+    for (int j = a; j < e; j++) if (color_class(j, color_s, perm, own_lo, own_hi, sub, nsub) == q) rows_orig[w++] = perm[j];
   }
 }
 

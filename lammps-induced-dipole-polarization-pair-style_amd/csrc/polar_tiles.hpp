@@ -521,7 +521,7 @@ static __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_field_tile(
                                                     const int *__restrict__ un_j, int un_pitch,
                                                     const unsigned short *__restrict__ dd16, long long pitch16, SRec *s0,
                                                     SRec *s1, double *pend, const double *__restrict__ ef, Box box, double pd,
-                                                    ExpCoef K, const Scal *scal, double *__restrict__ slots) {
+                                                    ExpCoef K, const Scal *scal, double *__restrict__ slots, int nrec) {
   extern __shared__ __attribute__((aligned(16))) char tl_lds[];
   char *const recs = tl_lds + POLAR_TILE_LDS_REC;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -588,7 +588,13 @@ static __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_field_tile(
         const int gq = gw + lane, p = gq % 3;
         if (gw < np) {  // wave-uniform; lanes past the end fetch a valid piece into the slack behind the dummy
           // (the entry words were requested before U was known: beyond the list they are whatever the table held)
-          const unsigned voff = (gq < np ? (unsigned)(ent[u] & POLAR_TILE_RECMASK) : 0u) * 48u + (unsigned)p * 16u;
+          // Round 3's recorded abort (gpurun_out/r3_tile2_tests.log): a version of this line without the `gq < np` guard let the
+          // lanes past a tile's list turn whatever the table held behind it -- words of an earlier, larger step, or of a fresh
+          // hipMalloc -- into record numbers of up to 2^26: a 3 GB offset, a global read far outside the record table.  The guard
+          // keeps stale words out; the clamp to the table (nrec = the dummy record, the last one) makes ANY word harmless.
+          unsigned recno = gq < np ? (unsigned)(ent[u] & POLAR_TILE_RECMASK) : 0u;
+          recno = recno < (unsigned)nrec ? recno : (unsigned)nrec;
+          const unsigned voff = recno * 48u + (unsigned)p * 16u;
           lpa_dma(sb, voff, lds0 + (unsigned)gw * 16u);
         }
       }

@@ -161,10 +161,10 @@ def test_restart_record_of_the_polarization_keywords(pkg):
     p = pkg.PolarPair(0)
     p.settings(["2.5", "12.8345", "precision", "1e-9", "max_iterations", "77", "damp_type", "exponential", "damp", "1.9",
                 "polar_gamma", "1.01", "use_previous", "yes", "dd_cutoff", "11.5", "restart_polar", "yes",
-                "polar_gs_ranked", "no", "polar_gs", "yes"])
+                "polar_gs_ranked", "no", "polar_gs", "yes", "deterministic", "yes", "polar_sor", "1.2", "rccl_halo", "yes"])
     rec = p.restart_pack()
     magic, ver, nb = struct.unpack("<iii", rec[:12])
-    assert magic == 0x524C4F50 and ver == 1 and nb == len(rec) - 12
+    assert magic == 0x524C4F50 and ver == 2 and nb == len(rec) - 12   # version 2: + deterministic, rccl_halo, polar_accel, polar_sor
     q = pkg.PolarPair(0)
     q.settings(["2.5", "12.8345"])          # what read_restart_settings does first: cutoffs from the stock record
     assert q.get_settings().polar_gs_ranked == 1 and q.get_settings().restart_polar == 0
@@ -172,6 +172,22 @@ def test_restart_record_of_the_polarization_keywords(pkg):
     a, b = p.get_settings(), q.get_settings()
     for k, _ in pkg.Settings._fields_:
         assert getattr(a, k) == getattr(b, k), k
+    assert b.deterministic == 1 and b.rccl_halo == 1 and abs(b.polar_sor - 1.2) < 1e-15
+    # a version-1 record (round 3's files) is still read; the keywords it does not carry keep the values in force
+    v1 = struct.pack("<iii", 0x524C4F50, 1, 72) + rec[12:12 + 72]
+    q1 = pkg.PolarPair(0)
+    q1.settings(["2.5", "12.8345"])
+    q1.restart_unpack(v1)
+    c = q1.get_settings()
+    assert c.iterations_max == 77 and c.polar_gs == 1 and c.dd_cutoff == 11.5 and c.deterministic == 0 and c.polar_sor == 1.0
+    # polar_set_settings: a zero-initialised struct means omega = 1, values outside (0, 2) are refused
+    z = pkg.Settings()
+    z.cut_lj_global, z.cut_coul, z.iterations_max, z.polar_gs_ranked = 2.5, 12.8345, 50, 1
+    q1._ck(q1.L.polar_set_settings(q1.h, z))
+    assert q1.get_settings().polar_sor == 1.0
+    z.polar_sor = 2.5
+    with pytest.raises(pkg.PolarError, match="polar_sor"):
+        q1._ck(q1.L.polar_set_settings(q1.h, z))
     # a stream that continues with something else (reference-format file): refused, nothing changes
     r = pkg.PolarPair(0)
     r.settings(["2.5", "12.8345"])
