@@ -185,7 +185,9 @@ int polar_create(int device, polar_handle **out) {
     HIPCHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto &row : h->ev_near) for (auto &e : row) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&h->ev_half, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&h->ev_stepdone, hipEventDisableTiming));
-    if (const char *e = getenv("POLAR_PIPELINE")) h->pipeline = atoi(e) != 0;
+#ifdef POLAR_LAB
+    if (const char *e = getenv("POLAR_PIPELINE")) h->pipeline = atoi(e) != 0;   // lab: the region pipeline (lost: profiles/r04_lab_region_pipeline.txt)
+#endif
     if (getenv("POLAR_NO_OVERLAP")) h->overlap_lj = false;
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
     HIPCHECK(hipHostMalloc((void **)&h->h_flags, 16 * sizeof(int)));

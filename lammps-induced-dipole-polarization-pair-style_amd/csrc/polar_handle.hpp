@@ -188,7 +188,7 @@ struct polar_handle {
   int color_nsub = 1;          // 1: none; 2 (multi-GPU): boundary rows, then interior rows; 4 (single GPU, region pipeline): half A near / far from the cut, half B near / far
   DBuf<int> d_bflag; int bflag_n = 0;   // multi-GPU: sub-class by original index (polar_dist_set_halo: 0 = a peer receives this row's dipole, 1 = not), bflag_n = atoms it was made for
   DBuf<int> d_sub;             // region pipeline: sub-class by original index (k_region_sub)
-  int pipeline = 1;            // single GPU, list-mode GS: the two halves of the box on two streams, a half's next phase gated by the other half's NEAR rows only (POLAR_PIPELINE=0: one launch per phase)
+  int pipeline = 0;            // single GPU, list-mode GS: the two halves of the box on two streams, a half's next phase gated by the other half's NEAR rows only.  OFF: it loses (10.6 against 9.2 ms per step at 135k atoms, profiles/r04_lab_region_pipeline.txt); POLAR_PIPELINE=1 switches it on in the LAB build only
   hipStream_t stream2 = nullptr; hipEvent_t ev_near[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}, ev_half = nullptr, ev_stepdone = nullptr;
   bool pipe_active = false; long long pipe_g = 0;   // the running solve uses the pipeline; phases issued so far
   int *h_nl_stage[2] = {nullptr, nullptr}; hipEvent_t ev_nl[2] = {nullptr, nullptr};   // pinned double buffer of the neighbor-list upload
