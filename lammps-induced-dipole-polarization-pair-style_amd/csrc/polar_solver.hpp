@@ -1419,7 +1419,7 @@ __device__ __forceinline__ double readlane_d(double v, int k) {  // k wave-unifo
 
 // ONE wave: the sequential recurrence over the 64 atoms b0..b0+63 of the sweep order
 // (PS.cpp:1158-1180).  Lane l owns atom b0+l; step k: mu_k <- alpha_k (E_k + F_k), and every lane
-// folds T_{l,k} dmu_k into its running field.  Tensor rows are prefetched four steps ahead.
+// folds T_{l,k} dmu_k into its running field.
 static __global__ __launch_bounds__(64) void k_gs_seq_T6(int n, long long np, int b0, const double *__restrict__ T6,
                                                   AtomRec *__restrict__ rec, const double *__restrict__ ef,
                                                   double *__restrict__ F, double *__restrict__ dmu_blk,
@@ -1438,15 +1438,21 @@ static __global__ __launch_bounds__(64) void k_gs_seq_T6(int n, long long np, in
   // T_{k,l} = T_{l,k}: read row (b0+k), columns b0..b0+63 -> consecutive lanes, 512 contiguous bytes per component
   const double *tcol = T6 + (size_t)b0 * 6 * np + i;
   const size_t rowstride = (size_t)np * 6;
-  double ta[4][6], tb[4][6];
+  // Tensor rows are prefetched four to eight steps ahead, in registers.  Round 4 measured this wave with rocprofv3 (config 0:
+  // 10.4 us per block = 160 ns per step) and tried what a load-bound reading suggests -- component-major tensor (512 instead
+  // of 3,072 bytes per load instruction), groups of 8 steps with 16 in flight (250 VGPRs), the block pulled into this XCD's
+  // L2 by the push kernel before it --: 10.1-10.4 us every time (profiles/r04_config0_chain.txt).  The step time is the
+  // chain of ~8 dependent FP64 instructions and six readlanes of ONE wave on an otherwise idle chip, not its loads.
+  constexpr int G = 4;
+  double ta[G][6], tb[G][6];
 #define POLAR_LOADT(BUF, K0)                                                     \
-  _Pragma("unroll") for (int u = 0; u < 4; u++) {                                \
+  _Pragma("unroll") for (int u = 0; u < G; u++) {                                \
     const int kk = (K0) + u < cnt ? (K0) + u : cnt - 1;                          \
     const double *t_ = tcol + (size_t)kk * rowstride;                            \
     _Pragma("unroll") for (int c = 0; c < 6; c++) BUF[u][c] = t_[(size_t)c * np]; \
   }
 #define POLAR_STEPT(BUF, K0)                                                     \
-  _Pragma("unroll") for (int u = 0; u < 4; u++) {                                \
+  _Pragma("unroll") for (int u = 0; u < G; u++) {                                \
     const int k = (K0) + u;                                                      \
     if (k < cnt) {                                                               \
       const double nx = a * (Ex + Fx), ny = a * (Ey + Fy), nz = a * (Ez + Fz);   \
@@ -1460,11 +1466,13 @@ static __global__ __launch_bounds__(64) void k_gs_seq_T6(int n, long long np, in
     }                                                                            \
   }
   POLAR_LOADT(ta, 0);
-  for (int k0 = 0; k0 < cnt; k0 += 8) {
-    POLAR_LOADT(tb, k0 + 4);
+  POLAR_LOADT(tb, G);
+#pragma unroll 1
+  for (int k0 = 0; k0 < cnt; k0 += 2 * G) {
     POLAR_STEPT(ta, k0);
-    POLAR_LOADT(ta, k0 + 8);
-    POLAR_STEPT(tb, k0 + 4);
+    POLAR_LOADT(ta, k0 + 2 * G);
+    POLAR_STEPT(tb, k0 + G);
+    POLAR_LOADT(tb, k0 + 3 * G);
   }
 #undef POLAR_LOADT
 #undef POLAR_STEPT
@@ -1503,116 +1511,6 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_gs_push_T6(int n, long l
   }
   fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
   if (lane == 0) { F[3 * j] += fx; F[3 * j + 1] += fy; F[3 * j + 2] += fz; }
-}
-
-// ONE launch per block of the exact-order Gauss-Seidel (round 4; rounds 1-3: k_gs_seq_T6 + k_gs_push_T6 = two launches per
-// block, 44 per iteration of config 0): the recurrence of block b (workgroup 0) runs BESIDE the push of block b - 1's dipole
-// changes into the fields of all other rows (the other workgroups).  Workgroup 0 first brings the 64 rows of block b up to
-// date itself (its four waves push block b - 1 into 16 rows each, result into LDS), then its wave 0 walks the recurrence.
-// dmu is double-buffered: this launch reads dmu[buf ^ 1] (written by the launch before it) and writes dmu[buf].  pb0 < 0: no block to push
-// (the very first launch of a solve).  Rounds 1-3 tried this fusion and lost (343 against 283 us per iteration): the one wave
-// of the recurrence was bound by its 3 KB-per-instruction tensor loads, which the component-major layout has removed.
-static __global__ __launch_bounds__(256) void k_gs_fused_T6(int n, long long np, int b0, int pb0, int buf, const double *__restrict__ T6,
-                                                     AtomRec *__restrict__ rec, const double *__restrict__ ef,
-                                                     double *__restrict__ F, double *__restrict__ dmu2,
-                                                     const Scal *scal, double *__restrict__ slots) {
-  if (scal->done) return;
-  __shared__ double Fsh[64][3];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const double *dprev = dmu2 + 3 * 64 * (buf ^ 1);
-  const int pcnt = (pb0 >= 0 && pb0 != b0) ? min(64, n - pb0) : 0;   // (a system of one block: its own changes are already in its fields)
-  double bdx = 0.0, bdy = 0.0, bdz = 0.0;
-  if (lane < pcnt) { bdx = dprev[3 * lane]; bdy = dprev[3 * lane + 1]; bdz = dprev[3 * lane + 2]; }
-  if (blockIdx.x > 0) {   // ---- push of block pb0 into every row outside blocks pb0 and b0 ----
-    const int j = (blockIdx.x - 1) * POLAR_ROWS_PER_BLOCK + wv;
-    if (j >= n || pcnt == 0 || (j >= pb0 && j < pb0 + 64) || (j >= b0 && j < b0 + 64)) return;
-    if (rec[j].a == 0.0) return;  // mu_j stays 0: its field is never read
-    double fx = 0, fy = 0, fz = 0;
-    if (lane < pcnt) {
-      double t[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) t[c] = T6[((size_t)j * 6 + c) * np + pb0 + lane];
-      fx = -(t[0] * bdx + t[1] * bdy + t[2] * bdz);
-      fy = -(t[1] * bdx + t[3] * bdy + t[4] * bdz);
-      fz = -(t[2] * bdx + t[4] * bdy + t[5] * bdz);
-    }
-    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
-    if (lane == 0) { F[3 * j] += fx; F[3 * j + 1] += fy; F[3 * j + 2] += fz; }
-    return;
-  }
-  // ---- workgroup 0: the rows of block b0 first (16 per wave), then the recurrence ----
-  const int cnt = min(64, n - b0);
-  for (int r0 = 0; r0 < 16; r0 += 4) {
-    double t[4][6];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int jr = b0 + 16 * wv + r0 + u;
-      const int jj = jr < n ? jr : b0;
-#pragma unroll
-      for (int c = 0; c < 6; c++) t[u][c] = (lane < pcnt) ? T6[((size_t)jj * 6 + c) * np + pb0 + lane] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int row = 16 * wv + r0 + u, jr = b0 + row;
-      double fx = -(t[u][0] * bdx + t[u][1] * bdy + t[u][2] * bdz);
-      double fy = -(t[u][1] * bdx + t[u][3] * bdy + t[u][4] * bdz);
-      double fz = -(t[u][2] * bdx + t[u][4] * bdy + t[u][5] * bdz);
-      fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
-      if (lane == 0 && jr < n) { Fsh[row][0] = F[3 * jr] + fx; Fsh[row][1] = F[3 * jr + 1] + fy; Fsh[row][2] = F[3 * jr + 2] + fz; }
-    }
-  }
-  __syncthreads();
-  if (wv != 0) return;
-  const bool act = lane < cnt;
-  const int i = act ? b0 + lane : b0;
-  const AtomRec r = rec[i];
-  const double a = act ? r.a : 0.0;
-  double mx = r.mx, my = r.my, mz = r.mz;
-  const double mx0 = mx, my0 = my, mz0 = mz;
-  double Fx = act ? Fsh[lane][0] : 0.0, Fy = act ? Fsh[lane][1] : 0.0, Fz = act ? Fsh[lane][2] : 0.0;
-  const double Ex = ef[3 * i], Ey = ef[3 * i + 1], Ez = ef[3 * i + 2];
-  const double *tcol = T6 + (size_t)b0 * 6 * np + i;
-  const size_t rowstride = (size_t)np * 6;
-  double ta[4][6], tb[4][6];
-#define POLAR_LOADT(BUF, K0)                                                     \
-  _Pragma("unroll") for (int u = 0; u < 4; u++) {                                \
-    const int kk = (K0) + u < cnt ? (K0) + u : cnt - 1;                          \
-    const double *t_ = tcol + (size_t)kk * rowstride;                            \
-    _Pragma("unroll") for (int c = 0; c < 6; c++) BUF[u][c] = t_[(size_t)c * np]; \
-  }
-#define POLAR_STEPT(BUF, K0)                                                     \
-  _Pragma("unroll") for (int u = 0; u < 4; u++) {                                \
-    const int k = (K0) + u;                                                      \
-    if (k < cnt) {                                                               \
-      const double nx = a * (Ex + Fx), ny = a * (Ey + Fy), nz = a * (Ez + Fz);   \
-      const double cdx = readlane_d(nx - mx, k), cdy = readlane_d(ny - my, k),   \
-                   cdz = readlane_d(nz - mz, k);                                 \
-      if (lane == k) { mx = nx; my = ny; mz = nz; }                              \
-      Fx -= BUF[u][0] * cdx + BUF[u][1] * cdy + BUF[u][2] * cdz;                 \
-      Fy -= BUF[u][1] * cdx + BUF[u][3] * cdy + BUF[u][4] * cdz;                 \
-      Fz -= BUF[u][2] * cdx + BUF[u][4] * cdy + BUF[u][5] * cdz;                 \
-    }                                                                            \
-  }
-  POLAR_LOADT(ta, 0);
-  for (int k0 = 0; k0 < cnt; k0 += 8) {
-    POLAR_LOADT(tb, k0 + 4);
-    POLAR_STEPT(ta, k0);
-    POLAR_LOADT(ta, k0 + 8);
-    POLAR_STEPT(tb, k0 + 4);
-  }
-#undef POLAR_LOADT
-#undef POLAR_STEPT
-  double *dcur = dmu2 + 3 * 64 * buf;
-  double dsq = 0.0;
-  if (act) {
-    const double tx = mx - mx0, ty = my - my0, tz = mz - mz0;
-    dsq = tx * tx + ty * ty + tz * tz;
-    rec[i].mx = mx; rec[i].my = my; rec[i].mz = mz;
-    F[3 * i] = Fx; F[3 * i + 1] = Fy; F[3 * i + 2] = Fz;
-    dcur[3 * lane] = tx; dcur[3 * lane + 1] = ty; dcur[3 * lane + 2] = tz;
-  }
-  dsq = wave_sum(dsq);
-  if (lane == 0 && dsq != 0.0) atomicAdd(slots + (size_t)((b0 >> 6) & (POLAR_NSLOT - 1)) * POLAR_SLOT_STRIDE + SL_CHANGE, dsq);
 }
 
 // ------------------------------------------------------------------------------------------

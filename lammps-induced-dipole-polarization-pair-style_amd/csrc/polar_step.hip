@@ -765,23 +765,17 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     }
   } else if (h->dense_gs) {  // exact-order blocked Gauss-Seidel on the HBM-resident tensor
     const long long np = ((long long)n + 63) / 64 * 64;   // row pitch of the component-major tensor
-    h->d_T6.ensure((size_t)n * 6 * np + 64); h->d_dmu.ensure(2 * 3 * 64);
+    h->d_T6.ensure((size_t)n * 6 * np + 64); h->d_dmu.ensure(2 * 3 * 64 + 8);
     if (expd) k_build_T6<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
     else      k_build_T6<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
     k_dense_field<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_T6.p, h->d_rec0.p, h->d_F.p);
-    // one launch per block: the recurrence of block b beside the push of block b - 1 (k_gs_fused_T6)
-    const bool fused = !getenv("POLAR_GS_TWO_LAUNCH");
-    int launch_no = 0;
-    int pb0 = -1;
+    // (one launch per block -- the recurrence of block b in workgroup 0 beside the push of block b - 1 in the others -- was
+    //  built again this round on the component-major tensor and lost again: 458 against 313 us per iteration,
+    //  profiles/r04_config0_chain.txt: workgroup 0's serial part sets the launch time and nothing overlaps it)
     for (int sw = 0; sw < max_sweeps; sw++) {
       for (int b0 = 0; b0 < n; b0 += 64) {
-        if (fused) {
-          k_gs_fused_T6<<<1 + nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, b0, pb0, (launch_no++) & 1, h->d_T6.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
-          pb0 = b0;
-        } else {
-          k_gs_seq_T6<<<1, 64, 0, s>>>(n, np, b0, h->d_T6.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
-          k_gs_push_T6<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, b0, h->d_T6.p, h->d_rec0.p, h->d_dmu.p, h->d_F.p, h->d_scal.p);
-        }
+        k_gs_seq_T6<<<1, 64, 0, s>>>(n, np, b0, h->d_T6.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
+        k_gs_push_T6<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, b0, h->d_T6.p, h->d_rec0.p, h->d_dmu.p, h->d_F.p, h->d_scal.p);
       }
       debug_trace(h, sw, false);
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, nullptr, 0);
