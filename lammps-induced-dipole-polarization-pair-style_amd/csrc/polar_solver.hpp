@@ -1451,18 +1451,24 @@ static __global__ __launch_bounds__(64) void k_gs_seq_T6(int n, long long np, in
     const double *t_ = tcol + (size_t)kk * rowstride;                            \
     _Pragma("unroll") for (int c = 0; c < 6; c++) BUF[u][c] = t_[(size_t)c * np]; \
   }
+  // The critical path of a step is: broadcast of step k's change (readlane) -> lane k + 1 folds it into its field -> its own
+  // change -> broadcast.  It is kept to FOUR dependent FP64 instructions: the field takes the three products as three chained
+  // FMAs (not product, two FMAs and a subtraction), and the change is ONE FMA, a F + (a E - mu) with the bracket formed when the
+  // block starts (not a (E + F), then minus mu: three instructions) -- 12 instead of 22 FP64 instructions per step.  (It did
+  // not shorten the step either: 160 ns before and after, profiles/r04_config0_chain.txt.)
+  const double cx0 = a * Ex - mx, cy0 = a * Ey - my, cz0 = a * Ez - mz;
 #define POLAR_STEPT(BUF, K0)                                                     \
   _Pragma("unroll") for (int u = 0; u < G; u++) {                                \
     const int k = (K0) + u;                                                      \
     if (k < cnt) {                                                               \
-      const double nx = a * (Ex + Fx), ny = a * (Ey + Fy), nz = a * (Ez + Fz);   \
-      const double bdx = readlane_d(nx - mx, k), bdy = readlane_d(ny - my, k),   \
-                   bdz = readlane_d(nz - mz, k);                                 \
-      if (lane == k) { mx = nx; my = ny; mz = nz; }                              \
+      const double ddx = fma(a, Fx, cx0), ddy = fma(a, Fy, cy0), ddz = fma(a, Fz, cz0); \
+      const double bdx = readlane_d(ddx, k), bdy = readlane_d(ddy, k),           \
+                   bdz = readlane_d(ddz, k);                                     \
+      if (lane == k) { mx += ddx; my += ddy; mz += ddz; }                        \
       /* the diagonal block T_kk is stored as zero: lane k leaves its own field alone */ \
-      Fx -= BUF[u][0] * bdx + BUF[u][1] * bdy + BUF[u][2] * bdz;                 \
-      Fy -= BUF[u][1] * bdx + BUF[u][3] * bdy + BUF[u][4] * bdz;                 \
-      Fz -= BUF[u][2] * bdx + BUF[u][4] * bdy + BUF[u][5] * bdz;                 \
+      Fx = fma(-BUF[u][2], bdz, fma(-BUF[u][1], bdy, fma(-BUF[u][0], bdx, Fx))); \
+      Fy = fma(-BUF[u][4], bdz, fma(-BUF[u][3], bdy, fma(-BUF[u][1], bdx, Fy))); \
+      Fz = fma(-BUF[u][5], bdz, fma(-BUF[u][4], bdy, fma(-BUF[u][2], bdx, Fz))); \
     }                                                                            \
   }
   POLAR_LOADT(ta, 0);

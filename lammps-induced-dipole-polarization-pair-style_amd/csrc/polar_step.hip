@@ -765,13 +765,14 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     }
   } else if (h->dense_gs) {  // exact-order blocked Gauss-Seidel on the HBM-resident tensor
     const long long np = ((long long)n + 63) / 64 * 64;   // row pitch of the component-major tensor
-    h->d_T6.ensure((size_t)n * 6 * np + 64); h->d_dmu.ensure(2 * 3 * 64 + 8);
+    h->d_T6.ensure((size_t)n * 6 * np + 64); h->d_dmu.ensure(3 * 64 + 8);
     if (expd) k_build_T6<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
     else      k_build_T6<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
     k_dense_field<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_T6.p, h->d_rec0.p, h->d_F.p);
-    // (one launch per block -- the recurrence of block b in workgroup 0 beside the push of block b - 1 in the others -- was
-    //  built again this round on the component-major tensor and lost again: 458 against 313 us per iteration,
-    //  profiles/r04_config0_chain.txt: workgroup 0's serial part sets the launch time and nothing overlaps it)
+    // two launches per block of 64 atoms.  Round 4 built two one-launch-per-block forms on the component-major tensor -- the
+    // recurrence of block b in workgroup 0 beside the push of block b - 1 in the others, with 64-atom blocks (19.8 us per
+    // launch) and with 128-atom blocks, two rows per lane, the pre-push without cross-lane reductions (43.9 us per launch) --
+    // and both lost against 10.4 + 4.7 us for these two (profiles/r04_config0_chain.txt)
     for (int sw = 0; sw < max_sweeps; sw++) {
       for (int b0 = 0; b0 < n; b0 += 64) {
         k_gs_seq_T6<<<1, 64, 0, s>>>(n, np, b0, h->d_T6.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
