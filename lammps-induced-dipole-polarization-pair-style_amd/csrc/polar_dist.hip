@@ -36,6 +36,7 @@ struct RcclApi {
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr;
 };
 std::once_flag g_rccl_once;
 RcclApi g_rccl;
@@ -67,6 +68,7 @@ void rccl_open() {
   *(void **)(&api.CommCount) = dlsym(api.lib, "ncclCommCount");
   *(void **)(&api.CommAbort) = dlsym(api.lib, "ncclCommAbort");
   *(void **)(&api.CommGetAsyncError) = dlsym(api.lib, "ncclCommGetAsyncError");
+  *(void **)(&api.CommSplit) = dlsym(api.lib, "ncclCommSplit");
   api.ready = true;
   g_rccl = api;   // published only when complete: a failed attempt leaves no half-filled table behind
 }
@@ -84,7 +86,10 @@ const int kRing = 8;   // events kept per stream: a phase waits for an exchange 
 }  // namespace
 
 struct polar_dist {
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;      // point-to-point exchanges (communication stream)
+  ncclComm_t comm_red = nullptr;  // all-reduces (compute stream): a communicator of its own where ncclCommSplit exists -- RCCL orders the
+                                  // operations of ONE communicator across streams, and the stop rule's all-reduce would wait for the
+                                  // exchange in flight on the other stream; the same communicator otherwise
   int rank = 0, nranks = 1, device = 0;
   std::string err;
   // halo plan of the handle this driver steps: peers, and per peer the rows it sends / the rows it receives (atom indices)
@@ -273,6 +278,13 @@ int polar_dist_create(const void *id128, int rank, int nranks, int device, polar
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     RCCLCHECK(rccl().CommInitRank(&d->comm, nranks, id, rank));
+    d->comm_red = d->comm;
+    // OFF by default: two communicators whose kernels run side by side have never met a second GPU here, one communicator on
+    // two streams is the form the one-rank RCCL test exercises (POLAR_DIST_SPLIT_COMM=1 switches the second one on)
+    if (rccl().CommSplit && getenv("POLAR_DIST_SPLIT_COMM") && atoi(getenv("POLAR_DIST_SPLIT_COMM")) != 0) {
+      ncclComm_t second = nullptr;
+      if (rccl().CommSplit(d->comm, 0, rank, &second, nullptr) == ncclSuccess && second) d->comm_red = second;   // (collective; on failure: one communicator)
+    }
     d->d_red.ensure(128);
     HIPCHECK(hipHostMalloc((void **)&d->h_red, 128 * sizeof(double)));
     const double inf = INFINITY;
@@ -288,6 +300,7 @@ int polar_dist_destroy(polar_dist *d) {
   if (!d) return POLAR_OK;
   (void)hipSetDevice(d->device);
   if (d->xs) (void)hipStreamSynchronize(d->xs);
+  if (d->comm_red && d->comm_red != d->comm) { try { (void)rccl().CommDestroy(d->comm_red); } catch (const std::exception &) {} }
   if (d->comm) { try { (void)rccl().CommDestroy(d->comm); } catch (const std::exception &) {} }
   for (auto &e : d->ev_phase) if (e) (void)hipEventDestroy(e);
   for (auto &e : d->ev_xdone) if (e) (void)hipEventDestroy(e);
@@ -406,6 +419,7 @@ int polar_dist_exchange(polar_dist *d, polar_handle *h) {
 int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_result *out) {
   return dist_guarded(d, [&]() {
     if (!h || !out) throw InputError("polar_dist_step: null pointer");
+    if (!d->comm) throw std::runtime_error("polar_dist_step: the communicator was aborted after a failure inside an earlier step");
     need_device(h);
     HIPCHECK(hipSetDevice(h->device));
     RcclApi &R = rccl();
@@ -421,6 +435,10 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
       std::string berr;
       try {
         if (!(st.dd_cutoff > 0.0)) throw InputError("polar_dist_step needs list mode (dd_cutoff > 0): exact mode runs as replicas only");
+        // (everything the sweeps could refuse is refused HERE, where the ranks can still agree on it)
+        if (st.polar_accel > 0 && !(d->my_class >= 0 && d->lag >= 0 && gs && h->sweep_kernel == 2))
+          throw InputError("polar_accel across ranks needs the shared colouring (polar_dist_set_schedule with classes and lag >= 0) and polar_gs / polar_gs_ranked");
+        if (st.polar_accel > 0 && deterministic(h)) throw InputError("polar_accel and `deterministic yes` exclude each other");
         step_begin_lists(h, eflag, vflag);
       } catch (const InputError &e) { brc = POLAR_ERR_INPUT; berr = e.what();
       } catch (const NoDevice &e) { brc = POLAR_ERR_NO_DEVICE; berr = e.what();
@@ -473,7 +491,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
             if (g > 0) HIPCHECK(hipStreamWaitEvent(s, d->ev_xdone[(g - 1) % kRing], 0));   // no late unpack may land on the mixed dipoles
             accel_export(h, ared + 1);
             if (!lazy) k_fold_change<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, ared, nullptr, 0);
-            RCCLCHECK(R.AllReduce(ared, ared, 1 + 2 * POLAR_ACCEL_MAXM, ncclDouble, ncclSum, d->comm, s));
+            RCCLCHECK(R.AllReduce(ared, ared, 1 + 2 * POLAR_ACCEL_MAXM, ncclDouble, ncclSum, d->comm_red, s));
             d->allreduces++;
             if (!lazy) k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), 0, st.iterations_max, st.polar_precision, 0, ared, 1, nullptr, 0);
             accel_step(h, ared + 1);
@@ -482,7 +500,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
             const double *gc = d->d_red.p + 1;   // +inf: "not converged yet"
             if ((sw % d->reduce_every) == d->reduce_every - 1 || sw >= st.iterations_max) {
               k_fold_change<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, d->d_red.p, det_part(h), det_npart(h));
-              RCCLCHECK(R.AllReduce(d->d_red.p, d->d_red.p, 1, ncclDouble, ncclSum, d->comm, s));
+              RCCLCHECK(R.AllReduce(d->d_red.p, d->d_red.p, 1, ncclDouble, ncclSum, d->comm_red, s));
               d->allreduces++;
               gc = d->d_red.p;
             }
@@ -511,7 +529,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
             const double *gc = d->d_red.p + 1;
             if ((sw % d->reduce_every) == d->reduce_every - 1 || sw >= st.iterations_max) {
               k_fold_change<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, d->d_red.p, det_part(h), det_npart(h));
-              RCCLCHECK(R.AllReduce(d->d_red.p, d->d_red.p, 1, ncclDouble, ncclSum, d->comm, s));
+              RCCLCHECK(R.AllReduce(d->d_red.p, d->d_red.p, 1, ncclDouble, ncclSum, d->comm_red, s));
               d->allreduces++;
               gc = d->d_red.p;
             }
@@ -533,7 +551,11 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
         }
       }
       } catch (...) {
-        if (R.CommAbort && d->comm) { (void)R.CommAbort(d->comm); d->comm = nullptr; }
+        if (R.CommAbort && d->comm) {
+          if (d->comm_red && d->comm_red != d->comm) (void)R.CommAbort(d->comm_red);
+          (void)R.CommAbort(d->comm);
+          d->comm = d->comm_red = nullptr;
+        }
         h->in_step = false;
         throw;
       }

@@ -341,3 +341,59 @@ def test_halo_plan_selects_boundary_layers_of_slabs():
         near = own[(np.sum(d * d, axis=2) < 25.0).any(axis=1)]
         assert set(near.tolist()) <= set(ids.tolist())
         assert len(ids) < 0.7 * len(own)            # and it is a real subset for slabs
+
+
+def test_rank_classes_never_give_two_peers_the_same_turn():
+    """Turns of the colouring shared by the ranks (polar_dist_set_schedule): greedy colouring of the peer graph in rank order.
+    A ring of an even number of slabs takes 2 turns, an odd ring 3, ranks that all see each other one turn each."""
+    par = importlib.import_module(PKG + ".parallel")
+    ring = lambda n: [[(r - 1) % n, (r + 1) % n] for r in range(n)]
+    for n, want in ((2, 2), (4, 2), (8, 2), (3, 3), (5, 3), (7, 3)):
+        peers = [sorted(set(p) - {r}) for r, p in enumerate(ring(n))]
+        cls, ncls = par.rank_classes(peers)
+        assert ncls == want and all(cls[r] != cls[q] for r in range(n) for q in peers[r])
+    full = [[q for q in range(4) if q != r] for r in range(4)]          # thin slabs: everybody is everybody's peer
+    cls, ncls = par.rank_classes(full)
+    assert ncls == 4 and sorted(cls) == [0, 1, 2, 3]
+    bricks = [[q for q in range(8) if q != r] for r in range(8)]        # 2 x 2 x 2 bricks in a periodic box
+    assert par.rank_classes(bricks)[1] == 8
+    assert par.rank_classes([[]]) == ([0], 1)
+
+
+def test_ghost_map_of_a_compact_shard_points_at_the_owners(wl):
+    """polar_dist_set_ghosts input: every periodic image a compact shard holds is its owner's position plus whole box vectors,
+    and the owner is one of the shard's local atoms (own or halo)."""
+    par = importlib.import_module(PKG + ".parallel")
+    sg = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 1, 1, 3, extra_args=["use_previous", "no", "dd_cutoff", "9.0"], build_list=False)
+    order, key, glue = wl.slab_order(sg, axis=2, glue_dist=1.6)
+    sg = wl.permute_locals(sg, order)
+    counts, offs = wl.split_sorted(key[order], 3, glue)
+    reach = float(sg.extra["cutneigh"]) + 1e-6
+    plan = par.P2PHaloPlan(sg.x[:sg.nlocal], sg.prd, offs, reach)
+    for r in range(3):
+        sc = wl.compact_shard_geometric(sg, np.arange(offs[r], offs[r + 1]), plan.halo_of(r), reach)
+        owner, shift = par.ghost_map(sc)
+        assert len(owner) == sc.nghost and owner.min() >= 0 and owner.max() < sc.nlocal
+        assert np.allclose(sc.x[sc.nlocal:], sc.x[owner] + shift, atol=0, rtol=0)
+        k = shift / np.asarray(sg.prd)
+        assert np.max(np.abs(k - np.round(k))) < 1e-12 and np.all(np.any(np.round(k) != 0, axis=1))   # whole box vectors, never zero
+
+
+def test_bench_launcher_refuses_to_print_an_n1_line_for_gpus_n():
+    """`python bench.py --gpus 2` by itself becomes the launcher of two ranks; where that many ranks cannot
+    be had -- here: no GPU at all -- it exits non-zero with a one-line reason and prints no result line."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    if importlib.import_module(PKG).device_count() >= 2:
+        pytest.skip("a multi-GPU box: the launcher would really start the ranks")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    reason = [ln for ln in r.stderr.splitlines() if ln.startswith("bench.py:")]
+    assert len(reason) == 1 and ("no MI355X" in reason[0] or "needs 2 GPUs" in reason[0])
+    # a launcher around it with the wrong rank count is refused too (never n_gpus = WORLD_SIZE for another --gpus)
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode != 0 and "WORLD_SIZE=2" in (r2.stderr + r2.stdout)
