@@ -116,6 +116,7 @@ struct polar_dist {
   DBuf<int> d_gowner; DBuf<double> d_gshift;
   long long ng = 0, gfirst = 0;
   polar_result local{};                         // this rank's own share of the last step (energies, virial, pairs)
+  double host_us_rccl = 0.0, host_us_loop = 0.0; // host time of the last step: inside RCCL calls / issuing the whole sweep loop (POLAR_DEBUG prints them)
 };
 
 namespace {
@@ -133,6 +134,8 @@ int dist_guarded(polar_dist *d, F &&fn) {
 void p2p(polar_dist *d, const int *soff, const int *roff, const double *sendbuf, double *recvbuf, int unit, hipStream_t s) {
   const int np = (int)d->peers.size();
   RcclApi &R = rccl();
+  struct Clock { polar_dist *d; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                 ~Clock() { d->host_us_rccl += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } } clock{d};
   RCCLCHECK(R.GroupStart());
   for (int k = 0; k < np; k++) {
     const long long a = roff[k], b = roff[k + 1];
@@ -460,6 +463,8 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
       dist_exchange(d, h);  // the other ranks' initial guess (all halo atoms)
       // ---- the sweeps.  From here on a rank-local failure cannot be agreed on any more (the others are inside their
       //      exchanges): the communicator is aborted so that they see an error instead of waiting.
+      d->host_us_rccl = d->host_us_loop = 0.0;
+      const auto t_loop = std::chrono::steady_clock::now();
       try {
       if (!st.zodid && phased) {
         const int nc = d->plan_nc, lag = deterministic(h) ? 0 : d->lag;
@@ -559,6 +564,9 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
         h->in_step = false;
         throw;
       }
+      d->host_us_loop = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop).count();
+      if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] dist step (rank %d): sweep loop on the host %.0f us (of it inside RCCL calls %.0f us, state reads included), %d + %d exchanges, %d all-reduces\n",
+                                         d->rank, d->host_us_loop, d->host_us_rccl, d->exchanges, d->phase_exchanges, d->allreduces);
       rc = polar_step_finish(h, out);
       d->local = *out;
       // a rank whose rows outgrew their pitch reports POLAR_RETRY_STEP: the flag is max-reduced so that all ranks repeat

@@ -654,7 +654,11 @@ def bench_distributed(args, rank, world, local_rank):
             driver.set_cadence(REDUCE_EVERY, 4)
             # one colouring shared by the ranks + per-phase exchanges on a second stream (POLAR_DIST_LAG=-1: the round-3
             # schedule, every rank colouring for itself and one exchange per sweep)
-            lag = int(os.environ.get("POLAR_DIST_LAG", "1"))
+            # Which schedule: per-phase exchanges cost ~12-17 us per phase of event and exchange traffic that nothing hides
+            # (one rank, real RCCL: profiles/r04_dist_schedule_cost.txt) and save 4-6 of 38 sweeps; one exchange per sweep costs
+            # ~23 us + the link per sweep.  With phases of ~50 us (>= ~100k own atoms per rank) the per-phase schedule wins,
+            # with the ~29-us phases of 66k atoms per rank the two are on par and the simpler one is taken.
+            lag = int(os.environ.get("POLAR_DIST_LAG", "1" if (hi - lo) >= 100000 else "-1"))
             cls, ncls = rank_classes([plan.peers(r) for r in range(world)])
             driver.set_schedule(lag, cls[rank], ncls if lag >= 0 else 0)
             driver.set_ghosts(p, *ghost_map(s))

@@ -109,7 +109,9 @@ def deliver(snap):
 
 
 for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have enlarged a row pitch: POLAR_RETRY_STEP)
-    phase_lag = int(wspec[5:]) if wspec.startswith("phase") else -1
+    # "phaseL" or "phaseLeK": per-phase schedule, delivery L phases late, an exchange only after every K-th phase (and the last)
+    phase_lag = int(wspec[5:].split("e")[0]) if wspec.startswith("phase") else -1
+    phase_every = int(wspec.split("e")[-1]) if wspec.startswith("phase") and "e" in wspec[5:] else 1
     for r, be in enumerate(bes):
         be.pair.set_colors(col_ref[shard_ids[r]] if phase_lag >= 0 else None)
     for be in bes:
@@ -129,7 +131,8 @@ for wspec in ws * 2 if len(grid) == 3 else ws:   # (a first pass may only have e
                 for r, be in enumerate(bes):
                     if c < ncs[r]:
                         be.pair._ck(be.pair.L.polar_step_sweep_phase(be.pair.h, c, 0))
-                pending.append((g, snapshot()))
+                if (c + 1) % phase_every == 0 or c == ncol_ref - 1:
+                    pending.append((g, snapshot()))
                 g += 1
         elif nparts > 1:
             for part in range(nparts):
