@@ -70,41 +70,51 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int nto
   double acc = 0.0;
   long long beg = 0, end = ntotal;
   if (!ALLPAIRS) row_range(nl, i, beg, end);
-  for (long long base = beg; base < end; base += 64) {
-    const long long p = base + lane;
-    bool hit = false;
-    double term = 0.0;
-    if (p < end) {
-      const int j = ALLPAIRS ? (int)p : (nl_j[p] & POLAR_NL_MASK);
-      if (j != i) {
-        double dx, dy, dz, aj;
-        int mj;
-        if (ALLPAIRS) {
-          dx = xi - x[3 * j]; dy = yi - x[3 * j + 1]; dz = zi - x[3 * j + 2];
-          aj = alpha[j]; mj = mol[j];
-        } else {
-          const AtomRec rj = rec[j];
-          min_image_rint(box, xi, yi, zi, rj.x, rj.y, rj.z, dx, dy, dz);
-          aj = rj.a; mj = mol_s[j];
-        }
-        const double r = sqrt(dx * dx + dy * dy + dz * dz);
-        const bool molok = (mi != mj) || mi == 0;
-        if (PASS == 1) {
-          if (ai > 0 && aj > 0 && molok) rmin = fmin(rmin, r);
-        } else if (rmin * 1.5 > r && molok) {
-          hit = true;
-          term = ai * aj;
-        }
+  // one partner per lane and trip; the all-pairs form requests four trips' worth of partners at once (one wave walks ~10^4
+  // partners: a memory latency per trip was 97 + 69 us per step at 1349 atoms) and then takes them in the same order
+  constexpr int U = ALLPAIRS ? 4 : 1;
+  for (long long base = beg; base < end; base += 64 * U) {
+    double px[U], py[U], pz[U], pa[U];
+    int pj[U], pm[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long long p = base + 64 * u + lane;
+      pj[u] = i;   // (a lane past the end looks at the atom itself: skipped below)
+      if (p < end) pj[u] = ALLPAIRS ? (int)p : (nl_j[p] & POLAR_NL_MASK);
+      if (ALLPAIRS) {
+        px[u] = x[3 * pj[u]]; py[u] = x[3 * pj[u] + 1]; pz[u] = x[3 * pj[u] + 2];
+        pa[u] = alpha[pj[u]]; pm[u] = mol[pj[u]];
+      } else {
+        const AtomRec rj = rec[pj[u]];
+        px[u] = rj.x; py[u] = rj.y; pz[u] = rj.z; pa[u] = rj.a; pm[u] = mol_s[pj[u]];
       }
     }
-    if (PASS == 2) {
-      // add the (few) qualifying terms in ascending j, like the reference's serial loop, so that
-      // ties in rank_metric -- and with them the ranked sweep order -- come out bit-identical
-      unsigned long long m = __ballot(hit);
-      while (m) {
-        const int b = __ffsll((long long)m) - 1;
-        acc += __shfl(term, b, 64);
-        m &= m - 1;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      bool hit = false;
+      double term = 0.0;
+      if (pj[u] != i) {
+        double dx, dy, dz;
+        if (ALLPAIRS) { dx = xi - px[u]; dy = yi - py[u]; dz = zi - pz[u]; }
+        else min_image_rint(box, xi, yi, zi, px[u], py[u], pz[u], dx, dy, dz);
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const bool molok = (mi != pm[u]) || mi == 0;
+        if (PASS == 1) {
+          if (ai > 0 && pa[u] > 0 && molok) rmin = fmin(rmin, r);
+        } else if (rmin * 1.5 > r && molok) {
+          hit = true;
+          term = ai * pa[u];
+        }
+      }
+      if (PASS == 2) {
+        // add the (few) qualifying terms in ascending j, like the reference's serial loop, so that
+        // ties in rank_metric -- and with them the ranked sweep order -- come out bit-identical
+        unsigned long long m = __ballot(hit);
+        while (m) {
+          const int b = __ffsll((long long)m) - 1;
+          acc += __shfl(term, b, 64);
+          m &= m - 1;
+        }
       }
     }
   }
@@ -115,6 +125,23 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int nto
   } else {
     if (lane == 0) rank_metric[i] = acc;  // identical in every lane
   }
+}
+
+// The ranked sweep order on the device: position of atom i = how many atoms come before it in a STABLE descending sort by
+// rank_metric (== the reference's bubble sort, PS.cpp:1130-1143): those with a larger metric, and those with the same metric
+// and a smaller index.  One wave per atom, n^2 comparisons (exact mode: a few thousand atoms); order[pos] = i, pos[i].
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_rank_order(int n, const double *__restrict__ rk, int *__restrict__ order, int *__restrict__ pos) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const double ri = rk[i];
+  int before = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const double rj = j < n ? rk[j] : 0.0;
+    before += __popcll(__ballot(j < n && (rj > ri || (rj == ri && j < i))));
+  }
+  if (lane == 0) { pos[i] = before; order[before] = i; }
 }
 
 // ------------------------------------------------------------------------------------------

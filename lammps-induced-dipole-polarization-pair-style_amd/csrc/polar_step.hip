@@ -765,18 +765,43 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     }
   } else if (h->dense_gs) {  // exact-order blocked Gauss-Seidel on the HBM-resident tensor
     const long long np = ((long long)n + 63) / 64 * 64;   // row pitch of the component-major tensor
-    h->d_T6.ensure((size_t)n * 6 * np + 64); h->d_dmu.ensure(3 * 64 + 8);
+    h->d_T6.ensure((size_t)n * 6 * np + 64);
     if (expd) k_build_T6<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
     else      k_build_T6<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
     k_dense_field<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_T6.p, h->d_rec0.p, h->d_F.p);
-    // two launches per block of 64 atoms.  Round 4 built two one-launch-per-block forms on the component-major tensor -- the
-    // recurrence of block b in workgroup 0 beside the push of block b - 1 in the others, with 64-atom blocks (19.8 us per
-    // launch) and with 128-atom blocks, two rows per lane, the pre-push without cross-lane reductions (43.9 us per launch) --
-    // and both lost against 10.4 + 4.7 us for these two (profiles/r04_config0_chain.txt)
+    // ONE launch per block of B atoms, nothing sequential inside it: d = G cb - N d' (polar_solver.hpp, k_gs_blk).  G and N
+    // are formed here, once per step.
+    const int B = n >= 1024 ? 256 : n >= 384 ? 128 : 64, R = 3 * B, nb = (n + B - 1) / B;   // (at least two blocks: dense_gs needs n > 64)
+    const size_t RR = (size_t)R * R;
+    h->d_Minv.ensure(nb * RR); h->d_gsN.ensure(nb * RR); h->d_gsAT.ensure(nb * RR); h->d_cb.ensure(3 * (size_t)n + 3);
+    h->d_dmu.ensure(2 * (size_t)R + 8);
+    if (B > 64) HIPCHECK(hipMemsetAsync(h->d_Minv.p, 0, nb * RR * sizeof(double), s));   // (what lies right of the diagonal pieces)
+    k_gs_blockinv<<<nb * (B / 64) * (POLAR_GS64 / POLAR_GSB_COLS), 64, 0, s>>>(n, np, h->d_T6.p, h->d_rec0.p, h->d_Minv.p, R, (long long)RR, B / 64);
+    for (int m = 64; m < B; m *= 2) {
+      // two triangles of m atoms side by side on G's diagonal become one of 2 m: G = [[G1, 0], [-G2 (A T21) G1, G2]];
+      // Y = (A T21) G1, then the piece below G1 = -G2 Y.  All pairs of all blocks in one batch.
+      const int per = B / (2 * m), nz = nb * per, q = 3 * m;
+      const long long inner = (long long)2 * q * (R + 1), qq = (long long)q * q;
+      double *AT21 = h->d_gsAT.p, *Y = h->d_gsN.p;   // (scratch here; filled for good below)
+      const GsBatch dense{qq, 0, 1}, diag{(long long)RR, inner, per};
+      k_gs_expand<<<dim3(m / 64, m / 4, nz), 256, 0, s>>>(n, np, h->d_T6.p, h->d_rec0.p, B, nb, 1, m, AT21, q, qq);
+      k_gs_gemm<false><<<dim3(q / 64, q / 64, nz), 256, 0, s>>>(q, 1.0, AT21, q, dense, h->d_Minv.p, R, diag, Y, q, dense);
+      k_gs_gemm<true><<<dim3(q / 64, q / 64, nz), 256, 0, s>>>(q, -1.0, h->d_Minv.p + (size_t)q * (R + 1), R, diag, Y, q, dense, h->d_Minv.p + (size_t)q * R, R, diag);
+    }
+    const GsBatch whole{(long long)RR, 0, 1};
+    k_gs_expand<<<dim3(B / 64, B / 4, nb), 256, 0, s>>>(n, np, h->d_T6.p, h->d_rec0.p, B, nb, 0, B, h->d_gsAT.p, R, (long long)RR);
+    k_gs_gemm<true><<<dim3(R / 64, R / 64, nb), 256, 0, s>>>(R, 1.0, h->d_Minv.p, R, whole, h->d_gsAT.p, R, whole, h->d_gsN.p, R, whole);
+    k_gs_cb_init<<<nblk(n, 256), 256, 0, s>>>(n, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_cb.p);
+    int prev = -1, flip = 0;
+    const int grid = R / POLAR_GS_WAVES + nblk(n, POLAR_GS_WAVES);
     for (int sw = 0; sw < max_sweeps; sw++) {
-      for (int b0 = 0; b0 < n; b0 += 64) {
-        k_gs_seq_T6<<<1, 64, 0, s>>>(n, np, b0, h->d_T6.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_dmu.p, h->d_scal.p, h->d_slots.p);
-        k_gs_push_T6<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, b0, h->d_T6.p, h->d_rec0.p, h->d_dmu.p, h->d_F.p, h->d_scal.p);
+      for (int b0 = 0; b0 < n; b0 += B) {
+        const int next0 = b0 + B < n ? b0 + B : 0;
+#define POLAR_GS_BLK(BB) k_gs_blk<BB><<<grid, 64 * POLAR_GS_WAVES, 0, s>>>(n, np, b0, prev, next0, h->d_T6.p, h->d_Minv.p, h->d_gsN.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_cb.p, \
+                                                            h->d_dmu.p + R * flip, h->d_dmu.p + R * (flip ^ 1), h->d_scal.p, h->d_slots.p)
+        if (B == 256) POLAR_GS_BLK(256); else if (B == 128) POLAR_GS_BLK(128); else POLAR_GS_BLK(64);
+#undef POLAR_GS_BLK
+        prev = b0; flip ^= 1;
       }
       debug_trace(h, sw, false);
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, nullptr, 0);
@@ -936,24 +961,16 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   h->dense_gs = false;
   const bool gs_mode = (st.polar_gs || st.polar_gs_ranked) && !st.zodid;
   bool ranked_done = false;
-  if (ap && gs_mode && n > 0 && 48.0 * (double)n * (double)n <= 4.0e9 && !getenv("POLAR_NO_DENSE_GS")) {
+  if (ap && gs_mode && n > 64 && 48.0 * (double)n * (double)n <= 4.0e9 && !getenv("POLAR_NO_DENSE_GS")) {   // (n <= 64: one block, the matrix-free form)
     // exact-order Gauss-Seidel on the HBM-resident tensor: put the atoms in SWEEP order first
     // (s space = ranked order), so blocks of the sweep are contiguous rows/columns of T6
     h->dense_gs = true;
     if (st.polar_gs_ranked) {
       launch_rank<true>(h, 1); launch_rank<true>(h, 2);  // a2 (orig space: needs only x/alpha/mol)
       ranked_done = true;
-      std::vector<double> rk(n);
-      std::vector<int> order(n), pos(n);
-      HIPCHECK(hipMemcpyAsync(rk.data(), h->d_rank.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipStreamSynchronize(s));
-      std::iota(order.begin(), order.end(), 0);
-      // stable descending sort == the reference's bubble sort (PS.cpp:1130-1143)
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rk[a] > rk[b]; });
-      for (int k = 0; k < n; k++) pos[order[k]] = k;
+      // stable descending sort == the reference's bubble sort (PS.cpp:1130-1143), on the device: no host round trip
       h->d_perm.ensure(n + 1); h->d_inv.ensure(n + 1);
-      HIPCHECK(hipMemcpy(h->d_perm.p, order.data(), n * sizeof(int), hipMemcpyHostToDevice));
-      HIPCHECK(hipMemcpy(h->d_inv.p, pos.data(), n * sizeof(int), hipMemcpyHostToDevice));
+      k_rank_order<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, h->d_rank.p, h->d_perm.p, h->d_inv.p);
       h->sorted = true;
     }
   }

@@ -721,6 +721,45 @@ def test_matrix_free_exact_gauss_seidel_matches_reference_golden(variant, wl, pk
         assert out["iterations"] == 30 and out["status"] == 0
 
 
+@pytest.mark.parametrize("n,ranked", [(65, True), (130, False), (383, True), (384, False), (700, True), (1023, False), (1030, True), (1500, False)])
+def test_exact_gauss_seidel_by_block_inverses_matches_the_matrix_free_recurrence(n, ranked, wl, pkg, oracle, monkeypatch):
+    """Exact mode with the tensor in HBM sweeps block by block with d = G cb - N d' (csrc/polar_solver.hpp, k_gs_blk: blocks of
+    64, 128 or 256 atoms by system size, G joined from 64-atom triangles).  Sizes on both sides of every switch, with a last
+    block of 1 to 255 atoms, a third of the atoms without polarizability and -- use_previous -- dipoles handed in for all of
+    them: the same dipoles as the matrix-free recurrence (k_gs_block_seq, the form the reference goldens pin) after a fixed
+    number of sweeps, i.e. far from convergence, and as the oracle at the smallest size."""
+    rng = np.random.default_rng(n)
+    d = wl.synth(n, seed=3)
+    alpha = d["alpha"].copy()
+    alpha[rng.random(len(alpha)) < 0.33] = 0.0
+    prd = d["prd"]
+    cut = min(0.49 * float(prd.min()) - 1.5, 9.0)
+    extra = ["use_previous", "yes", "damp_type", "exponential", "damp", "2.1304", "polar_gs_ranked" if ranked else "polar_gs", "yes",
+             "fixed_iteration", "yes", "max_iterations", "4"]
+    st = wl.parse_pair_style_args(["2.5", repr(cut)] + extra)
+    g = wl.ewald_g(1.0e-4, d["q"], st.cut_coul, prd)
+    s = wl.make_system(d["x"], d["q"], alpha, d["type"], d["molecule"], np.zeros(3), prd, d["ntypes"], wl.synth_coeff_rows(), st,
+                       g, bonds=None, exclude_intra=True, skin=1.0, name=f"blockinv{n}")
+    mu0 = 1.0e-3 * rng.standard_normal((s.nlocal, 3))       # (also on the atoms without polarizability: gone after one step)
+    outs = {}
+    for form in ("dense", "matrix_free"):
+        if form == "matrix_free":
+            monkeypatch.setenv("POLAR_NO_DENSE_GS", "1")
+        p = pkg.pair_from_system(s)
+        outs[form] = p.compute(eflag=1, vflag=2, mu=mu0)
+        p.close()
+    a, b = outs["dense"], outs["matrix_free"]
+    scale = np.max(np.abs(b["mu"]))
+    assert a["sweeps"] == b["sweeps"] and a["status"] == b["status"] == 0
+    assert np.max(np.abs(a["mu"] - b["mu"])) / scale < 1e-11
+    assert rel(a["eng_pol"], b["eng_pol"], 1e-9) < 1e-10
+    assert np.all(a["mu"][alpha[: s.nlocal] == 0.0] == 0.0)
+    if n <= 130:
+        ref = oracle.compute(s, eflag=1, vflag=2, mu0=mu0)
+        assert np.max(np.abs(a["mu"] - ref["mu"])) / scale < TOL
+        assert rel(a["eng_pol"], ref["eng_pol"], 1e-9) < TOL
+
+
 @pytest.mark.parametrize("mode", ["precision", "fixed", "jacobi"])
 def test_in_library_rccl_driver_with_one_rank(mode, wl, pkg, oracle):
     """the C++ multi-GPU driver (polar_dist_*: RCCL opened by the library itself, per sweep pack ->
