@@ -961,7 +961,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
   h->dense_gs = false;
   const bool gs_mode = (st.polar_gs || st.polar_gs_ranked) && !st.zodid;
   bool ranked_done = false;
-  if (ap && gs_mode && n > 64 && 48.0 * (double)n * (double)n <= 4.0e9 && !getenv("POLAR_NO_DENSE_GS")) {   // (n <= 64: one block, the matrix-free form)
+  if (ap && gs_mode && n > 64 && 48.0 * (double)n * (double)n <= 3.2e10 && !getenv("POLAR_NO_DENSE_GS")) {   // (n <= 64: one block, the matrix-free form; 32 GB of tensor = 25,819 atoms)
     // exact-order Gauss-Seidel on the HBM-resident tensor: put the atoms in SWEEP order first
     // (s space = ranked order), so blocks of the sweep are contiguous rows/columns of T6
     h->dense_gs = true;

@@ -734,8 +734,8 @@ def test_exact_gauss_seidel_by_block_inverses_matches_the_matrix_free_recurrence
     alpha[rng.random(len(alpha)) < 0.33] = 0.0
     prd = d["prd"]
     cut = min(0.49 * float(prd.min()) - 1.5, 9.0)
-    extra = ["use_previous", "yes", "damp_type", "exponential", "damp", "2.1304", "polar_gs_ranked" if ranked else "polar_gs", "yes",
-             "fixed_iteration", "yes", "max_iterations", "4"]
+    extra = ["use_previous", "yes", "damp_type", "exponential", "damp", "2.1304", "fixed_iteration", "yes", "max_iterations", "4"]
+    extra += ["polar_gs_ranked", "yes"] if ranked else ["polar_gs_ranked", "no", "polar_gs", "yes"]
     st = wl.parse_pair_style_args(["2.5", repr(cut)] + extra)
     g = wl.ewald_g(1.0e-4, d["q"], st.cut_coul, prd)
     s = wl.make_system(d["x"], d["q"], alpha, d["type"], d["molecule"], np.zeros(3), prd, d["ntypes"], wl.synth_coeff_rows(), st,
