@@ -52,9 +52,24 @@ namespace {
 // `row(i)` = where atom i's numneigh[i] entries lie on the host (LAMMPS' pages, or a caller's flat array).
 template <typename RowFn>
 void upload_neighbor_rows(polar_handle *h, int inum, const int *ilist, const int *numneigh, RowFn row) {
+  // The list leaves on its OWN stream and the call returns when the last row has been packed into pinned memory, not when the
+  // last byte has arrived: the tail of the transfer (270 MB at 134,900 atoms: ~5 ms of PCIe) runs under whatever the caller does
+  // next -- polar_set_atoms, the first kernels of polar_compute --; the LJ/Coulomb loop's stream waits for `ev_list_up` before
+  // it touches the list (launch_lj).  One pinned 32-MB buffer per chunk of the list (kept for the next list; a ring beyond 2 GB).
   const int n = h->nlocal, nall = h->nlocal + h->nghost;
-  std::vector<long long> first((size_t)std::max(n, 1), 0);
-  std::vector<int> nn((size_t)std::max(n, 1), 0);
+  if (!h->up_stream) {
+    HIPCHECK(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_list_up, hipEventDisableTiming));
+  }
+  hipStream_t s = h->up_stream;
+  HIPCHECK(hipStreamSynchronize(s));            // the previous list's transfer reads the staging buffers refilled below
+  HIPCHECK(hipStreamSynchronize(h->stream));    // (and its consumers are done with the device arrays that may be re-allocated)
+  if (h->lj_stream) HIPCHECK(hipStreamSynchronize(h->lj_stream));
+  h->list_up_pending = false;
+  std::vector<long long> &first = h->h_first;
+  std::vector<int> &nn = h->h_nn;
+  first.assign((size_t)std::max(n, 1), 0);
+  nn.assign((size_t)std::max(n, 1), 0);
   std::vector<long long> at((size_t)inum + 1, 0);
   long long total = 0;
   for (int ii = 0; ii < inum; ii++) {
@@ -67,27 +82,28 @@ void upload_neighbor_rows(polar_handle *h, int inum, const int *ilist, const int
   at[inum] = total;
   h->inum = inum; h->nneigh = total;
   h->d_ilist.ensure(inum + 1); h->d_numneigh.ensure(n + 1); h->d_first.ensure(n + 1); h->d_neigh.ensure((size_t)total + 1);
-  hipStream_t s = h->stream;
-  HIPCHECK(hipMemcpyAsync(h->d_ilist.p, ilist, inum * sizeof(int), hipMemcpyHostToDevice, s));
+  h->h_ilist.assign(ilist, ilist + inum);       // (the caller's ilist may change after the call)
+  HIPCHECK(hipMemcpyAsync(h->d_ilist.p, h->h_ilist.data(), inum * sizeof(int), hipMemcpyHostToDevice, s));
   HIPCHECK(hipMemcpyAsync(h->d_numneigh.p, nn.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
   HIPCHECK(hipMemcpyAsync(h->d_first.p, first.data(), n * sizeof(long long), hipMemcpyHostToDevice, s));
   const long long CH = 8ll << 20;   // entries per buffer (32 MB)
-  if (!h->h_nl_stage[0]) {
-    for (int k = 0; k < 2; k++) {
-      HIPCHECK(hipHostMalloc((void **)&h->h_nl_stage[k], (size_t)CH * sizeof(int)));
-      HIPCHECK(hipEventCreateWithFlags(&h->ev_nl[k], hipEventDisableTiming));
-    }
-  }
+  constexpr size_t kRing = 64;      // at most 2 GB of pinned staging; longer lists reuse buffers as their transfers end
   HostPool &pool = HostPool::get();
   const int nt = pool.width();
   std::vector<int> bad((size_t)nt * 16, 0);
-  int chunk = 0;
+  size_t chunk = 0;
   for (int ii0 = 0; ii0 < inum;) {
     int ii1 = ii0;
     while (ii1 < inum && at[ii1 + 1] - at[ii0] <= CH) ii1++;
     if (ii1 == ii0) throw InputError("a neighbor row of more than 8M entries");
-    const int buf = chunk & 1;
-    if (chunk >= 2) HIPCHECK(hipEventSynchronize(h->ev_nl[buf]));   // the upload that last used this buffer is over
+    const size_t buf = chunk % kRing;
+    if (buf >= h->h_nl_stage.size()) {
+      int *p = nullptr; hipEvent_t e = nullptr;
+      HIPCHECK(hipHostMalloc((void **)&p, (size_t)CH * sizeof(int)));
+      HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->h_nl_stage.push_back(p); h->ev_nl.push_back(e);
+    }
+    if (chunk >= kRing) HIPCHECK(hipEventSynchronize(h->ev_nl[buf]));   // the transfer that last used this buffer is over
     int *dst = h->h_nl_stage[buf];
     const long long t0 = at[ii0], cnt = at[ii1] - t0;
     pool.run([&](int part) {
@@ -111,7 +127,8 @@ void upload_neighbor_rows(polar_handle *h, int inum, const int *ilist, const int
     HIPCHECK(hipEventRecord(h->ev_nl[buf], s));
     ii0 = ii1; chunk++;
   }
-  HIPCHECK(hipStreamSynchronize(s));   // (first / nn are stack vectors; the caller's list may change after the call)
+  HIPCHECK(hipEventRecord(h->ev_list_up, s));
+  h->list_up_pending = true;
   h->neigh_set = true;
   h->sym_valid = false;
   if (h->colors_valid) h->colors_recheck = true;  // reneighbor step: the colour phases are re-validated (k_nl_build)
@@ -209,7 +226,10 @@ int polar_destroy(polar_handle *h) {
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1, h->ev_dl0, h->ev_dl1, h->ev_mu_ready}) if (e) (void)hipEventDestroy(e);
     if (h->dl_stream) (void)hipStreamDestroy(h->dl_stream);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
-    for (int k = 0; k < 2; k++) { if (h->h_nl_stage[k]) (void)hipHostFree(h->h_nl_stage[k]); if (h->ev_nl[k]) (void)hipEventDestroy(h->ev_nl[k]); }
+    if (h->up_stream) { (void)hipStreamSynchronize(h->up_stream); (void)hipStreamDestroy(h->up_stream); }
+    if (h->ev_list_up) (void)hipEventDestroy(h->ev_list_up);
+    for (int *p : h->h_nl_stage) (void)hipHostFree(p);
+    for (hipEvent_t e : h->ev_nl) (void)hipEventDestroy(e);
     for (auto &row : h->ev_near) for (auto &e : row) if (e) (void)hipEventDestroy(e);
     if (h->ev_half) (void)hipEventDestroy(h->ev_half);
     if (h->ev_stepdone) (void)hipEventDestroy(h->ev_stepdone);
@@ -576,6 +596,7 @@ int polar_build_neighbors(polar_handle *h, const double *cutneighsq, const int *
   return guarded(h, [&]() {
     need_device(h);
     HIPCHECK(hipSetDevice(h->device));
+    if (h->list_up_pending) { HIPCHECK(hipStreamSynchronize(h->up_stream)); h->list_up_pending = false; }   // (an uploaded list still on its way into the arrays rebuilt here)
     if (!h->atoms_set || !h->box_set) throw std::runtime_error("polar_build_neighbors before polar_set_box/polar_set_atoms");
     if (!h->types_set) throw std::runtime_error("polar_build_neighbors before the pair tables were set");
     if (!cutneighsq || !special_flag) throw InputError("polar_build_neighbors: null cutneighsq/special_flag");

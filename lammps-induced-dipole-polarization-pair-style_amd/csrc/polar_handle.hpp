@@ -191,7 +191,11 @@ struct polar_handle {
   int pipeline = 0;            // single GPU, list-mode GS: the two halves of the box on two streams, a half's next phase gated by the other half's NEAR rows only.  OFF: it loses (10.6 against 9.2 ms per step at 135k atoms, profiles/r04_lab_region_pipeline.txt); POLAR_PIPELINE=1 switches it on in the LAB build only
   hipStream_t stream2 = nullptr; hipEvent_t ev_near[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}, ev_half = nullptr, ev_stepdone = nullptr;
   bool pipe_active = false; long long pipe_g = 0;   // the running solve uses the pipeline; phases issued so far
-  int *h_nl_stage[2] = {nullptr, nullptr}; hipEvent_t ev_nl[2] = {nullptr, nullptr};   // pinned double buffer of the neighbor-list upload
+  // the neighbor list's upload: its own stream, one pinned buffer (+ event) per 32-MB chunk, host copies of the row tables that
+  // must outlive the call, the event its consumers wait for
+  std::vector<int *> h_nl_stage; std::vector<hipEvent_t> ev_nl;
+  hipStream_t up_stream = nullptr; hipEvent_t ev_list_up = nullptr; bool list_up_pending = false;
+  std::vector<long long> h_first; std::vector<int> h_nn, h_ilist;
   hipStream_t lp_stream = nullptr;   // where launch_field_lp puts its kernels when set (else `stream`)
   bool colors_global = false;  // the colouring in force is consistent across the ranks of a multi-GPU run (halo rows carry their owners' colours)
   std::vector<int> user_colors;  // polar_set_colors: a colouring imposed by the caller (original order, -1 = none)
@@ -363,7 +367,9 @@ class HostPool {
   HostPool() {
     pid_ = getpid();
     const unsigned hw = std::thread::hardware_concurrency();
-    const int n = hw >= 16 ? 7 : (hw >= 4 ? 3 : (hw >= 2 ? (int)hw - 1 : 0));   // (eight-way where the cores are: packing 270 MB of list rows is the longest job)
+    // eight-way where the cores are: packing 270 MB of list rows is the longest job (5.4 ms = the PCIe time of the same bytes);
+    // sixteen-way was slower on a GPU box's share of its host (6.1-6.4 ms, gpurun_out/r4y_md.txt)
+    const int n = hw >= 16 ? 7 : (hw >= 4 ? 3 : (hw >= 2 ? (int)hw - 1 : 0));
     for (int t = 0; t < n; t++) th_.emplace_back([this, t]() { loop(t); });
   }
   ~HostPool() {

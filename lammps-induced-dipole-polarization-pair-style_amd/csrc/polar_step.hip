@@ -884,6 +884,9 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
       HIPCHECK(hipStreamWaitEvent(h->lj_stream, h->ev_fork, 0));
     }
     hipStream_t s = h->lj_forked ? h->lj_stream : ms;  // shadows the main stream inside this block
+    if (h->list_up_pending) {   // the uploaded list may still be on its way (upload_neighbor_rows returns before its transfer has ended)
+      HIPCHECK(hipStreamWaitEvent(s, h->ev_list_up, 0));   // (every step until the next list: free once the event has fired)
+    }
     HIPCHECK(hipEventRecord(h->ev_lj0, s));
     LJCoulParams P = h->P;
     P.newton_pair = h->newton_pair; P.nlocal = n; P.cut_coulsq = st.cut_coul * st.cut_coul; P.full_list = h->full_list; P.ablate = 0;
