@@ -535,7 +535,7 @@ void color_finish(polar_handle *h, bool ranked, int ncolors) {
   const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
   h->d_ccnt.ensure(ncc + 1); h->d_coff.ensure(ncc + 2);
   k_color_cellcount<<<nblk(ncell, 128), 128, 0, s>>>(ncell, nclass, h->d_cell_first.p, h->d_cell_fill.p, h->d_color_s.p, h->d_ccnt.p, h->d_perm.p, lo, hi, sub, nsub);
-  k_exclusive_scan<int><<<1, 1024, 0, s>>>((long long)ncc, h->d_ccnt.p, h->d_coff.p);
+  launch_scan((long long)ncc, h->d_ccnt.p, h->d_coff.p, h->d_scan_a, s);
   for (int q = 0; q <= nclass; q++)
     HIPCHECK(hipMemcpyAsync(h->h_coff + q, h->d_coff.p + (size_t)q * ncell, sizeof(long long), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));  // (also: `relabel` is a stack vector)

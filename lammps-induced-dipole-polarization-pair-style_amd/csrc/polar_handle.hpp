@@ -85,6 +85,7 @@ inline void zero_many(hipStream_t s, std::initializer_list<std::pair<void *, siz
   k_zero_many<<<std::max(blocks, 1), 256, 0, s>>>(jobs);
 }
 // grid of a kernel that places its workgroups with xcd_block(): 8 * ceil(nblocks / 8)
+// (exclusive scans: launch_scan in polar_step.hip)
 inline int nblk_xcd(long long n, int per) { return ((nblk(n, per) + 7) / 8) * 8; }
 
 // widths of the simulation cell between opposite faces: the box lengths, or V / |face area| when the box is tilted
@@ -141,6 +142,7 @@ struct polar_handle {
   long long ncell = 0;
   bool sorted = false;  // true while the records are in cell order (list mode)
   DBuf<long long> d_first, d_sym_first;
+  DBuf<long long> d_scan_a, d_scan_b;   // workgroup totals of launch_scan: main stream / the LJ-Coulomb side stream
   DBuf<int> d_sym_cnt, d_sym_fill, d_sym_j;
   bool sym_valid = false;  // symmetrised list matches the uploaded half list
   DBuf<AtomRec> d_rec0, d_rec1;
@@ -439,6 +441,7 @@ struct TileUnavailable : std::runtime_error {
 };
 
 // ---- polar_step.hip ---------------------------------------------------------------------------------------------------
+void launch_scan(long long n, const int *in, long long *out, DBuf<long long> &tot, hipStream_t s);
 void build_cells(polar_handle *h);
 void compute_slots(polar_handle *h);
 void build_lists(polar_handle *h);

@@ -3,6 +3,17 @@
 // forces and tallies.  All arithmetic of the hot path runs in the kernels of polar_kernels.hpp.
 #include "polar_handle.hpp"
 
+// exclusive scan of n ints (out: n + 1 long longs), polar_lists.hpp
+void launch_scan(long long n, const int *in, long long *out, DBuf<long long> &tot, hipStream_t s) {
+  const int nb = (int)std::max<long long>(1, (n + POLAR_SCAN_ITEMS - 1) / POLAR_SCAN_ITEMS);
+  tot.ensure((size_t)nb + 1);
+  k_scan_block<<<nb, 1024, 0, s>>>(n, in, out, tot.p);
+  if (nb > 1) {
+    k_scan_totals<<<1, 1024, 0, s>>>(nb, tot.p, out + n);
+    k_scan_add<<<nblk(n - POLAR_SCAN_ITEMS, 256), 256, 0, s>>>(n, out, tot.p);
+  }
+}
+
 void build_cells(polar_handle *h) {
   const polar_settings &st = h->ph.st;
   const int n = h->nlocal;
@@ -58,7 +69,7 @@ void build_cells(polar_handle *h) {
   h->d_cell_first.ensure(ncell + 2); h->d_perm.ensure(n + 1); h->d_inv.ensure(n + 1);
   zero_many(s, {{h->d_cell_cnt.p, (size_t)(ncell + 1) * sizeof(int)}, {h->d_cell_fill.p, 2 * (size_t)(ncell + 1) * sizeof(int)}});
   k_cell_count<<<nblk(n, 256), 256, 0, s>>>(n, h->d_x.p, g, h->box, h->d_cell_id.p, h->d_cell_cnt.p);
-  k_exclusive_scan<int><<<1, 1024, 0, s>>>(ncell, h->d_cell_cnt.p, h->d_cell_first.p);
+  launch_scan(ncell, h->d_cell_cnt.p, h->d_cell_first.p, h->d_scan_a, s);
   k_cell_fill<<<nblk(n, 256), 256, 0, s>>>(n, h->d_cell_id.p, h->d_cell_first.p, h->d_cell_fill.p,
                                            (h->pol_first || h->sweep_kernel == 4) ? h->d_cell_fill.p + ncell + 1 : nullptr, h->d_alpha.p, h->d_perm.p, h->d_inv.p);
   // the order inside a cell follows the atomics of k_cell_fill: put it into atom order -- always, not only for `deterministic
@@ -475,7 +486,7 @@ void build_units(polar_handle *h) {
   const int *rows = gs ? h->d_rows.p : own_rows(h);
   h->d_ulead.ensure((size_t)tot + 1); h->d_upos.ensure((size_t)tot + 2); h->d_unit.ensure((size_t)tot + 1); h->d_udesc.ensure((size_t)tot + 1);
   k_unit_flag<<<nblk(tot, 256), 256, 0, s>>>(tot, rows, h->d_perm.p, h->d_cell_id.p, P, h->d_ulead.p);
-  k_exclusive_scan<int><<<1, 1024, 0, s>>>((long long)tot, h->d_ulead.p, h->d_upos.p);
+  launch_scan((long long)tot, h->d_ulead.p, h->d_upos.p, h->d_scan_a, s);
   k_unit_fill<<<nblk(tot, 256), 256, 0, s>>>(tot, rows, h->d_perm.p, h->d_cell_id.p, P, h->d_ulead.p, h->d_upos.p, h->d_unit.p);
   std::vector<long long> first((size_t)P.n + 1);
   for (int q = 0; q <= P.n; q++)
@@ -911,7 +922,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
       HIPCHECK(hipMemsetAsync(h->d_sym_cnt.p, 0, (nall + 1) * sizeof(int), s));
       HIPCHECK(hipMemsetAsync(h->d_sym_fill.p, 0, (nall + 1) * sizeof(int), s));
       k_sym_count<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_cnt.p);
-      k_exclusive_scan<int><<<1, 1024, 0, s>>>(nall, h->d_sym_cnt.p, h->d_sym_first.p);
+      launch_scan(nall, h->d_sym_cnt.p, h->d_sym_first.p, h->d_scan_b, s);
       h->sym_typed = h->lj_typed && nall < (1 << 24) && h->ntypes < 64;
       k_sym_fill<<<g0, block, 0, s>>>(h->inum, h->d_ilist.p, h->d_numneigh.p, h->d_first.p, h->d_neigh.p, h->d_sym_first.p,
                                       h->d_sym_fill.p, h->d_sym_j.p, h->sym_typed ? h->d_type.p : nullptr);
