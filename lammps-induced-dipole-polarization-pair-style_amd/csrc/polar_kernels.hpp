@@ -17,8 +17,9 @@
 // Reference line numbers ("PS.cpp") are into
 // /root/reference/src/pair_lj_cut_coul_long_polarization.cpp.
 //
-// The kernels live in five headers: polar_common.hpp (types, wave helpers, image rules),
-// polar_rows.hpp (the per-row kernels of a step), polar_solver.hpp (the dipole solver),
+// The kernels live in seven headers: polar_common.hpp (types, wave helpers, image rules),
+// polar_rows.hpp (the per-row kernels of a step), polar_solver.hpp (the dipole solver: list-mode sweep, loop control),
+// polar_exact.hpp (exact mode's exact-order Gauss-Seidel), polar_accel.hpp (Anderson mixing, `polar_accel`),
 // polar_lists.hpp (list mode: cells, neighbor lists, exchange), polar_tiles.hpp (list mode: the tile sweep
 // -- one workgroup per cell, neighbour records staged in LDS -- and its builder).
 #pragma once
@@ -26,5 +27,7 @@
 #include "polar_common.hpp"
 #include "polar_rows.hpp"
 #include "polar_solver.hpp"
+#include "polar_exact.hpp"
+#include "polar_accel.hpp"
 #include "polar_lists.hpp"
 #include "polar_tiles.hpp"

@@ -689,7 +689,7 @@ void debug_trace(polar_handle *h, int sw, bool /*jacobi*/) {
 }
 
 // `polar_accel m` (extension keyword): Anderson mixing of depth m on the sweep map of the list-mode Gauss-Seidel
-// (kernels and formulas: polar_solver.hpp, k_accel_*).  accel_begin: buffers, x_0 = the initial guess of the own rows; returns
+// (kernels and formulas: polar_accel.hpp, k_accel_*).  accel_begin: buffers, x_0 = the initial guess of the own rows; returns
 // whether the keyword applies to this solve.  accel_step: after a sweep (and its end-of-sweep decision) -- differences and
 // their dot products, the m x m solve, the mixed iterate into the records.  `global_dots`: multi-GPU, the all-reduced dot
 // products in device memory ([2 * POLAR_ACCEL_MAXM] doubles); the local ones are then exported first (accel_export).
@@ -780,7 +780,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     if (expd) k_build_T6<0><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
     else      k_build_T6<1><<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_rec0.p, h->box, st.polar_damp, h->d_T6.p);
     k_dense_field<<<nblk(n, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(n, np, h->d_T6.p, h->d_rec0.p, h->d_F.p);
-    // ONE launch per block of B atoms, nothing sequential inside it: d = G cb - N d' (polar_solver.hpp, k_gs_blk).  G and N
+    // ONE launch per block of B atoms, nothing sequential inside it: d = G cb - N d' (polar_exact.hpp, k_gs_blk).  G and N
     // are formed here, once per step.
     const int B = n >= 1024 ? 256 : n >= 384 ? 128 : 64, R = 3 * B, nb = (n + B - 1) / B;   // (at least two blocks: dense_gs needs n > 64)
     const size_t RR = (size_t)R * R;

@@ -116,7 +116,7 @@ def test_energy_per_cell_is_the_same_in_every_box(full):
 def test_exact_mode_at_the_largest_size_the_reference_ran(wl, pkg, monkeypatch):
     """MOF5+H2 `replicate 2 2 2` = 10,792 atoms in EXACT mode (46.5 s per step in the reference, dense
     matrix 8.4 GB): the packed tensor (5.6 GB) stays in HBM and the sweep runs block by block with d = G cb - N d'
-    (csrc/polar_solver.hpp, k_gs_blk).  (a) After three sweeps -- far from convergence -- the dipoles are those of the
+    (csrc/polar_exact.hpp, k_gs_blk).  (a) After three sweeps -- far from convergence -- the dipoles are those of the
     matrix-free recurrence (k_gs_block_seq, pinned by the reference goldens at 1,349 atoms).  (b) It converges to 1e-11 in the
     sweeps the single cell needs."""
     fixed = ["use_previous", "no", "polar_gs_ranked", "yes", "fixed_iteration", "yes", "max_iterations", "2"]

@@ -723,7 +723,7 @@ def test_matrix_free_exact_gauss_seidel_matches_reference_golden(variant, wl, pk
 
 @pytest.mark.parametrize("n,ranked", [(65, True), (130, False), (383, True), (384, False), (700, True), (1023, False), (1030, True), (1500, False)])
 def test_exact_gauss_seidel_by_block_inverses_matches_the_matrix_free_recurrence(n, ranked, wl, pkg, oracle, monkeypatch):
-    """Exact mode with the tensor in HBM sweeps block by block with d = G cb - N d' (csrc/polar_solver.hpp, k_gs_blk: blocks of
+    """Exact mode with the tensor in HBM sweeps block by block with d = G cb - N d' (csrc/polar_exact.hpp, k_gs_blk: blocks of
     64, 128 or 256 atoms by system size, G joined from 64-atom triangles).  Sizes on both sides of every switch, with a last
     block of 1 to 255 atoms, a third of the atoms without polarizability and -- use_previous -- dipoles handed in for all of
     them: the same dipoles as the matrix-free recurrence (k_gs_block_seq, the form the reference goldens pin) after a fixed
