@@ -168,7 +168,9 @@ int polar_set_positions(polar_handle *h, int nlocal, int nghost, const double *x
 /* positions of the atoms [lo, hi) only (x = [hi-lo][3]): a rank of a multi-GPU run uploads its own atoms and lets
  * polar_dist_positions fetch the rest from their owners */
 int polar_set_positions_range(polar_handle *h, int lo, int hi, const double *x);
-/* NeighList inum/ilist/numneigh/firstneigh (src/neigh_list.h:46-50); call when neighbor->ago == 0 */
+/* NeighList inum/ilist/numneigh/firstneigh (src/neigh_list.h:46-50); call when neighbor->ago == 0.  The rows are validated and
+ * copied into pinned memory before the call returns (the caller's arrays may change afterwards); the transfer to the device
+ * finishes under the calls that follow -- the LJ/Coulomb loop of the next polar_compute waits for it. */
 int polar_set_neighbors(polar_handle *h, int inum, const int *ilist, const int *numneigh,
                         int *const *firstneigh);
 /* same list already flattened: firstneigh[i] = offset of atom i's entries in neigh[] */
