@@ -307,7 +307,7 @@ template <int B>
 static __global__ __launch_bounds__(64 * POLAR_GS_WAVES) void k_gs_blk(int n, long long np, int b0, int p0, int next0, const double *__restrict__ T6,
                                                  const double *__restrict__ G, const double *__restrict__ Nm, AtomRec *rec,
                                                  const double *__restrict__ ef, double *F, double *cb, const double *__restrict__ dmu_prev,
-                                                 double *__restrict__ dmu_out, const Scal *scal, double *__restrict__ slots) {
+                                                 double *__restrict__ dmu_out, const Scal *scal, double *__restrict__ dsq_part) {
   if (scal->done) return;
   constexpr int R = 3 * B, WV = POLAR_GS_WAVES, DW = R / WV;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -337,8 +337,9 @@ static __global__ __launch_bounds__(64 * POLAR_GS_WAVES) void k_gs_blk(int n, lo
       double dsq = 0.0;
 #pragma unroll
       for (int v = 0; v < WV; v++) dsq += dsh[v] * dsh[v];
-      // one slot per (block, workgroup) while they last: a fixed association of the sweep's sum (two adds into a slot commute)
-      if (dsq != 0.0) atomicAdd(slots + (size_t)(((b0 / B) * DW + blockIdx.x) & (POLAR_NSLOT - 1)) * POLAR_SLOT_STRIDE + SL_CHANGE, dsq);
+      // one entry per (block, workgroup), rewritten every sweep: k_solver_step adds them up in a fixed order (its `part` input),
+      // so the sweep's sum |dmu|^2 -- and with it the iteration count at a knife edge -- is the same run to run
+      dsq_part[(size_t)(b0 / B) * DW + blockIdx.x] = dsq;
     }
     return;
   }

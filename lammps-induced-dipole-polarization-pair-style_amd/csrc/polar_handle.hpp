@@ -136,7 +136,7 @@ struct polar_handle {
   DBuf<double> d_x, d_q, d_alpha, d_f, d_ef, d_F, d_mu, d_rank, d_dmu, d_tab, d_lj;
   DBuf<int> d_type, d_mol, d_order, d_pos, d_ilist, d_numneigh, d_neigh, d_rows;
   DBuf<int> d_mol_s, d_perm, d_inv, d_rows_orig, d_ownrows;  // s-space bookkeeping (see polar_kernels.hpp)
-  DBuf<double> d_ef_s, d_T6, d_Minv, d_gsN, d_gsAT, d_cb, d_eatom, d_vatom, d_dd_r2, d_fpol;
+  DBuf<double> d_ef_s, d_T6, d_Minv, d_gsN, d_gsAT, d_cb, d_gs_part, d_eatom, d_vatom, d_dd_r2, d_fpol;
   bool dense_gs = false;   // exact-order GS on the HBM-resident tensor (atoms in sweep order)
   CellGrid grid{};
   long long ncell = 0;

@@ -804,18 +804,20 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     k_gs_gemm<true><<<dim3(R / 64, R / 64, nb), 256, 0, s>>>(R, 1.0, h->d_Minv.p, R, whole, h->d_gsAT.p, R, whole, h->d_gsN.p, R, whole);
     k_gs_cb_init<<<nblk(n, 256), 256, 0, s>>>(n, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_cb.p);
     int prev = -1, flip = 0;
-    const int grid = R / POLAR_GS_WAVES + nblk(n, POLAR_GS_WAVES);
+    const int grid = R / POLAR_GS_WAVES + nblk(n, POLAR_GS_WAVES), npart = nb * (R / POLAR_GS_WAVES);
+    h->d_gs_part.ensure((size_t)npart + 1);
+    HIPCHECK(hipMemsetAsync(h->d_gs_part.p, 0, (size_t)npart * sizeof(double), s));
     for (int sw = 0; sw < max_sweeps; sw++) {
       for (int b0 = 0; b0 < n; b0 += B) {
         const int next0 = b0 + B < n ? b0 + B : 0;
 #define POLAR_GS_BLK(BB) k_gs_blk<BB><<<grid, 64 * POLAR_GS_WAVES, 0, s>>>(n, np, b0, prev, next0, h->d_T6.p, h->d_Minv.p, h->d_gsN.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_cb.p, \
-                                                            h->d_dmu.p + R * flip, h->d_dmu.p + R * (flip ^ 1), h->d_scal.p, h->d_slots.p)
+                                                            h->d_dmu.p + R * flip, h->d_dmu.p + R * (flip ^ 1), h->d_scal.p, h->d_gs_part.p)
         if (B == 256) POLAR_GS_BLK(256); else if (B == 128) POLAR_GS_BLK(128); else POLAR_GS_BLK(64);
 #undef POLAR_GS_BLK
         prev = b0; flip ^= 1;
       }
       debug_trace(h, sw, false);
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, nullptr, 0);
+      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, h->d_gs_part.p, npart);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;

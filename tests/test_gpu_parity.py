@@ -760,6 +760,25 @@ def test_exact_gauss_seidel_by_block_inverses_matches_the_matrix_free_recurrence
         assert rel(a["eng_pol"], ref["eng_pol"], 1e-9) < TOL
 
 
+def test_exact_mode_is_bit_reproducible(wl, pkg):
+    """Exact mode takes no atomics on its way to the dipoles: a row's field is folded by one wave in a fixed order, the rows of
+    d = G cb - N d' are plain dot products, and the sweep's sum |dmu|^2 is added up from one entry per workgroup in a fixed
+    order (k_solver_step's `part` input) -- so two runs of the knife-edge deck (30 of 30 iterations) give the same
+    dipoles bit for bit and the same iteration count, as the serial reference does."""
+    s, _ = wl.load_fixture(os.path.join(GOLD, "mof5_h2.npz"),
+                           extra_args=["use_previous", "no", "polar_gs_ranked", "yes", "precision", "1e-11", "max_iterations", "30"])
+    outs = []
+    for rep in range(3):
+        p = pkg.pair_from_system(s)
+        outs.append(p.compute(eflag=1, vflag=2))
+        p.close()
+    for o in outs[1:]:
+        assert o["iterations"] == outs[0]["iterations"] == 30 and o["status"] == 0
+        assert np.array_equal(o["mu"], outs[0]["mu"])
+        assert o["rms_dmu"] == outs[0]["rms_dmu"]
+        assert abs(o["eng_pol"] - outs[0]["eng_pol"]) < 1e-13 * abs(o["eng_pol"])   # (the energies are tallied through atomic slots)
+
+
 @pytest.mark.parametrize("mode", ["precision", "fixed", "jacobi"])
 def test_in_library_rccl_driver_with_one_rank(mode, wl, pkg, oracle):
     """the C++ multi-GPU driver (polar_dist_*: RCCL opened by the library itself, per sweep pack ->
