@@ -6,6 +6,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $R/gpurun_out/${tag}_bench_headline.log 2>&1
 echo "profiled rc=$?"
 cd $R
-timeout -k 10 600 python bench.py > gpurun_out/${tag}_bench_full.log 2>&1
+SECONDS=0; timeout -k 10 900 python bench.py > gpurun_out/${tag}_bench_full.log 2> gpurun_out/${tag}_bench_full.err; echo "bench wall ${SECONDS} s"
 echo "full rc=$?"
 tail -1 gpurun_out/${tag}_bench_full.log | cut -c1-300
