@@ -302,3 +302,26 @@ def test_results_come_back_the_same_with_and_without_the_static_field(wl, pkg):
     assert np.array_equal(c["ef_static"], a["ef_static"]) and not np.any(b["ef_static"])
     assert np.any(a["ef_static"])
     p.close()
+
+
+def test_neighbor_arrays_may_change_once_polar_set_neighbors_has_returned(wl, pkg):
+    """polar_set_neighbors* copies the rows into pinned memory before it returns and lets the transfer to the device finish under
+    the calls that follow (include/polar_mi355x.h): a caller -- LAMMPS re-uses its neighbor pages -- may overwrite its arrays at
+    once.  36,423 atoms: 18 M list entries = three 32-MB chunks on the upload stream.  The same list handed over twice, the
+    caller's copy destroyed right after the second hand-over: same forces and energies as the run that kept it."""
+    extra = ["use_previous", "no", "polar_gs_ranked", "yes", "dd_cutoff", "12.8345", "fixed_iteration", "yes", "max_iterations", "3",
+             "deterministic", "yes"]       # (four sweeps are far from the fixed point: only the deterministic sweep repeats itself there)
+    s = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 3, 3, 3, extra_args=extra)
+    p = pkg.pair_from_system(s)
+    ref = p.compute(eflag=1, vflag=2)
+    ilist, numneigh = np.array(s.ilist, dtype=np.int32), np.array(s.numneigh, dtype=np.int32)
+    firstneigh, neigh = np.array(s.firstneigh, dtype=np.int64), np.array(s.neigh, dtype=np.int32)
+    assert neigh.size > 2 * (8 << 20)
+    p.set_neighbors_csr(ilist, numneigh, firstneigh, neigh)
+    neigh[:] = 0; numneigh[:] = 0; firstneigh[:] = 0; ilist[:] = 0          # (the transfer may still be under way)
+    out = p.compute(eflag=1, vflag=2)
+    p.close()
+    assert out["status"] == ref["status"] == 0 and out["sweeps"] == ref["sweeps"]
+    assert np.max(np.abs(out["f"] - ref["f"])) < 1e-7 * np.max(np.abs(ref["f"]))
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert abs(out[k] - ref[k]) < 1e-9 * abs(ref[k]), k

@@ -701,7 +701,7 @@ def test_colour_clash_on_a_reneighbor_step_relays_the_rows(kernel, wl, pkg, orac
 @pytest.mark.parametrize("variant", ["ranked", "gs", "config0_max30", "nodamp_fallback30"])
 def test_matrix_free_exact_gauss_seidel_matches_reference_golden(variant, wl, pkg, oracle, monkeypatch):
     """The exact-order Gauss-Seidel WITHOUT the HBM-resident tensor (k_gs_block_seq / k_gs_block_push: what a system
-    beyond 9,128 atoms gets, e.g. the 10,792-atom replica BASELINE.md quotes a reference timing for), forced on MOF5+H2
+    beyond 25,819 atoms or of no more than 64 gets), forced on MOF5+H2
     with POLAR_NO_DENSE_GS: same reference goldens, same iteration counts (30 of 30 on the knife-edge deck)."""
     monkeypatch.setenv("POLAR_NO_DENSE_GS", "1")
     hits = [(pth, info) for pth, info in golden_refs("mof5_h2") if info["variant"] == variant]
