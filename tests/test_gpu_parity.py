@@ -832,7 +832,7 @@ def test_in_library_rccl_driver_with_one_rank(mode, wl, pkg, oracle):
     p.close()
 
 
-def _mock_dist(tmp_path, *args, pitch=0):
+def _mock_dist(tmp_path, *args, pitch=0, reps=None):
     """tests/dist_mock/run_mock_dist.py in a process of its own (the stand-in must be the first "RCCL" the library opens)"""
     import json
     import shutil
@@ -846,6 +846,8 @@ def _mock_dist(tmp_path, *args, pitch=0):
     subprocess.check_call([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(here, "dist_mock", "fake_rccl.cpp")])
     env = dict(os.environ, POLAR_RCCL_LIB=so)
     env.pop("POLAR_DIST_LAG", None)
+    if reps:
+        env["MOCK_REPS"] = reps
     if pitch:   # rows outgrow this pitch on the first step: every rank must agree to repeat it (max-reduced POLAR_RETRY_STEP)
         env["POLAR_INIT_PITCH"] = str(pitch)
     r = subprocess.run([sys.executable, os.path.join(here, "dist_mock", "run_mock_dist.py")] + [str(a) for a in args],
@@ -885,6 +887,24 @@ def test_in_library_driver_with_several_ranks_on_a_mock_transport(world, solver,
     for k in ("eng_pol", "eng_vdwl", "eng_coul"):
         assert rel(res["local_sum"][k], ranks[0][k], 1e-9) < 1e-12
     assert np.max(np.abs(np.array(res["local_virial_sum"]) - np.array(res["virial"]))) < 1e-10 * max(1.0, np.max(np.abs(res["virial"])))
+
+
+@pytest.mark.parametrize("schedule", ["legacy", "lag1"])
+def test_in_library_driver_with_eight_ranks_on_a_mock_transport(schedule, pkg, tmp_path):
+    """The rank count of the scaling run: EIGHT ranks (threads over the stand-in transport) on a 2 x 2 x 8 replica cut into eight
+    z slabs one cell thick -- every rank has two peers and no interior rows, as on BASELINE configs[4] --, round 3's schedule
+    (what `bench.py --gpus 8` takes) and the shared colouring with per-phase exchanges: same fixed point as the unsharded
+    handle, every rank stopping at the same sweep, classes alternating along the ring."""
+    res = _mock_dist(tmp_path, 8, "precision", 2, schedule, reps="2x2x8")
+    ref, ranks = res["ref"], res["ranks"]
+    assert len(ranks) == 8 and all(k["status"] == 0 for k in ranks)
+    for k in ranks:
+        assert k["sweeps"] == ranks[0]["sweeps"] and k["dd_pairs"] == ref["dd_pairs"] and k["npeers"] == 2
+        assert rel(k["eng_pol"], ranks[0]["eng_pol"]) < 1e-14
+    assert res["mu_err"] < TOL and rel(ranks[0]["eng_pol"], ref["eng_pol"]) < 1e-9
+    assert ref["sweeps"] <= ranks[0]["sweeps"] <= ref["sweeps"] + (14 if schedule == "legacy" else 6)
+    if schedule != "legacy":
+        assert res["color_clashes"] == 0 and res["classes"] == [0, 1] * 4
 
 
 @pytest.mark.parametrize("world,solver,reduce_every,schedule,pitch", [
