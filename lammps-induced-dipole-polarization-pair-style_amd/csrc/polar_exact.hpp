@@ -242,46 +242,54 @@ static __global__ __launch_bounds__(256) void k_gs_expand(int n, long long np, c
   o[2 * (size_t)ld] = t[2]; o[2 * (size_t)ld + 1] = t[4]; o[2 * (size_t)ld + 2] = t[5];
 }
 
-// C = alpha A B, row-major, batched over blockIdx.z (GsBatch: where a member sits); m, n, k multiples of 64 / 64 / 16.  LOWER: A is lower triangular (the
-// k range of a row tile ends with the tile).  A plain LDS-tiled FP64 product (64 x 64 per workgroup, 4 x 4 per thread): it
-// runs once per step on a few 192..384-square matrices.
+// C = alpha A B, row-major, batched over blockIdx.z (GsBatch: where a member sits); m, n, k multiples of 64.  LOWER: A is
+// lower triangular (the k range of a row tile ends with the tile).  The one GEMM-shaped piece of the path, on the matrix cores:
+// v_mfma_f64_16x16x4_f64, 64 x 64 of C per workgroup, 32 x 32 per wave = 2 x 2 MFMA tiles, operands staged through LDS k-major
+// (lane l feeds A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15]; a result register holds C[row (l >> 4) + 4 reg][col l & 15]).
+// It runs once per step on a few 192..768-square matrices (G's joins and N = G A T).
 struct GsBatch { long long outer, inner; int per; };   // batch member z sits at (z / per) * outer + (z % per) * inner
+typedef double gs_d4 __attribute__((ext_vector_type(4)));
 template <bool LOWER>
 static __global__ __launch_bounds__(256) void k_gs_gemm(int k, double alpha, const double *__restrict__ A, long long lda, GsBatch bA,
                                                  const double *__restrict__ Bm, long long ldb, GsBatch bB,
                                                  double *__restrict__ C, long long ldc, GsBatch bC) {
-  __shared__ double As[16][65];
-  __shared__ double Bs[16][64];
+  constexpr int KC = 32;   // k per LDS stage
+  __shared__ double As[KC][65];
+  __shared__ double Bs[KC][64];
   const int z = blockIdx.z;
   A += (size_t)(z / bA.per) * bA.outer + (size_t)(z % bA.per) * bA.inner;
   Bm += (size_t)(z / bB.per) * bB.outer + (size_t)(z % bB.per) * bB.inner;
   C += (size_t)(z / bC.per) * bC.outer + (size_t)(z % bC.per) * bC.inner;
-  const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  double acc[4][4] = {};
-  const int kend = LOWER ? min(k, row0 + 64) : k;
-  for (int k0 = 0; k0 < kend; k0 += 16) {
+  const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, wr = (w >> 1) * 32, wc = (w & 1) * 32, l15 = lane & 15, l4 = lane >> 4;
+  gs_d4 acc[2][2] = {};
+  const int kend = LOWER ? min(k, row0 + 64) : k;   // (a multiple of 64)
+  for (int k0 = 0; k0 < kend; k0 += KC) {
 #pragma unroll
-    for (int e = tid; e < 1024; e += 256) {
-      As[e & 15][e >> 4] = A[(size_t)(row0 + (e >> 4)) * lda + k0 + (e & 15)];
+    for (int e = tid; e < 64 * KC; e += 256) {
+      As[e % KC][e / KC] = A[(size_t)(row0 + e / KC) * lda + k0 + e % KC];
       Bs[e >> 6][e & 63] = Bm[(size_t)(k0 + (e >> 6)) * ldb + col0 + (e & 63)];
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-      double av[4], bv[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) { av[i] = As[kk][ty * 4 + i]; bv[i] = Bs[kk][tx * 4 + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int jx = 0; jx < 4; jx++) acc[i][jx] = fma(av[i], bv[jx], acc[i][jx]);
+    for (int ks = 0; ks < KC / 4; ks++) {
+      const int kk = 4 * ks + l4;
+      const double a0 = As[kk][wr + l15], a1 = As[kk][wr + 16 + l15];
+      const double b0 = Bs[kk][wc + l15], b1 = Bs[kk][wc + 16 + l15];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-    for (int jx = 0; jx < 4; jx++) C[(size_t)(row0 + ty * 4 + i) * ldc + col0 + tx * 4 + jx] = alpha * acc[i][jx];
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        C[(size_t)(row0 + wr + 16 * rb + l4 + 4 * r) * ldc + col0 + wc + 16 * cb + l15] = alpha * acc[rb][cb][r];
 }
 
 // cb = a (E + F) - mu for every atom, from the field the solve starts with
