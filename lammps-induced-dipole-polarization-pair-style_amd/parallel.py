@@ -32,6 +32,10 @@ import time
 import numpy as np
 
 
+# E_pol per MOF5+H2 cell of the replicated boxes (dd_cutoff = cut_coul = 12.8345, precision 1e-11) on ONE GPU: -706.9202902735 / 100 cells
+# (configs[2]), -1526.94782699085 / 216 (configs[3]), -2771.127537872 / 392 (configs[4])
+E_POL_PER_CELL = -7.069202902735
+
 def split_rows(n, world):
     """Contiguous row ranges, as equal as possible."""
     base, rem = divmod(n, world)
@@ -740,6 +744,11 @@ def bench_distributed(args, rank, world, local_rank):
                                    "LJ/Coulomb lists built on the device",
                        "natoms": n_total, "sweeps": out["sweeps"], "iterations": out["iterations"], "colors": out["ncolors"],
                        "dd_pairs": out["dd_pairs"], "eng_pol": out["eng_pol"], "rms_dmu_last_sweep": out["rms_dmu"],
+                       # a result check the line carries itself: every box here is whole copies of ONE cell wider than two cutoffs, so
+                       # E_pol per cell is a property of the cell (tests/test_gpu_fullsize.py); the single-GPU value at precision 1e-11
+                       # (configs[2], [3] and [4] on one GPU agree on it to 1e-9)
+                       "eng_pol_per_cell": out["eng_pol"] / float(np.prod(reps)), "eng_pol_per_cell_one_gpu": E_POL_PER_CELL,
+                       "eng_pol_rel_dev_from_one_gpu": abs(out["eng_pol"] / float(np.prod(reps)) - E_POL_PER_CELL) / abs(E_POL_PER_CELL),
                        "ms_per_dipole_iteration": 1e3 * dt / args.steps / max(out["sweeps"], 1),
                        "ms_device_rank0": {k2: out[k2] for k2 in ("ms_total", "ms_list", "ms_ljcoul", "ms_static", "ms_solve", "ms_force")},
                        "atoms_held_rank0": n_held, "halo_rows_per_rank": plan.counts, "rows_per_rank": counts,
