@@ -244,7 +244,7 @@ int polar_destroy(polar_handle *h) {
     h->d_type.release(); h->d_mol.release(); h->d_order.release(); h->d_pos.release(); h->d_ilist.release();
     h->d_numneigh.release(); h->d_neigh.release(); h->d_rows.release(); h->d_first.release();
     h->d_sym_first.release(); h->d_sym_cnt.release(); h->d_sym_fill.release(); h->d_sym_j.release();
-    h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release(); h->d_scan_a.release(); h->d_scan_b.release(); h->d_T6.release(); h->d_Minv.release(); h->d_gsN.release(); h->d_gsAT.release(); h->d_cb.release(); h->d_gs_part.release();
+    h->d_mol_s.release(); h->d_perm.release(); h->d_inv.release(); h->d_rows_orig.release(); h->d_ownrows.release(); h->d_ef_s.release(); h->d_scan_a.release(); h->d_scan_b.release(); h->d_gs_cnt.release(); h->d_T6.release(); h->d_Minv.release(); h->d_gsN.release(); h->d_gsAT.release(); h->d_cb.release(); h->d_gs_part.release();
     h->d_rec0.release(); h->d_rec1.release(); h->d_scal.release(); h->d_slots.release();
     h->d_cell_id.release(); h->d_cell_cnt.release(); h->d_cell_fill.release();
     h->d_nl_cnt.release(); h->d_dd_cnt.release(); h->d_dd_wrap.release(); h->d_lpdesc.release(); h->d_slot.release(); h->d_color_orig.release(); h->d_color_s.release(); h->d_trace.release(); h->d_cl_orig.release(); h->d_cl_cnt.release(); h->d_cl_wrap.release(); h->d_cl_tw.release(); h->d_cl_s.release(); h->d_nl_j.release(); h->d_dd_j.release();

@@ -311,11 +311,13 @@ static __global__ __launch_bounds__(256) void k_gs_cb_init(int n, const AtomRec 
 // Nothing in a launch depends on anything else in it.  (Needs at least two blocks: with one, cb of the block would be written
 // and read in the same launch.)
 #define POLAR_GS_WAVES 4   // waves per workgroup of k_gs_blk
+// the end-of-sweep logic on a sweep's last launch: cnt = a zeroed counter (nullptr: no tail), npart = entries of dsq_part
+struct GsTail { int *cnt; int npart, nlocal, fixed_iteration, iterations_max; double precision; };
 template <int B>
 static __global__ __launch_bounds__(64 * POLAR_GS_WAVES) void k_gs_blk(int n, long long np, int b0, int p0, int next0, const double *__restrict__ T6,
                                                  const double *__restrict__ G, const double *__restrict__ Nm, AtomRec *rec,
                                                  const double *__restrict__ ef, double *F, double *cb, const double *__restrict__ dmu_prev,
-                                                 double *__restrict__ dmu_out, const Scal *scal, double *__restrict__ dsq_part) {
+                                                 double *__restrict__ dmu_out, const Scal *scal, double *dsq_part, GsTail tail) {
   if (scal->done) return;
   constexpr int R = 3 * B, WV = POLAR_GS_WAVES, DW = R / WV;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -341,13 +343,40 @@ static __global__ __launch_bounds__(64 * POLAR_GS_WAVES) void k_gs_blk(int n, lo
       if (i < n) { double *m = x == 0 ? &rec[i].mx : x == 1 ? &rec[i].my : &rec[i].mz; *m += acc; }
     }
     __syncthreads();
+    __shared__ int lastwg;
     if (threadIdx.x == 0) {
       double dsq = 0.0;
 #pragma unroll
       for (int v = 0; v < WV; v++) dsq += dsh[v] * dsh[v];
-      // one entry per (block, workgroup), rewritten every sweep: k_solver_step adds them up in a fixed order (its `part` input),
-      // so the sweep's sum |dmu|^2 -- and with it the iteration count at a knife edge -- is the same run to run
-      dsq_part[(size_t)(b0 / B) * DW + blockIdx.x] = dsq;
+      // one entry per (block, workgroup), rewritten every sweep and added up in a fixed order, so the sweep's sum |dmu|^2 -- and
+      // with it the iteration count at a knife edge -- is the same run to run
+      double *mine = dsq_part + (size_t)(b0 / B) * DW + blockIdx.x;
+      if (!tail.cnt) *mine = dsq;
+      else {
+        // the sweep's LAST launch: the workgroups count themselves out and the last one applies the end-of-sweep logic.  The entry
+        // goes out as an atomic (performed at the coherence point: a plain store could still sit in this XCD's L2 when a workgroup
+        // on another XCD adds the entries up); a workgroup-scope release = "the atomic has been acknowledged", no cache flush
+        atomicExch((unsigned long long *)mine, (unsigned long long)__double_as_longlong(dsq));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const int last = atomicAdd(tail.cnt, 1) == DW - 1;
+        if (last) atomicExch(tail.cnt, 0);
+        lastwg = last;
+      }
+    }
+    if (!tail.cnt) return;
+    __syncthreads();
+    if (!lastwg) return;
+    double v = 0.0;   // thread t adds entries t, t + 256, ...; the wave sums, then the waves in order: a fixed association
+    for (int k2 = threadIdx.x; k2 < tail.npart; k2 += 64 * WV) v += __hip_atomic_load(dsq_part + k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) dsh[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sum = 0.0;
+#pragma unroll
+      for (int q2 = 0; q2 < WV; q2++) sum += dsh[q2];
+      solver_decide(const_cast<Scal *>(scal), sum, nullptr, tail.nlocal, tail.fixed_iteration, tail.iterations_max, tail.precision, 0, 1);
     }
     return;
   }

@@ -142,6 +142,7 @@ struct polar_handle {
   long long ncell = 0;
   bool sorted = false;  // true while the records are in cell order (list mode)
   DBuf<long long> d_first, d_sym_first;
+  DBuf<int> d_gs_cnt;   // a zeroed counter: exact mode's end-of-sweep logic on a sweep's last launch (GsTail)
   DBuf<long long> d_scan_a, d_scan_b;   // workgroup totals of launch_scan: main stream / the LJ-Coulomb side stream
   DBuf<int> d_sym_cnt, d_sym_fill, d_sym_j;
   bool sym_valid = false;  // symmetrised list matches the uploaded half list

@@ -1270,6 +1270,27 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_dd_scalars(const int *__
 
 #endif  // POLAR_LAB
 
+// The end-of-sweep logic (PS.cpp:1193-1236) by ONE thread, given the sweep's sum |dmu|^2: shared by k_solver_step and by the tail
+// of exact mode's last launch of a sweep (k_gs_blk).  `count` > 1: the logic of several sweeps at once (fixed-iteration
+// Gauss-Seidel takes no decision between sweeps, so the host launches k_solver_step only before and after the last one).
+__device__ __forceinline__ void solver_decide(Scal *scal, double sum, const double *global_change, int nlocal, int fixed_iteration,
+                                              int iterations_max, double precision, int jacobi, int count) {
+  scal->change = sum;  // this handle's own sum (exported to the all-reduce in multi-GPU runs)
+  // multi-GPU: the all-reduced sum over ranks arrives through global_change (device memory)
+  const double change = (global_change ? *global_change : sum) / ((double)nlocal * 3.0);
+  scal->last_change = change;
+  for (int c = 0; c < count; c++) {
+    scal->sweeps += 1;
+    int keep = 1;
+    if (!fixed_iteration) keep = change > precision * precision;
+    else if (scal->iterations >= iterations_max) { scal->done = 1; return; }  // returns BEFORE the copy
+    if (jacobi) scal->cur ^= 1;  // "mu = mu_new"
+    scal->iterations += 1;
+    if (scal->iterations > iterations_max) { scal->status = 1; scal->done = 1; return; }
+    if (!keep) { scal->done = 1; return; }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // a7 loop control, one thread: the reference's end-of-sweep logic (PS.cpp:1193-1236) kept on the
 // device so the host never has to look at ||dmu||^2 between sweeps.
@@ -1290,22 +1311,7 @@ static __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step(Scal *scal, 
   if (threadIdx.x != 0) return;
   double sum = 0.0;
   for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
-  scal->change = sum;  // this handle's own sum (exported to the all-reduce in multi-GPU runs)
-  // multi-GPU: the all-reduced sum over ranks arrives through global_change (device memory)
-  const double change = (global_change ? *global_change : sum) / ((double)nlocal * 3.0);
-  scal->last_change = change;
-  // `count` > 1: the end-of-sweep logic of several sweeps at once (fixed-iteration Gauss-Seidel takes
-  // no decision between sweeps, so the host launches this only before and after the last one)
-  for (int c = 0; c < count; c++) {
-    scal->sweeps += 1;
-    int keep = 1;
-    if (!fixed_iteration) keep = change > precision * precision;
-    else if (scal->iterations >= iterations_max) { scal->done = 1; return; }  // returns BEFORE the copy
-    if (jacobi) scal->cur ^= 1;  // "mu = mu_new"
-    scal->iterations += 1;
-    if (scal->iterations > iterations_max) { scal->status = 1; scal->done = 1; return; }
-    if (!keep) { scal->done = 1; return; }
-  }
+  solver_decide(scal, sum, global_change, nlocal, fixed_iteration, iterations_max, precision, jacobi, count);
 }
 
 // fold the change slots into scal->change without touching the loop state (multi-GPU export)

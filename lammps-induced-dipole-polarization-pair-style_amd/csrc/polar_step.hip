@@ -807,17 +807,22 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     const int grid = R / POLAR_GS_WAVES + nblk(n, POLAR_GS_WAVES), npart = nb * (R / POLAR_GS_WAVES);
     h->d_gs_part.ensure((size_t)npart + 1);
     HIPCHECK(hipMemsetAsync(h->d_gs_part.p, 0, (size_t)npart * sizeof(double), s));
+    // the sweep's last launch carries the end-of-sweep logic (GsTail) unless something has to happen between the two (`debug yes`)
+    const bool tail_on = !st.debug;
+    if (tail_on && !h->d_gs_cnt.p) { h->d_gs_cnt.ensure(8); HIPCHECK(hipMemsetAsync(h->d_gs_cnt.p, 0, 8 * sizeof(int), s)); }
     for (int sw = 0; sw < max_sweeps; sw++) {
       for (int b0 = 0; b0 < n; b0 += B) {
         const int next0 = b0 + B < n ? b0 + B : 0;
+        const GsTail tail = (tail_on && b0 + B >= n) ? GsTail{h->d_gs_cnt.p, npart, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision}
+                                                     : GsTail{nullptr, 0, 0, 0, 0, 0.0};
 #define POLAR_GS_BLK(BB) k_gs_blk<BB><<<grid, 64 * POLAR_GS_WAVES, 0, s>>>(n, np, b0, prev, next0, h->d_T6.p, h->d_Minv.p, h->d_gsN.p, h->d_rec0.p, h->d_ef_s.p, h->d_F.p, h->d_cb.p, \
-                                                            h->d_dmu.p + R * flip, h->d_dmu.p + R * (flip ^ 1), h->d_scal.p, h->d_gs_part.p)
+                                                            h->d_dmu.p + R * flip, h->d_dmu.p + R * (flip ^ 1), h->d_scal.p, h->d_gs_part.p, tail)
         if (B == 256) POLAR_GS_BLK(256); else if (B == 128) POLAR_GS_BLK(128); else POLAR_GS_BLK(64);
 #undef POLAR_GS_BLK
         prev = b0; flip ^= 1;
       }
       debug_trace(h, sw, false);
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, h->d_gs_part.p, npart);
+      if (!tail_on) k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, h->d_gs_part.p, npart);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;
