@@ -166,55 +166,69 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_dense_field(int n, long 
 // rows of d spread over 3 B / 4 workgroups.  The same numbers as the recurrence up to rounding (other summation order).
 // Rounds 1-4 walked the recurrence with one wave: 160 ns per step whatever was done to it (profiles/r04_config0_chain.txt).
 #define POLAR_GS64 192   // scalars of 64 atoms
-// G of 64 atoms: one wave per 32 columns, the columns in LDS.  Rows three at a time (atom k): row k of G = e_k - a_k sum_{j<k}
-// T_kj (rows of j); the two half-waves take even and odd j.  Tensor row k + 1 is fetched into LDS (one coalesced request per
-// component) while row k is worked on.  `ld`, `stride`, `per`: G of 64-atom piece p lands at G + (p / per) * stride +
-// (p % per) * 192 * (ld + 1) -- the diagonal pieces of a larger block's G.
-#define POLAR_GSB_COLS 32
+// G of 64 atoms: one wave per 16 columns, the columns in LDS.  Rows three at a time (atom k): row k of G = e_k - a_k sum_{j<k}
+// T_kj (rows of j); the four quarter-waves take j = 0, 1, 2, 3 mod 4.  The tensor rows arrive four atoms at a time: the next
+// four rows (6 x 4 coalesced requests) are fetched into the other LDS buffer while the current four are worked on -- one
+// memory latency per four steps instead of one per step, and that one mostly hidden.  `ld`, `stride`, `per`: G of 64-atom
+// piece p lands at G + (p / per) * stride + (p % per) * 192 * (ld + 1) -- the diagonal pieces of a larger block's G.
+#define POLAR_GSB_COLS 16
+#define POLAR_GSB_ROWS 4
 static __global__ __launch_bounds__(64) void k_gs_blockinv(int n, long long np, const double *__restrict__ T6,
                                                     const AtomRec *__restrict__ rec, double *__restrict__ G, int ld, long long stride, int per) {
   __shared__ double col[POLAR_GS64][POLAR_GSB_COLS];
-  __shared__ double trow[2][6][64];
-  constexpr int PARTS = POLAR_GS64 / POLAR_GSB_COLS;
+  __shared__ double trow[2][POLAR_GSB_ROWS][6][64];
+  constexpr int PARTS = POLAR_GS64 / POLAR_GSB_COLS, RB = POLAR_GSB_ROWS;
   const int piece = blockIdx.x / PARTS, b0 = piece * 64, cnt = min(64, n - b0);
-  const int lane = threadIdx.x, t = lane & 31, half = lane >> 5, q = (blockIdx.x % PARTS) * POLAR_GSB_COLS + t;
+  const int lane = threadIdx.x, t = lane & (POLAR_GSB_COLS - 1), quarter = lane / POLAR_GSB_COLS, q = (blockIdx.x % PARTS) * POLAR_GSB_COLS + t;
   double *out = G + (size_t)(piece / per) * stride + (size_t)(piece % per) * POLAR_GS64 * ((size_t)ld + 1) + q;
   if (cnt <= 0) {   // a piece past the end of the system: identity
-    for (int r = half; r < POLAR_GS64; r += 2) out[(size_t)r * ld] = r == q ? 1.0 : 0.0;
+    for (int r = quarter; r < POLAR_GS64; r += 4) out[(size_t)r * ld] = r == q ? 1.0 : 0.0;
     return;
   }
   const int j0 = ((blockIdx.x % PARTS) * POLAR_GSB_COLS) / 3;   // rows above a column's own atom are zero: start at the workgroup's first
   const int jl = lane < cnt ? lane : 0;                          // (columns past the end are never used)
-#pragma unroll
-  for (int c = 0; c < 6; c++) trow[0][c][lane] = T6[((size_t)b0 * 6 + c) * np + b0 + jl];
-  for (int k = 0; k < 64; k++) {
-    __syncthreads();
-    double nx[6];
-    const int kn = k + 1 < cnt ? k + 1 : 0;
-#pragma unroll
-    for (int c = 0; c < 6; c++) nx[c] = T6[((size_t)(b0 + kn) * 6 + c) * np + b0 + jl];
-    double m0 = q == 3 * k ? 1.0 : 0.0, m1 = q == 3 * k + 1 ? 1.0 : 0.0, m2 = q == 3 * k + 2 ? 1.0 : 0.0;
-    const double a = k < cnt ? rec[b0 + k].a : 0.0;                       // (uniform)
-    if (a != 0.0 && j0 < k) {
-      const double(*tr)[64] = trow[k & 1];
-      double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll 4
-      for (int j = j0 + half; j < k; j += 2) {
-        const double t0 = tr[0][j], t1 = tr[1][j], t2 = tr[2][j], t3 = tr[3][j], t4 = tr[4][j], t5 = tr[5][j];
-        const double p0 = col[3 * j][t], p1 = col[3 * j + 1][t], p2 = col[3 * j + 2][t];
-        s0 += t0 * p0 + t1 * p1 + t2 * p2;
-        s1 += t1 * p0 + t3 * p1 + t4 * p2;
-        s2 += t2 * p0 + t4 * p1 + t5 * p2;
-      }
-      s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-      m0 -= a * s0; m1 -= a * s1; m2 -= a * s2;
-    }
-    if (half == 0) { col[3 * k][t] = m0; col[3 * k + 1][t] = m1; col[3 * k + 2][t] = m2; }
-#pragma unroll
-    for (int c = 0; c < 6; c++) trow[(k + 1) & 1][c][lane] = nx[c];
+  double nx[RB][6];
+#define POLAR_GSB_FETCH(K0)                                                                            \
+  _Pragma("unroll") for (int u = 0; u < RB; u++) {                                                     \
+    const int kr = (K0) + u < cnt ? (K0) + u : 0;                                                      \
+    _Pragma("unroll") for (int c = 0; c < 6; c++) nx[u][c] = T6[((size_t)(b0 + kr) * 6 + c) * np + b0 + jl]; \
   }
+#define POLAR_GSB_STAGE(BUF)                                                                           \
+  _Pragma("unroll") for (int u = 0; u < RB; u++)                                                       \
+    _Pragma("unroll") for (int c = 0; c < 6; c++) trow[BUF][u][c][lane] = nx[u][c];
+  POLAR_GSB_FETCH(0);
+  POLAR_GSB_STAGE(0);
+  for (int k0 = 0; k0 < 64; k0 += RB) {
+    const int buf = (k0 / RB) & 1;
+    if (k0 + RB < 64) { POLAR_GSB_FETCH(k0 + RB); }   // in flight while the four steps below run
+    for (int u = 0; u < RB; u++) {
+      const int k = k0 + u;
+      __syncthreads();   // (rows of col written by the step before; at u = 0 also the staged tensor rows)
+      double m0 = q == 3 * k ? 1.0 : 0.0, m1 = q == 3 * k + 1 ? 1.0 : 0.0, m2 = q == 3 * k + 2 ? 1.0 : 0.0;
+      const double a = k < cnt ? rec[b0 + k].a : 0.0;                       // (uniform)
+      if (a != 0.0 && j0 < k) {
+        const double(*tr)[64] = trow[buf][u];
+        double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll 4
+        for (int j = j0 + quarter; j < k; j += 4) {
+          const double t0 = tr[0][j], t1 = tr[1][j], t2 = tr[2][j], t3 = tr[3][j], t4 = tr[4][j], t5 = tr[5][j];
+          const double p0 = col[3 * j][t], p1 = col[3 * j + 1][t], p2 = col[3 * j + 2][t];
+          s0 += t0 * p0 + t1 * p1 + t2 * p2;
+          s1 += t1 * p0 + t3 * p1 + t4 * p2;
+          s2 += t2 * p0 + t4 * p1 + t5 * p2;
+        }
+        s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        m0 -= a * s0; m1 -= a * s1; m2 -= a * s2;
+      }
+      if (quarter == 0) { col[3 * k][t] = m0; col[3 * k + 1][t] = m1; col[3 * k + 2][t] = m2; }
+    }
+    if (k0 + RB < 64) { POLAR_GSB_STAGE(buf ^ 1); }   // (the other buffer: its last readers passed the barriers of this group's steps)
+  }
+#undef POLAR_GSB_FETCH
+#undef POLAR_GSB_STAGE
   __syncthreads();
-  for (int r = half; r < POLAR_GS64; r += 2) out[(size_t)r * ld] = col[r][t];
+  for (int r = quarter; r < POLAR_GS64; r += 4) out[(size_t)r * ld] = col[r][t];
 }
 
 // A T[rows][cols] written out densely (row-major, leading dimension ld, batch member z = blockIdx.z at out + z * stride):
