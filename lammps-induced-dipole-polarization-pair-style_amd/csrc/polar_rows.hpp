@@ -67,6 +67,8 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int nto
                zi = ALLPAIRS ? x[3 * i + 2] : rec[i].z, ai = ALLPAIRS ? alpha[i] : rec[i].a;
   const int mi = ALLPAIRS ? mol[i] : mol_s[i];
   double rmin = (PASS == 1) ? 1000.0 : __longlong_as_double((long long)scal->rmin_bits);
+  double rmin2 = 1.0e6;                                    // PASS 1: smallest r^2 seen (1000^2: the reference's start value)
+  const double far2 = (rmin * 1.5) * (rmin * 1.5) * 1.000001;   // PASS 2: r^2 beyond this cannot satisfy rmin * 1.5 > r
   double acc = 0.0;
   long long beg = 0, end = ntotal;
   if (!ALLPAIRS) row_range(nl, i, beg, end);
@@ -97,11 +99,13 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int nto
         double dx, dy, dz;
         if (ALLPAIRS) { dx = xi - px[u]; dy = yi - py[u]; dz = zi - pz[u]; }
         else min_image_rint(box, xi, yi, zi, px[u], py[u], pz[u], dx, dy, dz);
-        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const double rsq = dx * dx + dy * dy + dz * dz;
         const bool molok = (mi != pm[u]) || mi == 0;
+        // (the square root only where it decides: it is monotone and correctly rounded, so the smallest r is the root of the
+        //  smallest r^2, and a pair well outside 1.5 rmin cannot pass the reference's test `rmin * 1.5 > r`)
         if (PASS == 1) {
-          if (ai > 0 && pa[u] > 0 && molok) rmin = fmin(rmin, r);
-        } else if (rmin * 1.5 > r && molok) {
+          if (ai > 0 && pa[u] > 0 && molok) rmin2 = fmin(rmin2, rsq);
+        } else if (rsq < far2 && molok && rmin * 1.5 > sqrt(rsq)) {
           hit = true;
           term = ai * pa[u];
         }
@@ -119,7 +123,7 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int nto
     }
   }
   if (PASS == 1) {
-    rmin = wave_min(rmin);
+    rmin = wave_min(fmin(rmin, sqrt(rmin2)));
     if (lane == 0)
       atomicMin((unsigned long long *)slot_ptr(slots, SL_RMIN), (unsigned long long)__double_as_longlong(rmin));
   } else {
