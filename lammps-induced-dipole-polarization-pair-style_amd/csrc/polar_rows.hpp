@@ -58,11 +58,14 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int nto
                                                       const AtomRec *__restrict__ rec,
                                                       const int *__restrict__ mol_s, Scal *scal,
                                                       double *__restrict__ slots,
-                                                      double *__restrict__ rank_metric) {
+                                                      double *__restrict__ rank_metric, int nchunk) {
   // ALLPAIRS: orig space (x/alpha/mol incl. ghosts).  List mode: s space (records, mol_s).
+  // nchunk > 1 (PASS 1 of the all-pairs form only: a minimum does not care about order): the partners of an atom are split
+  // over nchunk waves -- one wave per atom leaves an exact-mode system of a thousand atoms with one wave per SIMD
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (i >= nlocal) return;
+  const int gw = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (gw >= nlocal * nchunk) return;
+  const int i = gw % nlocal, chunk = gw / nlocal;
   const double xi = ALLPAIRS ? x[3 * i] : rec[i].x, yi = ALLPAIRS ? x[3 * i + 1] : rec[i].y,
                zi = ALLPAIRS ? x[3 * i + 2] : rec[i].z, ai = ALLPAIRS ? alpha[i] : rec[i].a;
   const int mi = ALLPAIRS ? mol[i] : mol_s[i];
@@ -72,6 +75,7 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_rank(int nlocal, int nto
   double acc = 0.0;
   long long beg = 0, end = ntotal;
   if (!ALLPAIRS) row_range(nl, i, beg, end);
+  else if (nchunk > 1) { const long long per = ((ntotal + nchunk - 1) / nchunk + 255) / 256 * 256; beg = chunk * per; end = beg + per < ntotal ? beg + per : ntotal; }
   // one partner per lane and trip; the all-pairs form requests four trips' worth of partners at once (one wave walks ~10^4
   // partners: a memory latency per trip was 97 + 69 us per step at 1349 atoms) and then takes them in the same order
   constexpr int U = ALLPAIRS ? 4 : 1;

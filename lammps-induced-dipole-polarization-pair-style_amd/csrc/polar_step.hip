@@ -210,12 +210,14 @@ static void launch_rank(polar_handle *h, int pass) {
   const int n = h->nlocal, ntot = h->nlocal + h->nghost;
   dim3 grid(nblk(n, POLAR_ROWS_PER_BLOCK)), block(POLAR_BLOCK);
   if (pass == 2) k_fold_scal<<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, 1);
+  // pass 1 of the all-pairs form: the partners of an atom over several waves while there are few atoms (a minimum: any order)
+  const int nchunk = (AP && pass == 1) ? std::max(1, std::min(16, 8192 / std::max(n, 1))) : 1;
   if (pass == 1)
-    k_rank<AP, 1><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch},
-                                                 h->d_nl_j.p, h->d_rec0.p, h->d_mol_s.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
+    k_rank<AP, 1><<<nblk((long long)n * nchunk, POLAR_ROWS_PER_BLOCK), block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch},
+                                                 h->d_nl_j.p, h->d_rec0.p, h->d_mol_s.p, h->d_scal.p, h->d_slots.p, h->d_rank.p, nchunk);
   else
     k_rank<AP, 2><<<grid, block, 0, h->stream>>>(n, ntot, h->d_x.p, h->d_alpha.p, h->d_mol.p, h->box, RowList{h->d_nl_cnt.p, h->nl_pitch},
-                                                 h->d_nl_j.p, h->d_rec0.p, h->d_mol_s.p, h->d_scal.p, h->d_slots.p, h->d_rank.p);
+                                                 h->d_nl_j.p, h->d_rec0.p, h->d_mol_s.p, h->d_scal.p, h->d_slots.p, h->d_rank.p, 1);
 }
 
 void launch_rank_pass(polar_handle *h, bool allpairs, int pass) {
