@@ -148,13 +148,13 @@ void p2p(polar_dist *d, const int *soff, const int *roff, const double *sendbuf,
   RCCLCHECK(R.GroupEnd());
 }
 // one dipole exchange of ALL halo atoms with the peers, enqueued on the handle's stream
-void dist_exchange(polar_dist *d, polar_handle *h) {
+void dist_exchange(polar_dist *d, polar_handle *h, bool packed = false) {   // packed: the send buffer has been filled already (k_solver_step_gather)
   const int np = (int)d->peers.size();
   if (np == 0) return;
   const long long ns = d->send_off[np], nr = d->recv_off[np];
   hipStream_t s = h->stream;
   const MuView mv = mu_view(h);
-  if (ns > 0) k_mu_gather_idx<<<nblk(ns, 256), 256, 0, s>>>(ns, d->d_send_idx.p, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, mv, d->d_send.p);
+  if (ns > 0 && !packed) k_mu_gather_idx<<<nblk(ns, 256), 256, 0, s>>>(ns, d->d_send_idx.p, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, mv, d->d_send.p);
   p2p(d, d->send_off.data(), d->recv_off.data(), d->d_send.p, d->d_recv.p, 3, s);
   // (own_lo = own_hi = 0: the plan lists exactly the rows to overwrite; a self-exchange rewrites own rows with their own values)
   if (nr > 0) k_mu_scatter_idx<<<nblk(nr, 256), 256, 0, s>>>(nr, d->d_recv_idx.p, h->sorted ? h->d_inv.p : nullptr, h->d_scal.p, mv, d->d_recv.p, 0, 0);
@@ -527,6 +527,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
         const bool lazy = st.fixed_iteration && gs;
         if (st.polar_accel > 0) throw InputError("polar_accel across ranks needs the shared colouring (polar_dist_set_schedule with classes and lag >= 0)");
         for (int sw = 0; sw < max_sweeps; sw++) {
+          bool packed = false;
           sweep_once(h, false);
           if (!st.fixed_iteration) {
             // the stop rule (PS.cpp:1194-1210) needs the sum over all ranks: one all-reduced double every `reduce_every` sweeps;
@@ -538,6 +539,16 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
               d->allreduces++;
               gc = d->d_red.p;
             }
+            // Gauss-Seidel: the end-of-sweep logic and the pack of the halo dipoles in one launch (Jacobi flips its buffers in the
+            // logic and packs afterwards)
+            const long long ns = d->peers.empty() ? 0 : d->send_off[d->peers.size()];
+            if (gs && ns > 0) {
+              k_solver_step_gather<<<1 + nblk(ns, POLAR_NSLOT), POLAR_NSLOT, 0, s>>>(
+                  h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gc,
+                  gc == d->d_red.p ? nullptr : det_part(h), gc == d->d_red.p ? 0 : det_npart(h), ns, d->d_send_idx.p,
+                  h->sorted ? h->d_inv.p : nullptr, mu_view(h), d->d_send.p);
+              packed = true;
+            } else
             k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
                                                   gs ? 0 : 1, gc, 1, gc == d->d_red.p ? nullptr : det_part(h), gc == d->d_red.p ? 0 : det_npart(h));
           } else if (lazy) {
@@ -548,7 +559,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
             k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
                                                   gs ? 0 : 1, nullptr, 1, det_part(h), det_npart(h));
           }
-          dist_exchange(d, h);
+          dist_exchange(d, h, packed);
           if (!st.fixed_iteration && (sw % d->check_every) == d->check_every - 1) {
             read_scal(h);  // identical on every rank: same all-reduced sum (sweeps past the end are no-ops on the device)
             if (h->h_scal->done) break;

@@ -1174,6 +1174,36 @@ static __global__ void k_mu_gather_idx(long long n, const int *__restrict__ idx,
   const double *r = mu_of(v, scal, inv ? inv[o] : o);
   dst[3 * t] = r[1]; dst[3 * t + 1] = r[3]; dst[3 * t + 2] = r[5];
 }
+// The end-of-sweep logic and the pack of the halo dipoles in ONE launch (round 4; the multi-GPU driver's one-exchange-per-sweep
+// schedule, Gauss-Seidel): workgroup 0 is k_solver_step, the others k_mu_gather_idx.  The two do not touch each other's data
+// (in-place sweeps never flip `cur`), and a dependent launch costs ~5 us whatever it does: 38 sweeps x 1 launch.
+static __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_step_gather(Scal *scal, double *__restrict__ slots, int nlocal, int fixed_iteration,
+                                                                  int iterations_max, double precision, const double *__restrict__ global_change,
+                                                                  const double *__restrict__ part, int npart, long long n,
+                                                                  const int *__restrict__ idx, const int *__restrict__ inv, MuView v,
+                                                                  double *__restrict__ dst) {
+  if (blockIdx.x == 0) {
+    if (scal->done) return;
+    __shared__ double red[POLAR_NSLOT / 64];
+    double c = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
+    slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE] = 0.0;
+    for (int k = threadIdx.x; k < npart; k += POLAR_NSLOT) c += part[k];
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double sum = 0.0;
+    for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+    solver_decide(scal, sum, global_change, nlocal, fixed_iteration, iterations_max, precision, 0, 1);
+    return;
+  }
+  const long long t = (blockIdx.x - 1) * (long long)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int o = idx[t];
+  if (o < 0) return;
+  const double *r = mu_of(v, scal, inv ? inv[o] : o);
+  dst[3 * t] = r[1]; dst[3 * t + 1] = r[3]; dst[3 * t + 2] = r[5];
+}
 static __global__ void k_mu_scatter_idx(long long n, const int *__restrict__ idx, const int *__restrict__ inv, const Scal *scal,
                                  MuView v, const double *__restrict__ src, int own_lo, int own_hi) {
   long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
