@@ -163,6 +163,13 @@ def config0_exact(torch, pkg, wl, steps=10, warmup=2):
             "reference_cpu_s_per_step": 0.85}
 
 
+def exact_iteration_bytes(n, B=256):
+    """HBM bytes one iteration of exact mode's block sweep reads at n atoms (n >= 1024: blocks of 256 atoms)."""
+    npitch = (n + 63) // 64 * 64
+    nb = (n + B - 1) // B
+    return 48.0 * n * npitch + nb * 1.5 * (3 * B) ** 2 * 8.0
+
+
 def exact_replica(torch, pkg, wl, steps=3, warmup=1):
     """The largest system the reference itself was run on: MOF5+H2 `replicate 2 2 2`, 10,792 atoms,
     EXACT reference semantics (all minimum-image pairs: 116 M ordered pairs, a 5.6 GB packed tensor in HBM), ranked GS to
@@ -176,7 +183,12 @@ def exact_replica(torch, pkg, wl, steps=3, warmup=1):
             "natoms": s.nlocal, "steps": steps, "ms_per_step": 1e3 * dt / steps, "atom_steps_per_s": s.nlocal * steps / dt,
             "iterations": out["iterations"], "status": out["status"], "ms_per_dipole_iteration": ms_solve / steps / max(out["sweeps"], 1),
             "ms_solve": ms_solve / steps, "eng_pol": out["eng_pol"], "reference_cpu_s_per_step": 46.5,
-            "speedup_over_reference_cpu": 46.5 / (dt / steps)}
+            "speedup_over_reference_cpu": 46.5 / (dt / steps),
+            # what an iteration of the exact-order sweep reads (csrc/polar_exact.hpp, k_gs_blk): the packed tensor once (48 B per ordered
+            # pair, rows padded to 64) and G and N of every 256-atom block (lower triangle + full square of 768^2 doubles), over the
+            # time of an iteration INCLUDING the once-per-step build of G and N and the 4.4-us floor of its 43 dependent launches
+            "hbm_bytes_per_iteration": exact_iteration_bytes(s.nlocal),
+            "hbm_frac": exact_iteration_bytes(s.nlocal) / (1e-3 * ms_solve / steps / max(out["sweeps"], 1)) / 8.0e12}
 
 
 def synth_config(torch, pkg, wl, natoms, steps, warmup):
