@@ -69,3 +69,14 @@ def test_list_and_row_kernels_stay_within_their_budgets(usage):
         assert v["VGPRs"] <= 128, (k, v)
     for k, v in _pick(usage, "k_ljcoul").items():
         assert v["VGPRs"] <= 128, (k, v)
+
+
+def test_exact_mode_block_sweep_stays_light(usage):
+    """k_gs_blk (exact mode: one launch per block of the sweep, csrc/polar_exact.hpp) is a stream of dot products: many waves per
+    SIMD hide its one round of loads; the FP64 MFMA product keeps its accumulators in AGPRs."""
+    ks = _pick(usage, "k_gs_blkILi")
+    assert len(ks) == 3, list(ks)
+    for k, v in ks.items():
+        assert v["VGPRs"] <= 64, (k, v)
+    for k, v in _pick(usage, "k_gs_gemm").items():
+        assert v["VGPRs"] <= 128, (k, v)
