@@ -199,12 +199,6 @@ int polar_create(int device, polar_handle **out) {
     HIPCHECK(hipEventCreateWithFlags(&h->ev_mu_ready, hipEventDisableTiming));
     for (auto &e : h->ev_fchunk) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHECK(hipStreamCreateWithFlags(&h->dl_stream, hipStreamNonBlocking));
-    HIPCHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    for (auto &row : h->ev_near) for (auto &e : row) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&h->ev_half, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&h->ev_stepdone, hipEventDisableTiming));
-#ifdef POLAR_LAB
-    if (const char *e = getenv("POLAR_PIPELINE")) h->pipeline = atoi(e) != 0;   // lab: the region pipeline (lost: profiles/r04_lab_region_pipeline.txt)
-#endif
     if (getenv("POLAR_NO_OVERLAP")) h->overlap_lj = false;
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
     HIPCHECK(hipHostMalloc((void **)&h->h_flags, 16 * sizeof(int)));
@@ -225,15 +219,10 @@ int polar_destroy(polar_handle *h) {
     if (h->lj_stream) { (void)hipStreamSynchronize(h->lj_stream); (void)hipStreamDestroy(h->lj_stream); }
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_lj0, h->ev_lj1, h->ev_dl0, h->ev_dl1, h->ev_mu_ready}) if (e) (void)hipEventDestroy(e);
     if (h->dl_stream) (void)hipStreamDestroy(h->dl_stream);
-    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->up_stream) { (void)hipStreamSynchronize(h->up_stream); (void)hipStreamDestroy(h->up_stream); }
     if (h->ev_list_up) (void)hipEventDestroy(h->ev_list_up);
     for (int *p : h->h_nl_stage) (void)hipHostFree(p);
     for (hipEvent_t e : h->ev_nl) (void)hipEventDestroy(e);
-    for (auto &row : h->ev_near) for (auto &e : row) if (e) (void)hipEventDestroy(e);
-    if (h->ev_half) (void)hipEventDestroy(h->ev_half);
-    if (h->ev_stepdone) (void)hipEventDestroy(h->ev_stepdone);
-    h->d_sub.release();
     for (hipEvent_t e : h->ev_fchunk) if (e) (void)hipEventDestroy(e);
     h->d_ljpos.release(); h->d_ljaux.release(); h->d_tag.release(); h->d_nspecial.release(); h->d_special.release();
     h->d_ljcell_id.release(); h->d_ljcell_cnt.release(); h->d_ljcell_fill.release(); h->d_ljcell_first.release(); h->d_cutneighsq.release();

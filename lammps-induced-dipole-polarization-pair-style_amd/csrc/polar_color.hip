@@ -351,7 +351,7 @@ void color_adjacency(polar_handle *h, bool with_halo) {
   if (!h->h_cflags) {
     HIPCHECK(hipHostMalloc((void **)&h->h_cflags, 96 * sizeof(int)));
     HIPCHECK(hipHostMalloc((void **)&h->h_cstat, 128 * sizeof(double)));
-    HIPCHECK(hipHostMalloc((void **)&h->h_coff, 72 * sizeof(long long)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_coff, POLAR_MAX_CLASS_OFF * sizeof(long long)));
   }
   h->d_cdeg.ensure(n + 1); h->d_cprio.ensure(n + 1);
   h->d_color_s.ensure(n + 1); h->d_color_orig.ensure(n + 1); h->d_cflags.ensure(96); h->d_cstat.ensure(128); h->d_crelabel.ensure(64);
@@ -512,25 +512,12 @@ void color_finish(polar_handle *h, bool ranked, int ncolors) {
   for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
   HIPCHECK(hipMemcpyAsync(h->d_crelabel.p, relabel.data(), 64 * sizeof(int), hipMemcpyHostToDevice, s));
   k_color_relabel<<<nblk(n, 256), 256, 0, s>>>(n, h->d_crelabel.p, h->d_perm.p, h->d_color_s.p, h->d_color_orig.p);
-  // rows of every phase in cell order, by sub-class inside a phase: multi-GPU: boundary rows first (polar_dist_set_halo);
-  // single GPU: the region pipeline's four classes (polar_step.hip, solve)
+  // rows of every phase in cell order, by sub-class inside a phase: multi-GPU: boundary rows first (polar_dist_set_halo)
   const int *sub = nullptr;
   int nsub = 1;
   if (h->bflag_n == n && sharded(h) && !deterministic(h)) { sub = h->d_bflag.p; nsub = 2; }
-  else if (h->pipeline && !sharded(h) && !deterministic(h) && 4 * ncolors + 1 <= 72) {
-    // cut along the longest box dimension; "near" = within the dipole cutoff of a cutting plane, plus a margin for the
-    // motion between two colourings (a far row that drifted closer only races with weakly coupled rows: > 10 A away)
-    int axis = 0;
-    for (int k = 1; k < 3; k++) if (h->box.prd[k] > h->box.prd[axis]) axis = k;
-    const double reach = h->ph.st.dd_cutoff + 1.5;
-    if (h->box.periodic[axis] && !h->box.triclinic && h->box.prd[axis] >= 4.0 * reach + 8.0) {
-      h->d_sub.ensure((size_t)n + 1);
-      k_region_sub<<<nblk(n, 256), 256, 0, s>>>(n, h->d_pos4.p, h->d_perm.p, axis, h->boxlo[axis], h->box.prd[axis], reach, h->d_sub.p);
-      sub = h->d_sub.p; nsub = 4;
-    }
-  }
   const int nclass = nsub * ncolors;
-  if (nclass > 71) throw std::runtime_error("colouring: too many phase classes");
+  if (nclass + 1 > POLAR_MAX_CLASS_OFF) throw std::runtime_error("colouring: too many phase classes");   // (cannot happen: ncolors <= 64, nsub <= 2)
   const size_t ncc = (size_t)nclass * ncell;
   const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
   h->d_ccnt.ensure(ncc + 1); h->d_coff.ensure(ncc + 2);
@@ -615,7 +602,7 @@ void apply_imposed_colors(polar_handle *h) {
   if (!h->h_cflags) {
     HIPCHECK(hipHostMalloc((void **)&h->h_cflags, 96 * sizeof(int)));
     HIPCHECK(hipHostMalloc((void **)&h->h_cstat, 128 * sizeof(double)));
-    HIPCHECK(hipHostMalloc((void **)&h->h_coff, 72 * sizeof(long long)));
+    HIPCHECK(hipHostMalloc((void **)&h->h_coff, POLAR_MAX_CLASS_OFF * sizeof(long long)));
   }
   h->d_color_s.ensure(n + 1); h->d_color_orig.ensure(n + 1); h->d_cstat.ensure(128); h->d_crelabel.ensure(64);
   HIPCHECK(hipMemcpyAsync(h->d_color_orig.p, h->user_colors.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));

@@ -369,10 +369,11 @@ static __global__ __launch_bounds__(64 * POLAR_GS_WAVES) void k_gs_blk(int n, lo
       else {
         // the sweep's LAST launch: the workgroups count themselves out and the last one applies the end-of-sweep logic.  The entry
         // goes out as an atomic (performed at the coherence point: a plain store could still sit in this XCD's L2 when a workgroup
-        // on another XCD adds the entries up); a workgroup-scope release = "the atomic has been acknowledged", no cache flush
+        // on another XCD adds the entries up), and the count is an agent-scope RELEASE: the HSA memory model orders the entry
+        // before the count for workgroups on other XCDs only then (a workgroup-scope fence happened to be enough with
+        // this compiler).  One thread of 3B/4 workgroups on one launch per sweep pays for it.
         atomicExch((unsigned long long *)mine, (unsigned long long)__double_as_longlong(dsq));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        const int last = atomicAdd(tail.cnt, 1) == DW - 1;
+        const int last = __hip_atomic_fetch_add(tail.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == DW - 1;
         if (last) atomicExch(tail.cnt, 0);
         lastwg = last;
       }
@@ -380,6 +381,7 @@ static __global__ __launch_bounds__(64 * POLAR_GS_WAVES) void k_gs_blk(int n, lo
     if (!tail.cnt) return;
     __syncthreads();
     if (!lastwg) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // pairs with the counting workgroups' release
     double v = 0.0;   // thread t adds entries t, t + 256, ...; the wave sums, then the waves in order: a fixed association
     for (int k2 = threadIdx.x; k2 < tail.npart; k2 += 64 * WV) v += __hip_atomic_load(dsq_part + k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     v = wave_sum(v);

@@ -16,6 +16,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <exception>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -35,6 +37,7 @@ using namespace polar;
 
 // bump when a kernel on the hot path changes: PMC files under profiles/ are keyed by it (bench.py, roofline.traffic)
 #define POLAR_KERNEL_VERSION "r04-lp3-v3"
+#define POLAR_MAX_CLASS_OFF 130   // phase classes of a colouring + 1: up to 64 colours, each split into boundary / interior rows on a sharded handle
 
 
 struct HipError : std::runtime_error {
@@ -61,6 +64,11 @@ struct DBuf {
     size_t want = n + n / 8 + 64;
     HIPCHECK(hipMalloc((void **)&p, want * sizeof(T)));
     cap = want;
+    // POLAR_POISON=1 (debugging aid): a fresh process gets zero pages from hipMalloc, a long-lived one gets recycled memory --
+    // fill every new buffer with 0x7F bytes (ints 2139062143, doubles 1.4e306) so that a read-before-write shows in the FIRST
+    // call of a process instead of the ninetieth (the abort of round 4)
+    static const bool poison = getenv("POLAR_POISON") && atoi(getenv("POLAR_POISON")) != 0;
+    if (poison) HIPCHECK(hipMemset(p, 0x7F, want * sizeof(T)));
   }
   void release() {
     if (p) (void)hipFree(p);
@@ -188,18 +196,13 @@ struct polar_handle {
   // colour phases (cutoff-mode Gauss-Seidel)
   std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
   std::vector<int> color_sub;  // [ncolors * color_nsub + 1] offsets of the sub-classes inside the phases (class = colour * nsub + sub)
-  int color_nsub = 1;          // 1: none; 2 (multi-GPU): boundary rows, then interior rows; 4 (single GPU, region pipeline): half A near / far from the cut, half B near / far
+  int color_nsub = 1;          // 1: none; 2 (multi-GPU): boundary rows, then interior rows
   DBuf<int> d_bflag; int bflag_n = 0;   // multi-GPU: sub-class by original index (polar_dist_set_halo: 0 = a peer receives this row's dipole, 1 = not), bflag_n = atoms it was made for
-  DBuf<int> d_sub;             // region pipeline: sub-class by original index (k_region_sub)
-  int pipeline = 0;            // single GPU, list-mode GS: the two halves of the box on two streams, a half's next phase gated by the other half's NEAR rows only.  OFF: it loses (10.6 against 9.2 ms per step at 135k atoms, profiles/r04_lab_region_pipeline.txt); POLAR_PIPELINE=1 switches it on in the LAB build only
-  hipStream_t stream2 = nullptr; hipEvent_t ev_near[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}, ev_half = nullptr, ev_stepdone = nullptr;
-  bool pipe_active = false; long long pipe_g = 0;   // the running solve uses the pipeline; phases issued so far
   // the neighbor list's upload: its own stream, one pinned buffer (+ event) per 32-MB chunk, host copies of the row tables that
   // must outlive the call, the event its consumers wait for
   std::vector<int *> h_nl_stage; std::vector<hipEvent_t> ev_nl;
   hipStream_t up_stream = nullptr; hipEvent_t ev_list_up = nullptr; bool list_up_pending = false;
   std::vector<long long> h_first; std::vector<int> h_nn, h_ilist;
-  hipStream_t lp_stream = nullptr;   // where launch_field_lp puts its kernels when set (else `stream`)
   bool colors_global = false;  // the colouring in force is consistent across the ranks of a multi-GPU run (halo rows carry their owners' colours)
   std::vector<int> user_colors;  // polar_set_colors: a colouring imposed by the caller (original order, -1 = none)
   bool user_colors_clashed = false;
@@ -220,7 +223,7 @@ struct polar_handle {
   DBuf<long long> d_coff;
   int *h_cflags = nullptr;        // pinned: round counters / fold counters of the device colouring
   double *h_cstat = nullptr;      // pinned: rows and rank sums per colour
-  long long *h_coff = nullptr;    // pinned: first row of every phase
+  long long *h_coff = nullptr;    // pinned: first row of every phase class (POLAR_MAX_CLASS_OFF entries: 64 colours x 2 sub-classes + 1)
   int cadj_pitch = 16;            // conflict-list entries per atom (grown when an atom has more neighbours within the colour distance)
   int host_colors = 0;            // lab (POLAR_HOST_COLORS): rounds 1-2's host-side conflict graph + DSATUR instead of the device colouring
   int colors_reused = 0, colors_rebuilt = 0;
@@ -352,19 +355,30 @@ class HostPool {
  public:
   static HostPool &get() { static HostPool p; return p; }
   int width() const { return (int)th_.size() + 1; }
+  // An exception in any part (helper or caller) is rethrown here, AFTER every part has finished: the helpers run `fn` through a
+  // pointer into the caller's frame and must never outlive it, and an exception that escaped a helper thread would be
+  // std::terminate -- an abort with no message under a test runner.
   void run(const std::function<void(int)> &fn, int parts) {
     if (parts <= 1 || th_.empty() || getpid() != pid_) { for (int k = 0; k < parts; k++) fn(k); return; }   // (a forked child has no helpers)
     std::unique_lock<std::mutex> job(job_m_);   // one job at a time
     {
       std::lock_guard<std::mutex> g(m_);
-      fn_ = &fn; parts_ = parts; pending_ = std::min(parts - 1, (int)th_.size()); gen_++;
+      fn_ = &fn; parts_ = parts; pending_ = std::min(parts - 1, (int)th_.size()); gen_++; failed_ = nullptr;
     }
     cv_.notify_all();
-    fn(0);
-    for (int k = (int)th_.size() + 1; k < parts; k++) fn(k);   // (more parts than threads: the caller takes the rest)
+    std::exception_ptr mine;
+    try {
+      fn(0);
+      for (int k = (int)th_.size() + 1; k < parts; k++) fn(k);   // (more parts than threads: the caller takes the rest)
+    } catch (...) { mine = std::current_exception(); }
     std::unique_lock<std::mutex> g(m_);
     done_.wait(g, [&] { return pending_ == 0; });
     fn_ = nullptr;
+    std::exception_ptr theirs = failed_;
+    failed_ = nullptr;
+    g.unlock();
+    if (mine) std::rethrow_exception(mine);
+    if (theirs) std::rethrow_exception(theirs);
   }
  private:
   HostPool() {
@@ -393,8 +407,10 @@ class HostPool {
         if (t + 1 < parts_) { fn = fn_; part = t + 1; }
       }
       if (fn) {
-        (*fn)(part);
+        std::exception_ptr ex;
+        try { (*fn)(part); } catch (...) { ex = std::current_exception(); }
         std::lock_guard<std::mutex> g(m_);
+        if (ex && !failed_) failed_ = ex;
         if (--pending_ == 0) done_.notify_all();
       }
     }
@@ -403,6 +419,7 @@ class HostPool {
   std::mutex m_, job_m_;
   std::condition_variable cv_, done_;
   const std::function<void(int)> *fn_ = nullptr;
+  std::exception_ptr failed_;   // first exception of a helper in the running job
   int parts_ = 0, pending_ = 0;
   unsigned long long gen_ = 0;
   bool stop_ = false;

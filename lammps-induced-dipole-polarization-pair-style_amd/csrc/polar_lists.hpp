@@ -514,8 +514,7 @@ static __global__ void k_color_relabel(int n, const int *__restrict__ relabel, c
 // polarizable atoms this handle owns (halo atoms carry their owners' colours and are skipped).  Without `bflag` a class is a
 // colour; with `sub` (a sub-class 0 .. nsub-1 per atom, by original index) class nsub * c + k holds colour c's rows of
 // sub-class k: multi-GPU: 0 = boundary rows ("a peer receives this row's dipole"), 1 = interior rows, so that a phase can
-// send its boundary rows off while the interior rows are still swept; single GPU: the four (half of the box, near / far
-// from the cut) classes of the region pipeline.
+// send its boundary rows off while the interior rows are still swept.
 __device__ __forceinline__ int color_class(int j, const int *__restrict__ color_s, const int *__restrict__ perm, int own_lo, int own_hi,
                                            const int *__restrict__ sub, int nsub) {
   const int c = color_s[j];
@@ -523,22 +522,6 @@ __device__ __forceinline__ int color_class(int j, const int *__restrict__ color_
   const int o = perm[j];
   if (o < own_lo || o >= own_hi) return -1;
   return sub ? nsub * c + sub[o] : c;
-}
-// sub-class of every atom for the region pipeline of the single-GPU sweep (polar_step.hip, solve): the box is cut in two
-// halves along `axis` (fractional coordinate below / above one half, seen from `origin`); 2 * region + (0: within `reach`
-// of one of the two cutting planes -- a row that may see rows of the other half --, 1: farther away)
-static __global__ void k_region_sub(int n, const double4 *__restrict__ pos4, const int *__restrict__ perm, int axis, double lo, double len,
-                                    double reach, int *__restrict__ sub) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double4 p = pos4[i];
-  const double v = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
-  double fr = (v - lo) / len;
-  fr -= floor(fr);
-  const int region = fr < 0.5 ? 0 : 1;
-  const double d0 = fmin(fr, 1.0 - fr), d1 = fabs(fr - 0.5);   // to the plane at 0 (= 1) and to the plane at 1/2
-  const bool near = fmin(d0, d1) * len < reach;
-  sub[perm[i]] = 2 * region + (near ? 0 : 1);
 }
 static __global__ void k_color_cellcount(long long ncell, int nclass, const long long *__restrict__ cell_first, const int *__restrict__ npol,
                                   const int *__restrict__ color_s, int *__restrict__ cnt, const int *__restrict__ perm, int own_lo, int own_hi,

@@ -309,8 +309,7 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
 #else
 #define POLAR_LAB_ARG
 #endif
-  hipStream_t lps = h->lp_stream ? h->lp_stream : h->stream;
-#define FL(D, NT, DT) k_field_lp<EP, D, NT, DT><<<nblk_xcd(nrows, qb / 64), qb, lds, lps>>>(                   \
+#define FL(D, NT, DT) k_field_lp<EP, D, NT, DT><<<nblk_xcd(nrows, qb / 64), qb, lds, h->stream>>>(                   \
       nrows, row0, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                               \
       st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, omega, h->d_lp_pend.p POLAR_LAB_ARG)
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
@@ -531,7 +530,6 @@ void launch_field_lp2(polar_handle *h, int q) {
 }
 #endif
 
-static void sweep_pipelined(polar_handle *h);
 void sweep_once(polar_handle *h, bool ap) {
   const polar_settings &st = h->ph.st;
   const bool gs = st.polar_gs || st.polar_gs_ranked;
@@ -559,7 +557,6 @@ void sweep_once(polar_handle *h, bool ap) {
 #endif
   if (!ap && h->sweep_kernel == 2) {
     if (!gs) { launch_field_lp<EP_JACOBI>(h, own_n(h), h->d_lpdesc.p); return; }
-    if (h->pipe_active && h->part_n <= 1) { sweep_pipelined(h); return; }
     const int ncol = (int)h->color_off.size() - 1;
     const int c0 = h->part_n > 1 ? ncol * h->part_k / h->part_n : 0, c1 = h->part_n > 1 ? ncol * (h->part_k + 1) / h->part_n : ncol;
     for (int c = c0; c < c1; c++)  // (polar_step_sweep_part: a window of the colour phases)
@@ -596,40 +593,6 @@ void sweep_phase(polar_handle *h, int c, int part) {
   const int lo = part == 2 ? m : a, hi = part == 1 ? m : b;
   launch_field_lp<EP_INPLACE>(h, hi - lo, h->d_lpdesc.p + lo);
 }
-// one sub-class of a colour phase (region pipeline), on stream `s`
-static void sweep_sub(polar_handle *h, int c, int sub, hipStream_t s) {
-  const int q = c * h->color_nsub + sub;
-  const int lo = h->color_sub[q], hi = h->color_sub[q + 1];
-  h->lp_stream = s;
-  struct Restore { polar_handle *h; ~Restore() { h->lp_stream = nullptr; } } restore{h};
-  launch_field_lp<EP_INPLACE>(h, hi - lo, h->d_lpdesc.p + lo);
-}
-// The region pipeline of the single-GPU Gauss-Seidel sweep.  A colour phase is a quarter of a sweep: ~50 us at 135k atoms,
-// of which the ramp and the drain of its one launch leave the chip a fifth idle, and phases cannot overlap:
-// their rows depend on each other within the cutoff.  Rows FARTHER than a cutoff from the other half of the box do not: the
-// box is cut in two halves, every phase of a half runs as two launches -- the rows NEAR the cut, then the far rows -- on the
-// half's own stream, and a half's phase c + 1 waits (event) only for the other half's NEAR rows of phase c.  The far rows of
-// one half then fill the chip while the other half's next phase starts: one join per SWEEP (the end-of-sweep decision)
-// instead of one drain per phase.  Same rows, same phases, same dependencies between coupled rows as the plain sweep.
-static void sweep_pipelined(polar_handle *h) {
-  const int ncol = (int)h->color_off.size() - 1;
-  hipStream_t S[2] = {h->stream, h->stream2};
-  for (int c = 0; c < ncol; c++, h->pipe_g++)
-    for (int r = 0; r < 2; r++) {
-      // phase g of a half waits for the other half's near rows of phase g - 1 (its own earlier launches: stream order)
-      if (h->pipe_g > 0) HIPCHECK(hipStreamWaitEvent(S[r], h->ev_near[1 - r][(h->pipe_g - 1) & 3], 0));
-      sweep_sub(h, c, 2 * r, S[r]);
-      HIPCHECK(hipEventRecord(h->ev_near[r][h->pipe_g & 3], S[r]));
-      sweep_sub(h, c, 2 * r + 1, S[r]);
-    }
-  HIPCHECK(hipEventRecord(h->ev_half, S[1]));
-  HIPCHECK(hipStreamWaitEvent(S[0], h->ev_half, 0));   // join: the end-of-sweep decision follows on the main stream
-}
-static void pipeline_release(polar_handle *h) {         // after the main stream's end-of-sweep work: the other half may go on
-  HIPCHECK(hipEventRecord(h->ev_stepdone, h->stream));
-  HIPCHECK(hipStreamWaitEvent(h->stream2, h->ev_stepdone, 0));
-}
-
 template <bool AP, int DAMP>
 void launch_force(polar_handle *h, int eflag, int vglobal, double *vatom, double *fdst) {
   const bool vpair = vglobal || vatom;
@@ -757,20 +720,14 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
     // launches (all sweeps but the last, then the last one, whose sum |dmu|^2 is the one reported)
     const bool lazy = st.fixed_iteration && gs;
     const bool accel = accel_begin(h, ap);   // `polar_accel m`: Anderson mixing between the sweeps
-    // region pipeline (two halves of the box on two streams): when the rows were laid out for it (colouring) and nothing
-    // needs the phases one at a time
-    struct Pipe { polar_handle *h; ~Pipe() { h->pipe_active = false; } } pipe_guard{h};
-    h->pipe_active = !ap && gs && h->sweep_kernel == 2 && h->color_nsub == 4 && h->stream2 && !deterministic(h) && !st.debug;
-    h->pipe_g = 0;
     for (int sw = 0; sw < max_sweeps; sw++) {
       sweep_once(h, ap);
       debug_trace(h, sw, !gs);
-      if (accel && lazy && sw < max_sweeps - 1) { accel_step(h, nullptr); if (h->pipe_active) pipeline_release(h); }   // (no decision to wait for; nothing after the last sweep)
+      if (accel && lazy && sw < max_sweeps - 1) accel_step(h, nullptr);   // (no decision to wait for; nothing after the last sweep)
       if (lazy && sw < max_sweeps - 2) continue;
       const int count = (lazy && sw == max_sweeps - 2) ? max_sweeps - 1 : 1;
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count, det_part(h), det_npart(h));
       if (accel && !lazy) accel_step(h, nullptr);   // (a no-op on the device once the stop rule has fired: the result is G(x_k) of the last sweep)
-      if (h->pipe_active) pipeline_release(h);
       if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
         read_scal(h);
         if (h->h_scal->done) break;

@@ -294,9 +294,20 @@ void PairLJCutCoulLongPolarizationMI355X::build_rccl_plan()
   sflat.push_back(0); rflat.push_back(0); peers.push_back(0); sc.push_back(0); rc_.push_back(0);   // (never empty pointers)
   if (polar_dist_set_halo(dist,h,(int) peers.size() - 1,peers.data(),sc.data(),sflat.data(),rc_.data(),rflat.data()) < 0)
     error->one(FLERR,polar_dist_last_error(dist));
-  // ONE colouring shared by the ranks: they colour in turns, and no two peers may share a turn -- greedy colouring of the peer
-  // graph in rank order, computed identically by every rank from the gathered peer lists.  Boundary dipoles then travel after
-  // every colour phase on the library's communication stream, at most one phase late (polar_dist_set_schedule, lag 1).
+  // Schedule (polar_dist_set_schedule).  Default: every rank colours for itself and ALL halo dipoles travel once per sweep on
+  // the compute stream (lag -1) -- one stream, one communicator, the only form that has run on real RCCL, and by the one-rank
+  // measurements the cheaper one below ~100k own atoms per rank.  POLAR_DIST_LAG=0|1|2 switches to ONE
+  // colouring shared by the ranks -- they colour in turns, no two peers sharing a turn: greedy colouring of the peer graph in
+  // rank order, computed identically by every rank from the gathered peer lists -- with colour c's boundary dipoles travelling
+  // after phase c on the library's communication stream, at most `lag` phases late.  lag >= 1 lets an unpack land while the next
+  // phase reads the halo dipoles: results are then not reproducible run to run, and `deterministic yes` refuses it.
+  int lag = -1;
+  polar_settings pst;
+  check(polar_get_settings(h,&pst));
+  if (const char *e = getenv("POLAR_DIST_LAG")) lag = atoi(e);
+  if (lag < -1 || lag > 2) error->all(FLERR,"Pair style lj/cut/coul/long/polarization rccl_halo: POLAR_DIST_LAG is -1, 0, 1 or 2");
+  if (lag >= 1 && pst.deterministic)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization rccl_halo: deterministic yes needs POLAR_DIST_LAG <= 0");
   std::vector<int> ispeer(np,0), allpeer((size_t) np*np,0), cls(np,0);
   for (size_t k = 0; k + 1 < peers.size(); k++) if (peers[k] != me) ispeer[peers[k]] = 1;
   MPI_Allgather(ispeer.data(),np,MPI_INT,allpeer.data(),np,MPI_INT,world);
@@ -311,7 +322,7 @@ void PairLJCutCoulLongPolarizationMI355X::build_rccl_plan()
     cls[r] = c;
     if (c + 1 > ncls) ncls = c + 1;
   }
-  if (polar_dist_set_schedule(dist,1,cls[me],ncls) < 0) error->one(FLERR,polar_dist_last_error(dist));
+  if (polar_dist_set_schedule(dist,lag,cls[me],lag >= 0 ? ncls : 0) < 0) error->one(FLERR,polar_dist_last_error(dist));
 }
 
 void PairLJCutCoulLongPolarizationMI355X::exchange_dipoles()
