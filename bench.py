@@ -314,40 +314,207 @@ def visible_gpus():
     return 0
 
 
-def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) of this same file under
-    torch.distributed.run as CHILD processes, relay rank 0's one JSON line, return the launcher's exit code.  Never prints an
-    N = 1 line for a --gpus N request: if N ranks cannot be had the exit code is non-zero and stderr says why in one line.
-    POLAR_DIST_BACKEND=gloo (rehearsal): the ranks share whatever GPUs exist, exchanges staged through the host."""
-    import socket
-    import subprocess
+# ---- the launcher: never touches the GPU; children are FRESH processes under a wall-clock budget -------------------------------
+# Why it exists: the first multi-GPU run on hardware must not be able to lose its numbers.  A child prints its
+# headline line (flushed) as soon as the timed steps are over and a superseding line once its extra legs are in; the launcher keeps
+# the LAST COMPLETE line, kills a child that outlives its budget (the whole process group: torchrun and its ranks) and still
+# prints what it has, marked "extras": "timed out".  Other schedules of the N-rank solve run as SEPARATE child jobs, so a hang in
+# one of them costs one sub-object of the record, not the headline.
+BUDGET_HEADLINE_S = float(os.environ.get("POLAR_BENCH_BUDGET", "900"))       # one child job: workload build + warmup + steps + extras
+BUDGET_SCHEDULE_S = float(os.environ.get("POLAR_BENCH_BUDGET_SCHEDULE", "300"))  # one alternative-schedule job (no extras)
+EPOL_TOL = 1e-7   # |E_pol per cell - the one-GPU value| / |.|: beyond this the N-rank line is a wrong result and the exit code says so
 
+# name -> (environment of the ranks, extra pair_style keywords): how `bench.py --gpus N` is asked to exchange the halo dipoles.
+# "legacy" is the headline: one stream, one communicator, one exchange of all halo dipoles + one all-reduce per sweep -- the form
+# closest to what has run on real RCCL (one rank exchanging with itself).
+SCHEDULES = {
+    "legacy": ({"POLAR_DIST_LAG": "-1"}, []),
+    "lag1": ({"POLAR_DIST_LAG": "1", "POLAR_DIST_SPLIT_COMM": "1"}, []),
+    "legacy_accel4": ({"POLAR_DIST_LAG": "-1"}, ["polar_accel", "4"]),
+}
+
+
+def is_result_line(ln):
+    return ln.startswith("{") and '"metric"' in ln and ln.rstrip().endswith("}")
+
+
+def run_child(cmd, env, budget_s, log=None):
+    """Run one child job; returns (last complete result line or None, return code or None when killed, timed_out).
+    The child gets its own session so that the whole tree (torchrun + ranks) can be killed; it is never re-executed."""
+    import signal
+    import subprocess
+    import threading
+
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1, start_new_session=True)
+    last = [None]
+
+    def pump():
+        for ln in proc.stdout:
+            ln = ln.rstrip("\n")
+            if is_result_line(ln):
+                try:
+                    json.loads(ln)
+                    last[0] = ln
+                    continue
+                except ValueError:
+                    pass
+            print(ln, file=log or sys.stderr, flush=True)
+
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    timed_out = False
+    try:
+        rc = proc.wait(timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        timed_out, rc = True, None
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+    t.join(timeout=5)
+    return last[0], rc, timed_out
+
+
+def schedule_summary(line):
+    """What the merged record keeps of one schedule's job."""
+    c = line.get("config", {})
+    keep = ("sweeps", "iterations", "eng_pol_per_cell", "eng_pol_rel_dev_from_one_gpu", "schedule", "rccl_ranks", "calibration", "sweep_loop")
+    out = {"ms_per_step": line.get("ms_per_step"), "value": line.get("value")}
+    out.update({k: c.get(k) for k in keep if k in c})
+    return out
+
+
+def rank_command(n, port, argv):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch(n, argv, probe=visible_gpus, make_cmd=None, schedules=None, out=None):
+    """`python bench.py [--gpus N]` without a launcher around it.  N = 1: ONE child (`--direct`) under a budget.  N > 1: N ranks
+    (one per GPU) under torch.distributed.run as a CHILD job for the headline schedule, then one more child job per alternative
+    schedule, merged into config.schedules.  Prints exactly ONE JSON line (the last complete line of the headline job, merged)
+    and returns the exit code: non-zero when the headline job failed, printed no line, or its E_pol check is off.
+    Never prints an N = 1 line for a --gpus N request.  POLAR_DIST_BACKEND=gloo (rehearsal): the ranks share whatever GPUs exist.
+    ``probe``, ``make_cmd``: injectable for the CPU tests (fake children)."""
+    out = out or sys.stdout
     backend = os.environ.get("POLAR_DIST_BACKEND", "nccl")
-    have = visible_gpus()
+    have = probe()
     if have < 1:
         print("bench.py: no MI355X visible: the HIP path has no CPU fallback", file=sys.stderr)
         return 2
-    if backend == "nccl" and have < n:
+    if n > 1 and backend == "nccl" and have < n:
         print(f"bench.py: --gpus {n} needs {n} GPUs, this node shows {have} (RCCL takes one rank per device; "
               "POLAR_DIST_BACKEND=gloo rehearses the ranks on shared devices)", file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-    for ln in r.stdout.splitlines():
-        if ln not in lines:
-            print(ln, file=sys.stderr)
-    if r.returncode != 0 or not lines:
-        print(f"bench.py: the {n}-rank run failed (exit code {r.returncode}" + ("" if lines else ", no result line") + ")", file=sys.stderr)
-        return r.returncode or 3
-    print(lines[-1])
-    return 0
+    env["POLAR_BENCH_LAUNCHER"] = "1"                   # the child may print its headline early and a superseding line later
+    dist_mode = n > 1 or bool(os.environ.get("POLAR_FORCE_DIST"))   # (the variable: one RCCL rank rehearses the N-rank path on a 1-GPU box)
+    if make_cmd is None:
+        make_cmd = (lambda name, extra_argv: rank_command(n, free_port(), list(argv) + list(extra_argv))) if dist_mode \
+            else (lambda name, extra_argv: [sys.executable, os.path.abspath(__file__), "--direct"] + list(argv) + list(extra_argv))
+    names = list(schedules if schedules is not None else (SCHEDULES if dist_mode else ["single"]))
+    head = names[0]
+    t0 = time.time()
+    # (the ranks themselves turn --schedule NAME into the driver's settings and the extra keywords: SCHEDULES)
+    ln, rc, timed_out = run_child(make_cmd(head, ["--schedule", head] if dist_mode else []), env, BUDGET_HEADLINE_S)
+    if ln is None:
+        why = "timed out" if timed_out else f"exit code {rc}"
+        print(f"bench.py: the {'headline' if dist_mode else 'bench'} job ({n} rank(s)) gave no result line ({why})", file=sys.stderr)
+        return (rc or 3) if not timed_out else 3
+    line = json.loads(ln)
+    if timed_out:
+        line["extras"] = "timed out"
+    elif rc != 0:
+        line["extras"] = f"child exit code {rc}"
+    exit_code = 0 if (rc == 0 or timed_out) else rc
+    if dist_mode:
+        line.setdefault("config", {})["schedules"] = {head: schedule_summary(line)}
+        line["config"]["headline_schedule"] = head
+        for name in names[1:]:
+            extra = ["--schedule", name, "--no-extras"]
+            try:
+                sl, src, sto = run_child(make_cmd(name, extra), env, BUDGET_SCHEDULE_S)
+                if sl is None:
+                    line["config"]["schedules"][name] = {"error": "timed out" if sto else f"no result line (exit code {src})"}
+                else:
+                    sub = schedule_summary(json.loads(sl))
+                    if sto:
+                        sub["note"] = "timed out after its line"
+                    elif src != 0:
+                        sub["exit_code"] = src
+                    line["config"]["schedules"][name] = sub
+            except Exception as e:  # noqa: BLE001 -- a schedule job must never cost the headline
+                line["config"]["schedules"][name] = {"error": repr(e)}
+        dev = line["config"].get("eng_pol_rel_dev_from_one_gpu")
+        if dev is not None and not (dev <= EPOL_TOL):
+            print(f"bench.py: E_pol per cell is {dev:.2e} off the one-GPU value (tolerance {EPOL_TOL:.0e}): wrong result", file=sys.stderr)
+            exit_code = exit_code or 4
+    line["launcher_wall_s"] = time.time() - t0
+    print(json.dumps(line), file=out, flush=True)
+    return exit_code
+
+
+class Emitter:
+    """Exactly ONE result line from this process tree, whatever happens after the timed steps.
+    headline(line): the measured record exists from here on.  Under this file's own launcher (POLAR_BENCH_LAUNCHER, which relays
+    the LAST complete line) it is printed at once and superseded later; under a foreign launcher (the driver's torchrun) it is
+    held back.  final(line) prints the complete record.  If the extra legs outlive their budget -- a hang in an RCCL call, a
+    stuck leg -- a watchdog thread prints the stored line marked "extras": "timed out in <leg>" and ends the process with exit
+    code 0 (every rank arms the same watchdog, so the job ends).  Ranks other than 0 never print."""
+
+    def __init__(self, is_rank0, budget_s):
+        import threading
+
+        self.rank0, self.budget = is_rank0, budget_s
+        self.early = bool(os.environ.get("POLAR_BENCH_LAUNCHER"))
+        self.lock = threading.Lock()
+        self.line, self.done, self.stage, self.timer = None, False, "extras", None
+        self._threading = threading
+
+    def headline(self, line):
+        with self.lock:
+            self.line = json.loads(json.dumps(line)) if line is not None else None   # (a private copy: the legs go on editing theirs)
+            if self.rank0 and self.early and line is not None:
+                print(json.dumps(line), flush=True)
+        self.timer = self._threading.Timer(self.budget, self._expire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def final(self, line):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.timer is not None:
+                self.timer.cancel()
+            if self.rank0 and line is not None:
+                print(json.dumps(line), flush=True)
+
+    def _expire(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank0 and self.line is not None:
+                self.line["extras"] = f"timed out in {self.stage} after {self.budget:.0f} s"
+                print(json.dumps(self.line), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
 
 
 def main():
@@ -361,13 +528,18 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip the configs[1] / 529k / MD-shaped legs")
     ap.add_argument("--synth", type=int, default=0, help="use the SURVEY 8(d) synthetic generator with this many atoms instead of the replicated cell")
     ap.add_argument("--extra", nargs="*", default=[], help="extra pair_style keywords (experiments)")
+    ap.add_argument("--direct", action="store_true", help="N = 1: run in THIS process (profilers, scripts); default: a budgeted child of the launcher")
+    ap.add_argument("--schedule", default="", help=f"N > 1: how the ranks exchange the halo dipoles, one of {sorted(SCHEDULES)} (default: legacy)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("POLAR_FORCE_LAUNCH")):
-        # `python bench.py --gpus N` by itself: become the launcher of N ranks.  Nothing here has touched the GPU (no torch,
-        # no HIP call): the ranks are fresh children, never a re-exec of an initialised process.
-        raise SystemExit(launch_ranks(args.gpus))
+    if args.schedule and args.schedule not in SCHEDULES:
+        raise SystemExit(f"bench.py: --schedule is one of {sorted(SCHEDULES)}")
+    if "WORLD_SIZE" not in os.environ and not args.direct:
+        # `python bench.py [--gpus N]` by itself: become the launcher.  Nothing here has touched the GPU (no torch, no HIP
+        # call): the workers are fresh children under a budget, never a re-exec of an initialised process.
+        argv = [a for a in sys.argv[1:]]
+        raise SystemExit(launch(args.gpus, argv))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -401,18 +573,6 @@ def main():
     p = pkg.pair_from_system(s, device=0)
     out, dt, ms_solve, launches = timed_steps(torch, p, args.steps, args.warmup)
     p.close()
-    # The same sweeps with the chip to themselves: in the timed region above a3 (LJ + Ewald-real) runs beside them on its
-    # low-priority side stream -- it shortens the step and stretches the sweeps, whose launch time therefore says less about
-    # the kernel the faster the other kernels get.  A few extra steps with a3 kept on the main stream (POLAR_NO_OVERLAP):
-    # reported as roofline.alone, never as the headline.
-    os.environ["POLAR_NO_OVERLAP"] = "1"
-    try:
-        p2 = pkg.pair_from_system(s, device=0)
-        out2, dt2, ms_solve2, launches2 = timed_steps(torch, p2, 5, 2)
-        p2.close()
-    finally:
-        os.environ.pop("POLAR_NO_OVERLAP", None)
-
     n = s.nlocal
     config = {"workload": workload, "natoms": n, "sweeps": out["sweeps"], "iterations": out["iterations"], "colors": out["ncolors"],
               "dd_pairs": out["dd_pairs"], "ms_per_dipole_iteration": (ms_solve / args.steps) / max(out["sweeps"], 1),
@@ -425,27 +585,57 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": config,
         "roofline": roofline(s, out, ms_solve, launches, args.steps, pkg),
     }
-    alone = roofline(s, out2, ms_solve2, launches2, 5, pkg)
-    line["roofline"]["alone"] = {"what": "the same launches with a3 kept off its side stream (5 extra steps): the sweep kernel by itself",
-                                 "ms_per_launch": alone["ms_per_launch"], "achieved": alone["achieved"], "frac": alone["frac"],
-                                 "ms_per_step": 1e3 * dt2 / 5}
+    if not args.no_cpu_baseline:   # pure host work (the oracle on one core, ~15 s): part of the headline record
+        try:
+            line["cpu_baseline"] = cpu_baseline(wl, cfg["solver"])
+        except Exception as e:  # noqa: BLE001
+            line["cpu_baseline"] = {"error": repr(e)}
+    # ---- the measured record exists from here on: no later leg can lose it ----
+    em = Emitter(True, float(os.environ.get("POLAR_BENCH_EXTRAS_BUDGET", "700")))
+    em.headline(line)
+
+    def leg(where, name, fn):
+        """One extra leg: an exception (or a watchdog expiry) inside it costs its own sub-object, nothing else."""
+        em.stage = name
+        t0 = time.time()
+        try:
+            where[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            where[name] = {"error": repr(e), "after_s": time.time() - t0}
+
+    def alone():
+        # The same sweeps with the chip to themselves: in the timed region a3 (LJ + Ewald-real) runs beside them on its
+        # low-priority side stream -- it shortens the step and stretches the sweeps, whose launch time therefore says less
+        # about the kernel the faster the other kernels get.  A few extra steps with a3 kept on the main stream
+        # (POLAR_NO_OVERLAP): reported as roofline.alone, never as the headline.
+        os.environ["POLAR_NO_OVERLAP"] = "1"
+        try:
+            p2 = pkg.pair_from_system(s, device=0)
+            out2, dt2, ms_solve2, launches2 = timed_steps(torch, p2, 5, 2)
+            p2.close()
+        finally:
+            os.environ.pop("POLAR_NO_OVERLAP", None)
+        r = roofline(s, out2, ms_solve2, launches2, 5, pkg)
+        return {"what": "the same launches with a3 kept off its side stream (5 extra steps): the sweep kernel by itself",
+                "ms_per_launch": r["ms_per_launch"], "achieved": r["achieved"], "frac": r["frac"], "ms_per_step": 1e3 * dt2 / 5}
+
+    leg(line["roofline"], "alone", alone)
     if not args.no_extras and not args.synth and not args.reps:
-        config["md_leg"] = md_leg(pkg, s)
-        config["md_leg_device_neigh"] = md_leg(pkg, s, device_neigh=True)
-        config["md_leg_use_previous"] = md_leg(pkg, s, device_neigh=True, use_previous=True)
-        config["md_leg_ballistic"] = md_leg(pkg, s, steps=200, device_neigh=True, motion="ballistic", temperature=300.0)
-        config["config0_1349_exact"] = config0_exact(torch, pkg, wl)
-        config["exact_10792_replica"] = exact_replica(torch, pkg, wl)
-        config["config2_synth_131k"] = synth_config(torch, pkg, wl, 131072, steps=min(args.steps, 5), warmup=1)
-        config["config1_36k"] = sub_config(torch, pkg, wl, 1, steps=max(args.steps, 10), warmup=args.warmup)
-        config["config4_529k_one_gpu"] = sub_config(torch, pkg, wl, 4, steps=min(args.steps, 5), warmup=1, device_neigh=True)
+        leg(config, "md_leg", lambda: md_leg(pkg, s))
+        leg(config, "md_leg_device_neigh", lambda: md_leg(pkg, s, device_neigh=True))
+        leg(config, "md_leg_use_previous", lambda: md_leg(pkg, s, device_neigh=True, use_previous=True))
+        leg(config, "md_leg_ballistic", lambda: md_leg(pkg, s, steps=200, device_neigh=True, motion="ballistic", temperature=300.0))
+        leg(config, "config0_1349_exact", lambda: config0_exact(torch, pkg, wl))
+        leg(config, "exact_10792_replica", lambda: exact_replica(torch, pkg, wl))
+        leg(config, "config2_synth_131k", lambda: synth_config(torch, pkg, wl, 131072, steps=min(args.steps, 5), warmup=1))
+        leg(config, "config1_36k", lambda: sub_config(torch, pkg, wl, 1, steps=max(args.steps, 10), warmup=args.warmup))
+        leg(config, "config1_36k_deterministic_no", lambda: sub_config(torch, pkg, wl, 1, steps=max(args.steps, 10), warmup=args.warmup, extra=("deterministic", "no")))
+        leg(config, "config4_529k_one_gpu", lambda: sub_config(torch, pkg, wl, 4, steps=min(args.steps, 5), warmup=1, device_neigh=True))
         # opt-in extension keywords on the headline box (NOT the headline: the reference has neither)
-        config["config2_polar_sor_1p15"] = sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("polar_sor", "1.15"))
-        config["config2_polar_accel_4"] = sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("polar_accel", "4"))
-        config["config2_deterministic"] = sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("deterministic", "yes"))
-    if not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(wl, cfg["solver"])
-    print(json.dumps(line))
+        leg(config, "config2_polar_sor_1p15", lambda: sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("polar_sor", "1.15")))
+        leg(config, "config2_polar_accel_4", lambda: sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("polar_accel", "4")))
+        leg(config, "config2_deterministic", lambda: sub_config(torch, pkg, wl, 2, steps=max(args.steps, 10), warmup=args.warmup, extra=("deterministic", "yes")))
+    em.final(line)
 
 
 if __name__ == "__main__":

@@ -349,6 +349,12 @@ int polar_step_sweep_end_host(polar_handle *h, double global_change);
  *                          A rank that fails before the first exchange (bad input, allocation) makes EVERY rank return an
  *                          error: the begin status is max-reduced first.
  *   polar_dist_exchange    one dipole exchange by itself (tests)
+ *   polar_dist_profile     enable != 0: the following polar_dist_step calls put timed events between the parts of their sweep
+ *                          loop (a few us each: not for a timed region); polar_dist_profile_get = the last such step's device
+ *                          time by part, in ms[POLAR_DIST_PROF_PARTS]: [0] other (waiting for an exchange issued on the
+ *                          communication stream, host looks at the loop state), [1] sweep kernels, [2] stop rule (fold,
+ *                          all-reduce, end-of-sweep logic), [3] exchanges on the compute stream (pack, send / receive, unpack),
+ *                          [4] polar_accel's mixing kernels -- the figures a scaling model of the schedule is calibrated on
  *   polar_dist_comm_count  ncclCommCount of the communicator (the number of ranks RCCL itself sees) */
 #define POLAR_DIST_ID_BYTES 128
 typedef struct polar_dist polar_dist;
@@ -367,6 +373,9 @@ int polar_dist_exchange(polar_dist *d, polar_handle *h);
 int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_result *out);
 int polar_dist_local_result(const polar_dist *d, polar_result *out);
 int polar_dist_counters(const polar_dist *d, int *exchanges, int *allreduces);
+#define POLAR_DIST_PROF_PARTS 5
+int polar_dist_profile(polar_dist *d, int enable);
+int polar_dist_profile_get(const polar_dist *d, double *ms_by_part, int *intervals);
 
 #ifdef __cplusplus
 }

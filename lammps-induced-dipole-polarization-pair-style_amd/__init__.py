@@ -175,6 +175,8 @@ EXPORTS = {
     "polar_dist_exchange": (C.c_int, [C.c_void_p, C.c_void_p]),
     "polar_dist_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Result)]),
     "polar_dist_counters": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "polar_dist_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "polar_dist_profile_get": (C.c_int, [C.c_void_p, _dp, _ip]),
 }
 
 
@@ -552,6 +554,22 @@ class PolarDist:
 
     def comm_count(self):
         return self._ck(self.L.polar_dist_comm_count(self.d))
+
+    PROFILE_PARTS = ("other", "sweep_kernels", "stop_rule", "exchange", "accel")
+
+    def profile(self, enable=True):
+        """Timed events between the parts of the sweep loop of the following steps (a few us each: not inside a timed region)."""
+        self._ck(self.L.polar_dist_profile(self.d, 1 if enable else 0))
+
+    def profile_get(self):
+        """Device time of the last profiled step's sweep loop by part, in ms: {other (waits for exchanges on the communication
+        stream, host looks at the loop state), sweep_kernels, stop_rule, exchange (on the compute stream), accel}, + intervals."""
+        ms = (C.c_double * len(self.PROFILE_PARTS))()
+        n = C.c_int()
+        self._ck(self.L.polar_dist_profile_get(self.d, ms, C.byref(n)))
+        out = {k: float(v) for k, v in zip(self.PROFILE_PARTS, ms)}
+        out["intervals"] = n.value
+        return out
 
     def exchange(self, pair):
         self._ck(self.L.polar_dist_exchange(self.d, pair.h))

@@ -117,9 +117,32 @@ struct polar_dist {
   long long ng = 0, gfirst = 0;
   polar_result local{};                         // this rank's own share of the last step (energies, virial, pairs)
   double host_us_rccl = 0.0, host_us_loop = 0.0; // host time of the last step: inside RCCL calls / issuing the whole sweep loop (POLAR_DEBUG prints them)
+  // polar_dist_profile: timed events between the parts of the sweep loop; the interval that ENDS at mark k belongs to part prof_kind[k]
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kind; size_t prof_n = 0;
+  double prof_ms[POLAR_DIST_PROF_PARTS] = {0, 0, 0, 0, 0}; int prof_intervals = 0;
 };
 
 namespace {
+enum { PK_OTHER = 0, PK_SWEEP, PK_REDUCE, PK_XCHG, PK_ACCEL };
+inline void prof_mark(polar_dist *d, hipStream_t s, int kind) {
+  if (!d->prof_on) return;
+  if (d->prof_n == d->prof_ev.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); d->prof_ev.push_back(e); d->prof_kind.push_back(0); }
+  d->prof_kind[d->prof_n] = kind;
+  HIPCHECK(hipEventRecord(d->prof_ev[d->prof_n++], s));
+}
+// after the step's last synchronisation: the device time of the sweep loop by part
+inline void prof_fold(polar_dist *d) {
+  if (!d->prof_on) return;
+  for (double &v : d->prof_ms) v = 0.0;
+  d->prof_intervals = 0;
+  for (size_t k = 1; k < d->prof_n; k++) {
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, d->prof_ev[k - 1], d->prof_ev[k]));
+    d->prof_ms[d->prof_kind[k]] += ms;
+    d->prof_intervals++;
+  }
+}
 template <typename F>
 int dist_guarded(polar_dist *d, F &&fn) {
   if (!d) return POLAR_ERR_STATE;
@@ -307,6 +330,7 @@ int polar_dist_destroy(polar_dist *d) {
   if (d->comm) { try { (void)rccl().CommDestroy(d->comm); } catch (const std::exception &) {} }
   for (auto &e : d->ev_phase) if (e) (void)hipEventDestroy(e);
   for (auto &e : d->ev_xdone) if (e) (void)hipEventDestroy(e);
+  for (auto &e : d->prof_ev) if (e) (void)hipEventDestroy(e);
   if (d->xs) (void)hipStreamDestroy(d->xs);
   d->d_send_idx.release(); d->d_recv_idx.release(); d->d_send.release(); d->d_recv.release(); d->d_red.release();
   d->d_csend_idx.release(); d->d_crecv_idx.release(); d->d_csend.release(); d->d_crecv.release(); d->d_gowner.release(); d->d_gshift.release();
@@ -439,8 +463,8 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
       try {
         if (!(st.dd_cutoff > 0.0)) throw InputError("polar_dist_step needs list mode (dd_cutoff > 0): exact mode runs as replicas only");
         // (everything the sweeps could refuse is refused HERE, where the ranks can still agree on it)
-        if (st.polar_accel > 0 && !(d->my_class >= 0 && d->lag >= 0 && gs && h->sweep_kernel == 2))
-          throw InputError("polar_accel across ranks needs the shared colouring (polar_dist_set_schedule with classes and lag >= 0) and polar_gs / polar_gs_ranked");
+        if (st.polar_accel > 0 && !(gs && h->sweep_kernel == 2 && !st.zodid))
+          throw InputError("polar_accel across ranks needs the Gauss-Seidel sweep of list mode (polar_gs / polar_gs_ranked)");
         if (st.polar_accel > 0 && deterministic(h)) throw InputError("polar_accel and `deterministic yes` exclude each other");
         step_begin_lists(h, eflag, vflag);
       } catch (const InputError &e) { brc = POLAR_ERR_INPUT; berr = e.what();
@@ -465,6 +489,8 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
       //      exchanges): the communicator is aborted so that they see an error instead of waiting.
       d->host_us_rccl = d->host_us_loop = 0.0;
       const auto t_loop = std::chrono::steady_clock::now();
+      d->prof_n = 0;
+      prof_mark(d, s, PK_OTHER);
       try {
       if (!st.zodid && phased) {
         const int nc = d->plan_nc, lag = deterministic(h) ? 0 : d->lag;
@@ -484,23 +510,30 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
         for (int sw = 0; sw < max_sweeps; sw++) {
           for (int c = 0; c < nc; c++, g++) {
             if (g - 1 - lag >= 0) HIPCHECK(hipStreamWaitEvent(s, d->ev_xdone[(g - 1 - lag) % kRing], 0));
+            prof_mark(d, s, PK_OTHER);   // (stamped once the wait is over: what ends here is the exposed part of an exchange)
             const bool mine = c < (int)h->color_off.size() - 1;   // (a rank may hold no row of the last colours)
             if (mine) sweep_phase(h, c, split ? 1 : 0);
             HIPCHECK(hipEventRecord(d->ev_phase[g % kRing], s));
             if (mine && split) sweep_phase(h, c, 2);
+            prof_mark(d, s, PK_SWEEP);
             HIPCHECK(hipStreamWaitEvent(d->xs, d->ev_phase[g % kRing], 0));
             dist_exchange_color(d, h, c, d->xs);
             HIPCHECK(hipEventRecord(d->ev_xdone[g % kRing], d->xs));
           }
           if (accel && (!lazy || sw < max_sweeps - 1)) {
             if (g > 0) HIPCHECK(hipStreamWaitEvent(s, d->ev_xdone[(g - 1) % kRing], 0));   // no late unpack may land on the mixed dipoles
+            prof_mark(d, s, PK_OTHER);
             accel_export(h, ared + 1);
+            prof_mark(d, s, PK_ACCEL);
             if (!lazy) k_fold_change<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, ared, nullptr, 0);
             RCCLCHECK(R.AllReduce(ared, ared, 1 + 2 * POLAR_ACCEL_MAXM, ncclDouble, ncclSum, d->comm_red, s));
             d->allreduces++;
             if (!lazy) k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), 0, st.iterations_max, st.polar_precision, 0, ared, 1, nullptr, 0);
+            prof_mark(d, s, PK_REDUCE);
             accel_step(h, ared + 1);
+            prof_mark(d, s, PK_ACCEL);
             dist_exchange(d, h);
+            prof_mark(d, s, PK_XCHG);
           } else if (!st.fixed_iteration) {
             const double *gc = d->d_red.p + 1;   // +inf: "not converged yet"
             if ((sw % d->reduce_every) == d->reduce_every - 1 || sw >= st.iterations_max) {
@@ -511,6 +544,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
             }
             k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
                                                   0, gc, 1, gc == d->d_red.p ? nullptr : det_part(h), gc == d->d_red.p ? 0 : det_npart(h));
+            prof_mark(d, s, PK_REDUCE);
           }
           if (lazy) {
             if (sw == max_sweeps - 2 || sw == max_sweeps - 1 || max_sweeps == 1)
@@ -523,13 +557,34 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
           }
         }
         if (g > 0) HIPCHECK(hipStreamWaitEvent(s, d->ev_xdone[(g - 1) % kRing], 0));   // every halo dipole is its owner's final one
+        prof_mark(d, s, PK_OTHER);
       } else if (!st.zodid) {
         const bool lazy = st.fixed_iteration && gs;
-        if (st.polar_accel > 0) throw InputError("polar_accel across ranks needs the shared colouring (polar_dist_set_schedule with classes and lag >= 0)");
+        // `polar_accel m` with one exchange per sweep: the same mixing as above on the map "one sweep of every rank against the
+        // halo dipoles of the previous one" (block-Jacobi across the ranks) -- everything on the compute stream, one all-reduce
+        // (1 + 16 doubles) and one exchange of all halo rows per sweep
+        const bool accel = gs && accel_begin(h, false);
+        double *ared = d->d_red.p + 64;   // [0] sum (dmu)^2, [1 .. 16] the dot products
         for (int sw = 0; sw < max_sweeps; sw++) {
           bool packed = false;
           sweep_once(h, false);
-          if (!st.fixed_iteration) {
+          prof_mark(d, s, PK_SWEEP);
+          if (accel) {
+            if (!lazy || sw < max_sweeps - 1) {
+              accel_export(h, ared + 1);
+              prof_mark(d, s, PK_ACCEL);
+              if (!lazy) k_fold_change<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, ared, nullptr, 0);
+              RCCLCHECK(R.AllReduce(ared, ared, 1 + 2 * POLAR_ACCEL_MAXM, ncclDouble, ncclSum, d->comm_red, s));
+              d->allreduces++;
+              if (!lazy) k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), 0, st.iterations_max, st.polar_precision, 0, ared, 1, nullptr, 0);
+              prof_mark(d, s, PK_REDUCE);
+              accel_step(h, ared + 1);
+              prof_mark(d, s, PK_ACCEL);
+            }
+            if (lazy && (sw == max_sweeps - 2 || sw == max_sweeps - 1 || max_sweeps == 1))
+              k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
+                                                    0, nullptr, (sw == max_sweeps - 2) ? max_sweeps - 1 : 1, det_part(h), det_npart(h));
+          } else if (!st.fixed_iteration) {
             // the stop rule (PS.cpp:1194-1210) needs the sum over all ranks: one all-reduced double every `reduce_every` sweeps;
             // in between the end-of-sweep logic is told "not converged yet" (+inf)
             const double *gc = d->d_red.p + 1;
@@ -559,10 +614,13 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
             k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
                                                   gs ? 0 : 1, nullptr, 1, det_part(h), det_npart(h));
           }
+          if (!accel) prof_mark(d, s, PK_REDUCE);
           dist_exchange(d, h, packed);
+          prof_mark(d, s, PK_XCHG);
           if (!st.fixed_iteration && (sw % d->check_every) == d->check_every - 1) {
             read_scal(h);  // identical on every rank: same all-reduced sum (sweeps past the end are no-ops on the device)
             if (h->h_scal->done) break;
+            prof_mark(d, s, PK_OTHER);
           }
         }
       }
@@ -579,6 +637,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
       if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] dist step (rank %d): sweep loop on the host %.0f us (of it inside RCCL calls %.0f us, state reads included), %d + %d exchanges, %d all-reduces\n",
                                          d->rank, d->host_us_loop, d->host_us_rccl, d->exchanges, d->phase_exchanges, d->allreduces);
       rc = polar_step_finish(h, out);
+      prof_fold(d);
       d->local = *out;
       // a rank whose rows outgrew their pitch reports POLAR_RETRY_STEP: the flag is max-reduced so that all ranks repeat
       // together; the same call sums energies, virial and pair counts over the ranks
@@ -608,6 +667,17 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
 int polar_dist_local_result(const polar_dist *d, polar_result *out) {
   if (!d || !out) return POLAR_ERR_STATE;
   *out = d->local;
+  return POLAR_OK;
+}
+int polar_dist_profile(polar_dist *d, int enable) {
+  if (!d) return POLAR_ERR_STATE;
+  d->prof_on = enable != 0;
+  return POLAR_OK;
+}
+int polar_dist_profile_get(const polar_dist *d, double *ms_by_part, int *intervals) {
+  if (!d || !ms_by_part) return POLAR_ERR_STATE;
+  for (int k = 0; k < POLAR_DIST_PROF_PARTS; k++) ms_by_part[k] = d->prof_ms[k];
+  if (intervals) *intervals = d->prof_intervals;
   return POLAR_OK;
 }
 int polar_dist_counters(const polar_dist *d, int *exchanges, int *allreduces) {

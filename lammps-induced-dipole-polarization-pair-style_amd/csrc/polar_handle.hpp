@@ -68,7 +68,10 @@ struct DBuf {
     // fill every new buffer with 0x7F bytes (ints 2139062143, doubles 1.4e306) so that a read-before-write shows in the FIRST
     // call of a process instead of the ninetieth (the abort of round 4)
     static const bool poison = getenv("POLAR_POISON") && atoi(getenv("POLAR_POISON")) != 0;
-    if (poison) HIPCHECK(hipMemset(p, 0x7F, want * sizeof(T)));
+    if (poison) {   // (the fill runs on the null stream, which the library's non-blocking streams do not wait for: finish it here)
+      HIPCHECK(hipMemset(p, 0x7F, want * sizeof(T)));
+      HIPCHECK(hipDeviceSynchronize());
+    }
   }
   void release() {
     if (p) (void)hipFree(p);

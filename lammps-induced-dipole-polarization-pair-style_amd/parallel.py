@@ -531,17 +531,317 @@ class HostStagedDist:
 
 
 # --------------------------------------------------------------------------------------------
+# DESIGN section 6's projection of the N-rank step, by (ranks, schedule): sweeps from the emulation on mock ranks, sweep-kernel
+# time per sweep from one shard stepped alone, exposed exchange + all-reduce per sweep from the one-rank RCCL runs (+ ~13 us
+# of link assumed), non-sweep time of a rank's step.  The first hardware run is compared with these (config.calibration.model).
+MODEL = {
+    (2, "legacy"): dict(ms_per_step=12.5, sweeps=38, us_sweep_kernels_per_sweep=232, us_exchange_and_stop_rule_per_sweep=36, ms_non_sweep=2.3),
+    (2, "lag1"): dict(ms_per_step=12.1, sweeps=35, us_sweep_kernels_per_sweep=232, us_exchange_and_stop_rule_per_sweep=48, ms_non_sweep=2.3),
+    (4, "legacy"): dict(ms_per_step=7.8, sweeps=38, us_sweep_kernels_per_sweep=129, us_exchange_and_stop_rule_per_sweep=36, ms_non_sweep=1.5),
+    (8, "legacy"): dict(ms_per_step=7.2, sweeps=38, us_sweep_kernels_per_sweep=117, us_exchange_and_stop_rule_per_sweep=36, ms_non_sweep=1.4),
+    (8, "lag1"): dict(ms_per_step=8.1, sweeps=34, us_sweep_kernels_per_sweep=117, us_exchange_and_stop_rule_per_sweep=80, ms_non_sweep=1.4),
+}
+
+
+class RankJob:
+    """One rank of `bench.py --gpus N`: the shard of the box this rank owns, and -- per schedule -- a handle, the library's RCCL
+    driver (or, for the rehearsal backends, the Python sweep loop) and the measurements."""
+
+    def __init__(self, args, rank, world, local_rank, torch, dist, backend_name):
+        self.args, self.rank, self.world, self.local_rank = args, rank, world, local_rank
+        self.torch, self.dist, self.backend_name = torch, dist, backend_name
+        self.pkg = importlib.import_module(__package__)
+        self.wl = importlib.import_module(__package__ + ".workload")
+        import bench as B  # repo root is on sys.path (bench.py put it there)
+
+        self.B = B
+        self.p = self.be = self.driver = None
+        self.driver_fallback = None
+
+    # -- the box and this rank's share of it (once) --------------------------------------------------------------------------
+    def build_shard(self, keywords):
+        args, world, rank, wl, B = self.args, self.world, self.rank, self.wl, self.B
+        k = args.config or (4 if world >= 8 else (3 if world > 1 else 2))
+        self.cfg = cfg = dict(B.CONFIGS[k])
+        if args.reps:
+            cfg["reps"] = tuple(args.reps)
+        self.reps = cfg["reps"]
+        sg = B.build_workload(wl, self.reps, list(args.extra) + list(keywords), build_list=False, solver=cfg["solver"])   # atoms + ghosts, no host list
+        self.n_total = sg.nlocal
+        if os.environ.get("POLAR_DIST_SPLIT", "slabs") == "rows":
+            counts, offs = split_rows(self.n_total, world)   # equal row ranges of the replica order (cuts through replica cells)
+        else:
+            # geometric z slabs of equal atom counts; a sorbate molecule and a cluster of bonded framework atoms (< 1.6 A
+            # apart: the strongest couplings) stay on one rank (workload.slab_order): two peers per rank and the thinnest halo
+            # whatever the number of ranks, and 37 instead of 40 sweeps on 8 slabs
+            glue_dist = float(os.environ.get("POLAR_DIST_GLUE", "1.6"))
+            grid = [int(v) for v in os.environ.get("POLAR_DIST_GRID", "").replace("x", ",").split(",") if v]
+            if len(grid) == 3 and grid[0] * grid[1] * grid[2] == world and (grid[0] > 1 or grid[1] > 1):
+                order, offs = wl.brick_order(sg, grid, glue_dist=glue_dist)   # bricks (opt-in): up to 7 peers per rank at 2 x 2 x 2
+                sg = wl.permute_locals(sg, order)
+                counts = [int(offs[r + 1] - offs[r]) for r in range(world)]
+            else:
+                order, key, glue = wl.slab_order(sg, axis=2, glue_dist=glue_dist)
+                sg = wl.permute_locals(sg, order)
+                counts, offs = wl.split_sorted(key[order], world, glue)
+        self.counts, self.offs = counts, offs
+        self.lo, self.hi = int(offs[rank]), int(offs[rank + 1])
+        # reach = the neighbor-list cutoff of the LJ/Coulomb rows (max cut + skin) -- it covers the dd cutoff
+        self.reach = float(sg.extra["cutneigh"]) + 1e-6
+        self.mode = os.environ.get("POLAR_HALO_MODE", "p2p")
+        if self.mode == "allgather":
+            self.s = sg   # every rank holds ALL atoms and owns the rows [lo, hi); one all-gather of the halos per sweep
+            self.plan = HaloPlan(sg.x[:sg.nlocal], sg.prd, offs, self.reach)
+            self.rows_own = int(np.count_nonzero(sg.alpha[self.lo:self.hi]))
+        else:
+            # default: every rank holds only [own | halo | ghosts] (per-step cost independent of the number of ranks) and
+            # exchanges face layers point-to-point with its slab neighbours
+            self.plan = P2PHaloPlan(sg.x[:sg.nlocal], sg.prd, offs, self.reach)
+            self.s = wl.compact_shard_geometric(sg, np.arange(self.lo, self.hi), self.plan.halo_of(rank), self.reach)
+            self.rows_own = int(np.count_nonzero(self.s.alpha[:self.hi - self.lo]))
+        self.n_held = self.s.nlocal + self.s.nghost
+
+    # -- one schedule: handle + driver ----------------------------------------------------------------------------------------
+    def open(self, name, lag, split_comm, accel=0):
+        """(Re)create the handle and the driver for schedule ``name``.  Collective: every rank, same arguments."""
+        self.close()
+        torch, dist, pkg, rank, world, local_rank = self.torch, self.dist, self.pkg, self.rank, self.world, self.local_rank
+        s, lo, hi, plan = self.s, self.lo, self.hi, self.plan
+        if accel and s.settings.polar_accel != accel:
+            import copy
+            import dataclasses
+            s = copy.copy(s)
+            s.settings = dataclasses.replace(s.settings, polar_accel=int(accel))
+        self.name, self.lag, self.ncls = name, lag, 0
+        if self.mode == "allgather":
+            self.p = pkg.pair_from_system(s, device=local_rank, device_neigh=True, row_range=(lo, hi))
+            self.be = HipShardBackend(self.p, lo, hi, local_rank)
+            self.halo = (plan, halo_buffers(self.be, plan, rank)) if world > 1 else None
+        else:
+            self.p = pkg.pair_from_system(s, device=local_rank, device_neigh=True, row_range=(0, hi - lo))
+            self.be = HipShardBackend(self.p, 0, hi - lo, local_rank, global_count=self.n_total)
+            self.halo = (plan, p2p_buffers(self.be, plan, rank, compact_lo=lo))
+        be = self.be
+        if world > 1:
+            # establish the connections of torch's communicator (peer-to-peer channels are created lazily at first use) outside
+            # any timed region: one exchange of the still empty buffers plus one tiny all-reduce
+            if isinstance(plan, P2PHaloPlan):
+                hb = self.halo[1]
+                ops = []
+                for kk, r in enumerate(hb["peers"]):
+                    a, b = 3 * hb["seg_in"][kk], 3 * hb["seg_in"][kk + 1]
+                    if b > a:
+                        ops.append(dist.P2POp(dist.irecv, hb["recv"][a:b], r))
+                for kk, r in enumerate(hb["peers"]):
+                    a, b = 3 * hb["seg_out"][kk], 3 * hb["seg_out"][kk + 1]
+                    if b > a:
+                        ops.append(dist.P2POp(dist.isend, hb["send"][a:b], r))
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            t = be.scalars_tensor([0.0])
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+        # The per-sweep loop: the library's own C++ driver (polar_dist_*: RCCL calls enqueued by the library, no Python between
+        # two sweeps) whenever the backend is RCCL and the exchange is point-to-point; the Python loop (run_step) remains for the
+        # rehearsal backends (gloo: ranks sharing a GPU, exchanges staged through the host) and for the all-gather variant.
+        self.driver, self.driver_fallback = None, None
+        if self.backend_name == "nccl" and isinstance(plan, P2PHaloPlan) and os.environ.get("POLAR_DIST_DRIVER", "cpp") == "cpp":
+            ids = [pkg.PolarDist.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            driver_error = None
+            try:
+                if split_comm:
+                    os.environ["POLAR_DIST_SPLIT_COMM"] = "1"   # (read by polar_dist_create: a communicator of its own for the all-reduces)
+                else:
+                    os.environ.pop("POLAR_DIST_SPLIT_COMM", None)
+                self.driver = pkg.PolarDist(ids[0], rank, world, device=local_rank)
+                peers = plan.peers(rank)
+                n_own = hi - lo
+                send_lists = [(np.asarray(plan.send[rank][r]) - lo).astype(np.int32) for r in peers]
+                recv_lists, at = [], n_own
+                for r in peers:
+                    m = len(plan.send[r][rank])
+                    recv_lists.append(np.arange(at, at + m, dtype=np.int32))
+                    at += m
+                self.driver.set_halo(self.p, peers, send_lists, recv_lists)
+                self.driver.set_cadence(REDUCE_EVERY, 4)
+                cls, self.ncls = rank_classes([plan.peers(r) for r in range(world)])
+                self.driver.set_schedule(lag, cls[rank], self.ncls if lag >= 0 else 0)
+                self.driver.set_ghosts(self.p, *ghost_map(s))
+            except Exception as e:  # noqa: BLE001 -- the communicator could not be made on this rank: all ranks must take the same loop
+                driver_error = repr(e)
+            ok = torch.tensor([0.0 if driver_error else 1.0], dtype=torch.float64, device=be.dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:  # same HIP kernels, the sweep loop in Python over torch.distributed instead (said in the JSON line)
+                if self.driver is not None and not driver_error:
+                    self.driver.close()
+                self.driver = None
+                self.driver_fallback = driver_error or "another rank could not create the RCCL communicator"
+                print(f"[rank {rank}] polar_dist driver unavailable ({self.driver_fallback}): Python sweep loop", file=sys.stderr, flush=True)
+
+    def close(self):
+        if self.driver is not None:
+            self.driver.close()
+        if self.p is not None:
+            self.p.close()
+        self.driver = self.p = self.be = None
+
+    def one_step(self, timer=None):
+        if self.driver is not None:
+            return self.driver.step(self.p, 1, 2)
+        return run_step(self.be, self.dist, self.rank, self.world, self.counts, self.offs, gather_buf=None, halo=self.halo, timer=timer)
+
+    def timed(self, steps, warmup):
+        """`warmup` untimed steps (at least one: lists, colours, connections), then EXACTLY `steps` steps between barrier +
+        synchronize on both sides; the MAX over the ranks of the wall time."""
+        torch, dist = self.torch, self.dist
+        for _ in range(max(warmup, 1)):
+            out = self.one_step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        timer = SweepTimer(torch)
+        t0 = time.perf_counter()
+        for it in range(steps):  # the event pairs cost ~5 % of a step: only the last timed step carries them (Python loop only)
+            out = self.one_step(timer if (it == steps - 1 and self.driver is None) else None)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.be.dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return out, float(dt.item()), timer
+
+    def calibrate(self):
+        """ONE more step with the library's timed events between the parts of its sweep loop (outside any timed region), then the
+        MAX over the ranks of every figure: what DESIGN section 6's model  t = sweeps x (sweep kernels + exposed exchange + stop
+        rule) + non-sweep  is calibrated on.  None without the in-library driver."""
+        if self.driver is None:
+            return None
+        torch, dist = self.torch, self.dist
+        self.driver.profile(True)
+        try:
+            o = self.driver.step(self.p, 1, 2)
+            pr = self.driver.profile_get()
+        finally:
+            self.driver.profile(False)
+        keys = ["sweep_kernels", "exchange", "stop_rule", "other", "accel"]
+        loc = [pr[k] for k in keys] + [o["ms_solve"], o["ms_total"] - o["ms_solve"], o["ms_total"], float(o["sweeps"]), o["ms_list"], o["ms_static"], o["ms_force"], o["ms_ljcoul"]]
+        t = torch.tensor(loc, dtype=torch.float64, device=self.be.dev)
+        tmin = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        v, vmin = t.cpu().numpy(), tmin.cpu().numpy()
+        sw = max(v[8], 1.0)
+        exposed = max(v[5] - v[0] - v[2] - v[4], 0.0)   # solve minus sweep kernels, stop rule and mixing: exchanges on the compute stream + waits for the communication stream + host looks
+        cal = {"what": "one extra step with timed events between the parts of the sweep loop (polar_dist_profile); every figure is the MAX over the "
+                       "ranks (min in *_min); exposed exchange = solve - sweep kernels - stop rule - mixing",
+               "sweeps": int(v[8]), "ms_solve": v[5], "ms_non_sweep": v[6], "ms_device_step": v[7],
+               "ms_sweep_kernels": v[0], "ms_exchange_on_compute_stream": v[1], "ms_stop_rule": v[2], "ms_waits_and_host_looks": v[3], "ms_accel_mixing": v[4],
+               "ms_exposed_exchange": exposed,
+               "us_sweep_kernels_per_sweep": 1e3 * v[0] / sw, "us_exposed_exchange_per_sweep": 1e3 * exposed / sw, "us_stop_rule_per_sweep": 1e3 * v[2] / sw,
+               "ms_sweep_kernels_min": vmin[0], "ms_solve_min": vmin[5], "ms_non_sweep_min": vmin[6],
+               "ms_list": v[9], "ms_static": v[10], "ms_force": v[11], "ms_ljcoul_side_stream": v[12],
+               "profile_intervals": pr["intervals"]}
+        model = MODEL.get((self.world, self.name))
+        if model:
+            cal["model"] = dict(model, source="DESIGN.md section 6 (projection from one-GPU measurements)")
+        return cal
+
+    def md_leg(self):
+        """MD-shaped leg (driver only): every rank moves ITS OWN atoms each step (thermal-size jitter, inside the skin), uploads them
+        (polar_set_positions_range: PCIe), fetches the halo atoms' positions from their owners over RCCL and rebuilds the ghost
+        images (polar_dist_positions) -- north_star "ghost x ... over xGMI" --; on the last step the device list is rebuilt."""
+        if self.driver is None:
+            return None
+        torch, dist, p, s = self.torch, self.dist, self.p, self.s
+        rng = np.random.default_rng(1000 + self.rank)
+        n_own = self.hi - self.lo
+        x_own0 = np.ascontiguousarray(s.x[:n_own])
+        disp = np.zeros_like(x_own0)
+        md_steps, every = 10, 10
+        t_steps, sw = [], []
+        self.one_step()
+        for k in range(md_steps):
+            disp += rng.normal(scale=0.01, size=disp.shape)
+            dist.barrier()
+            t1 = time.perf_counter()
+            p.set_positions_range(0, n_own, x_own0 + disp)
+            self.driver.positions(p)
+            if k % every == every - 1:
+                p.build_neighbors_from_system(s)
+            o2 = self.driver.step(p, 1, 2)
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=self.be.dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_steps.append(1e3 * float(tt.item())); sw.append(o2["sweeps"])
+        return {"what": f"{md_steps} steps; per step every rank uploads its own atoms' new positions (jitter 0.01 A per step), halo positions and ghost images "
+                        "through polar_dist_positions (RCCL), polar_dist_step; the device list rebuilt on the last step; wall clock, max over ranks",
+                "ms_per_step_md": float(np.mean(t_steps[:-1])), "ms_reneighbor_step": t_steps[-1], "sweeps_per_step": float(np.mean(sw)),
+                "atom_steps_per_s_md": self.n_total / (float(np.mean(t_steps[:-1])) * 1e-3)}
+
+    def record(self, out, dt, timer, steps, warmup):
+        """The JSON line of the schedule that was just timed (rank 0 prints it; every rank builds it: same numbers)."""
+        B, pkg, world, plan, counts, reps = self.B, self.pkg, self.world, self.plan, self.counts, self.reps
+        n_total, lag, ncls, driver = self.n_total, self.lag, self.ncls, self.driver
+        # roofline of the dominant kernel on this rank (same accounting as the single-GPU line, bench.py)
+        if driver is not None:  # the library's own events around the solve of the last step (exchanges and all-reduces included)
+            launches = max(out["sweeps"], 1) * max(out["ncolors"], 1)
+            ms_launch = out["ms_solve"] / launches
+        else:
+            launches = max(len(timer.pairs), 1) * max(out["ncolors"], 1)
+            ms_launch = timer.total_ms() / launches
+        pairs_rank = out["dd_pairs"] / world          # dd_pairs was all-reduced; equal shares of a uniform box
+        bytes_launch = (4.0 * pairs_rank + 112.0 * self.rows_own) / max(out["ncolors"], 1)
+        achieved = bytes_launch / max(ms_launch * 1e-3, 1e-12) / 1e9
+        per_cell = out["eng_pol"] / float(np.prod(reps))
+        backend_txt = "RCCL" if self.backend_name == "nccl" else "REHEARSAL: " + self.backend_name + ", host-staged, ranks sharing a GPU"
+        if driver is not None and lag >= 0:
+            sched = (f"one colouring shared by the ranks ({ncls} turns), colour c's boundary dipoles exchanged after phase c on a second stream, "
+                     f"a phase waits for the exchange issued {lag + 1} phase(s) earlier")
+        else:
+            sched = "every rank colours for itself, one exchange of all halo dipoles per sweep on the compute stream (block-Jacobi across ranks)"
+        if self.s.settings.polar_accel or "polar_accel" in self.args.extra or self.name.endswith("accel4"):
+            sched += "; polar_accel (Anderson mixing, the dot products on the stop rule's all-reduce)"
+        return {
+            "metric": "atom-steps/sec", "value": n_total * steps / dt, "unit": "atom-steps/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": B.describe(self.cfg, n_total) + f"; {world} rank(s), {counts[0]} own atoms per GPU (z slabs), "
+                                   f"colour-phase GS per rank + {'all-gather' if isinstance(plan, HaloPlan) else 'point-to-point exchange'} "
+                                   f"of the halo dipoles ({backend_txt}), LJ/Coulomb lists built on the device",
+                       "natoms": n_total, "sweeps": out["sweeps"], "iterations": out["iterations"], "colors": out["ncolors"],
+                       "dd_pairs": out["dd_pairs"], "eng_pol": out["eng_pol"], "rms_dmu_last_sweep": out["rms_dmu"],
+                       # a result check the line carries itself: every box here is whole copies of ONE cell wider than two cutoffs, so
+                       # E_pol per cell is a property of the cell (tests/test_gpu_fullsize.py); the single-GPU value at precision 1e-11
+                       # (configs[2], [3] and [4] on one GPU agree on it to 1e-9)
+                       "eng_pol_per_cell": per_cell, "eng_pol_per_cell_one_gpu": E_POL_PER_CELL,
+                       "eng_pol_rel_dev_from_one_gpu": abs(per_cell - E_POL_PER_CELL) / abs(E_POL_PER_CELL),
+                       "ms_per_dipole_iteration": 1e3 * dt / steps / max(out["sweeps"], 1),
+                       "ms_device_rank0": {k2: out[k2] for k2 in ("ms_total", "ms_list", "ms_ljcoul", "ms_static", "ms_solve", "ms_force")},
+                       "atoms_held_rank0": self.n_held, "halo_rows_per_rank": plan.counts, "rows_per_rank": counts,
+                       "peers_rank0": len(plan.peers(0)) if hasattr(plan, "peers") else None,
+                       "stop_rule_allreduce_every_sweeps": REDUCE_EVERY,
+                       "rccl_ranks": driver.comm_count() if driver is not None else None,
+                       "schedule_name": self.name, "schedule": sched,
+                       "sweep_loop": ("in-library C++ driver (polar_dist_step): RCCL send / receive groups and the all-reduced stop rule enqueued by the "
+                                      "library, state read every 4 sweeps") if driver is not None
+                                     else "Python loop over the stepwise C-ABI (torch.distributed collectives)" + (f" -- C++ driver unavailable: {self.driver_fallback}" if self.driver_fallback else ""),
+                       "exchanges_last_step": out.get("exchanges"), "allreduces_last_step": out.get("allreduces"),
+                       "kernel_version": pkg.kernel_version()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; rank 0; {pkg.kernel_version()})",
+                         "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch},
+        }
+
+
 def bench_distributed(args, rank, world, local_rank):
     """bench.py --gpus N (N > 1): STRONG scaling on a fixed box -- BASELINE configs[3] (6x6x6 = 291,384 atoms) for
-    N = 2, 4 and configs[4] (7x7x8 = 528,808 atoms) for N = 8, ranked GS to precision 1e-11 -- one rank per GPU,
-    contiguous row ranges (z slabs: the replicas are stored z-outermost), every rank holding only
-    [own | halo | ghosts], LJ/Coulomb lists of the own rows built on the device, halo dipoles exchanged
-    point-to-point with the slab neighbours once per sweep, one all-reduced double every second sweep for the stop rule."""
+    N = 2, 4 and configs[4] (7x7x8 = 528,808 atoms) for N = 8, ranked GS to precision 1e-11 -- one rank per GPU, z slabs, every
+    rank holding only [own | halo | ghosts], LJ/Coulomb lists of the own rows built on the device, halo dipoles exchanged
+    point-to-point with the slab neighbours.  --schedule picks how (bench.SCHEDULES); the headline is "legacy".
+    The record cannot be lost after the timed steps (bench.Emitter): the headline line exists before any extra leg starts."""
     import torch
     import torch.distributed as dist
 
-    pkg = importlib.import_module(__package__)
-    wl = importlib.import_module(__package__ + ".workload")
     import bench as B  # repo root is on sys.path (bench.py put it there)
 
     global REDUCE_EVERY
@@ -562,210 +862,68 @@ def bench_distributed(args, rank, world, local_rank):
     if os.environ.get("POLAR_DIST_GRAPH") == "1":
         # graph capture needs a non-default stream: everything of this run (library kernels, RCCL) goes onto one side stream
         torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
-    k = args.config or (4 if world >= 8 else (3 if world > 1 else 2))
-    cfg = dict(B.CONFIGS[k])
-    if args.reps:
-        cfg["reps"] = tuple(args.reps)
-    reps = cfg["reps"]
-    cut = B.CUT_COUL
-    sg = B.build_workload(wl, reps, args.extra, build_list=False, solver=cfg["solver"])   # atoms + ghosts, no host list
-    n_total = sg.nlocal
-    if os.environ.get("POLAR_DIST_SPLIT", "slabs") == "rows":
-        counts, offs = split_rows(n_total, world)   # equal row ranges of the replica order (cuts through replica cells)
-    else:
-        # geometric z slabs of equal atom counts; a sorbate molecule and a cluster of bonded framework atoms (< 1.6 A
-        # apart: the strongest couplings) stay on one rank (workload.slab_order): two peers per rank and the thinnest halo
-        # whatever the number of ranks (row ranges cut replica cells in the middle unless the ranks divide the replicas,
-        # which leaves three peers and half-cells of interleaved atoms), and 37 instead of 40 sweeps on 8 slabs
-        glue_dist = float(os.environ.get("POLAR_DIST_GLUE", "1.6"))
-        grid = [int(v) for v in os.environ.get("POLAR_DIST_GRID", "").replace("x", ",").split(",") if v]
-        if len(grid) == 3 and grid[0] * grid[1] * grid[2] == world and (grid[0] > 1 or grid[1] > 1):
-            # bricks (opt-in): recursive bisection into equal counts; up to 7 peers per rank at 2 x 2 x 2 instead of 2
-            order, offs = wl.brick_order(sg, grid, glue_dist=glue_dist)
-            sg = wl.permute_locals(sg, order)
-            counts = [int(offs[r + 1] - offs[r]) for r in range(world)]
-        else:
-            order, key, glue = wl.slab_order(sg, axis=2, glue_dist=glue_dist)
-            sg = wl.permute_locals(sg, order)
-            counts, offs = wl.split_sorted(key[order], world, glue)
-    lo, hi = int(offs[rank]), int(offs[rank + 1])
-    # reach = the neighbor-list cutoff of the LJ/Coulomb rows (max cut + skin) -- it covers the dd cutoff
-    reach = float(sg.extra["cutneigh"]) + 1e-6
-    mode = os.environ.get("POLAR_HALO_MODE", "p2p")
-    if mode == "allgather":
-        # every rank holds ALL atoms and owns the rows [lo, hi); one all-gather of the halos per sweep
-        s = sg
-        p = pkg.pair_from_system(s, device=local_rank, device_neigh=True, row_range=(lo, hi))
-        be = HipShardBackend(p, lo, hi, local_rank)
-        plan = HaloPlan(s.x[:s.nlocal], s.prd, offs, reach)
-        halo = (plan, halo_buffers(be, plan, rank)) if world > 1 else None
-        rows_own = int(np.count_nonzero(s.alpha[lo:hi]))
-    else:
-        # default: every rank holds only [own | halo | ghosts] (per-step cost independent of the number of
-        # ranks) and exchanges face layers point-to-point with its slab neighbours
-        plan = P2PHaloPlan(sg.x[:sg.nlocal], sg.prd, offs, reach)
-        s = wl.compact_shard_geometric(sg, np.arange(lo, hi), plan.halo_of(rank), reach)
-        p = pkg.pair_from_system(s, device=local_rank, device_neigh=True, row_range=(0, hi - lo))
-        be = HipShardBackend(p, 0, hi - lo, local_rank, global_count=n_total)
-        halo = (plan, p2p_buffers(be, plan, rank, compact_lo=lo))
-        rows_own = int(np.count_nonzero(s.alpha[:hi - lo]))
-    n_held = s.nlocal + s.nghost
-    del sg
-    if world > 1:
-        # establish the RCCL connections (peer-to-peer channels are created lazily at first use) outside
-        # the timed region even when the driver asks for zero warmup steps: one exchange of the still
-        # empty buffers plus one tiny all-reduce
-        if isinstance(plan, P2PHaloPlan):
-            hb = halo[1]
-            ops = []
-            for kk, r in enumerate(hb["peers"]):
-                a, b = 3 * hb["seg_in"][kk], 3 * hb["seg_in"][kk + 1]
-                if b > a:
-                    ops.append(dist.P2POp(dist.irecv, hb["recv"][a:b], r))
-            for kk, r in enumerate(hb["peers"]):
-                a, b = 3 * hb["seg_out"][kk], 3 * hb["seg_out"][kk + 1]
-                if b > a:
-                    ops.append(dist.P2POp(dist.isend, hb["send"][a:b], r))
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        t = be.scalars_tensor([0.0])
-        dist.all_reduce(t)
-        torch.cuda.synchronize()
-    gbuf = None
-    # The per-sweep loop: the library's own C++ driver (polar_dist_*: RCCL calls enqueued by the library on its compute
-    # stream, no Python between two sweeps) whenever the backend is RCCL and the exchange is point-to-point; the Python loop
-    # below (run_step) remains for the rehearsal backends (gloo: ranks sharing a GPU, exchanges staged through the host) and
-    # for the all-gather variant.
-    driver = None
-    driver_fallback = None
-    lag, ncls = -1, 0
-    if backend_name == "nccl" and isinstance(plan, P2PHaloPlan) and os.environ.get("POLAR_DIST_DRIVER", "cpp") == "cpp":
-        ids = [pkg.PolarDist.unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(ids, src=0)
-        driver_error = None
+
+    def settings_of(name, explicit):
+        """(lag, split communicator, polar_accel depth) of a schedule; without --schedule the environment may override (experiments)."""
+        env, kw = B.SCHEDULES[name]
+        lag = int(env.get("POLAR_DIST_LAG", "-1"))
+        split = env.get("POLAR_DIST_SPLIT_COMM", "0") == "1"
+        if not explicit:
+            lag = int(os.environ.get("POLAR_DIST_LAG", lag))
+            split = os.environ.get("POLAR_DIST_SPLIT_COMM", "1" if split else "0") == "1"
+        accel = int(kw[kw.index("polar_accel") + 1]) if "polar_accel" in kw else 0
+        return lag, split, accel
+
+    name = args.schedule or "legacy"
+    job = RankJob(args, rank, world, local_rank, torch, dist, backend_name)
+    job.build_shard(B.SCHEDULES[name][1])
+    lag, split, accel = settings_of(name, bool(args.schedule))
+    job.open(name, lag, split, accel)
+    out, dt, timer = job.timed(args.steps, args.warmup)
+    line = job.record(out, dt, timer, args.steps, args.warmup)
+    config = line["config"]
+    # ---- the measured record exists from here on ----
+    em = B.Emitter(rank == 0, float(os.environ.get("POLAR_BENCH_EXTRAS_BUDGET", "420")))
+    em.headline(line)
+
+    def leg(where, key, fn):
+        em.stage = key
+        t0 = time.time()
         try:
-            driver = pkg.PolarDist(ids[0], rank, world, device=local_rank)
-            peers = plan.peers(rank)
-            n_own = hi - lo
-            send_lists = [(np.asarray(plan.send[rank][r]) - lo).astype(np.int32) for r in peers]
-            recv_lists, at = [], n_own
-            for r in peers:
-                m = len(plan.send[r][rank])
-                recv_lists.append(np.arange(at, at + m, dtype=np.int32))
-                at += m
-            driver.set_halo(p, peers, send_lists, recv_lists)
-            driver.set_cadence(REDUCE_EVERY, 4)
-            # one colouring shared by the ranks + per-phase exchanges on a second stream (POLAR_DIST_LAG=-1: the round-3
-            # schedule, every rank colouring for itself and one exchange per sweep)
-            # Which schedule: per-phase exchanges cost ~12-17 us per phase of event and exchange traffic that nothing hides
-            # (one rank, real RCCL: profiles/r04_dist_schedule_cost.txt) and save 4-6 of 38 sweeps; one exchange per sweep costs
-            # ~23 us + the link per sweep.  With phases of ~50 us (>= ~100k own atoms per rank) the per-phase schedule wins,
-            # with the ~29-us phases of 66k atoms per rank the two are on par and the simpler one is taken.
-            lag = int(os.environ.get("POLAR_DIST_LAG", "1" if (hi - lo) >= 100000 else "-1"))
-            cls, ncls = rank_classes([plan.peers(r) for r in range(world)])
-            driver.set_schedule(lag, cls[rank], ncls if lag >= 0 else 0)
-            driver.set_ghosts(p, *ghost_map(s))
-        except Exception as e:  # noqa: BLE001 -- the communicator could not be made on this rank: all ranks must take the same loop
-            driver_error = repr(e)
-        ok = torch.tensor([0.0 if driver_error else 1.0], dtype=torch.float64, device=be.dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok.item()) < 1.0:  # same HIP kernels, the sweep loop in Python over torch.distributed instead (said in the JSON line)
-            if driver is not None and not driver_error:
-                driver.close()
-            driver = None
-            driver_fallback = driver_error or "another rank could not create the RCCL communicator"
-            print(f"[rank {rank}] polar_dist driver unavailable ({driver_fallback}): Python sweep loop", file=sys.stderr, flush=True)
+            where[key] = fn()
+        except Exception as e:  # noqa: BLE001 -- (a rank-local exception leaves the other ranks in a collective: the watchdog ends the job)
+            where[key] = {"error": repr(e), "after_s": time.time() - t0}
 
-    def one_step(timer=None):
-        if driver is not None:
-            return driver.step(p, 1, 2)
-        return run_step(be, dist, rank, world, counts, offs, gather_buf=gbuf, halo=halo, timer=timer)
+    leg(config, "calibration", job.calibrate)
+    if not args.no_extras:
+        leg(config, "md_leg", job.md_leg)
+        own_launcher = bool(os.environ.get("POLAR_BENCH_LAUNCHER"))
+        if not own_launcher and not args.schedule and job.driver is not None:
+            # under a foreign launcher (the driver's own torch.distributed.run) nobody starts the other schedules as jobs of their
+            # own: they run here, in this process, AFTER the headline is safe -- a hang costs what follows it, the watchdog prints
+            config["schedules"] = {name: B.schedule_summary(line)}
+            config["headline_schedule"] = name
+            for other in B.SCHEDULES:
+                if other == name:
+                    continue
 
-    for _ in range(max(args.warmup, 1)):
-        out = one_step()
-    dist.barrier()
-    torch.cuda.synchronize()
-    timer = SweepTimer(torch)
-    t0 = time.perf_counter()
-    for it in range(args.steps):  # the event pairs cost ~5 % of a step: only the last timed step carries them
-        out = one_step(timer if it == args.steps - 1 else None)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.dev)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
-    # MD-shaped leg (driver only): every rank moves ITS OWN atoms each step (thermal-size jitter, inside the skin), uploads them
-    # (polar_set_positions_range: PCIe), fetches the halo atoms' positions from their owners over RCCL and rebuilds the ghost
-    # images (polar_dist_positions) -- north_star "ghost x ... over xGMI" --; every 10th step the device list is rebuilt.
-    md = None
-    if driver is not None and not args.no_extras:
-        rng = np.random.default_rng(1000 + rank)
-        n_own = hi - lo
-        x_own0 = np.ascontiguousarray(s.x[:n_own])
-        disp = np.zeros_like(x_own0)
-        md_steps, every = 10, 10
-        t_steps, sw = [], []
-        one_step()
-        for k in range(md_steps):
-            disp += rng.normal(scale=0.01, size=disp.shape)
-            dist.barrier()
-            t1 = time.perf_counter()
-            p.set_positions_range(0, n_own, x_own0 + disp)
-            driver.positions(p)
-            if k % every == every - 1:
-                p.build_neighbors_from_system(s)
-            o2 = driver.step(p, 1, 2)
-            torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=be.dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_steps.append(1e3 * float(tt.item())); sw.append(o2["sweeps"])
-        md = {"what": f"{md_steps} steps; per step every rank uploads its own atoms' new positions (jitter 0.01 A per step), halo positions and ghost images "
-                      "through polar_dist_positions (RCCL), polar_dist_step; the device list rebuilt on the last step; wall clock, max over ranks",
-              "ms_per_step_md": float(np.mean(t_steps[:-1])), "ms_reneighbor_step": t_steps[-1], "sweeps_per_step": float(np.mean(sw)),
-              "atom_steps_per_s_md": n_total / (float(np.mean(t_steps[:-1])) * 1e-3)}
-    # roofline of the dominant kernel on this rank (same accounting as the single-GPU line, bench.py)
-    launches = max(len(timer.pairs), 1) * max(out["ncolors"], 1)
-    ms_launch = timer.total_ms() / launches
-    if driver is not None:  # the library's own events around the solve of the last step (exchanges and all-reduces included)
-        launches = max(out["sweeps"], 1) * max(out["ncolors"], 1)
-        ms_launch = out["ms_solve"] / launches
-    pairs_rank = out["dd_pairs"] / world          # dd_pairs was all-reduced; equal shares of a uniform box
-    bytes_launch = (4.0 * pairs_rank + 112.0 * rows_own) / max(out["ncolors"], 1)
-    achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
-    if rank == 0:
-        line = {
-            "metric": "atom-steps/sec", "value": n_total * args.steps / dt, "unit": "atom-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": B.describe(cfg, n_total) + f"; {world} rank(s), {counts[0]} own atoms per GPU (z slabs), "
-                                   f"colour-phase GS per rank + {'all-gather' if isinstance(plan, HaloPlan) else 'point-to-point exchange'} "
-                                   f"of the halo dipoles per sweep ({'RCCL' if backend_name == 'nccl' else 'REHEARSAL: ' + backend_name + ', host-staged, ranks sharing a GPU'}), "
-                                   "LJ/Coulomb lists built on the device",
-                       "natoms": n_total, "sweeps": out["sweeps"], "iterations": out["iterations"], "colors": out["ncolors"],
-                       "dd_pairs": out["dd_pairs"], "eng_pol": out["eng_pol"], "rms_dmu_last_sweep": out["rms_dmu"],
-                       # a result check the line carries itself: every box here is whole copies of ONE cell wider than two cutoffs, so
-                       # E_pol per cell is a property of the cell (tests/test_gpu_fullsize.py); the single-GPU value at precision 1e-11
-                       # (configs[2], [3] and [4] on one GPU agree on it to 1e-9)
-                       "eng_pol_per_cell": out["eng_pol"] / float(np.prod(reps)), "eng_pol_per_cell_one_gpu": E_POL_PER_CELL,
-                       "eng_pol_rel_dev_from_one_gpu": abs(out["eng_pol"] / float(np.prod(reps)) - E_POL_PER_CELL) / abs(E_POL_PER_CELL),
-                       "ms_per_dipole_iteration": 1e3 * dt / args.steps / max(out["sweeps"], 1),
-                       "ms_device_rank0": {k2: out[k2] for k2 in ("ms_total", "ms_list", "ms_ljcoul", "ms_static", "ms_solve", "ms_force")},
-                       "atoms_held_rank0": n_held, "halo_rows_per_rank": plan.counts, "rows_per_rank": counts,
-                       "peers_rank0": len(plan.peers(0)) if hasattr(plan, "peers") else None,
-                       "stop_rule_allreduce_every_sweeps": REDUCE_EVERY,
-                       "rccl_ranks": driver.comm_count() if driver is not None else None,
-                       "schedule": (f"one colouring shared by the ranks ({ncls} turns), colour c's boundary dipoles exchanged after phase c on a second stream, "
-                                    f"a phase waits for the exchange issued {lag + 1} phase(s) earlier" if driver is not None and lag >= 0
-                                    else "every rank colours for itself, one exchange of all halo dipoles per sweep (block-Jacobi across ranks)"),
-                       "sweep_loop": ("in-library C++ driver (polar_dist_step): pack kernel, ncclGroupStart/Send/Recv/End, unpack kernel on the "
-                                      "communication stream, the all-reduced stop rule on the compute stream, state read every 4 sweeps") if driver is not None
-                                     else "Python loop over the stepwise C-ABI (torch.distributed collectives)" + (f" -- C++ driver unavailable: {driver_fallback}" if driver_fallback else ""),
-                       "exchanges_last_step": out.get("exchanges"), "allreduces_last_step": out.get("allreduces"), "md_leg": md,
-                       "kernel_version": pkg.kernel_version()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": f"k_field_lp (dipole-field sweep, one launch per colour phase; rank 0; {pkg.kernel_version()})",
-                         "bytes_per_launch": bytes_launch, "ms_per_launch": ms_launch},
-        }
-        print(json.dumps(line))
-    dist.destroy_process_group()
+                def run_other(other=other):
+                    l2, s2, a2 = settings_of(other, True)
+                    job.open(other, l2, s2, a2)
+                    o2, dt2, tm2 = job.timed(args.steps, args.warmup)
+                    sub = job.record(o2, dt2, tm2, args.steps, args.warmup)
+                    sub["config"]["calibration"] = job.calibrate()
+                    return B.schedule_summary(sub)
+
+                leg(config["schedules"], other, run_other)
+    em.final(line)
+    bad = not (config["eng_pol_rel_dev_from_one_gpu"] <= B.EPOL_TOL)
+    try:
+        job.close()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+    if bad:   # every rank holds the same all-reduced energy: the same exit code everywhere
+        if rank == 0:
+            print(f"bench.py: E_pol per cell is {config['eng_pol_rel_dev_from_one_gpu']:.2e} off the one-GPU value: wrong result", file=sys.stderr)
+        sys.exit(4)
