@@ -800,7 +800,8 @@ class RankJob:
         else:
             sched = "every rank colours for itself, one exchange of all halo dipoles per sweep on the compute stream (block-Jacobi across ranks)"
         if self.s.settings.polar_accel or "polar_accel" in self.args.extra or self.name.endswith("accel4"):
-            sched += "; polar_accel (Anderson mixing, the dot products on the stop rule's all-reduce)"
+            sched += ("; polar_accel (Anderson mixing, the dot products on the stop rule's all-reduce)" if driver is not None
+                      else "; polar_accel asked for but NOT applied: the Python sweep loop of the rehearsal backends has no mixing step")
         return {
             "metric": "atom-steps/sec", "value": n_total * steps / dt, "unit": "atom-steps/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,

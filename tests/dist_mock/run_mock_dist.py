@@ -16,6 +16,7 @@ usage: run_mock_dist.py <world> <solver: precision|fixed|jacobi> [reduce_every] 
                        with lag 0 the ranks together run the single-GPU iteration
             badinput   rank 1 is given a setting the driver refuses: every rank must come back with an error, none may hang
             accel1     lag1 with `polar_accel 4` on every rank (Anderson mixing with all-reduced dot products)
+            accelL     the legacy schedule (one exchange of all halo dipoles per sweep, one stream) with `polar_accel 4`
             md0/md1    five steps with every atom moved between them: own positions uploaded per rank
                        (polar_set_positions_range), halo positions and ghost images through polar_dist_positions"""
 import importlib
@@ -38,7 +39,7 @@ solver = sys.argv[2]
 reduce_every = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 schedule = sys.argv[4] if len(sys.argv) > 4 else "lag1"
 md = schedule.startswith("md")
-lag = -1 if schedule in ("legacy", "badinput") else int(schedule[-1])
+lag = -1 if schedule in ("legacy", "badinput", "accelL") else int(schedule[-1])
 imposed = schedule.startswith("imposed")
 extra = {"precision": ["polar_gs_ranked", "yes", "fixed_iteration", "no", "precision", "1e-11", "max_iterations", "200"],
          "fixed": ["polar_gs_ranked", "yes", "fixed_iteration", "yes", "max_iterations", "12"],
@@ -123,12 +124,15 @@ def rank_main(r):
             if md and k > 0:
                 p.set_positions_range(0, hi - lo, sc.x[:hi - lo] + disps[k][gid])
                 d.positions(p)
+            if k == nsteps - 1:
+                d.profile(True)          # the last step carries the timed events of polar_dist_profile
             out = d.step(p, 1, 2)
             if md:
                 mu_k = p.download("mu", 3 * (hi - lo)).reshape(-1, 3)
                 hist[r].append((float(out["eng_pol"]), mu_k))
         outs[r] = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in out.items()}
         outs[r]["npeers"] = len(peers)
+        outs[r]["profile"] = d.profile_get()
         outs[r]["comm_count"] = d.comm_count()
         loc = d.local_result()
         locs[r] = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in loc.items()}
@@ -162,7 +166,7 @@ res = {
     "world": world, "solver": solver, "reduce_every": reduce_every, "schedule": schedule, "natoms": n_total, "classes": classes,
     "classes_ok": all(classes[r] != classes[q] for r in range(world) for q in plan.peers(r)),   # no two peers colour in the same turn
     "ref": {k: refs[-1][k] for k in ("eng_pol", "eng_vdwl", "eng_coul", "sweeps", "iterations", "dd_pairs", "status", "ncolors")},
-    "ranks": [{k: o[k] for k in ("eng_pol", "eng_vdwl", "eng_coul", "sweeps", "iterations", "dd_pairs", "status", "exchanges", "allreduces", "npeers", "ncolors", "comm_count")} for o in outs],
+    "ranks": [{k: o[k] for k in ("eng_pol", "eng_vdwl", "eng_coul", "sweeps", "iterations", "dd_pairs", "status", "exchanges", "allreduces", "npeers", "ncolors", "comm_count", "profile", "ms_solve")} for o in outs],
     "local_sum": {k: float(sum(l[k] for l in locs)) for k in ("eng_pol", "eng_vdwl", "eng_coul")},
     "local_virial_sum": np.sum([l["virial"] for l in locs], axis=0).tolist(), "virial": outs[0]["virial"],
     "mu_err": float(np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref))),

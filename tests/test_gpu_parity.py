@@ -889,6 +889,26 @@ def test_in_library_driver_with_several_ranks_on_a_mock_transport(world, solver,
     assert np.max(np.abs(np.array(res["local_virial_sum"]) - np.array(res["virial"]))) < 1e-10 * max(1.0, np.max(np.abs(res["virial"])))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_in_library_driver_polar_accel_with_one_exchange_per_sweep(world, pkg, tmp_path):
+    """`polar_accel 4` on the LEGACY schedule (round 5: what `bench.py --gpus N --schedule legacy_accel4` runs): every rank colours
+    for itself, the sweep map is "one sweep of every rank against the halo dipoles of the previous one", every rank mixes with the
+    same all-reduced coefficients, one exchange of all halo rows after the mix -- everything on the compute stream.  Same fixed
+    point as the unsharded handle, fewer sweeps than its plain iteration; and the profile events of the last step add up."""
+    res = _mock_dist(tmp_path, world, "precision", 1, "accelL")
+    ref, ranks = res["ref"], res["ranks"]
+    assert len(ranks) == world and all(k["status"] == 0 for k in ranks)
+    for k in ranks:
+        assert rel(k["eng_pol"], ranks[0]["eng_pol"]) < 1e-14 and k["sweeps"] == ranks[0]["sweeps"] and k["dd_pairs"] == ref["dd_pairs"]
+        assert k["sweeps"] + 1 <= k["exchanges"] <= k["sweeps"] + 5 and k["allreduces"] >= k["sweeps"]
+        pr = k["profile"]   # polar_dist_profile: the parts of the sweep loop on the device
+        assert pr["intervals"] >= 4 * k["sweeps"] and pr["sweep_kernels"] > 0 and pr["exchange"] > 0 and pr["stop_rule"] > 0 and pr["accel"] > 0
+        parts = pr["sweep_kernels"] + pr["exchange"] + pr["stop_rule"] + pr["accel"] + pr["other"]
+        assert parts <= k["ms_solve"] * 1.05 + 0.05 and parts >= 0.5 * k["ms_solve"]
+    assert res["mu_err"] < TOL and rel(ranks[0]["eng_pol"], ref["eng_pol"]) < 1e-9
+    assert ranks[0]["sweeps"] <= 0.85 * ref["sweeps"], (ranks[0]["sweeps"], ref["sweeps"])
+
+
 @pytest.mark.parametrize("schedule", ["legacy", "lag1"])
 def test_in_library_driver_with_eight_ranks_on_a_mock_transport(schedule, pkg, tmp_path):
     """The rank count of the scaling run: EIGHT ranks (threads over the stand-in transport) on a 2 x 2 x 8 replica cut into eight
