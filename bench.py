@@ -160,14 +160,31 @@ def config0_exact(torch, pkg, wl, steps=10, warmup=2):
                         "precision 1e-11, max_iterations 30", "natoms": s.nlocal, "steps": steps, "ms_per_step": 1e3 * dt / steps,
             "atom_steps_per_s": s.nlocal * steps / dt, "iterations": out["iterations"], "status": out["status"],
             "us_per_iteration": 1e3 * ms_solve / steps / max(out["sweeps"], 1), "ms_solve": ms_solve / steps, "eng_pol": out["eng_pol"],
-            "reference_cpu_s_per_step": 0.85}
+            "reference_cpu_s_per_step": 0.85, "roofline_k_gs_blk": exact_pmc(s.nlocal)}
 
 
-def exact_iteration_bytes(n, B=256):
-    """HBM bytes one iteration of exact mode's block sweep reads at n atoms (n >= 1024: blocks of 256 atoms)."""
-    npitch = (n + 63) // 64 * 64
+def exact_iteration_bytes(n, npol, B=256):
+    """HBM bytes one iteration of exact mode's block sweep reads at n atoms, npol of them polarizable (n >= 1024: blocks of 256
+    atoms): per block launch the block's 256 tensor columns of every POLARIZABLE row (the push skips rows with alpha = 0: their
+    field is never read) -- 48 B per (row, column) --, the block's G (lower triangle) and N (3B x 3B doubles), the small vectors."""
     nb = (n + B - 1) // B
-    return 48.0 * n * npitch + nb * 1.5 * (3 * B) ** 2 * 8.0
+    return nb * (48.0 * npol * B + 1.5 * (3 * B) ** 2 * 8.0 + 24.0 * (n + 3 * B))
+
+
+def exact_pmc(natoms):
+    """roofline-shaped fields of k_gs_blk from the committed rocprofv3 passes (profiles/exact_traffic_pmc.json, tools/r5_a.sh +
+    tools/r5_exact_summary.py): kernel time from --kernel-trace --stats, traffic from separate FETCH_SIZE / WRITE_SIZE passes."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "exact_traffic_pmc.json")) as fh:
+            t = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if natoms == t.get("natoms"):
+        return {k: t.get(k) for k in ("kernel", "launches_per_iteration", "us_per_launch", "algorithmic_bytes_per_launch", "achieved_gb_s", "peak_gb_s", "frac",
+                                      "traffic_bytes_per_launch", "tcc_hit_rate", "share_of_gpu_time", "source")}
+    if natoms == 1349 and "config0_1349" in t:
+        return dict(t["config0_1349"], kernel=t.get("kernel"), source=t.get("source"))
+    return None
 
 
 def exact_replica(torch, pkg, wl, steps=3, warmup=1):
@@ -179,16 +196,19 @@ def exact_replica(torch, pkg, wl, steps=3, warmup=1):
     p = pkg.pair_from_system(s)
     out, dt, ms_solve, _ = timed_steps(torch, p, steps, warmup)
     p.close()
+    npol = int(np.count_nonzero(s.alpha[:s.nlocal]))
     return {"workload": "BASELINE.md section 2: MOF5+H2 replicate 2 2 2, 10,792 atoms, exact all-pairs mode (reference semantics), ranked GS, precision 1e-11",
             "natoms": s.nlocal, "steps": steps, "ms_per_step": 1e3 * dt / steps, "atom_steps_per_s": s.nlocal * steps / dt,
             "iterations": out["iterations"], "status": out["status"], "ms_per_dipole_iteration": ms_solve / steps / max(out["sweeps"], 1),
             "ms_solve": ms_solve / steps, "eng_pol": out["eng_pol"], "reference_cpu_s_per_step": 46.5,
             "speedup_over_reference_cpu": 46.5 / (dt / steps),
-            # what an iteration of the exact-order sweep reads (csrc/polar_exact.hpp, k_gs_blk): the packed tensor once (48 B per ordered
-            # pair, rows padded to 64) and G and N of every 256-atom block (lower triangle + full square of 768^2 doubles), over the
-            # time of an iteration INCLUDING the once-per-step build of G and N and the 4.4-us floor of its 43 dependent launches
-            "hbm_bytes_per_iteration": exact_iteration_bytes(s.nlocal),
-            "hbm_frac": exact_iteration_bytes(s.nlocal) / (1e-3 * ms_solve / steps / max(out["sweeps"], 1)) / 8.0e12}
+            # what an iteration of the exact-order sweep reads (csrc/polar_exact.hpp, k_gs_blk): the tensor rows of the POLARIZABLE atoms
+            # once (48 B per (row, column); round 4 counted every row: rows with alpha = 0 are skipped, and the FETCH_SIZE pass of
+            # round 5 shows exactly that) and G and N of every 256-atom block, over the time of an iteration INCLUDING the
+            # once-per-step build of G and N and the gaps between its 43 dependent launches (HIP events, live)
+            "hbm_bytes_per_iteration": exact_iteration_bytes(s.nlocal, npol),
+            "hbm_frac": exact_iteration_bytes(s.nlocal, npol) / (1e-3 * ms_solve / steps / max(out["sweeps"], 1)) / 8.0e12,
+            "roofline_k_gs_blk": exact_pmc(s.nlocal)}
 
 
 def synth_config(torch, pkg, wl, natoms, steps, warmup):

@@ -57,7 +57,14 @@ typedef struct {
   /* deterministic yes|no (extension keyword, list mode): no sweep launch reads a dipole that another wave of the same
    * launch writes -- updates are committed between launches and between the sub-phases of a tile -- so that a run,
    * `fixed_iteration` runs included, is reproducible bit for bit like the reference's serial loop (PS.cpp:1158-1180).
-   * Off by default: the in-place update converges to the same fixed point and saves the commit launches. */
+   * Keyword not given (POLAR_DET_AUTO = 0, also what a zero-initialised struct says): ON for `fixed_iteration yes` -- the
+   * reference returns one well-defined unconverged iterate there (PS.cpp:1211-1215), and the in-place race of a colour phase
+   * would make it differ from run to run at 4e-6 of the largest dipole --, OFF for precision runs: they converge to the same
+   * fixed point either way (run-to-run spread 1e-9) and save the commit launches (+5 %).  `deterministic no` (POLAR_DET_NO)
+   * keeps the in-place update for fixed-iteration runs as well. */
+#define POLAR_DET_AUTO 0
+#define POLAR_DET_YES 1
+#define POLAR_DET_NO 2
   int deterministic;
   /* polar_sor <omega> (extension keyword, list mode with polar_gs / polar_gs_ranked): successive over-relaxation of the
    * Gauss-Seidel update, mu <- mu + omega (alpha (E_static + E_ind) - mu).  1 (default) is the reference's update

@@ -400,7 +400,7 @@ class PolarPair:
         if st.dd_cutoff > 0:
             args += ["dd_cutoff", repr(st.dd_cutoff)]
         if getattr(st, "deterministic", 0):
-            args += ["deterministic", "yes"]
+            args += ["deterministic", "yes" if st.deterministic == 1 else "no"]
         if getattr(st, "polar_sor", 1.0) != 1.0:
             args += ["polar_sor", repr(float(st.polar_sor))]
         if getattr(st, "polar_accel", 0):

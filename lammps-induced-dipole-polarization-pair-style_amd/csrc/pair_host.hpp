@@ -150,7 +150,7 @@ class PairHost {
       else if (strcmp("dd_cutoff", k) == 0) st.dd_cutoff = numeric(v);  // extension keyword
       else if (strcmp("device_neigh", k) == 0) st.device_neigh = yesno(v);  // extension keyword
       else if (strcmp("restart_polar", k) == 0) st.restart_polar = yesno(v);  // extension keyword
-      else if (strcmp("deterministic", k) == 0) st.deterministic = yesno(v);  // extension keyword
+      else if (strcmp("deterministic", k) == 0) st.deterministic = yesno(v) ? POLAR_DET_YES : POLAR_DET_NO;  // extension keyword (not given: POLAR_DET_AUTO)
       else if (strcmp("rccl_halo", k) == 0) st.rccl_halo = yesno(v);          // extension keyword
       else if (strcmp("polar_accel", k) == 0) {                               // extension keyword
         st.polar_accel = inumeric(v);

@@ -444,7 +444,15 @@ inline bool sharded(const polar_handle *h) { return own_n(h) != h->nlocal; }
 // the dd rows of the current lists sit in the launch order of the colouring in force (a colouring rebuilt after the
 // lists were laid out -- a clash found on a reneighbor step, a changed alpha pattern -- makes them stale)
 inline bool slots_current(const polar_handle *h) { return h->slots_by_color && h->slots_epoch == h->color_epoch; }
-inline bool deterministic(const polar_handle *h) { return h->deterministic || h->ph.st.deterministic; }
+// `deterministic yes`, or -- keyword not given -- a fixed-iteration run: the reference returns ONE well-defined unconverged
+// iterate there (PS.cpp:1211-1215), and the in-place race of a colour phase would make it differ run to run (4e-6 of the
+// largest dipole after 13 sweeps, gpurun_out/r4a_tests.log) -- within an order of magnitude of the 1e-5 parity bar.
+// `deterministic no` keeps the in-place update; `polar_accel` (refused with the commit) keeps it too.
+inline bool deterministic(const polar_handle *h) {
+  const polar_settings &st = h->ph.st;
+  if (h->deterministic || st.deterministic == POLAR_DET_YES) return true;
+  return st.deterministic == POLAR_DET_AUTO && st.fixed_iteration && st.polar_accel == 0;
+}
 // `deterministic yes` with the row sweep: where the end-of-sweep kernels find the sweep's partial sums of (dmu)^2
 inline const double *det_part(const polar_handle *h) { return (deterministic(h) && h->ph.st.dd_cutoff > 0.0 && h->sweep_kernel == 2 && h->lp_npart > 0) ? h->d_lp_part.p : nullptr; }
 inline int det_npart(const polar_handle *h) { return det_part(h) ? h->lp_npart : 0; }

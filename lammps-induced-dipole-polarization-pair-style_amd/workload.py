@@ -346,7 +346,7 @@ class PolarSettings:
     dd_cutoff: float = 0.0  # extension: <=0 exact all-pairs (reference), >0 truncated
     device_neigh: int = 0   # extension: the LAMMPS shim builds the LJ/coul list on the device
     restart_polar: int = 0  # extension: restart files carry the polarization keywords
-    deterministic: int = 0  # extension: sweeps commit their updates between launches (bit-reproducible runs)
+    deterministic: int = 0  # extension: sweeps commit their updates between launches (bit-reproducible runs): 0 = not given (on for fixed_iteration), 1 = yes, 2 = no
     polar_sor: float = 1.0  # extension: over-relaxation factor of the list-mode Gauss-Seidel update (1 = reference)
     rccl_halo: int = 0      # extension: the LAMMPS shim's multi-rank sweeps run through the library's RCCL driver
     polar_accel: int = 0    # extension: Anderson mixing of this depth on the list-mode Gauss-Seidel sweep map (0 = off)
@@ -759,7 +759,7 @@ def parse_pair_style_args(args, base=None):
         elif k == "restart_polar":  # extension keyword (not in the reference)
             st.restart_polar = yn[v]
         elif k == "deterministic":  # extension keyword (not in the reference)
-            st.deterministic = yn[v]
+            st.deterministic = 1 if yn[v] else 2   # POLAR_DET_YES / POLAR_DET_NO (0 = keyword not given: on for fixed_iteration runs)
         elif k == "rccl_halo":  # extension keyword (not in the reference)
             st.rccl_halo = yn[v]
         elif k == "polar_accel":  # extension keyword (not in the reference)

@@ -306,8 +306,9 @@ void PairLJCutCoulLongPolarizationMI355X::build_rccl_plan()
   check(polar_get_settings(h,&pst));
   if (const char *e = getenv("POLAR_DIST_LAG")) lag = atoi(e);
   if (lag < -1 || lag > 2) error->all(FLERR,"Pair style lj/cut/coul/long/polarization rccl_halo: POLAR_DIST_LAG is -1, 0, 1 or 2");
-  if (lag >= 1 && pst.deterministic)
-    error->all(FLERR,"Pair style lj/cut/coul/long/polarization rccl_halo: deterministic yes needs POLAR_DIST_LAG <= 0");
+  const bool det = pst.deterministic == POLAR_DET_YES || (pst.deterministic == POLAR_DET_AUTO && pst.fixed_iteration && !pst.polar_accel);
+  if (lag >= 1 && det)
+    error->all(FLERR,"Pair style lj/cut/coul/long/polarization rccl_halo: deterministic yes (the default of fixed_iteration runs) needs POLAR_DIST_LAG <= 0");
   std::vector<int> ispeer(np,0), allpeer((size_t) np*np,0), cls(np,0);
   for (size_t k = 0; k + 1 < peers.size(); k++) if (peers[k] != me) ispeer[peers[k]] = 1;
   MPI_Allgather(ispeer.data(),np,MPI_INT,allpeer.data(),np,MPI_INT,world);
