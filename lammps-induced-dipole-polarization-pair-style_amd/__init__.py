@@ -39,9 +39,15 @@ class PolarError(RuntimeError):
         self.code = code
 
 
-def _sources():
-    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".hpp"))] + [
+def _sources(lab=False):
+    """What a library is built from: csrc/*.hip, csrc/*.hpp and the C-ABI header; the lab build also reads csrc/lab/* (kernels and
+    host code that were built, measured and shelved: the product translation units never include them)."""
+    src = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".hpp"))] + [
         os.path.join(os.path.dirname(_HERE), "include", "polar_mi355x.h")]
+    labdir = os.path.join(_CSRC, "lab")
+    if lab and os.path.isdir(labdir):
+        src += [os.path.join(labdir, f) for f in sorted(os.listdir(labdir)) if f.endswith((".hpp", ".inc"))]
+    return src
 
 
 TRANSLATION_UNITS = ("polar_api.hip", "polar_step.hip", "polar_color.hip", "polar_dist.hip")
@@ -56,7 +62,7 @@ def build(force=False, verbose=False, lab=True):
     for path, extra, tag in ((LIB_PATH, [], "product"), (LIB_PATH_LAB, ["-DPOLAR_LAB"], "lab")):
         if path == LIB_PATH_LAB and not lab:
             continue
-        stale = (not os.path.exists(path)) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in _sources())
+        stale = (not os.path.exists(path)) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in _sources(lab=(path == LIB_PATH_LAB)))
         if not (force or stale):
             continue
         odir = os.path.join(_CSRC, "build", tag)

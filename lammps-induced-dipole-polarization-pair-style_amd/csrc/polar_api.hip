@@ -158,25 +158,7 @@ int polar_create(int device, polar_handle **out) {
   if (const char *e = getenv("POLAR_COLOR_KEEP")) h->color_keep = atof(e);
   if (const char *e = getenv("POLAR_DETERMINISTIC")) h->deterministic = atoi(e) != 0;  // the same as the keyword `deterministic yes`
 #ifdef POLAR_LAB
-  if (const char *e = getenv("POLAR_ABLATE")) h->ablate = atoi(e);
-  if (const char *e = getenv("POLAR_HOST_COLORS")) h->host_colors = atoi(e) != 0;
-  if (const char *e = getenv("POLAR_SWEEP_KERNEL")) h->sweep_kernel = atoi(e);
-  if (const char *e = getenv("POLAR_TILE_WAVES")) h->tile_waves = atoi(e) == 8 ? 8 : 4;
-  if (const char *e = getenv("POLAR_TILE_WIDE")) h->tile_wide = atoi(e) != 0;
-  if (const char *e = getenv("POLAR_CACHE_R2")) h->cache_r2 = atoi(e);
-  if (const char *e = getenv("POLAR_LJ_TYPED")) h->lj_typed = atoi(e) != 0;
-  if (const char *e = getenv("POLAR_STATIC_XQ")) h->static_xq = atoi(e) != 0;
-  if (const char *e = getenv("POLAR_POL_FIRST")) h->pol_first = atoi(e) != 0;
-  if (const char *e = getenv("POLAR_LP_WG_PER_CU")) h->lp_wg_per_cu = atoi(e);
-  if (const char *e = getenv("POLAR_LP_QM")) h->lp_quad_major = atoi(e) != 0;
-  if (const char *e = getenv("POLAR_LP_TILES")) h->lp_tiles = atoi(e) == 1 ? 1 : 2;
-  if (const char *e = getenv("POLAR_LP_ROWS")) h->lp_rows = std::max(1, std::min(64, atoi(e)));
-  if (const char *e = getenv("POLAR_LP_PAIRS")) h->lp_pairs = atoi(e) != 0;
-  if (const char *e = getenv("POLAR_CLUSTER_DIST")) h->cluster_dist = atof(e);
-  if (const char *e = getenv("POLAR_CLUSTER_MAX")) h->cluster_max = std::max(1, std::min(4, atoi(e)));
-  if (const char *e = getenv("POLAR_LP_DEPTH")) { int v = atoi(e); h->lp_depth = (v == 2 || v == 3) ? v : 0; }
-  if (const char *e = getenv("POLAR_QUAD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->quad_block = v; }
-  if (const char *e = getenv("POLAR_FIELD_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) h->field_block = v; }
+#include "lab/api_env_knobs.inc"
 #endif
   int n = polar_device_count();
   if (n <= 0 || device < 0 || device >= n) {

@@ -4,312 +4,13 @@
 #include "polar_handle.hpp"
 
 #ifdef POLAR_LAB
-// ---- clusters of rows for k_field_cl and their colouring ------------------------------------------
-// Clusters: greedy, in cell order -- a seed atom takes its nearest unassigned polarizable neighbours while every
-// member stays within cluster_dist of every other (adjacency lists hold the atoms within color_dist, so
-// cluster_dist <= color_dist).  Two clusters conflict when any two of their members are closer than color_dist;
-// DSATUR colours the cluster graph, phases are ordered by the mean rank metric, members by descending rank metric
-// (the in-cluster update is sequential: PS.cpp:1130-1143's "most coupled first", restricted to the cluster).
-void build_cluster_colors(polar_handle *h, const std::vector<double> &rank, const std::vector<std::vector<int>> &cells,
-                          const std::vector<std::vector<int>> &adj) {
-  const int n = h->nlocal;
-  const polar_settings &st = h->ph.st;
-  const bool gs = st.polar_gs || st.polar_gs_ranked;
-  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
-  const double dcl = std::min(h->cluster_dist, h->color_dist), dcl2 = dcl * dcl;
-  auto dist2 = [&](int i, int j) { return min_image_dist2(h->box, &h->hx[3 * (size_t)i], &h->hx[3 * (size_t)j]); };
-  auto row_atom = [&](int i) { return i >= lo && i < hi && h->halpha[i] != 0.0; };
-  std::vector<int> cl_of((size_t)n, -1);
-  std::vector<int> mem;  // 4 per cluster
-  for (const auto &cell : cells)
-    for (int i : cell) {
-      if (!row_atom(i) || cl_of[i] >= 0) continue;
-      const int c = (int)(mem.size() / 4);
-      int m[4] = {i, -1, -1, -1}, cnt = 1;
-      cl_of[i] = c;
-      if (h->cluster_max > 1) {
-        std::vector<std::pair<double, int>> cand;
-        for (int j : adj[i])
-          if (row_atom(j) && cl_of[j] < 0) { const double d2 = dist2(i, j); if (d2 <= dcl2) cand.push_back({d2, j}); }
-        std::sort(cand.begin(), cand.end());
-        for (const auto &cj : cand) {
-          if (cnt >= h->cluster_max) break;
-          bool ok = true;
-          for (int k = 1; k < cnt; k++) ok = ok && dist2(m[k], cj.second) <= dcl2;
-          if (!ok) continue;
-          m[cnt++] = cj.second;
-          cl_of[cj.second] = c;
-        }
-      }
-      if (!rank.empty()) std::stable_sort(m, m + cnt, [&](int a, int b) { return rank[a] > rank[b]; });
-      mem.insert(mem.end(), m, m + 4);
-    }
-  const int ncl = (int)(mem.size() / 4);
-  // cluster graph
-  std::vector<std::vector<int>> cadj((size_t)ncl);
-  if (gs)
-    for (int c = 0; c < ncl; c++) {
-      for (int k = 0; k < 4; k++) {
-        const int a = mem[4 * (size_t)c + k];
-        if (a < 0) continue;
-        for (int b : adj[a]) { const int o = cl_of[b]; if (o >= 0 && o != c) cadj[c].push_back(o); }
-      }
-      std::sort(cadj[c].begin(), cadj[c].end());
-      cadj[c].erase(std::unique(cadj[c].begin(), cadj[c].end()), cadj[c].end());
-    }
-  std::vector<int> color((size_t)ncl, gs ? -1 : 0), satur((size_t)ncl, 0);
-  int ncolors = gs ? 0 : (ncl > 0 ? 1 : 0);
-  if (gs) {
-    std::vector<unsigned long long> seenmask((size_t)ncl, 0ull);
-    struct Key { int sat, deg, idx; };
-    auto lessk = [](const Key &a, const Key &b) {
-      if (a.sat != b.sat) return a.sat < b.sat;
-      if (a.deg != b.deg) return a.deg < b.deg;
-      return a.idx > b.idx;
-    };
-    std::vector<Key> heap;
-    heap.reserve((size_t)ncl * 2);
-    for (int c = 0; c < ncl; c++) heap.push_back(Key{0, (int)cadj[c].size(), c});
-    std::make_heap(heap.begin(), heap.end(), lessk);
-    while (!heap.empty()) {
-      std::pop_heap(heap.begin(), heap.end(), lessk);
-      const Key kx = heap.back();
-      heap.pop_back();
-      const int c = kx.idx;
-      if (color[c] >= 0 || kx.sat != satur[c]) continue;
-      int col = 0;
-      while (col < 64 && ((seenmask[c] >> col) & 1ull)) col++;
-      if (col >= 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
-      color[c] = col;
-      ncolors = std::max(ncolors, col + 1);
-      for (int o : cadj[c]) {
-        if (color[o] >= 0) continue;
-        if (!((seenmask[o] >> col) & 1ull)) {
-          seenmask[o] |= 1ull << col;
-          satur[o]++;
-          heap.push_back(Key{satur[o], (int)cadj[o].size(), o});
-          std::push_heap(heap.begin(), heap.end(), lessk);
-        }
-      }
-    }
-    // balance the phases: DSATUR leaves classes as uneven as 3k / 9k / 6k / 25k clusters, and a phase with few
-    // clusters cannot fill the GPU.  A cluster of the heaviest class moves to the lightest class none of its
-    // neighbours uses, while that narrows the spread (weights = rows per cluster).
-    if (getenv("POLAR_COLOR_BALANCE")) {  // measured: no gain (135k atoms: 246 vs 232 us per sweep), off by default
-      std::vector<long long> wsum((size_t)ncolors, 0);
-      std::vector<int> wcl((size_t)ncl, 0);
-      for (int c = 0; c < ncl; c++) {
-        for (int k = 0; k < 4; k++) wcl[c] += mem[4 * (size_t)c + k] >= 0;
-        wsum[color[c]] += wcl[c];
-      }
-      for (int pass = 0; pass < 8; pass++) {
-        long long moved = 0;
-        for (int c = 0; c < ncl; c++) {
-          const int from = color[c];
-          unsigned long long used = 0ull;
-          for (int o : cadj[c]) used |= 1ull << color[o];
-          int best = -1;
-          for (int k = 0; k < ncolors; k++)
-            if (k != from && !((used >> k) & 1ull) && wsum[k] + wcl[c] < wsum[from] && (best < 0 || wsum[k] < wsum[best])) best = k;
-          if (best >= 0) { wsum[from] -= wcl[c]; wsum[best] += wcl[c]; color[c] = best; moved++; }
-        }
-        if (!moved) break;
-      }
-    }
-    // phase order: colours by descending mean rank metric (ranked flavour) or by descending size
-    std::vector<double> key((size_t)ncolors, 0.0);
-    std::vector<int> cnt((size_t)ncolors, 0), ord((size_t)ncolors), relabel((size_t)ncolors);
-    for (int c = 0; c < ncl; c++)
-      for (int k = 0; k < 4; k++) {
-        const int a = mem[4 * (size_t)c + k];
-        if (a < 0) continue;
-        cnt[color[c]]++;
-        key[color[c]] += rank.empty() ? 1.0 : rank[a];
-      }
-    if (!rank.empty())
-      for (int c = 0; c < ncolors; c++) key[c] /= std::max(cnt[c], 1);
-    std::iota(ord.begin(), ord.end(), 0);
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] > key[b]; });
-    for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
-    for (int c = 0; c < ncl; c++) color[c] = relabel[color[c]];
-  }
-  // clusters sorted by colour (cell order inside a colour, i.e. the order they were formed in)
-  h->color_off.assign((size_t)ncolors + 1, 0);
-  for (int c = 0; c < ncl; c++) h->color_off[color[c] + 1]++;
-  for (int c = 0; c < ncolors; c++) h->color_off[c + 1] += h->color_off[c];
-  std::vector<int> fill(h->color_off.begin(), h->color_off.end() - 1);
-  h->h_cl.assign((size_t)ncl * 4, -1);
-  long long natoms = 0;
-  for (int c = 0; c < ncl; c++) {
-    const int slot = fill[color[c]]++;
-    for (int k = 0; k < 4; k++) { h->h_cl[4 * (size_t)slot + k] = mem[4 * (size_t)c + k]; natoms += mem[4 * (size_t)c + k] >= 0; }
-  }
-  h->ncl = ncl;
-  h->color_nsub = 1; h->color_sub.clear();
-  h->d_cl_orig.ensure((size_t)ncl * 4 + 4);
-  h->d_cl_s.ensure((size_t)ncl + 1);
-  if (ncl > 0) HIPCHECK(hipMemcpy(h->d_cl_orig.p, h->h_cl.data(), (size_t)ncl * 4 * sizeof(int), hipMemcpyHostToDevice));
-  if (getenv("POLAR_DEBUG")) {
-    fprintf(stderr, "[polar] %d clusters of %lld rows (%.2f per cluster, dist %.2f), %d colour phases:", ncl, natoms,
-            ncl ? (double)natoms / ncl : 0.0, dcl, ncolors);
-    for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
-    fprintf(stderr, "\n");
-  }
-  h->color_epoch++;
-  h->colors_valid = true;
-}
-
+#include "lab/color_clusters_host.inc"
 #else
 inline void build_cluster_colors(polar_handle *, const std::vector<double> &, const std::vector<std::vector<int>> &, const std::vector<std::vector<int>> &) { throw std::logic_error("lab build only"); }
 #endif  // POLAR_LAB
 
 #ifdef POLAR_LAB
-// ---- host-side greedy distance colouring for the colour-phase Gauss-Seidel (cutoff mode) ----
-// Atoms of one colour are >= color_dist apart, so the couplings treated Jacobi-style inside a
-// phase are weak and the splitting M = D + L_colour stays convergent for the SPD dipole system
-// (DESIGN.md "colour-phase Gauss-Seidel").  Visit order = ranked order when polar_gs_ranked.
-void build_colors(polar_handle *h, const std::vector<double> &rank) {
-  const int n = h->nlocal;
-  const double dc = h->color_dist, dcsq = dc * dc;
-  int nc[3];
-  long long ncell = 1;
-  double width[3];
-  box_widths(h->box, width);
-  for (int k = 0; k < 3; k++) { nc[k] = std::max(1, (int)std::floor(width[k] / dc)); nc[k] = std::min(nc[k], 512); ncell *= nc[k]; }
-  auto cellof = [&](int i, int c[3]) {
-    double fr3[3];
-    frac_coords(h->box, h->boxlo, h->hx[3 * (size_t)i], h->hx[3 * (size_t)i + 1], h->hx[3 * (size_t)i + 2], fr3);
-    for (int k = 0; k < 3; k++) {
-      double fr = fr3[k];
-      fr -= std::floor(fr);
-      c[k] = std::min(nc[k] - 1, (int)(fr * nc[k]));
-    }
-  };
-  // 1. conflict graph: polarizable atoms closer than color_dist (cell grid of edge >= color_dist)
-  std::vector<std::vector<int>> cells((size_t)ncell);
-  for (int i = 0; i < n; i++) {
-    if (h->halpha[i] == 0.0) continue;  // never updated: needs no phase
-    int c[3];
-    cellof(i, c);
-    cells[((size_t)c[2] * nc[1] + c[1]) * nc[0] + c[0]].push_back(i);
-  }
-  std::vector<std::vector<int>> adj((size_t)n);
-  for (int i = 0; i < n; i++) {
-    if (h->halpha[i] == 0.0) continue;
-    int c[3];
-    cellof(i, c);
-    int seen[27], nseen = 0;
-    for (int dz = -1; dz <= 1; dz++)
-      for (int dy = -1; dy <= 1; dy++)
-        for (int dx = -1; dx <= 1; dx++) {
-          int b[3] = {c[0] + dx, c[1] + dy, c[2] + dz};
-          bool ok = true;
-          for (int k = 0; k < 3; k++) {
-            if (h->box.periodic[k]) b[k] = (b[k] + nc[k]) % nc[k];
-            else if (b[k] < 0 || b[k] >= nc[k]) ok = false;
-          }
-          if (!ok) continue;
-          const int cj = (int)(((size_t)b[2] * nc[1] + b[1]) * nc[0] + b[0]);
-          bool dup = false;
-          for (int t = 0; t < nseen; t++) dup |= seen[t] == cj;
-          if (dup) continue;  // tiny grids: a cell reached through two offsets
-          seen[nseen++] = cj;
-          for (int j : cells[cj]) {
-            if (j == i) continue;
-            const double rsq = min_image_dist2(h->box, &h->hx[3 * (size_t)i], &h->hx[3 * (size_t)j]);
-            if (rsq < dcsq) adj[i].push_back(j);
-          }
-        }
-  }
-  if (h->sweep_kernel == 3) { build_cluster_colors(h, rank, cells, adj); return; }
-  // 2. DSATUR (Brelaz): always colour the vertex that sees the most distinct colours; ties by degree,
-  //    then by index (deterministic: every rank of a multi-GPU run derives the same colouring).
-  //    One colour fewer, and better balanced, than first-fit on the MOF test systems -> one launch
-  //    fewer per sweep.  Lazy max-heap: stale entries are skipped when popped.
-  std::vector<int> color((size_t)n, -1), satur((size_t)n, 0);
-  std::vector<unsigned long long> seenmask((size_t)n, 0ull);  // colours 0..63 seen by the neighbours
-  struct Key { int sat, deg, idx; };
-  auto lessk = [](const Key &a, const Key &b) {
-    if (a.sat != b.sat) return a.sat < b.sat;
-    if (a.deg != b.deg) return a.deg < b.deg;
-    return a.idx > b.idx;
-  };
-  std::vector<Key> heap;
-  heap.reserve((size_t)n * 2);
-  for (int i = 0; i < n; i++)
-    if (h->halpha[i] != 0.0) heap.push_back(Key{0, (int)adj[i].size(), i});
-  std::make_heap(heap.begin(), heap.end(), lessk);
-  int ncolors = 0;
-  while (!heap.empty()) {
-    std::pop_heap(heap.begin(), heap.end(), lessk);
-    const Key kx = heap.back();
-    heap.pop_back();
-    const int i = kx.idx;
-    if (color[i] >= 0 || kx.sat != satur[i]) continue;  // already coloured, or a stale entry
-    int col = 0;
-    while (col < 64 && ((seenmask[i] >> col) & 1ull)) col++;
-    if (col >= 64) throw std::runtime_error("colouring needs more than 64 colours: reduce POLAR_COLOR_DIST");
-    color[i] = col;
-    ncolors = std::max(ncolors, col + 1);
-    for (int j : adj[i]) {
-      if (color[j] >= 0) continue;
-      if (!((seenmask[j] >> col) & 1ull)) {
-        seenmask[j] |= 1ull << col;
-        satur[j]++;
-        heap.push_back(Key{satur[j], (int)adj[j].size(), j});
-        std::push_heap(heap.begin(), heap.end(), lessk);
-      }
-    }
-  }
-  // 3. phase order: "ranked" flavour = colours by descending mean rank metric (PS.cpp:192-227 ranks the
-  //    dipoles most likely to change first); otherwise by descending size.  Relabel accordingly.
-  {
-    std::vector<double> key((size_t)ncolors, 0.0);
-    std::vector<int> cnt((size_t)ncolors, 0), ord((size_t)ncolors), relabel((size_t)ncolors);
-    for (int i = 0; i < n; i++)
-      if (color[i] >= 0) { cnt[color[i]]++; key[color[i]] += rank.empty() ? 1.0 : rank[i]; }
-    if (!rank.empty())
-      for (int c = 0; c < ncolors; c++) key[c] /= std::max(cnt[c], 1);
-    std::iota(ord.begin(), ord.end(), 0);
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] > key[b]; });
-    for (int c = 0; c < ncolors; c++) relabel[ord[c]] = c;
-    for (int i = 0; i < n; i++)
-      if (color[i] >= 0) color[i] = relabel[color[i]];
-  }
-  std::vector<int> rows;
-  rows.reserve(n);
-  h->color_off.assign((size_t)ncolors + 1, 0);
-  // the colouring is global (every rank computes the same one); a sharded handle keeps only its rows
-  const int lo = own_lo(h), hi = own_lo(h) + own_n(h);
-  auto mine = [&](int i) { return color[i] >= 0 && i >= lo && i < hi; };
-  for (int i = 0; i < n; i++)
-    if (mine(i)) h->color_off[color[i] + 1]++;
-  for (int c = 0; c < ncolors; c++) h->color_off[c + 1] += h->color_off[c];
-  rows.resize((size_t)h->color_off[ncolors]);
-  std::vector<int> fill(h->color_off.begin(), h->color_off.end() - 1);
-  // inside a colour, keep the rows in cell order of the colouring grid: neighbouring waves of a
-  // phase then work on neighbouring atoms (shared records in L1/L2)
-  for (auto &cell : cells)
-    for (int i : cell)
-      if (mine(i)) rows[fill[color[i]]++] = i;
-  h->h_rows = rows;
-  h->color_nsub = 1; h->color_sub.clear();
-  h->color_epoch++;  // the launch order changed: dd rows laid out for an earlier colouring are stale (slots_current)
-  h->h_color.assign(color.begin(), color.end());
-  h->d_color_orig.ensure((size_t)n + 1);
-  if (n > 0) HIPCHECK(hipMemcpy(h->d_color_orig.p, h->h_color.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-  h->colors_rebuilt++;
-  h->d_rows_orig.ensure(rows.size() + 1);
-  h->d_rows.ensure(rows.size() + 1);
-  if (!rows.empty()) HIPCHECK(hipMemcpy(h->d_rows_orig.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
-  if (getenv("POLAR_DEBUG")) {
-    fprintf(stderr, "[polar] %d colour phases (dist %.2f):", ncolors, h->color_dist);
-    for (int c = 0; c < ncolors; c++) fprintf(stderr, " %d", h->color_off[c + 1] - h->color_off[c]);
-    fprintf(stderr, "\n");
-  }
-  h->colors_valid = true;
-}
-
+#include "lab/color_host_dsatur.inc"
 #else
 inline void build_colors(polar_handle *, const std::vector<double> &) { throw std::logic_error("host-side colouring: lab build only"); }
 #endif  // POLAR_LAB
@@ -537,18 +238,7 @@ void color_finish(polar_handle *h, bool ranked, int ncolors) {
                                                h->d_rows_orig.p, lo, hi, sub, nsub);
   lap("phase order + rows");
 #ifdef POLAR_LAB
-  if (getenv("POLAR_LP_SORT_T") && tot > 0) {   // lab: inside a phase the rows with the most trips first (stable: cell order inside a trip count)
-    std::vector<int> rows((size_t)tot), cnt((size_t)n), inv((size_t)n);
-    HIPCHECK(hipMemcpyAsync(rows.data(), h->d_rows_orig.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(cnt.data(), h->d_dd_cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(inv.data(), h->d_inv.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    for (int c = 0; c < ncolors; c++)
-      std::stable_sort(rows.begin() + h->color_off[c], rows.begin() + h->color_off[c + 1],
-                       [&](int a, int b) { return (cnt[inv[a]] + 63) / 64 > (cnt[inv[b]] + 63) / 64; });
-    HIPCHECK(hipMemcpyAsync(h->d_rows_orig.p, rows.data(), (size_t)tot * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHECK(hipStreamSynchronize(s));
-  }
+#include "lab/color_sort_by_trips.inc"
 #endif
   h->h_color.assign((size_t)n, 0);  // (its size says "a colouring for n atoms exists": the colours themselves live on the device)
   h->color_epoch++;

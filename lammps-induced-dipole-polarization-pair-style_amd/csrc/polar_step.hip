@@ -250,23 +250,7 @@ void launch_field_dyn(polar_handle *h, bool ap, int nrows, const int *rows) {
 }
 
 #ifdef POLAR_LAB
-// list-mode production sweep: component-per-lane quads (k_field_quad), one wave per row
-template <int EP>
-void launch_field_quad(polar_handle *h, int nrows, const int *rows) {
-  if (nrows <= 0) return;
-  const polar_settings &st = h->ph.st;
-  const int qb = h->quad_block;
-#define FQ(M) k_field_quad<EP, M><<<nblk_xcd(nrows, qb / 64), qb, 0, h->stream>>>(                 \
-      nrows, rows, h->d_rec0.p, h->d_rec1.p, h->box, RowList{h->d_dd_cnt.p, h->dd_pitch}, h->d_dd_j.p, h->d_dd_s.p, \
-      h->d_dd_r2.p, st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
-  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
-  if (h->stream_mode == 0) FQ(0);
-  else if (h->stream_mode == 2) { if (expd) FQ(3); else FQ(4); }
-  else if (expd) FQ(1);
-  else FQ(2);
-#undef FQ
-}
-
+#include "lab/launch_quad.inc"
 #else
 template <int EP> inline void launch_field_quad(polar_handle *, int, const int *) { throw std::logic_error("lab build only"); }
 #endif  // POLAR_LAB
@@ -314,37 +298,10 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
       st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, omega, h->d_lp_pend.p POLAR_LAB_ARG)
   const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
 #ifdef POLAR_LAB
-  if (h->lp_depth >= 2) {  // gathers kept lp_depth trips ahead (hand-counted waits), four tiles per wave
-    const int pb = std::min(qb, 256);
-    const size_t plds = (size_t)(pb / 64) * 4 * POLAR_LP_TILE;
-#define FA(D, DEPTH) k_field_lpa<EP, D, DEPTH><<<nblk_xcd(nrows, pb / 64), pb, plds, h->stream>>>(                  \
-      nrows, row0, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                                     \
-      st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
-    if (h->lp_depth == 2) { if (expd) FA(0, 2); else FA(1, 2); }
-    else                  { if (expd) FA(0, 3); else FA(1, 3); }
-#undef FA
-    return;
-  }
-  if (nt == 1 && !det) { if (expd) FL(0, 1, false); else FL(1, 1, false); return; }
+#include "lab/launch_lpa.inc"
 #endif
 #ifdef POLAR_LAB
-  if (h->lp_rows > 1 && qb <= 256) {  // several launch rows per wave (k_field_lpr)
-    const int R = h->lp_rows;
-    const size_t rlds = (size_t)(qb / 64) * 2 * POLAR_LP_TILE;
-#define FR(D, DT) k_field_lpr<EP, D, DT><<<nblk_xcd(nrows, (qb / 64) * R), qb, rlds, h->stream>>>(                         \
-      nrows, row0, desc, h->d_rec0.p, h->d_rec1.p, h->box, h->dd_pitch, h->d_dd_j.p,                               \
-      st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, omega, h->d_lp_pend.p, R)
-    if (det) { if (expd) FR(0, true); else FR(1, true); }
-    else     { if (expd) FR(0, false); else FR(1, false); }
-#undef FR
-    if (det) {
-      int launch_no = 0;
-      if (EP == EP_INPLACE) while (launch_no + 1 < (int)h->color_off.size() && h->color_off[launch_no] < row0) launch_no++;
-      k_lp_commit<<<nblk(nrows, 256), 256, 0, h->stream>>>(nrows, row0, desc, h->d_lp_pend.p, h->d_rec0.p, h->d_rec1.p, EP == EP_JACOBI ? 1 : 0,
-                                                        h->d_scal.p, h->d_lp_part.p + row0 / 256 + launch_no);
-    }
-    return;
-  }
+#include "lab/launch_lpr.inc"
 #endif
   if (det) {
     if (expd) FL(0, 2, true); else FL(1, 2, true);
@@ -362,104 +319,7 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
 }
 
 #ifdef POLAR_LAB
-// cluster sweep (k_field_cl): one wave per cluster, clusters [first, first + ncl) of the colour-sorted table
-template <int EP>
-void launch_field_cl(polar_handle *h, int ncl, int first) {
-  if (ncl <= 0) return;
-  const polar_settings &st = h->ph.st;
-  const int qb = std::min(h->quad_block, 256);
-  const int nt = h->lp_tiles;
-  const size_t lds = (size_t)(qb / 64) * nt * POLAR_LP_TILE;
-#define FC(D, NT) k_field_cl<EP, D, NT><<<nblk_xcd(ncl, qb / 64), qb, lds, h->stream>>>(                              \
-      ncl, first, h->d_cl_s.p, h->d_cl_tw.p, h->d_rec0.p, h->d_rec1.p, h->box, h->cl_pitch, h->d_dd_j.p,              \
-      st.dd_cutoff * st.dd_cutoff, st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, h->ablate)
-  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
-  if (nt == 1) { if (expd) FC(0, 1); else FC(1, 1); }
-  else         { if (expd) FC(0, 2); else FC(1, 2); }
-#undef FC
-}
-
-// ---- tile sweep: per-step tables (polar_tiles.hpp) ---------------------------------------------------
-inline size_t tile_lds_bytes(int records) { return POLAR_TILE_LDS_REC + (size_t)(records + 1) * sizeof(SRec) + POLAR_TILE_LDS_SLACK; }
-inline int tile_lds_cap() { return (int)((160 * 1024 - POLAR_TILE_LDS_REC - POLAR_TILE_LDS_SLACK - 256) / sizeof(SRec)) - 1; }  // records one workgroup can stage at all
-void build_tiles(polar_handle *h) {
-  const polar_settings &st = h->ph.st;
-  const int n = h->nlocal;
-  hipStream_t s = h->stream;
-  const double rc = st.dd_cutoff;
-  if (h->un_pitch == 0) {
-    long long npol = 0;
-    for (int a = 0; a < n; a++) npol += h->halpha[a] != 0.0;
-    const double dens = (h->dens > 0.0 ? h->dens : n / (h->box.prd[0] * h->box.prd[1] * h->box.prd[2])) * (double)npol / std::max(n, 1);
-    double e[3];
-    for (int k = 0; k < 3; k++) e[k] = h->box.prd[k] / h->grid.nc[k];
-    // what a cell's rows can see: the cell widened by the cutoff (Minkowski sum of a box and a sphere)
-    const double vol = e[0] * e[1] * e[2] + 2.0 * (e[0] * e[1] + e[1] * e[2] + e[0] * e[2]) * rc + M_PI * (e[0] + e[1] + e[2]) * rc * rc +
-                       4.18879020478639 * rc * rc * rc;
-    h->un_pitch = (int)(((long long)(1.25 * dens * vol) + 64 + 63) / 64 * 64);
-    h->pitch16 = ((long long)(1.5 * dens * 4.18879020478639 * rc * rc * rc) + 64 + 511) / 512 * 512;
-    if (const char *ip = getenv("POLAR_INIT_PITCH")) {  // tests: force the overflow paths
-      h->un_pitch = std::max(64, atoi(ip) / 64 * 64);
-      h->pitch16 = 512;
-    }
-    h->un_lds = 0;
-  }
-  if (h->un_pitch > tile_lds_cap()) throw TileUnavailable("tile sweep: a cell's neighbourhood does not fit the LDS of a compute unit");
-  if (h->un_lds <= 0 || h->un_lds > h->un_pitch) h->un_lds = h->un_pitch;
-  const long long ncell = h->ncell;
-  h->d_thdr.ensure((size_t)ncell + 1); h->d_trow.ensure((size_t)n + 1);
-  {  // the sweep requests entry words before it knows how many a tile holds: the table never contains stale garbage
-    const int *before = h->d_un_j.p;
-    h->d_un_j.ensure((size_t)ncell * h->un_pitch + 64);
-    if (h->d_un_j.p != before) HIPCHECK(hipMemsetAsync(h->d_un_j.p, 0, h->d_un_j.cap * sizeof(int), s));
-  }
-  h->d_dd16.ensure((size_t)std::max(n, 1) * h->pitch16 + 1024);
-  h->d_srec0.ensure((size_t)n + 1); h->d_srec1.ensure((size_t)n + 1);
-  if (deterministic(h)) h->d_pend.ensure(3 * (size_t)n + 3);
-  // (build_lists has just zeroed the flag words and the pair totals; its own k_nl_build lists no dd pair in this mode)
-  const size_t lds = 24 * (size_t)h->un_pitch + (4 * 128 + 2 * POLAR_TILE_MAXROWS) * sizeof(int) + 24 * sizeof(double) + 12 * sizeof(int) + 16;
-  if (lds > h->tile_build_lds_attr) {
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    h->tile_build_lds_attr = lds;
-  }
-  const int cap = std::min(h->un_pitch, h->un_lds);
-  k_tile_build<<<(int)ncell, 256, lds, s>>>(h->grid, h->box, h->d_pos4.p, h->d_cell_first.p, h->d_cell_fill.p, h->d_perm.p, own_lo(h),
-                                            own_lo(h) + own_n(h), rc * rc, h->color_dist * h->color_dist, h->tile_waves, h->tile_sw[0], h->tile_sw[1], h->tile_sw[2], cap, h->d_un_j.p, h->pitch16,
-                                            h->d_dd16.p, h->d_thdr.p, h->d_trow.p, h->d_rec0.p, h->d_overflow.p, h->d_ddtot.p);
-  HIPCHECK(hipMemcpyAsync(h->h_flags + 5, h->d_overflow.p + 5, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-}
-// NOTE: the builder indexes the union lists with the pitch it is given (`cap`), so the sweep must use the same value
-inline int tile_pitch(const polar_handle *h) { return std::min(h->un_pitch, h->un_lds); }
-
-template <int EP>
-void launch_field_tile(polar_handle *h, const TileLaunch &L) {
-  const polar_settings &st = h->ph.st;
-  const long long nt = (long long)L.count[0] * L.count[1] * L.count[2];
-  if (nt <= 0) return;
-  const bool expd = st.damping_type == POLAR_DAMP_EXPONENTIAL;
-  const bool det = deterministic(h) && EP == EP_INPLACE;
-  size_t lds = tile_lds_bytes(tile_pitch(h));
-  if (const char *e = getenv("POLAR_TILE_LDS_PAD")) lds += (size_t)atoi(e);  // LAB (temporary): residency experiment
-  const int inst = ((EP == EP_JACOBI ? 0 : (det ? 2 : 1)) * 2 + (expd ? 0 : 1)) * 2 + (h->tile_waves == 8 ? 1 : 0);
-#define FT(D, DT, W)                                                                                                           \
-  {                                                                                                                            \
-    if (lds > h->tile_lds_attr[inst]) {                                                                                        \
-      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_tile<EP, D, DT, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      h->tile_lds_attr[inst] = lds;                                                                                            \
-    }                                                                                                                          \
-    k_field_tile<EP, D, DT, W><<<nblk_xcd(nt, 1), 64 * W, lds, h->stream>>>(L, h->d_thdr.p, h->d_trow.p, h->d_un_j.p, tile_pitch(h),   \
-        h->d_dd16.p, h->pitch16, h->d_srec0.p, h->d_srec1.p, h->d_pend.p, h->d_ef_s.p, h->box, st.polar_damp,       \
-        make_expcoef(), h->d_scal.p, h->d_slots.p, h->nlocal);                                                                   \
-  }
-#define FW(D, DT) { if (h->tile_waves == 8) FT(D, DT, 8) else FT(D, DT, 4) }
-  if (det) { if (expd) FW(0, true) else FW(1, true) }
-  else     { if (expd) FW(0, false) else FW(1, false) }
-#undef FW
-#undef FT
-  if (det) k_tile_commit<<<(int)nt, 64, 0, h->stream>>>(L, h->d_thdr.p, h->d_trow.p, h->d_pend.p, h->d_srec0.p, h->d_scal.p);
-}
-
+#include "lab/launch_cluster_tile.inc"
 #else
 template <int EP> inline void launch_field_cl(polar_handle *, int, int) { throw std::logic_error("lab build only"); }
 inline size_t tile_lds_bytes(int) { return 0; }
@@ -470,64 +330,7 @@ template <int EP> inline void launch_field_tile(polar_handle *, const TileLaunch
 
 // one sweep over the rows this handle owns (Jacobi, or the colour phases)
 #ifdef POLAR_LAB
-// paired rows (lab): this step's units and their union lists; needs the colour rows in s space (map_color_rows) and the cells
-void build_units(polar_handle *h) {
-  const polar_settings &st = h->ph.st;
-  hipStream_t s = h->stream;
-  const bool gs = st.polar_gs || st.polar_gs_ranked;
-  PhaseOff P;
-  if (gs) {
-    P.n = (int)h->color_off.size() - 1;
-    if (P.n > 64) throw InputError("paired rows: more than 64 colour phases");
-    for (int q = 0; q <= P.n; q++) P.off[q] = h->color_off[q];
-  } else { P.n = 1; P.off[0] = 0; P.off[1] = own_n(h); }
-  const int tot = P.off[P.n];
-  h->unit_off.assign((size_t)P.n + 1, 0);
-  if (tot <= 0) return;
-  const int *rows = gs ? h->d_rows.p : own_rows(h);
-  h->d_ulead.ensure((size_t)tot + 1); h->d_upos.ensure((size_t)tot + 2); h->d_unit.ensure((size_t)tot + 1); h->d_udesc.ensure((size_t)tot + 1);
-  k_unit_flag<<<nblk(tot, 256), 256, 0, s>>>(tot, rows, h->d_perm.p, h->d_cell_id.p, P, h->d_ulead.p);
-  launch_scan((long long)tot, h->d_ulead.p, h->d_upos.p, h->d_scan_a, s);
-  k_unit_fill<<<nblk(tot, 256), 256, 0, s>>>(tot, rows, h->d_perm.p, h->d_cell_id.p, P, h->d_ulead.p, h->d_upos.p, h->d_unit.p);
-  std::vector<long long> first((size_t)P.n + 1);
-  for (int q = 0; q <= P.n; q++)
-    HIPCHECK(hipMemcpyAsync(&first[q], h->d_upos.p + P.off[q], sizeof(long long), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
-  for (int q = 0; q <= P.n; q++) h->unit_off[q] = (int)first[q];
-  const int nunits = h->unit_off[P.n];
-  if (h->upitch == 0) h->upitch = ((h->dd_pitch * 3 / 2 + 255) / 256) * 256;
-  for (int attempt = 0;; attempt++) {
-    h->d_udd_j.ensure((size_t)nunits * h->upitch + 1024);
-    zero_many(s, {{h->d_overflow.p + 4, 4 * sizeof(int)}, {h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long)}});
-    if (h->box.triclinic)
-      k_dd_units<true><<<nblk(nunits, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(nunits, h->d_unit.p, h->d_pos4.p, h->box, h->grid, h->d_cell_first.p, st.dd_cutoff * st.dd_cutoff,
-                                                                                 h->upitch, h->d_udd_j.p, h->d_udesc.p, h->lp_quad_major ? 1 : 0, h->nlocal, h->d_overflow.p + 4, h->d_ddtot.p);
-    else
-      k_dd_units<false><<<nblk(nunits, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(nunits, h->d_unit.p, h->d_pos4.p, h->box, h->grid, h->d_cell_first.p, st.dd_cutoff * st.dd_cutoff,
-                                                                                  h->upitch, h->d_udd_j.p, h->d_udesc.p, h->lp_quad_major ? 1 : 0, h->nlocal, h->d_overflow.p + 4, h->d_ddtot.p);
-    int over = 0;
-    HIPCHECK(hipMemcpyAsync(&over, h->d_overflow.p + 4, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    if (over <= h->upitch) break;
-    if (attempt > 2) throw std::runtime_error("paired rows: union list pitch overflow persists");
-    h->upitch = (((long long)over * 9 / 8 + 255) / 256) * 256;
-  }
-  if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] paired rows: %d units for %d rows, union pitch %lld\n", nunits, tot, h->upitch);
-}
-template <int EP>
-void launch_field_lp2(polar_handle *h, int q) {
-  const int nunits = h->unit_off[q + 1] - h->unit_off[q];
-  if (nunits <= 0) return;
-  const polar_settings &st = h->ph.st;
-  const size_t lds = (size_t)4 * 2 * POLAR_LP_TILE;
-  const double omega = EP == EP_INPLACE ? st.polar_sor : 1.0;
-  if (st.damping_type == POLAR_DAMP_EXPONENTIAL)
-    k_field_lp2<EP, 0><<<nblk_xcd(nunits, 4), 256, lds, h->stream>>>(nunits, (long long)h->unit_off[q], h->d_udesc.p, h->d_rec0.p, h->d_rec1.p, h->box, h->upitch,
-                                                                     h->d_udd_j.p, st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, omega);
-  else
-    k_field_lp2<EP, 1><<<nblk_xcd(nunits, 4), 256, lds, h->stream>>>(nunits, (long long)h->unit_off[q], h->d_udesc.p, h->d_rec0.p, h->d_rec1.p, h->box, h->upitch,
-                                                                     h->d_udd_j.p, st.polar_damp, make_expcoef(), h->d_ef_s.p, h->d_scal.p, h->d_slots.p, omega);
-}
+#include "lab/build_units_paired_rows.inc"
 #endif
 
 void sweep_once(polar_handle *h, bool ap) {
@@ -621,25 +424,7 @@ void read_scal(polar_handle *h) {
   HIPCHECK(hipStreamSynchronize(h->stream));
 }
 #ifdef POLAR_LAB
-// cluster mode, per step: members -> s space, union lists, descriptors (needs the colours AND this step's cell order)
-void build_cluster_lists(polar_handle *h) {
-  const polar_settings &st = h->ph.st;
-  hipStream_t s = h->stream;
-  const int ncl = h->ncl;
-  if (h->cl_pitch == 0) h->cl_pitch = ((h->dd_pitch * 5 / 4 + 255) / 256) * 256;
-  h->d_cl_cnt.ensure(ncl + 1); h->d_cl_wrap.ensure(ncl + 1); h->d_cl_tw.ensure(ncl + 1);
-  h->d_dd_j.ensure((size_t)std::max(ncl, 1) * h->cl_pitch + 256);
-  if (ncl <= 0) return;
-  k_map_rows_pad<<<nblk(4 * (long long)ncl, 256), 256, 0, s>>>(4 * ncl, h->d_inv.p, h->d_cl_orig.p, reinterpret_cast<int *>(h->d_cl_s.p));
-  zero_many(s, {{h->d_overflow.p + 4, 4 * sizeof(int)}, {h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long)}});
-  k_cl_build<<<nblk(ncl, POLAR_ROWS_PER_BLOCK), POLAR_BLOCK, 0, s>>>(
-      ClusterRows{h->d_cl_s.p, ncl}, h->d_pos4.p, h->box, h->grid, h->d_cell_first.p, st.dd_cutoff * st.dd_cutoff, h->cl_pitch,
-      h->d_cl_cnt.p, h->d_dd_j.p, h->nlocal, h->d_cl_wrap.p, h->d_overflow.p + 4, h->d_ddtot.p);
-  k_cl_desc<<<nblk(ncl, 256), 256, 0, s>>>(ncl, h->d_cl_cnt.p, h->cl_pitch, h->d_cl_wrap.p, h->d_cl_tw.p);
-  HIPCHECK(hipMemcpyAsync(h->h_flags + 4, h->d_overflow.p + 4, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipMemcpyAsync(h->h_ddtot, h->d_ddtot.p, 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-}
-
+#include "lab/build_cluster_lists.inc"
 #else
 void build_cluster_lists(polar_handle *) { throw std::logic_error("lab build only"); }
 #endif  // POLAR_LAB

@@ -80,3 +80,28 @@ def test_exact_mode_block_sweep_stays_light(usage):
         assert v["VGPRs"] <= 64, (k, v)
     for k, v in _pick(usage, "k_gs_gemm").items():
         assert v["VGPRs"] <= 128, (k, v)
+
+
+def test_product_translation_units_never_include_lab_code():
+    """the shelved kernels and host code live under csrc/lab/ and reach a translation unit only inside
+    `#ifdef POLAR_LAB`.  The dependency list of every translation unit WITHOUT -DPOLAR_LAB names no file of csrc/lab/; with it,
+    it does; and the built product library holds none of the lab kernels."""
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    seen_lab = set()
+    for src in SRCS:
+        for flags, want in (([], False), (["-DPOLAR_LAB"], True)):
+            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-MM", "--cuda-host-only"] + flags + [src],
+                               capture_output=True, text=True, cwd=CSRC)
+            assert r.returncode == 0, r.stderr[-2000:]
+            deps = [d for d in r.stdout.replace("\\\n", " ").split() if "/lab/" in d or d.startswith("lab/")]
+            if not want:
+                assert deps == [], (os.path.basename(src), deps)
+            seen_lab.update(os.path.basename(d) for d in deps)
+    on_disk = {f for f in os.listdir(os.path.join(CSRC, "lab")) if f.endswith((".hpp", ".inc"))}
+    assert seen_lab == on_disk, (sorted(on_disk - seen_lab), sorted(seen_lab - on_disk))    # (every lab file is reachable from the lab build, none is dead)
+    so = os.path.join(os.path.dirname(CSRC), "libpolar_mi355x.so")
+    if os.path.exists(so):
+        blob = open(so, "rb").read()
+        for name in (b"k_field_tile", b"k_field_quad", b"k_field_lpr", b"k_field_lp2", b"k_field_cl", b"k_region_sub", b"POLAR_ABLATE", b"POLAR_PIPELINE"):
+            assert name not in blob, name
