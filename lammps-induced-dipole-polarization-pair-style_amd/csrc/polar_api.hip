@@ -39,6 +39,33 @@ void upload_coul(polar_handle *h, double g_ewald, double qqrd2e, const double *s
   h->d_tab.ensure(8 * nt);
   HIPCHECK(hipMemcpy(h->d_tab.p, pack.data(), 8 * nt * sizeof(double), hipMemcpyHostToDevice));
   h->P.ctab = h->d_tab.p;
+  // How k_ljcoul_pers may find a pair's bin (polar_rows.hpp, ljcoul_row TAB): checked here, bin by bin, against the tables the
+  // caller handed over (Pair::init_tables, src/pair.cpp): r = a float whose low `shift` mantissa bits are zero and whose masked
+  // bits give the bin's own index; dr = the reciprocal of one bin step of that binade, an exact power of two.  Up to two bins may
+  // carry another dr (the last bin before the cutoff gets 1 / (cut_coulsq - r); the bin where the index wraps): they travel as
+  // parameters.  Anything else -> the tables stay in memory for r and dr (TAB 1).
+  h->P.tab_lowmask = nbits ? (1 << shift) - 1 : 0;
+  h->P.i_special[0] = h->P.i_special[1] = -1;
+  h->P.dr_special[0] = h->P.dr_special[1] = 0.0;
+  h->lj_tab_arith = false;
+  if (nbits) {
+    bool ok = shift > 0 && shift < 23;
+    int nspecial = 0;
+    for (size_t b = 0; b < nt && ok; b++) {
+      const double r = t[0][b], dr = t[1][b];
+      const float rf = (float)r;
+      int bits;
+      memcpy(&bits, &rf, sizeof(int));
+      if ((double)rf != r || (bits & h->P.tab_lowmask) != 0 || (size_t)((bits & mask) >> shift) != b) { ok = false; break; }
+      const int e = (bits >> 23) & 0xFF;
+      const double want = std::ldexp(1.0, 150 - shift - e);
+      if (dr != want) {
+        if (nspecial < 2) { h->P.i_special[nspecial] = (int)b; h->P.dr_special[nspecial] = dr; nspecial++; }
+        else ok = false;
+      }
+    }
+    h->lj_tab_arith = ok;
+  }
   h->coul_set = true;
 }
 }  // namespace
@@ -182,6 +209,8 @@ int polar_create(int device, polar_handle **out) {
     for (auto &e : h->ev_fchunk) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHECK(hipStreamCreateWithFlags(&h->dl_stream, hipStreamNonBlocking));
     if (getenv("POLAR_NO_OVERLAP")) h->overlap_lj = false;
+    if (const char *e = getenv("POLAR_LJ_PERS")) h->lj_pers = atoi(e);
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) h->ncu = ncu; }
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
     HIPCHECK(hipHostMalloc((void **)&h->h_flags, 16 * sizeof(int)));
     HIPCHECK(hipHostMalloc((void **)&h->h_ddtot, 64 * 16 * sizeof(unsigned long long)));

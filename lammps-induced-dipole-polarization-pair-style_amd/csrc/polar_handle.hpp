@@ -36,7 +36,7 @@
 using namespace polar;
 
 // bump when a kernel on the hot path changes: PMC files under profiles/ are keyed by it (bench.py, roofline.traffic)
-#define POLAR_KERNEL_VERSION "r04-lp3-v3"
+#define POLAR_KERNEL_VERSION "r05-lp3-v3"
 #define POLAR_MAX_CLASS_OFF 130   // phase classes of a colouring + 1: up to 64 colours, each split into boundary / interior rows on a sharded handle
 
 
@@ -242,6 +242,9 @@ struct polar_handle {
   long long lj_pitch = 0;
   DBuf<double4> d_ljpos; DBuf<int2> d_ljaux; DBuf<int> d_tag, d_nspecial, d_special, d_ljcell_id, d_ljcell_cnt, d_ljcell_fill; DBuf<long long> d_ljcell_first; DBuf<double> d_cutneighsq;
   int lj_typed = 1;              // LJ/Coulomb list entries carry the partner's type (POLAR_LJ_TYPED=0)
+  bool lj_tab_arith = false;     // the Coulomb tables are regular: a bin's r and dr can be rebuilt from the bits of (float)rsq (upload_coul)
+  int lj_pers = 1;               // a3 as the persistent kernel with the Coulomb bins in LDS where they fit (POLAR_LJ_PERS=0: one wave per row, bins from memory)
+  int ncu = 0;                   // compute units of the device
   bool sym_typed = false, dev_typed = false;
   int static_xq = 1;             // the static-field rows gather 32-byte {x, y, z, q} records instead of whole AtomRecs (POLAR_STATIC_XQ=0)
   int pol_first = 1;             // polarizable atoms first inside a cell (POLAR_POL_FIRST=0: arrival order)

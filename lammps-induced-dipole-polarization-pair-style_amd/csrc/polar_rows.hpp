@@ -162,6 +162,9 @@ struct LJCoulParams {
   int ncoultablebits, ncoulmask, ncoulshiftbits;
   int ablate;     // lab switch (POLAR_ABLATE & 32: no deposit on j)
   int typed_list; // list entries carry the partner's type in bits 24-29 (index in bits 0-23)
+  int tab_lowmask;     // (1 << ncoulshiftbits) - 1: the mantissa bits of (float)rsq below a bin's resolution
+  int i_special[2];    // bins whose drtable is not the regular 2^k (the last bin before the cutoff, the wrap of the index), -1: none
+  double dr_special[2];
   double tabinnersq, cut_coulsq, g_ewald, qqrd2e;
   double special_lj[4], special_coul[4];
   const double *ljpack;   // [(ntypes+1)^2][8] = cutsq, cut_ljsq, lj1, lj2, lj3, lj4, offset, pad
@@ -221,32 +224,29 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_sym_fill(int inum, const
 // one 4-byte gather of the type, the type-pair parameters out of LDS, and the Coulomb bin as one
 // 64-byte line -- the loop is bound by L1 transactions and by the three FP64 atomics that deposit
 // -F on j (LAMMPS' newton-on contract: ghosts are folded back by reverse_comm).
-template <bool EFLAG, bool VPAIR>
-static __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum, const int *__restrict__ ilist,
-                                                        const int *__restrict__ numneigh,
-                                                        const long long *__restrict__ first,
-                                                        const int *__restrict__ neigh,
-                                                        const double4 *__restrict__ xq, const int *__restrict__ type,
-                                                        double *__restrict__ f, double *__restrict__ slots,
-                                                        double *__restrict__ eatom, double *__restrict__ vatom,
-                                                        int vglobal) {
+// The work of ONE row (one wave).  TAB: where a pair finds its Coulomb bin (PS.cpp:268-285 reads rtable / drtable / ftable /
+// dftable / etable / detable / ctable / dctable):
+//   0  every table from memory, one 64-byte line per bin (three scattered 16-byte loads per pair);
+//   1  {f, df, e, de} of every bin from LDS (`ctab_lds`, 32 B per bin: 128 KB at the 12 table bits LAMMPS defaults to), {r, dr}
+//      from memory;
+//   2  {f, df, e, de} from LDS and r, dr REBUILT from the bits of (float)rsq: r = the float with its low `shift` mantissa bits
+//      cleared, dr = 2^(23 - shift - exponent) -- what Pair::init_tables stores for every regular bin (checked bin by bin on the
+//      host when the tables arrive, upload_coul; the at most two irregular bins -- the last one before the cutoff, the wrap of
+//      the index -- carry their dr in P.dr_special).  No table load is left per pair, only the (rare) special-bond correction.
+// The vector-memory unit was 80 % busy in the TAB 0 kernel, on 64 distinct lines per gather instruction and five such
+// instructions per trip: that, not the arithmetic and not the locality of the {x,y,z,q} gathers (profiles/r05_lab_ljcoul.txt),
+// bounded it.  Sums of a wave over the rows it walks stay in registers (esum / vsum) until the caller adds them to a slot.
+template <bool EFLAG, bool VPAIR, int TAB>
+__device__ __forceinline__ void ljcoul_row(const LJCoulParams &P, int i, int jnum, const int *__restrict__ jlist, const double4 pi,
+                                           const double4 *__restrict__ xq, const int *__restrict__ type, const double *lj_lds,
+                                           const double4 *ctab_lds, int lane, double *__restrict__ f, double *__restrict__ eatom,
+                                           double *__restrict__ vatom, double &ev_sum, double &ec_sum, double (&vsum)[6]) {
   const double EWALD_F = 1.12837917, EWALD_P = 0.3275911, A1 = 0.254829592, A2 = -0.284496736, A3 = 1.421413741,
                A4 = -1.453152027, A5 = 1.061405429;  // PS.cpp:43-49
-  extern __shared__ double lj_lds[];
   const int w = P.ntypes + 1;
-  for (int t = threadIdx.x; t < w * w * 8; t += blockDim.x) lj_lds[t] = P.ljpack[t];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int ii = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (ii >= inum) return;
-  const int i = ilist ? ilist[ii] : ii;
-  const double4 pi = xq[i];
   // row data is the same in every lane: scalar registers (see wave_uniform)
   const double qtmp = wave_uniform(pi.w), xtmp = wave_uniform(pi.x), ytmp = wave_uniform(pi.y), ztmp = wave_uniform(pi.z);
   const int itype = __builtin_amdgcn_readfirstlane(type[i]);
-  const int *jlist = neigh + first[i];
-  const int jnum = numneigh ? numneigh[i] : (int)(first[i + 1] - first[i]);
-  if (jnum == 0) return;
   double fx = 0, fy = 0, fz = 0, ev = 0, ec = 0;
   double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
   // software prefetch, two trips deep: the index of trip t+2 and the {x,y,z,q} of trip t+1 travel while
@@ -285,10 +285,24 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, i
           if (factor_coul < 1.0) forcecoul -= (1.0 - factor_coul) * prefactor;
         } else {
           const float rsqf = (float)rsq;  // union_int_float_t lookup, PS.cpp:268-272
-          const int itable = (__float_as_int(rsqf) & P.ncoulmask) >> P.ncoulshiftbits;
+          const int rbits = __float_as_int(rsqf);
+          const int itable = (rbits & P.ncoulmask) >> P.ncoulshiftbits;
           const double2 *bin = reinterpret_cast<const double2 *>(P.ctab + (size_t)itable * 8);
-          const double2 rdr = bin[0], fdf = bin[1];
-          if (EFLAG) tab_e = bin[2];
+          double2 rdr, fdf;
+          if (TAB == 2) {
+            rdr.x = (double)__int_as_float(rbits & ~P.tab_lowmask);
+            rdr.y = __hiloint2double((1173 - P.ncoulshiftbits - ((rbits >> 23) & 0xFF)) << 20, 0);   // 2^(23 - shift - (e - 127))
+            if (itable == P.i_special[0]) rdr.y = P.dr_special[0];
+            if (itable == P.i_special[1]) rdr.y = P.dr_special[1];
+          } else rdr = bin[0];
+          if (TAB == 0) {
+            fdf = bin[1];
+            if (EFLAG) tab_e = bin[2];
+          } else {
+            const double4 t4 = ctab_lds[itable];
+            fdf = make_double2(t4.x, t4.y);
+            if (EFLAG) tab_e = make_double2(t4.z, t4.w);
+          }
           fraction = ((double)rsqf - rdr.x) * rdr.y;
           forcecoul = qiqj * (fdf.x + fraction * fdf.y);
           if (factor_coul < 1.0) {
@@ -334,26 +348,98 @@ static __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, i
   }
   if (EFLAG) {
     ev = wave_sum(ev); ec = wave_sum(ec);
-    if (lane == 0) {
-      atomicAdd(slot_ptr(slots, SL_EVDWL), ev); atomicAdd(slot_ptr(slots, SL_ECOUL), ec);
-      // per-atom energy, src/pair.cpp:881-885: every pair of a full row carries weight 1/2, so the
-      // row total IS eatom[i] (one wave per row: plain store-add, no atomics)
-      if (eatom) eatom[i] += ev + ec;
-    }
+    ev_sum += ev; ec_sum += ec;
+    // per-atom energy, src/pair.cpp:881-885: every pair of a full row carries weight 1/2, so the
+    // row total IS eatom[i] (one wave per row: plain store-add, no atomics)
+    if (lane == 0 && eatom) eatom[i] += ev + ec;
   }
   if (VPAIR) {
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
-    if (lane == 0) {
-      if (vglobal) {
-        atomicAdd(slot_ptr(slots, SL_V0), v0); atomicAdd(slot_ptr(slots, SL_V1), v1); atomicAdd(slot_ptr(slots, SL_V2), v2);
-        atomicAdd(slot_ptr(slots, SL_V3), v3); atomicAdd(slot_ptr(slots, SL_V4), v4); atomicAdd(slot_ptr(slots, SL_V5), v5);
-      }
-      if (vatom) {  // src/pair.cpp:925-942
-        double *va = vatom + 6 * (size_t)i;
-        va[0] += v0; va[1] += v1; va[2] += v2; va[3] += v3; va[4] += v4; va[5] += v5;
-      }
+    vsum[0] += v0; vsum[1] += v1; vsum[2] += v2; vsum[3] += v3; vsum[4] += v4; vsum[5] += v5;
+    if (lane == 0 && vatom) {  // src/pair.cpp:925-942
+      double *va = vatom + 6 * (size_t)i;
+      va[0] += v0; va[1] += v1; va[2] += v2; va[3] += v3; va[4] += v4; va[5] += v5;
     }
   }
+}
+// a wave's sums over the rows it walked -> one accumulator slot (`slot`: any number, spread over the NSLOT lines)
+template <bool EFLAG, bool VPAIR>
+__device__ __forceinline__ void ljcoul_tally(double *__restrict__ slots, int slot, int lane, int vglobal, double ev, double ec, const double (&v)[6]) {
+  if (lane != 0) return;
+  double *s = slots + (size_t)(slot & (POLAR_NSLOT - 1)) * POLAR_SLOT_STRIDE;
+  if (EFLAG) { atomicAdd(s + SL_EVDWL, ev); atomicAdd(s + SL_ECOUL, ec); }
+  if (VPAIR && vglobal) {
+    atomicAdd(s + SL_V0, v[0]); atomicAdd(s + SL_V1, v[1]); atomicAdd(s + SL_V2, v[2]);
+    atomicAdd(s + SL_V3, v[3]); atomicAdd(s + SL_V4, v[4]); atomicAdd(s + SL_V5, v[5]);
+  }
+}
+
+// one wave per listed row, Coulomb bins from memory (TAB 0): tables beyond the LDS, `pair_modify table 0`, small systems
+template <bool EFLAG, bool VPAIR>
+static __global__ __launch_bounds__(POLAR_BLOCK) void k_ljcoul(LJCoulParams P, int inum, const int *__restrict__ ilist,
+                                                        const int *__restrict__ numneigh,
+                                                        const long long *__restrict__ first,
+                                                        const int *__restrict__ neigh,
+                                                        const double4 *__restrict__ xq, const int *__restrict__ type,
+                                                        double *__restrict__ f, double *__restrict__ slots,
+                                                        double *__restrict__ eatom, double *__restrict__ vatom,
+                                                        int vglobal) {
+  extern __shared__ double lj_lds[];
+  const int w = P.ntypes + 1;
+  for (int t = threadIdx.x; t < w * w * 8; t += blockDim.x) lj_lds[t] = P.ljpack[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int ii = blockIdx.x * POLAR_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ii >= inum) return;
+  const int i = ilist ? ilist[ii] : ii;
+  const int jnum = numneigh ? numneigh[i] : (int)(first[i + 1] - first[i]);
+  if (jnum == 0) return;
+  double ev = 0.0, ec = 0.0, v[6] = {0, 0, 0, 0, 0, 0};
+  ljcoul_row<EFLAG, VPAIR, 0>(P, i, jnum, neigh + first[i], xq[i], xq, type, lj_lds, nullptr, lane, f, eatom, vatom, ev, ec, v);
+  ljcoul_tally<EFLAG, VPAIR>(slots, blockIdx.x, lane, vglobal, ev, ec, v);
+}
+
+// PERSISTENT form with the Coulomb bins in LDS (TAB 1 / 2): one 1024-thread workgroup per CU loads {f, df, e, de} of every bin
+// (32 B x 2^ncoultablebits = 128 KB at 12 bits) behind the LJ table ONCE, then its 16 waves walk rows ii = first, first + stride, ...
+// A workgroup holds most of its CU's 160 KB of LDS while it runs: a3 shares the CU with kernels that need little LDS (cell
+// sort, list build, static field) and finishes before the sweeps start.
+#define POLAR_LJ_PERS_THREADS 1024
+template <bool EFLAG, bool VPAIR, int TAB>
+static __global__ __launch_bounds__(POLAR_LJ_PERS_THREADS) void k_ljcoul_pers(LJCoulParams P, int inum, const int *__restrict__ ilist,
+                                                        const int *__restrict__ numneigh,
+                                                        const long long *__restrict__ first,
+                                                        const int *__restrict__ neigh,
+                                                        const double4 *__restrict__ xq, const int *__restrict__ type,
+                                                        double *__restrict__ f, double *__restrict__ slots,
+                                                        double *__restrict__ eatom, double *__restrict__ vatom,
+                                                        int vglobal) {
+  extern __shared__ double lj_lds[];
+  const int w = P.ntypes + 1, nlj = (w * w * 8 + 3) & ~3;    // (the bins start 32-byte aligned)
+  double4 *ctab_lds = reinterpret_cast<double4 *>(lj_lds + nlj);
+  for (int t = threadIdx.x; t < w * w * 8; t += blockDim.x) lj_lds[t] = P.ljpack[t];
+  const int ntable = 1 << P.ncoultablebits;
+  for (int b = threadIdx.x; b < ntable; b += blockDim.x) {
+    const double2 *bin = reinterpret_cast<const double2 *>(P.ctab + (size_t)b * 8);
+    const double2 fdf = bin[1], ede = bin[2];
+    ctab_lds[b] = make_double4(fdf.x, fdf.y, ede.x, ede.y);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  double ev = 0.0, ec = 0.0;
+  // interleaved over the workgroups: rows ii, ii + 1, ... of neighbouring atoms run at the same time on different CUs, and every
+  // workgroup sees the same mix of row lengths
+  for (int ii = blockIdx.x + gridDim.x * wv; ii < inum; ii += gridDim.x * nwv) {
+    const int i = ilist ? ilist[ii] : ii;
+    const int jnum = numneigh ? numneigh[i] : (int)(first[i + 1] - first[i]);
+    if (jnum == 0) continue;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    ljcoul_row<EFLAG, VPAIR, TAB>(P, i, jnum, neigh + first[i], xq[i], xq, type, lj_lds, ctab_lds, lane, f, eatom, vatom, ev, ec, v);
+    // (the pairwise virial of a row goes out with the row: six running sums more would not fit the 128 registers of a
+    //  1024-thread workgroup; the energies of all rows of the wave go out once, below)
+    if (VPAIR) ljcoul_tally<false, true>(slots, ii, lane, vglobal, 0.0, 0.0, v);
+  }
+  const double none[6] = {0, 0, 0, 0, 0, 0};
+  ljcoul_tally<EFLAG, false>(slots, blockIdx.x * nwv + wv, lane, 0, ev, ec, none);
 }
 
 // ------------------------------------------------------------------------------------------

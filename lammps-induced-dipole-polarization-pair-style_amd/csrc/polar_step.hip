@@ -280,13 +280,13 @@ void launch_field_lp(polar_handle *h, int nrows, const int2 *desc) {
   if (nrows <= 0) return;
   const polar_settings &st = h->ph.st;
   const int qb = h->quad_block;
-  const int nt = h->lp_tiles;
+  const bool det = deterministic(h);
+  const int nt = det ? 2 : h->lp_tiles;   // (the one-tile instance is a lab variant of the in-place sweep only: the LDS request must match the instance launched)
   size_t lds = (size_t)(qb / 64) * nt * POLAR_LP_TILE;
   if (h->lp_wg_per_cu > 0) lds = std::max(lds, std::min((size_t)64 * 1024, (size_t)160 * 1024 / h->lp_wg_per_cu));  // lab: cap the residency
   // the launch requests dynamic LDS without raising the kernel's limit: beyond 64 KB (workgroups of more than 512 threads
   // with two tiles per wave) it would fail, and the failure would only surface at the next read of the loop state
   if (lds > (size_t)64 * 1024) throw InputError("k_field_lp: workgroup size x tiles needs more than 64 KB of LDS (POLAR_QUAD_BLOCK <= 512 with two tiles)");
-  const bool det = deterministic(h);
   const double omega = EP == EP_INPLACE ? st.polar_sor : 1.0;
 #ifdef POLAR_LAB
 #define POLAR_LAB_ARG , h->ablate
@@ -690,11 +690,29 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
     const long long *fi = symmetrise ? h->d_sym_first.p : h->d_first.p;
     const int *nj = symmetrise ? h->d_sym_j.p : h->d_neigh.p;
     if (h->inum > 0) {
-#define LJ(E, V) k_ljcoul<E, V><<<grid, block, ljlds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1 || lj_pairwise_virial)
       const bool vrow = vmode == 1 || vatom || lj_pairwise_virial;
-      if (eflag) { if (vrow) LJ(true, true); else LJ(true, false); }
-      else       { if (vrow) LJ(false, true); else LJ(false, false); }
+      // the persistent form with the Coulomb bins in LDS (k_ljcoul_pers) where the bins fit beside the LJ table and there are
+      // rows enough to fill the chip's 16 waves per CU; else one wave per row with the bins in memory
+      const size_t ljlds_al = ((ljlds / sizeof(double) + 3) & ~(size_t)3) * sizeof(double);
+      const size_t plds = ljlds_al + ((size_t)32 << P.ncoultablebits);
+      const bool pers = h->lj_pers && P.ncoultablebits > 0 && plds <= (size_t)160 * 1024 && h->ncu > 0 && (nrows_lj >= 16 * h->ncu || h->lj_pers >= 2);   // (POLAR_LJ_PERS=2: also for small systems -- tests)
+      if (pers) {
+#define LJP(E, V, T) do {                                                                                                              \
+          static size_t raised = 0;   /* (per template instance) */                                                                   \
+          if (raised < plds) { HIPCHECK(hipFuncSetAttribute((const void *)k_ljcoul_pers<E, V, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)); raised = plds; } \
+          k_ljcoul_pers<E, V, T><<<h->ncu, POLAR_LJ_PERS_THREADS, plds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1 || lj_pairwise_virial); \
+        } while (0)
+#define LJPT(E, V) do { if (h->lj_tab_arith) LJP(E, V, 2); else LJP(E, V, 1); } while (0)
+        if (eflag) { if (vrow) LJPT(true, true); else LJPT(true, false); }
+        else       { if (vrow) LJPT(false, true); else LJPT(false, false); }
+#undef LJPT
+#undef LJP
+      } else {
+#define LJ(E, V) k_ljcoul<E, V><<<grid, block, ljlds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1 || lj_pairwise_virial)
+        if (eflag) { if (vrow) LJ(true, true); else LJ(true, false); }
+        else       { if (vrow) LJ(false, true); else LJ(false, false); }
 #undef LJ
+      }
     }
     HIPCHECK(hipEventRecord(h->ev_lj1, s));
     if (h->lj_forked) HIPCHECK(hipEventRecord(h->ev_join, s));

@@ -33,6 +33,28 @@ def test_hip_matches_reference_golden(path, info, wl, pkg, oracle):
     z = np.load(path)
     s, _ = load_ref_system(wl, info)
     out = _run(pkg, s, info)
+    _check_golden(out, z, s, info, oracle)
+
+
+_LJ_REFS = [(p, i) for p, i in _REFS if i["variant"] in ("ranked", "newtoff", "newtoff_peratom", "peratom", "peratom_vpair", "vpair", "noeflag", "useprev2")]
+
+
+@pytest.mark.parametrize("path,info", _LJ_REFS, ids=[f"{i['case']}-{i['variant']}" for _, i in _LJ_REFS])
+def test_persistent_lj_coulomb_kernel_matches_reference_golden(path, info, wl, pkg, oracle, monkeypatch):
+    """a3 (PS.cpp:232-321) in its PERSISTENT form (round 5, k_ljcoul_pers: one 1024-thread workgroup per CU, the Coulomb bins
+    {f, df, e, de} in LDS, a bin's r and dr rebuilt from the bits of (float)rsq) is what boxes of more than ~4,000 list rows take;
+    the reference's examples are smaller, so POLAR_LJ_PERS=2 forces it here: same forces, E_vdwl / E_coul, virial and per-atom
+    tallies as the reference's own numbers -- half list with newton on and off, energy and virial flags in every combination."""
+    monkeypatch.setenv("POLAR_LJ_PERS", "2")
+    z = np.load(path)
+    s, _ = load_ref_system(wl, info)
+    out = _run(pkg, s, info)
+    _check_golden(out, z, s, info, oracle)
+    monkeypatch.setenv("POLAR_LJ_PERS", "0")   # and the one-wave-per-row form with the bins in memory (small systems, no table)
+    _check_golden(_run(pkg, s, info), z, s, info, oracle)
+
+
+def _check_golden(out, z, s, info, oracle):
     f = oracle.fold_ghost_forces(out["f"], s.owner, s.nlocal)
     assert force_rel_err(f, z["f"]) < TOL
     scale_mu = max(np.max(np.abs(z["mu"])), 1e-30)
