@@ -540,6 +540,8 @@ MODEL = {
     (4, "legacy"): dict(ms_per_step=7.8, sweeps=38, us_sweep_kernels_per_sweep=129, us_exchange_and_stop_rule_per_sweep=36, ms_non_sweep=1.5),
     (8, "legacy"): dict(ms_per_step=7.2, sweeps=38, us_sweep_kernels_per_sweep=117, us_exchange_and_stop_rule_per_sweep=36, ms_non_sweep=1.4),
     (8, "lag1"): dict(ms_per_step=8.1, sweeps=34, us_sweep_kernels_per_sweep=117, us_exchange_and_stop_rule_per_sweep=80, ms_non_sweep=1.4),
+    # (23 sweeps: the driver on 8 mock ranks, profiles/r05_lab_shards_n8_accel.txt; mixing ~35 us per sweep on top of the exchange)
+    (8, "legacy_accel4"): dict(ms_per_step=5.65, sweeps=23, us_sweep_kernels_per_sweep=117, us_exchange_and_stop_rule_per_sweep=34, us_accel_mixing_per_sweep=35, ms_non_sweep=1.4),
 }
 
 
