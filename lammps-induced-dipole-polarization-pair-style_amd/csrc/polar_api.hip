@@ -210,6 +210,7 @@ int polar_create(int device, polar_handle **out) {
     HIPCHECK(hipStreamCreateWithFlags(&h->dl_stream, hipStreamNonBlocking));
     if (getenv("POLAR_NO_OVERLAP")) h->overlap_lj = false;
     if (const char *e = getenv("POLAR_LJ_PERS")) h->lj_pers = atoi(e);
+    if (const char *e = getenv("POLAR_LJ_PERS_THREADS")) h->lj_pers_threads = std::max(256, std::min(POLAR_LJ_PERS_THREADS, (atoi(e) / 64) * 64));
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) h->ncu = ncu; }
     HIPCHECK(hipHostMalloc((void **)&h->h_scal, sizeof(Scal)));
     HIPCHECK(hipHostMalloc((void **)&h->h_flags, 16 * sizeof(int)));

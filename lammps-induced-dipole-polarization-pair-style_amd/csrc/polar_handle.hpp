@@ -245,6 +245,8 @@ struct polar_handle {
   bool lj_tab_arith = false;     // the Coulomb tables are regular: a bin's r and dr can be rebuilt from the bits of (float)rsq (upload_coul)
   int lj_pers = 1;               // a3 as the persistent kernel with the Coulomb bins in LDS where they fit (POLAR_LJ_PERS=0: one wave per row, bins from memory)
   int ncu = 0;                   // compute units of the device
+  int lj_pers_threads = 768;     // threads of a3's persistent workgroup (POLAR_LJ_PERS_THREADS: 256 ... 1024).  Sixteen waves of 128 registers take a CU's whole register file: nothing
+                                 // runs beside them; twelve leave a quarter of it to the list build.  Measured on one box (gpurun_out/r5l_*): 1024: 9.01, 768: 8.88, 512: 8.97, 384: 9.12, 256: 9.67 ms per step
   bool sym_typed = false, dev_typed = false;
   int static_xq = 1;             // the static-field rows gather 32-byte {x, y, z, q} records instead of whole AtomRecs (POLAR_STATIC_XQ=0)
   int pol_first = 1;             // polarizable atoms first inside a cell (POLAR_POL_FIRST=0: arrival order)

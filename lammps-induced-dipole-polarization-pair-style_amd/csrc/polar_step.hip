@@ -700,7 +700,7 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
 #define LJP(E, V, T) do {                                                                                                              \
           static size_t raised = 0;   /* (per template instance) */                                                                   \
           if (raised < plds) { HIPCHECK(hipFuncSetAttribute((const void *)k_ljcoul_pers<E, V, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)); raised = plds; } \
-          k_ljcoul_pers<E, V, T><<<h->ncu, POLAR_LJ_PERS_THREADS, plds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1 || lj_pairwise_virial); \
+          k_ljcoul_pers<E, V, T><<<h->ncu, h->lj_pers_threads, plds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1 || lj_pairwise_virial); \
         } while (0)
 #define LJPT(E, V) do { if (h->lj_tab_arith) LJP(E, V, 2); else LJP(E, V, 1); } while (0)
         if (eflag) { if (vrow) LJPT(true, true); else LJPT(true, false); }
