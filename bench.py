@@ -9,12 +9,20 @@ N = 1    : headline = BASELINE.json configs[2]: the MOF5+H2 example cell replica
              config.config1_36k          configs[1] (3x3x3 = 36,423 atoms, fixed_iteration 30)
              config.config4_529k_one_gpu configs[4]'s box (7x7x8 = 528,808 atoms) on ONE GPU: the denominator of
                                          the ">= 6x at 8 GPUs vs 1" target
-             config.md_leg               the headline box driven the way LAMMPS drives it: positions re-uploaded
-                                         through polar_set_atoms every step, f / mu downloaded, list re-upload +
-                                         colour rebuild + rank metric every 10th step.
+             config.config0_1349_exact / exact_10792_replica   exact (reference-semantics) mode, with the rocprofv3 /
+                                         FETCH_SIZE figures of its sweep kernel
+             config.md_leg*              the headline box driven the way LAMMPS drives it: positions re-uploaded
+                                         every step, f / mu downloaded, list re-upload + colour check every 10th step.
 N > 1    : strong scaling on a fixed box (BASELINE configs[3], configs[4]): 6x6x6 = 291,384 atoms for N = 2, 4;
-           7x7x8 = 528,808 atoms for N = 8 (other N: the 6x6x6 box); one rank per GPU, spatial slabs, point-to-point
-           halo exchange of the dipoles over RCCL once per sweep (parallel.py).
+           7x7x8 = 528,808 atoms for N = 8; one rank per GPU, spatial slabs, point-to-point halo exchange of the
+           dipoles over RCCL (parallel.py / csrc/polar_dist.hip).  --schedule picks how (SCHEDULES below); the headline
+           is "legacy" (one exchange per sweep, one stream); the others land in config.schedules; config.calibration =
+           per-rank-max device times of the parts of the sweep loop beside DESIGN section 6's prediction.
+
+How it runs (round 5): `python bench.py [--gpus N]` by itself is a LAUNCHER that never touches the GPU: the work runs in
+budgeted child processes (N = 1: `--direct`; N > 1: torch.distributed.run), the last complete line is relayed, alternative
+schedules are separate jobs.  Under a foreign launcher (WORLD_SIZE set) a rank runs directly and an Emitter guarantees exactly
+one line: the measured record exists as soon as the timed steps are over and no later leg can lose it.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     : dipole-field sweep kernel, algorithmic bytes / launch over the measured launch time

@@ -54,6 +54,26 @@ def test_persistent_lj_coulomb_kernel_matches_reference_golden(path, info, wl, p
     _check_golden(_run(pkg, s, info), z, s, info, oracle)
 
 
+@pytest.mark.parametrize("bits", [6, 9, 12, 13])
+@pytest.mark.parametrize("case", ["bulk_h2", "mof5_co2"])
+def test_persistent_lj_coulomb_kernel_with_other_table_sizes(case, bits, wl, pkg, oracle, monkeypatch):
+    """`pair_modify table N` with N other than LAMMPS' default 12: the bins' r / dr are rebuilt from the float's bits with
+    another shift (23 - mantissa bits of the index), the LDS image is 32 B x 2^N (13 bits: 256 KB -- beyond the LDS: the
+    one-wave-per-row form takes over by itself).  Against the oracle, which builds its tables for the same N (init_tables,
+    src/pair.cpp); mof5_co2 carries bonded pairs, whose special-bond correction reads ctable / dctable from memory."""
+    monkeypatch.setenv("POLAR_LJ_PERS", "2")
+    s, _ = wl.load_fixture(os.path.join(GOLD, case + ".npz"), extra_args=["use_previous", "no", "dd_cutoff", "9.0"], ncoultablebits=bits)
+    ref = oracle.compute(s, eflag=1, vflag=1)
+    p = pkg.pair_from_system(s)
+    out = p.compute(eflag=1, vflag=1)
+    p.close()
+    f = oracle.fold_ghost_forces(out["f"], s.owner, s.nlocal)
+    assert force_rel_err(f, oracle.fold_ghost_forces(ref["f"], s.owner, s.nlocal)) < TOL
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert rel(out[k], ref[k], 1e-9) < TOL, k
+    assert np.max(np.abs(out["virial"] - ref["virial"])) < TOL * max(1.0, np.max(np.abs(ref["virial"])))
+
+
 def _check_golden(out, z, s, info, oracle):
     f = oracle.fold_ghost_forces(out["f"], s.owner, s.nlocal)
     assert force_rel_err(f, z["f"]) < TOL
