@@ -551,7 +551,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
               k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision,
                                                     0, nullptr, (sw == max_sweeps - 2) ? max_sweeps - 1 : 1, det_part(h), det_npart(h));
           }
-          if (!st.fixed_iteration && (sw % d->check_every) == d->check_every - 1) {
+          if (!st.fixed_iteration && look_at_state(h, sw, d->check_every, d->reduce_every)) {
             read_scal(h);  // identical on every rank: same all-reduced sum (sweeps past the end are no-ops on the device)
             if (h->h_scal->done) break;
           }
@@ -617,7 +617,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
           if (!accel) prof_mark(d, s, PK_REDUCE);
           dist_exchange(d, h, packed);
           prof_mark(d, s, PK_XCHG);
-          if (!st.fixed_iteration && (sw % d->check_every) == d->check_every - 1) {
+          if (!st.fixed_iteration && look_at_state(h, sw, d->check_every, d->reduce_every)) {
             read_scal(h);  // identical on every rank: same all-reduced sum (sweeps past the end are no-ops on the device)
             if (h->h_scal->done) break;
             prof_mark(d, s, PK_OTHER);

@@ -195,6 +195,7 @@ struct polar_handle {
   DBuf<double> d_mu0;            // use_previous: the initial guess of the running step (a retry after a pitch overflow starts from it again)
   bool mu0_saved = false;
   int attempt = 0;               // which attempt of the running step (do_compute)
+  int last_sweeps = 0;           // sweeps of the last converged precision-mode solve of this handle (0: none yet): where the host first looks at the loop state (look_at_state)
   bool mu_host_in_sync = false;  // the caller's mu array still holds what the last polar_compute returned (no polar_set_atoms since)
   // colour phases (cutoff-mode Gauss-Seidel)
   std::vector<int> color_off;  // [ncolors+1] offsets into d_rows
@@ -461,6 +462,21 @@ inline bool deterministic(const polar_handle *h) {
 // `deterministic yes` with the row sweep: where the end-of-sweep kernels find the sweep's partial sums of (dmu)^2
 inline const double *det_part(const polar_handle *h) { return (deterministic(h) && h->ph.st.dd_cutoff > 0.0 && h->sweep_kernel == 2 && h->lp_npart > 0) ? h->d_lp_part.p : nullptr; }
 inline int det_npart(const polar_handle *h) { return det_part(h) ? h->lp_npart : 0; }
+// When the host looks at the device-resident loop state (a stream synchronisation: the queue drains, ~12 us before the next
+// sweep starts).  Without history: after every `every`-th sweep.  With the sweep count of the handle's LAST solve -- counts
+// change by a sweep or two from step to step, in MD as in the resident bench -- the first look comes where that solve ended
+// (one look instead of eight at 31 sweeps, no launches past the end), then after every sweep for a few, then the old cadence.
+// Sweeps launched past the end of a finished solve are no-ops on the device either way.  `step` = sweeps per possible
+// change of the state (multi-GPU: the all-reduce cadence; the state can only flip after an all-reduced sweep).
+inline bool look_at_state(const polar_handle *h, int sw, int every, int step = 1) {
+  const int done_sweeps = sw + 1;
+  const int pred = h->last_sweeps;
+  if (pred <= 0) return (sw % every) == every - 1;
+  if (done_sweeps < pred) return (done_sweeps % 16) == 0;   // (a coarse look on the way: a solve that ends much earlier than the last one wastes at most 16 no-op sweeps)
+  const int past = done_sweeps - pred;
+  if (past <= 4 * step) return (past % step) == 0;
+  return (past % every) == 0;
+}
 inline bool tile_mode(const polar_handle *h) { return h->ph.st.dd_cutoff > 0.0 && h->sweep_kernel == 4; }
 // where the dipoles live during a solve (exchange and debug kernels): the sweep records in tile mode, else the AtomRecs
 inline MuView mu_view(const polar_handle *h) {

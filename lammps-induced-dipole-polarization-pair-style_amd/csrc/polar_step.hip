@@ -513,7 +513,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
       const int count = (lazy && sw == max_sweeps - 2) ? max_sweeps - 1 : 1;
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count, det_part(h), det_npart(h));
       if (accel && !lazy) accel_step(h, nullptr);   // (a no-op on the device once the stop rule has fired: the result is G(x_k) of the last sweep)
-      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
+      if (!st.fixed_iteration && look_at_state(h, sw, check_every)) {
         read_scal(h);
         if (h->h_scal->done) break;
       }
@@ -567,7 +567,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
       }
       debug_trace(h, sw, false);
       if (!tail_on) k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, h->d_gs_part.p, npart);
-      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
+      if (!st.fixed_iteration && look_at_state(h, sw, check_every)) {
         read_scal(h);
         if (h->h_scal->done) break;
       }
@@ -599,7 +599,7 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
       }
       debug_trace(h, sw, false);
       k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, 0, nullptr, 1, nullptr, 0);
-      if (!st.fixed_iteration && (sw % check_every) == check_every - 1) {
+      if (!st.fixed_iteration && look_at_state(h, sw, check_every)) {
         read_scal(h);
         if (h->h_scal->done) break;
       }
@@ -864,6 +864,7 @@ int phase_finish(polar_handle *h, polar_result *out) {
   out->rms_dmu = std::sqrt(std::max(0.0, sc.last_change));
   h->ntrace = std::min(h->ntrace, sc.sweeps);
   out->iterations = sc.iterations; out->sweeps = sc.sweeps; out->status = sc.status ? POLAR_WARN_NOT_CONVERGED : POLAR_OK;
+  h->last_sweeps = (!st.fixed_iteration && !st.zodid && !sc.status && sc.done) ? sc.sweeps : 0;   // (where the next solve's first look at the loop state goes)
   if (!ap) {
     unsigned long long tot = 0;
     for (int k = 0; k < 64; k++) tot += h->h_ddtot[16 * k];
