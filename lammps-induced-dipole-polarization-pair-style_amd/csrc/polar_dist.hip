@@ -472,8 +472,14 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
       } catch (const HipError &e) { brc = POLAR_ERR_HIP; berr = e.what();
       } catch (const std::exception &e) { brc = POLAR_ERR_STATE; berr = e.what(); }
       const bool shared = d->my_class >= 0 && gs && !st.zodid && h->sweep_kernel == 2;
-      double flags[2] = {brc < 0 ? 1.0 : 0.0, (brc >= 0 && shared && (step_needs_colors(h) || !h->colors_global)) ? 1.0 : 0.0};
-      host_allreduce(d, h, flags, 2, ncclMax);
+      // (the same all-reduce makes the ranks agree on WHERE they look at the loop state -- look_at_state works from the sweep count
+      //  of the handle's last solve, and ranks that looked at different sweeps would leave the loop at different sweeps: one of
+      //  them would wait in an exchange for ever.  The counts are the same on every rank by construction; if they ever are not,
+      //  all ranks fall back to the fixed cadence)
+      double flags[4] = {brc < 0 ? 1.0 : 0.0, (brc >= 0 && shared && (step_needs_colors(h) || !h->colors_global)) ? 1.0 : 0.0,
+                         (double)h->last_sweeps, -(double)h->last_sweeps};
+      host_allreduce(d, h, flags, 4, ncclMax);
+      h->last_sweeps = (flags[2] == -flags[3]) ? (int)flags[2] : 0;
       if (flags[0] > 0.0) {
         h->in_step = false;
         if (brc < 0) { d->err = berr; h->err = berr; return brc; }
