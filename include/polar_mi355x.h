@@ -355,6 +355,9 @@ int polar_step_sweep_end_host(polar_handle *h, double global_change);
  *                          per-rank accumulators itself -- LAMMPS: compute pe, thermo, pressure -- must add).
  *                          A rank that fails before the first exchange (bad input, allocation) makes EVERY rank return an
  *                          error: the begin status is max-reduced first.
+ *                          A wait for the device that sees no progress for POLAR_DIST_TIMEOUT_S (180 s; or an asynchronous
+ *                          RCCL error) aborts the communicator and ends the step with an error: a peer that is not answering an
+ *                          exchange or an all-reduce is reported, not waited for for ever.
  *   polar_dist_exchange    one dipole exchange by itself (tests)
  *   polar_dist_profile     enable != 0: the following polar_dist_step calls put timed events between the parts of their sweep
  *                          loop (a few us each: not for a timed region); polar_dist_profile_get = the last such step's device

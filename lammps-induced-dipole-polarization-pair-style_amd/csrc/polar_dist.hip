@@ -118,6 +118,7 @@ struct polar_dist {
   polar_result local{};                         // this rank's own share of the last step (energies, virial, pairs)
   double host_us_rccl = 0.0, host_us_loop = 0.0; // host time of the last step: inside RCCL calls / issuing the whole sweep loop (POLAR_DEBUG prints them)
   // polar_dist_profile: timed events between the parts of the sweep loop; the interval that ENDS at mark k belongs to part prof_kind[k]
+  double timeout_s = 180.0;        // POLAR_DIST_TIMEOUT_S: how long a wait for the device may see no progress before the step gives up (a peer that is not answering)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kind; size_t prof_n = 0;
   double prof_ms[POLAR_DIST_PROF_PARTS] = {0, 0, 0, 0, 0}; int prof_intervals = 0;
@@ -141,6 +142,34 @@ inline void prof_fold(polar_dist *d) {
     HIPCHECK(hipEventElapsedTime(&ms, d->prof_ev[k - 1], d->prof_ev[k]));
     d->prof_ms[d->prof_kind[k]] += ms;
     d->prof_intervals++;
+  }
+}
+// Wait for stream `s` to drain -- every synchronisation of a step goes through here -- but not for ever: an exchange or an
+// all-reduce whose peer never answers (a rank that died, a schedule the ranks do not agree on) would otherwise leave this rank
+// inside hipStreamSynchronize with nothing to report.  After `timeout_s` without the stream draining, or as soon as RCCL
+// reports an asynchronous error, the communicators are aborted and the step ends with an error that says so.
+void dist_wait(polar_dist *d, hipStream_t s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long long spin = 0;; spin++) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return;
+    if (q != hipErrorNotReady) throw HipError(std::string("polar_dist: hipStreamQuery failed: ") + hipGetErrorString(q));
+    if (spin < 2000) continue;                                   // (a look at the loop state normally ends within microseconds)
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spin & 1023) != 0) continue;
+    ncclResult_t async = ncclSuccess;
+    const bool rccl_bad = d->comm && g_rccl.CommGetAsyncError && g_rccl.CommGetAsyncError(d->comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress;
+    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rccl_bad || waited > d->timeout_s) {
+      if (g_rccl.CommAbort && d->comm) {
+        if (d->comm_red && d->comm_red != d->comm) (void)g_rccl.CommAbort(d->comm_red);
+        (void)g_rccl.CommAbort(d->comm);
+        d->comm = d->comm_red = nullptr;
+      }
+      throw HipError(rccl_bad ? std::string("polar_dist: RCCL reported an asynchronous error while rank ") + std::to_string(d->rank) + " waited for the device: " + g_rccl.GetErrorString(async)
+                              : "polar_dist: rank " + std::to_string(d->rank) + " saw no progress on the device for " + std::to_string((int)waited) +
+                                    " s (POLAR_DIST_TIMEOUT_S): a peer rank is not answering an exchange or an all-reduce; the communicator was aborted");
+    }
   }
 }
 template <typename F>
@@ -204,7 +233,7 @@ void host_allreduce(polar_dist *d, polar_handle *h, double *vals, int count, ncc
   HIPCHECK(hipMemcpyAsync(d->d_red.p + 32, hr, count * sizeof(double), hipMemcpyHostToDevice, s));
   RCCLCHECK(rccl().AllReduce(d->d_red.p + 32, d->d_red.p + 32, count, ncclDouble, op, d->comm, s));
   HIPCHECK(hipMemcpyAsync(hr, d->d_red.p + 32, count * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
+  dist_wait(d, s);
   memcpy(vals, hr, count * sizeof(double));
 }
 // After a (re)colouring shared by the ranks: the exchange lists sorted by colour (stable inside a peer's segment: both ends
@@ -246,7 +275,7 @@ void build_phase_plan(polar_dist *d, polar_handle *h) {
     d->d_send.ensure((size_t)np * 64 + 64); d->d_recv.ensure((size_t)np * 64 + 64);
     HIPCHECK(hipMemcpy(d->d_send.p, mine.data(), mine.size() * sizeof(double), hipMemcpyHostToDevice));
     p2p(d, off.data(), off.data(), d->d_send.p, d->d_recv.p, 1, h->stream);
-    HIPCHECK(hipStreamSynchronize(h->stream));
+    dist_wait(d, h->stream);
     HIPCHECK(hipMemcpy(theirs.data(), d->d_recv.p, theirs.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int k = 0; k < np; k++)
       for (int c = 0; c < nc; c++)
@@ -319,6 +348,7 @@ int polar_dist_create(const void *id128, int rank, int nranks, int device, polar
     for (auto &e : d->ev_phase) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : d->ev_xdone) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char *e = getenv("POLAR_DIST_LAG")) d->lag = std::max(-1, std::min(2, atoi(e)));
+    if (const char *e = getenv("POLAR_DIST_TIMEOUT_S")) d->timeout_s = std::max(1.0, atof(e));
     return (int)POLAR_OK;
   });
 }
@@ -558,6 +588,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
                                                     0, nullptr, (sw == max_sweeps - 2) ? max_sweeps - 1 : 1, det_part(h), det_npart(h));
           }
           if (!st.fixed_iteration && look_at_state(h, sw, d->check_every, d->reduce_every)) {
+            dist_wait(d, s);
             read_scal(h);  // identical on every rank: same all-reduced sum (sweeps past the end are no-ops on the device)
             if (h->h_scal->done) break;
           }
@@ -624,6 +655,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
           dist_exchange(d, h, packed);
           prof_mark(d, s, PK_XCHG);
           if (!st.fixed_iteration && look_at_state(h, sw, d->check_every, d->reduce_every)) {
+            dist_wait(d, s);
             read_scal(h);  // identical on every rank: same all-reduced sum (sweeps past the end are no-ops on the device)
             if (h->h_scal->done) break;
             prof_mark(d, s, PK_OTHER);
@@ -642,6 +674,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
       d->host_us_loop = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop).count();
       if (getenv("POLAR_DEBUG")) fprintf(stderr, "[polar] dist step (rank %d): sweep loop on the host %.0f us (of it inside RCCL calls %.0f us, state reads included), %d + %d exchanges, %d all-reduces\n",
                                          d->rank, d->host_us_loop, d->host_us_rccl, d->exchanges, d->phase_exchanges, d->allreduces);
+      dist_wait(d, s);          // (the solve's last exchanges: polar_step_finish synchronises unconditionally)
       rc = polar_step_finish(h, out);
       prof_fold(d);
       d->local = *out;
@@ -657,7 +690,7 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
       RCCLCHECK(R.AllReduce(d->d_red.p + 3, d->d_red.p + 3, 14, ncclDouble, ncclSum, d->comm, s));
       RCCLCHECK(R.AllReduce(d->d_red.p + 2, d->d_red.p + 2, 1, ncclDouble, ncclMax, d->comm, s));
       HIPCHECK(hipMemcpyAsync(hr, d->d_red.p + 2, 15 * sizeof(double), hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipStreamSynchronize(s));
+      dist_wait(d, s);
       if (hr[14] > 0.0) { if (rc >= 0) { d->err = "polar_dist_step: another rank failed"; rc = POLAR_ERR_STATE; } else d->err = h->err; return rc; }
       if (hr[0] == 0.0) {
         out->eng_vdwl = hr[1]; out->eng_coul = hr[2]; out->eng_pol = hr[3]; out->u_self = hr[4]; out->u_ef = hr[5]; out->u_dd = hr[6];
