@@ -698,8 +698,9 @@ void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host) {
       const bool pers = h->lj_pers && P.ncoultablebits > 0 && plds <= (size_t)160 * 1024 && h->ncu > 0 && (nrows_lj >= 16 * h->ncu || h->lj_pers >= 2);   // (POLAR_LJ_PERS=2: also for small systems -- tests)
       if (pers) {
 #define LJP(E, V, T) do {                                                                                                              \
-          static size_t raised = 0;   /* (per template instance) */                                                                   \
-          if (raised < plds) { HIPCHECK(hipFuncSetAttribute((const void *)k_ljcoul_pers<E, V, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)); raised = plds; } \
+          static size_t raised[64] = {0};   /* (per template instance and device: the attribute belongs to the function ON a device) */ \
+          size_t &rs = raised[h->device & 63];                                                                                          \
+          if (rs < plds) { HIPCHECK(hipFuncSetAttribute((const void *)k_ljcoul_pers<E, V, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)); rs = plds; } \
           k_ljcoul_pers<E, V, T><<<h->ncu, h->lj_pers_threads, plds, s>>>(P, nrows_lj, il, nn, fi, nj, h->d_xq.p, h->d_type.p, h->d_f.p, h->d_slots.p, eatom, vatom, vmode == 1 || lj_pairwise_virial); \
         } while (0)
 #define LJPT(E, V) do { if (h->lj_tab_arith) LJP(E, V, 2); else LJP(E, V, 1); } while (0)
