@@ -362,6 +362,26 @@ SCHEDULES = {
 }
 
 
+_CHILDREN = []   # child jobs of this launcher that are still running (each in a session of its own)
+_BEST = [None]   # the best record in hand (dict), for a launcher that is told to stop
+
+
+def _stop_launcher(signum, frame):
+    """SIGTERM / SIGINT to the launcher: its children sit in sessions of their own and would otherwise keep the GPUs -- end them,
+    print the record in hand (marked), leave."""
+    import signal
+
+    for proc in list(_CHILDREN):
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+    if _BEST[0] is not None:
+        _BEST[0]["extras"] = f"launcher stopped by signal {signum}"
+        print(json.dumps(_BEST[0]), flush=True)
+    os._exit(128 + signum)
+
+
 def is_result_line(ln):
     return ln.startswith("{") and '"metric"' in ln and ln.rstrip().endswith("}")
 
@@ -374,6 +394,7 @@ def run_child(cmd, env, budget_s, log=None):
     import threading
 
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1, start_new_session=True)
+    _CHILDREN.append(proc)
     last = [None]
 
     def pump():
@@ -406,6 +427,8 @@ def run_child(cmd, env, budget_s, log=None):
             except subprocess.TimeoutExpired:
                 continue
     t.join(timeout=5)
+    if proc in _CHILDREN:
+        _CHILDREN.remove(proc)
     return last[0], rc, timed_out
 
 
@@ -456,8 +479,17 @@ def launch(n, argv, probe=visible_gpus, make_cmd=None, schedules=None, out=None)
         make_cmd = (lambda name, extra_argv: rank_command(n, free_port(), list(argv) + list(extra_argv))) if dist_mode \
             else (lambda name, extra_argv: [sys.executable, os.path.abspath(__file__), "--direct"] + list(argv) + list(extra_argv))
     names = list(schedules if schedules is not None else (SCHEDULES if dist_mode else ["single"]))
+    if dist_mode and "--schedule" in argv:   # an explicit --schedule: that one job, nothing beside it
+        names = [argv[argv.index("--schedule") + 1]] if argv.index("--schedule") + 1 < len(argv) else names
+        argv = [a for k, a in enumerate(argv) if a != "--schedule" and (k == 0 or argv[k - 1] != "--schedule")]
     head = names[0]
     t0 = time.time()
+    try:
+        import signal
+        signal.signal(signal.SIGTERM, _stop_launcher)
+        signal.signal(signal.SIGINT, _stop_launcher)
+    except (ValueError, OSError):   # (not the main thread: tests)
+        pass
     # (the ranks themselves turn --schedule NAME into the driver's settings and the extra keywords: SCHEDULES)
     ln, rc, timed_out = run_child(make_cmd(head, ["--schedule", head] if dist_mode else []), env, BUDGET_HEADLINE_S)
     if ln is None:
@@ -470,6 +502,7 @@ def launch(n, argv, probe=visible_gpus, make_cmd=None, schedules=None, out=None)
     elif rc != 0:
         line["extras"] = f"child exit code {rc}"
     exit_code = 0 if (rc == 0 or timed_out) else rc
+    _BEST[0] = line
     if dist_mode:
         line.setdefault("config", {})["schedules"] = {head: schedule_summary(line)}
         line["config"]["headline_schedule"] = head

@@ -137,3 +137,48 @@ def test_emitter_prints_exactly_one_line_under_a_foreign_launcher_even_when_the_
     r = subprocess.run([sys.executable, str(src)], env=env, capture_output=True, text=True, timeout=120)
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines[-1]["value"] == 2.0 and "extras" not in lines[-1] and len(lines) == (2 if own_launcher else 1)
+
+
+def test_a_launcher_told_to_stop_ends_its_children_and_prints_what_it_has(tmp_path):
+    """SIGTERM to the launcher (a driver's own timeout): the child jobs live in sessions of their own and must not be left on the
+    GPUs; the record in hand is printed, marked."""
+    import signal
+    pidfile = tmp_path / "child.pid"
+    head = fake_child(tmp_path, "head", f"print({HEAD!r}, flush=True)\n")
+    hang = fake_child(tmp_path, "hang", f"open({str(pidfile)!r}, 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    drv = tmp_path / "drv.py"
+    drv.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        cmds = {{"legacy": {head!r}, "lag1": {hang!r}}}
+        raise SystemExit(bench.launch(2, [], probe=lambda: 8, make_cmd=lambda name, extra: cmds[name] + list(extra), schedules=["legacy", "lag1"]))
+        """))
+    p = subprocess.Popen([sys.executable, str(drv)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    for _ in range(200):
+        if pidfile.exists() and pidfile.read_text().strip():
+            break
+        time.sleep(0.1)
+    child = int(pidfile.read_text())
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM
+    lines = [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0]["ms_per_step"] == 9.0 and "stopped by signal" in lines[0]["extras"]
+    time.sleep(0.5)
+    try:                           # the schedule job is gone (or a zombie nobody has reaped yet: not running either way)
+        state = [ln.split()[1] for ln in open(f"/proc/{child}/status") if ln.startswith("State:")][0]
+    except (FileNotFoundError, ProcessLookupError):
+        state = "gone"
+    assert state in ("gone", "Z", "X"), state
+
+
+def test_an_explicit_schedule_runs_that_job_alone(tmp_path, monkeypatch):
+    seen = []
+    ok = fake_child(tmp_path, "ok", f"print({HEAD!r}, flush=True)\n")
+    monkeypatch.setattr(bench, "BUDGET_HEADLINE_S", 30.0)
+    out = io.StringIO()
+    rc = bench.launch(2, ["--steps", "3", "--schedule", "lag1"], probe=lambda: 8,
+                      make_cmd=lambda name, extra: (seen.append((name, list(extra))) or ok), out=out)
+    assert rc == 0 and seen == [("lag1", ["--schedule", "lag1"])]
+    assert list(json.loads(out.getvalue())["config"]["schedules"]) == ["lag1"]
