@@ -921,11 +921,18 @@ def bench_distributed(args, rank, world, local_rank):
                 leg(config["schedules"], other, run_other)
     em.final(line)
     bad = not (config["eng_pol_rel_dev_from_one_gpu"] <= B.EPOL_TOL)
+    # the line is out: nothing below may keep the process (and with it the whole job) alive -- tearing communicators down
+    # can wait for a peer that an earlier leg lost
+    import threading
+    guard = threading.Timer(60.0, lambda: os._exit(4 if bad else 0))
+    guard.daemon = True
+    guard.start()
     try:
         job.close()
         dist.destroy_process_group()
     except Exception:  # noqa: BLE001
         pass
+    guard.cancel()
     if bad:   # every rank holds the same all-reduced energy: the same exit code everywhere
         if rank == 0:
             print(f"bench.py: E_pol per cell is {config['eng_pol_rel_dev_from_one_gpu']:.2e} off the one-GPU value: wrong result", file=sys.stderr)
