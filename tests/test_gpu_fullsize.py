@@ -151,3 +151,24 @@ def test_exact_mode_at_the_largest_size_the_reference_ran(wl, pkg, monkeypatch):
     # the reference as here, and the all-pairs model of this box is not translation invariant: 5e-4 between images.)
     lhs = out["u_self"] + out["u_ef"] + out["u_dd"]
     assert abs(lhs - out["eng_pol"]) < 1e-12 * abs(lhs)
+
+
+def test_both_forms_of_the_lj_coulomb_kernel_agree_at_full_size(wl, pkg, monkeypatch):
+    """a3 at configs[1]'s size (36,423 atoms + 30k ghosts: ten million list entries per row kernel) in its two forms -- the
+    persistent kernel with the Coulomb bins in LDS and their r / dr rebuilt from the float's bits (what a box of this size takes),
+    and one wave per row with every table in memory -- performs the same operations in the same order per pair: E_vdwl, E_coul and
+    the forces agree to rounding of the sums (different rows per accumulator slot), with energy and pairwise-virial flags on."""
+    extra = ["use_previous", "no", "polar_gs_ranked", "yes", "dd_cutoff", CUT, "fixed_iteration", "yes", "max_iterations", "2"]
+    s = wl.replicate_fixture(os.path.join(GOLD, "mof5_h2.npz"), 3, 3, 3, extra_args=extra)
+    outs = []
+    for pers in ("1", "0"):
+        monkeypatch.setenv("POLAR_LJ_PERS", pers)
+        p = pkg.pair_from_system(s)
+        outs.append(p.compute(eflag=1, vflag=1))
+        p.close()
+    a, b = outs
+    for k in ("eng_vdwl", "eng_coul", "eng_pol"):
+        assert abs(a[k] - b[k]) <= 1e-12 * abs(b[k]), k
+    scale = np.max(np.abs(b["f"]))
+    assert np.max(np.abs(a["f"] - b["f"])) <= 1e-12 * scale
+    assert np.max(np.abs(a["virial"] - b["virial"])) <= 1e-11 * np.max(np.abs(b["virial"]))
