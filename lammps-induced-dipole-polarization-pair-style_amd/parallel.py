@@ -538,10 +538,10 @@ MODEL = {
     (2, "legacy"): dict(ms_per_step=12.5, sweeps=38, us_sweep_kernels_per_sweep=232, us_exchange_and_stop_rule_per_sweep=36, ms_non_sweep=2.3),
     (2, "lag1"): dict(ms_per_step=12.1, sweeps=35, us_sweep_kernels_per_sweep=232, us_exchange_and_stop_rule_per_sweep=48, ms_non_sweep=2.3),
     (4, "legacy"): dict(ms_per_step=7.8, sweeps=38, us_sweep_kernels_per_sweep=129, us_exchange_and_stop_rule_per_sweep=36, ms_non_sweep=1.5),
-    (8, "legacy"): dict(ms_per_step=7.2, sweeps=38, us_sweep_kernels_per_sweep=117, us_exchange_and_stop_rule_per_sweep=36, ms_non_sweep=1.4),
-    (8, "lag1"): dict(ms_per_step=8.1, sweeps=34, us_sweep_kernels_per_sweep=117, us_exchange_and_stop_rule_per_sweep=80, ms_non_sweep=1.4),
-    # (23 sweeps: the driver on 8 mock ranks, profiles/r05_lab_shards_n8_accel.txt; mixing ~35 us per sweep on top of the exchange)
-    (8, "legacy_accel4"): dict(ms_per_step=5.65, sweeps=23, us_sweep_kernels_per_sweep=117, us_exchange_and_stop_rule_per_sweep=34, us_accel_mixing_per_sweep=35, ms_non_sweep=1.4),
+    (8, "legacy"): dict(ms_per_step=6.8, sweeps=38, us_sweep_kernels_per_sweep=108, us_exchange_and_stop_rule_per_sweep=34, ms_non_sweep=1.38),
+    (8, "lag1"): dict(ms_per_step=7.8, sweeps=34, us_sweep_kernels_per_sweep=108, us_exchange_and_stop_rule_per_sweep=80, ms_non_sweep=1.38),
+    # (23 sweeps: the driver on 8 mock ranks; 108 us of sweep kernels and 21 us of mixing per sweep: one shard stepped alone on the round-5 library -- profiles/r05_lab_shards_n8_accel.txt)
+    (8, "legacy_accel4"): dict(ms_per_step=5.2, sweeps=23, us_sweep_kernels_per_sweep=108, us_exchange_and_stop_rule_per_sweep=37, us_accel_mixing_per_sweep=21, ms_non_sweep=1.38),
 }
 
 
