@@ -87,31 +87,32 @@ static __global__ __launch_bounds__(256) void k_accel_diff(int nrows, long long 
 // The m x m system (Gram matrix of the differences + Tikhonov term: symmetric positive definite, no pivoting needed) is
 // eliminated by ONE WAVE with row i in the registers of lane i -- statically indexed, exchanged by shuffles: a one-thread
 // version with a local array cost 80 us per sweep (dynamic indexing = scratch memory).
+// The work of k_accel_solve, for a workgroup of any size >= 256 threads: EVERY thread of the workgroup calls it (barriers inside),
+// threads 0..255 do the work.  Not called once the solver has stopped.
 template <int M>
-static __global__ __launch_bounds__(256) void k_accel_solve(int nblocks, const double *__restrict__ partial, const Scal *scal, AccelState *st,
-                                                     double *__restrict__ local_out, const double *__restrict__ global, int ring) {
-  if (scal->done) return;
+__device__ __forceinline__ void accel_solve_body(int tid, int nblocks, const double *__restrict__ partial, AccelState *st,
+                                                 double *__restrict__ local_out, const double *__restrict__ global, int ring) {
   __shared__ double stripe[16][2 * M];
   __shared__ double sums[2 * M];
   static_assert(2 * M == 16, "the fold below deals 256 threads as 16 stripes x 16 values");
-  const int q = threadIdx.x & 15, sp = threadIdx.x >> 4;
-  if (!global) {
+  const int q = tid & 15, sp = (tid >> 4) & 15;
+  if (!global && tid < 256) {
     double v = 0.0;
     for (int b = sp; b < nblocks; b += 16) v += partial[(size_t)(2 * M) * b + q];
     stripe[sp][q] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 2 * M) {
+  if (tid < 2 * M) {
     double v = 0.0;
-    if (global) v = global[threadIdx.x];
-    else for (int k = 0; k < 16; k++) v += stripe[k][threadIdx.x];
-    sums[threadIdx.x] = v;
-    if (local_out && !global) local_out[threadIdx.x] = v;
+    if (global) v = global[tid];
+    else for (int k = 0; k < 16; k++) v += stripe[k][tid];
+    sums[tid] = v;
+    if (local_out && !global) local_out[tid] = v;
   }
   __syncthreads();
   if (local_out && !global) return;   // multi-GPU: this launch only exports the local sums; a second one, after the all-reduce, solves
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
+  if (tid >= 64) return;
+  const int lane = tid;
   const bool have_prev = st->sweeps > 0;
   __builtin_amdgcn_wave_barrier();
   if (!have_prev) { if (lane == 0) st->sweeps += 1; return; }   // first sweep: nothing to mix yet (x_1 = g_0)
@@ -162,6 +163,63 @@ static __global__ __launch_bounds__(256) void k_accel_solve(int nblocks, const d
     st->head = head;
     st->count = ok ? n : 0;           // not finite: restart the history; this step is a plain sweep
   }
+}
+template <int M>
+static __global__ __launch_bounds__(256) void k_accel_solve(int nblocks, const double *__restrict__ partial, const Scal *scal, AccelState *st,
+                                                     double *__restrict__ local_out, const double *__restrict__ global, int ring) {
+  if (scal->done) return;
+  accel_solve_body<M>(threadIdx.x, nblocks, partial, st, local_out, global, ring);
+}
+// Round 5: the single-workgroup launches around the mixing folded together (each dependent launch costs ~5 us; a rank's sweep at 8
+// GPUs is ~110 us).
+// k_accel_export: multi-GPU, before the all-reduce -- this rank's sum (dmu)^2 (what k_fold_change does; `fold`) into dst[0] and
+// its 2 M dot products (k_accel_solve's export mode) into dst[1 ..] in ONE launch.
+template <int M>
+static __global__ __launch_bounds__(POLAR_NSLOT) void k_accel_export(Scal *scal, double *__restrict__ slots, double *__restrict__ dst, int fold,
+                                                             int nblocks, const double *__restrict__ partial, AccelState *st, int ring) {
+  __shared__ double red[POLAR_NSLOT / 64];
+  if (fold) {
+    double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
+    slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE] = 0.0;
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sum = 0.0;
+      for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+      scal->change = sum;
+      dst[0] = sum;
+    }
+  }
+  if (scal->done) return;   // (uniform: set by an earlier launch)
+  accel_solve_body<M>(threadIdx.x, nblocks, partial, st, dst + 1, nullptr, ring);
+}
+// k_solver_accel: the end-of-sweep decision (k_solver_step; `decide`; multi-GPU: on the all-reduced change ared[0]) and, unless
+// it ended the solve, the mixing coefficients (k_accel_solve; multi-GPU: from the all-reduced dot products ared[1 ..]) in ONE launch.
+template <int M>
+static __global__ __launch_bounds__(POLAR_NSLOT) void k_solver_accel(Scal *scal, double *__restrict__ slots, int nlocal, int iterations_max, double precision,
+                                                             const double *__restrict__ ared, int decide, int nblocks,
+                                                             const double *__restrict__ partial, AccelState *st, int ring) {
+  if (scal->done) return;
+  __shared__ double red[POLAR_NSLOT / 64];
+  __shared__ int stop;
+  if (threadIdx.x == 0) stop = 0;
+  if (decide) {
+    double v = slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE];
+    slots[(size_t)threadIdx.x * POLAR_SLOT_STRIDE + SL_CHANGE] = 0.0;
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sum = 0.0;
+      for (int k = 0; k < POLAR_NSLOT / 64; k++) sum += red[k];
+      solver_decide(scal, sum, ared, nlocal, 0, iterations_max, precision, 0, 1);
+      stop = scal->done;
+    }
+  }
+  __syncthreads();
+  if (stop) return;
+  accel_solve_body<M>(threadIdx.x, nblocks, partial, st, nullptr, ared ? ared + 1 : nullptr, ring);
 }
 template <int M>
 static __global__ __launch_bounds__(256) void k_accel_mix(int nrows, long long pitch, const int2 *__restrict__ desc, AtomRec *__restrict__ rec,

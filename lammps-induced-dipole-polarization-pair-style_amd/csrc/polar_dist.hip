@@ -559,14 +559,12 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
           if (accel && (!lazy || sw < max_sweeps - 1)) {
             if (g > 0) HIPCHECK(hipStreamWaitEvent(s, d->ev_xdone[(g - 1) % kRing], 0));   // no late unpack may land on the mixed dipoles
             prof_mark(d, s, PK_OTHER);
-            accel_export(h, ared + 1);
+            if (lazy) accel_export(h, ared + 1); else accel_export_fused(h, ared);   // (precision mode: the rank's change and its dot products leave one launch)
             prof_mark(d, s, PK_ACCEL);
-            if (!lazy) k_fold_change<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, ared, nullptr, 0);
             RCCLCHECK(R.AllReduce(ared, ared, 1 + 2 * POLAR_ACCEL_MAXM, ncclDouble, ncclSum, d->comm_red, s));
             d->allreduces++;
-            if (!lazy) k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), 0, st.iterations_max, st.polar_precision, 0, ared, 1, nullptr, 0);
             prof_mark(d, s, PK_REDUCE);
-            accel_step(h, ared + 1);
+            if (lazy) accel_step(h, ared + 1); else accel_decide_mix(h, ared, false);   // (the decision on the all-reduced change and the coefficients: one launch)
             prof_mark(d, s, PK_ACCEL);
             dist_exchange(d, h);
             prof_mark(d, s, PK_XCHG);
@@ -608,14 +606,12 @@ int polar_dist_step(polar_dist *d, polar_handle *h, int eflag, int vflag, polar_
           prof_mark(d, s, PK_SWEEP);
           if (accel) {
             if (!lazy || sw < max_sweeps - 1) {
-              accel_export(h, ared + 1);
+              if (lazy) accel_export(h, ared + 1); else accel_export_fused(h, ared);   // (precision mode: the rank's change and its dot products leave one launch)
               prof_mark(d, s, PK_ACCEL);
-              if (!lazy) k_fold_change<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, ared, nullptr, 0);
               RCCLCHECK(R.AllReduce(ared, ared, 1 + 2 * POLAR_ACCEL_MAXM, ncclDouble, ncclSum, d->comm_red, s));
               d->allreduces++;
-              if (!lazy) k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), 0, st.iterations_max, st.polar_precision, 0, ared, 1, nullptr, 0);
               prof_mark(d, s, PK_REDUCE);
-              accel_step(h, ared + 1);
+              if (lazy) accel_step(h, ared + 1); else accel_decide_mix(h, ared, false);   // (the decision on the all-reduced change and the coefficients: one launch)
               prof_mark(d, s, PK_ACCEL);
             }
             if (lazy && (sw == max_sweeps - 2 || sw == max_sweeps - 1 || max_sweeps == 1))

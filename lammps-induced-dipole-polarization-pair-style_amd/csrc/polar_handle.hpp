@@ -504,6 +504,8 @@ void debug_trace(polar_handle *h, int sw, bool jacobi);
 bool accel_begin(polar_handle *h, bool ap);
 void accel_export(polar_handle *h, double *dev_local_dots);
 void accel_step(polar_handle *h, const double *global_dots);
+void accel_export_fused(polar_handle *h, double *ared);
+void accel_decide_mix(polar_handle *h, const double *ared, bool diff_first);
 void solve(polar_handle *h, bool ap, polar_result *out);
 void phase_begin(polar_handle *h, int eflag, int vflag, const double *mu_host);
 int phase_finish(polar_handle *h, polar_result *out);

@@ -470,6 +470,27 @@ void accel_export(polar_handle *h, double *dev_local_dots) {
                                                            h->d_acc_f.p, h->d_acc_g.p, h->d_acc_dF.p, h->d_acc_dG.p, h->d_acc_part.p, ring);
   k_accel_solve<POLAR_ACCEL_MAXM><<<1, 256, 0, h->stream>>>(nb, h->d_acc_part.p, h->d_scal.p, h->d_acc_state.p, dev_local_dots, nullptr, ring);
 }
+// Round 5, precision mode: the single-workgroup launches around the mixing folded together (polar_accel.hpp).
+// accel_export_fused: differences + partial dots, then this rank's sum (dmu)^2 into ared[0] and its dot products into ared[1 ..]
+// (multi-GPU, before the all-reduce).  accel_decide_mix: the end-of-sweep decision -- on ared[0] if given -- and the mixing
+// coefficients in one launch, then the mix; `diff_first`: single handle, where nothing has formed the differences yet.
+void accel_export_fused(polar_handle *h, double *ared) {
+  const int tot = h->acc_rows, nb = nblk(tot, 256), ring = std::min(h->ph.st.polar_accel, POLAR_ACCEL_MAXM);
+  k_accel_diff<POLAR_ACCEL_MAXM><<<nb, 256, 0, h->stream>>>(tot, h->acc_pitch, h->d_lpdesc.p, h->d_rec0.p, h->d_scal.p, h->d_acc_state.p, h->d_acc_x.p,
+                                                           h->d_acc_f.p, h->d_acc_g.p, h->d_acc_dF.p, h->d_acc_dG.p, h->d_acc_part.p, ring);
+  k_accel_export<POLAR_ACCEL_MAXM><<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, ared, 1, nb, h->d_acc_part.p, h->d_acc_state.p, ring);
+}
+void accel_decide_mix(polar_handle *h, const double *ared, bool diff_first) {
+  const polar_settings &st = h->ph.st;
+  const int tot = h->acc_rows, nb = nblk(tot, 256), ring = std::min(st.polar_accel, POLAR_ACCEL_MAXM);
+  if (diff_first)
+    k_accel_diff<POLAR_ACCEL_MAXM><<<nb, 256, 0, h->stream>>>(tot, h->acc_pitch, h->d_lpdesc.p, h->d_rec0.p, h->d_scal.p, h->d_acc_state.p, h->d_acc_x.p,
+                                                             h->d_acc_f.p, h->d_acc_g.p, h->d_acc_dF.p, h->d_acc_dG.p, h->d_acc_part.p, ring);
+  k_solver_accel<POLAR_ACCEL_MAXM><<<1, POLAR_NSLOT, 0, h->stream>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.iterations_max, st.polar_precision, ared, 1, nb,
+                                                                     h->d_acc_part.p, h->d_acc_state.p, ring);
+  k_accel_mix<POLAR_ACCEL_MAXM><<<nb, 256, 0, h->stream>>>(tot, h->acc_pitch, h->d_lpdesc.p, h->d_rec0.p, h->d_scal.p, h->d_acc_state.p, h->d_acc_x.p,
+                                                          h->d_acc_g.p, h->d_acc_dG.p);
+}
 void accel_step(polar_handle *h, const double *global_dots) {
   const int tot = h->acc_rows, nb = nblk(tot, 256), ring = std::min(h->ph.st.polar_accel, POLAR_ACCEL_MAXM);
   if (!global_dots)
@@ -511,8 +532,8 @@ void solve(polar_handle *h, bool ap, polar_result *out) {
       if (accel && lazy && sw < max_sweeps - 1) accel_step(h, nullptr);   // (no decision to wait for; nothing after the last sweep)
       if (lazy && sw < max_sweeps - 2) continue;
       const int count = (lazy && sw == max_sweeps - 2) ? max_sweeps - 1 : 1;
-      k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count, det_part(h), det_npart(h));
-      if (accel && !lazy) accel_step(h, nullptr);   // (a no-op on the device once the stop rule has fired: the result is G(x_k) of the last sweep)
+      if (accel && !lazy) accel_decide_mix(h, nullptr, true);   // differences, [decision + coefficients], mix: the mix is a no-op once the stop rule has fired (the result is G(x_k) of the last sweep)
+      else k_solver_step<<<1, POLAR_NSLOT, 0, s>>>(h->d_scal.p, h->d_slots.p, norm_count(h), st.fixed_iteration, st.iterations_max, st.polar_precision, gs ? 0 : 1, nullptr, count, det_part(h), det_npart(h));
       if (!st.fixed_iteration && look_at_state(h, sw, check_every)) {
         read_scal(h);
         if (h->h_scal->done) break;
